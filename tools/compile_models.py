@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Compile the reference fruitfly.xml (+ task rewrites) into flybody_amd/assets/*.npz.
+
+Run in a container that has the reference checkout:
+    python tools/compile_models.py [--xml /root/reference/flybody/fruitfly/assets/fruitfly.xml]
+The .npz files are committed: the GPU box has no /root/reference.
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from flybody_amd.mjcf_compile import (compile_model, save_model, walk_imitation_config,
+                                      flight_imitation_config)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--xml', default='/root/reference/flybody/fruitfly/assets/fruitfly.xml')
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'flybody_amd', 'assets'))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    for cfg in (walk_imitation_config(), flight_imitation_config()):
+        m = compile_model(a.xml, cfg)
+        path = os.path.join(a.out, cfg.name + '.npz')
+        save_model(m, path)
+        print(cfg.name, 'nq', len(m['qpos0']), 'nv', len(m['dof_bodyid']), 'nbody', len(m['body_parent']),
+              'nu', len(m['actuator_trntype']), 'ngeom', len(m['geom_type']), 'npair', len(m['pair_geom1']),
+              '->', path, os.path.getsize(path), 'bytes')
+
+if __name__ == '__main__':
+    main()
