@@ -1,0 +1,143 @@
+"""ctypes wrapper around the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker / reported baseline -- never by the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, 'liboracle.so')
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(('.c', '.h'))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(['make', '-s', '-C', _HERE])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.fbo_model_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.fbo_model_load.restype = C.c_int
+        L.fbo_data_create.argtypes = [C.c_void_p]; L.fbo_data_create.restype = C.c_void_p
+        L.fbo_field.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]; L.fbo_field.restype = C.POINTER(C.c_double)
+        L.fbo_dim.argtypes = [C.c_void_p, C.c_char_p]; L.fbo_dim.restype = C.c_int
+        for name in ('fbo_model_destroy', 'fbo_data_destroy', 'fbo_reset_state', 'fbo_kinematics', 'fbo_com_pos',
+                     'fbo_tendon', 'fbo_crb', 'fbo_factor_m', 'fbo_collision', 'fbo_make_constraint', 'fbo_transmission',
+                     'fbo_project_constraint', 'fbo_com_vel', 'fbo_passive', 'fbo_fwd_position', 'fbo_fwd_velocity',
+                     'fbo_fwd_actuation', 'fbo_fwd_acceleration', 'fbo_fwd_constraint', 'fbo_sensor_vel',
+                     'fbo_sensor_acc', 'fbo_euler', 'fbo_forward', 'fbo_step1', 'fbo_step2', 'fbo_step', 'fbo_env_reset'):
+            getattr(L, name).argtypes = [C.c_void_p]; getattr(L, name).restype = None
+        L.fbo_scalar.argtypes = [C.c_void_p, C.c_char_p]; L.fbo_scalar.restype = C.c_double
+        L.fbo_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; L.fbo_contacts.restype = C.c_int
+        L.fbo_rne.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.fbo_mul_m.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbo_jac.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.fbo_env_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.fbo_env_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.fbo_env_step_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return _LIB
+
+
+class _DataStruct(C.Structure):
+    pass
+
+
+class OracleModel:
+    def __init__(self, blob: bytes):
+        self._blob = blob
+        h = C.c_void_p()
+        if lib().fbo_model_load(blob, len(blob), C.byref(h)) != 0:
+            raise RuntimeError('fbo_model_load failed')
+        self.h = h
+
+    def dim(self, name: str) -> int:
+        return lib().fbo_dim(self.h, name.encode())
+
+    def __del__(self):
+        try:
+            lib().fbo_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+class OracleData:
+    """One environment's FP64 state on the CPU."""
+
+    def __init__(self, model: OracleModel):
+        self.model = model
+        self.h = C.c_void_p(lib().fbo_data_create(model.h))
+
+    def field(self, name: str) -> np.ndarray:
+        """Zero-copy numpy view of an internal array (e.g. 'qpos', 'xpos', 'qacc')."""
+        n = C.c_int()
+        p = lib().fbo_field(self.h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def call(self, stage: str):
+        getattr(lib(), 'fbo_' + stage)(self.h)
+
+    def rne(self, flg_acc: int) -> np.ndarray:
+        out = np.zeros(self.model.dim('nv'))
+        lib().fbo_rne(self.h, flg_acc, out.ctypes.data)
+        return out
+
+    def mul_m(self, v: np.ndarray) -> np.ndarray:
+        v = np.ascontiguousarray(v, float); out = np.zeros_like(v)
+        lib().fbo_mul_m(self.h, out.ctypes.data, v.ctypes.data)
+        return out
+
+    def jac(self, point, body: int):
+        nv = self.model.dim('nv')
+        jp = np.zeros((3, nv)); jr = np.zeros((3, nv))
+        pt = np.ascontiguousarray(point, float)
+        lib().fbo_jac(self.h, jp.ctypes.data, jr.ctypes.data, pt.ctypes.data, body)
+        return jp, jr
+
+    def scalar(self, name: str) -> float:
+        v = lib().fbo_scalar(self.h, name.encode())
+        if v == -1e300:
+            raise KeyError(name)
+        return v
+
+    def contacts(self) -> np.ndarray:
+        buf = np.zeros((64, 12))
+        n = lib().fbo_contacts(self.h, buf.ctypes.data, 64)
+        return buf[:n]
+
+    def configure_env(self, ref_qpos, ref_qvel, future_steps=64, terminal_com_dist=0.3, time_limit=10.0):
+        rq = np.ascontiguousarray(ref_qpos, float); rv = np.ascontiguousarray(ref_qvel, float)
+        lib().fbo_env_configure(self.h, rq.ctypes.data, rv.ctypes.data, rq.shape[0], future_steps,
+                                float(terminal_com_dist), float(time_limit))
+
+    def env_reset(self):
+        lib().fbo_env_reset(self.h)
+
+    def env_step(self, action):
+        a = np.ascontiguousarray(action, float)
+        lib().fbo_env_step(self.h, a.ctypes.data)
+
+    def __del__(self):
+        try:
+            lib().fbo_data_destroy(self.h)
+        except Exception:
+            pass
+
+
+def step_batch(datas, actions, nthreads=0):
+    arr = (C.c_void_p * len(datas))(*[d.h for d in datas])
+    a = np.ascontiguousarray(actions, float)
+    lib().fbo_env_step_batch(arr, len(datas), a.ctypes.data, nthreads)
