@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec of batched walk_imitation random-action rollouts.
+
+`python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run,
+one rank per GPU).  A "step" is one control step (10 physics substeps + observation / reward /
+termination epilogue) of every environment of the batch; environments are sharded across ranks
+with no data-path collective ("weak" scaling: 4096 envs per GPU, BASELINE.json configs[1]).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 5420.0       # fp32 words read+written per env control step
+ALGO_FLOP_PER_ENV_STEP = 9.0e6         # SURVEY.md 8(d) provisional estimate
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
+VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}
+
+
+def cpu_baseline(seconds=12.0):
+    """Own FP64 CPU oracle (a 'port', NOT CPU MuJoCo) timed on this box's host cores."""
+    import numpy as np
+    from flybody_amd.model_blob import load_npz, pack_model
+    from flybody_amd.reference import default_walking_reference
+    from oracle import fbo
+    arrays = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'walk_imitation.npz'))
+    om = fbo.OracleModel(pack_model(arrays))
+    cores = os.cpu_count() or 1
+    qp, qv = default_walking_reference()
+    envs = []
+    for _ in range(cores):
+        d = fbo.OracleData(om); d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset(); envs.append(d)
+    rng = np.random.default_rng(0)
+    nsteps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        a = np.clip(rng.normal(size=(cores, 59)), -1, 1)
+        fbo.step_batch(envs, a, cores)
+        nsteps += cores
+    dt = time.perf_counter() - t0
+    return {'value': nsteps / dt, 'unit': 'env steps/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{nsteps} walk_imitation control steps (one env per core, N(0,1) actions clipped to [-1,1]) '
+                      f'in {dt:.1f} s on the own FP64 C oracle with OpenMP -- NOT CPU MuJoCo'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--envs-per-gpu', type=int, default=4096)
+    ap.add_argument('--precision', type=int, default=int(os.environ.get('FB_PRECISION', '32')), choices=[32, 64])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    from flybody_amd import engine
+    from flybody_amd.reference import default_walking_reference
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    n_env = args.envs_per_gpu
+    model = engine.Model.from_asset('walk_imitation')
+    batch = engine.Batch(model, n_env, device=local_rank, precision=args.precision)
+    qp, qv = default_walking_reference()
+    batch.set_reference(qp, qv, terminal_com_dist=float('inf'))
+    stream = torch.cuda.current_stream().cuda_stream
+    batch.reset(stream=stream)
+    nu = model.dim('nu')
+    gen = torch.Generator(device='cuda'); gen.manual_seed(1234 + rank)
+    action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
+
+    def one_step():
+        # per-env random actions N(0,1) clipped to the canonical range
+        action.normal_(generator=gen).clamp_(-1.0, 1.0)
+        batch.step_ptr(action.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    batch.timing_begin(stream)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    kernel_ms, nlaunch = batch.timing_end(stream)      # HIP events on the launch stream
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    q = batch.get('QPOS')
+    finite = bool(np.isfinite(q).all())
+    if rank == 0:
+        total_env_steps = n_env * world * args.steps
+        value = total_env_steps / dt
+        per_launch_s = (kernel_ms / 1e3) / max(nlaunch, 1)
+        achieved_gbs = ALGO_BYTES_PER_ENV_STEP * n_env / per_launch_s / 1e9
+        out = {
+            'metric': 'env steps/sec (whole node), walk_imitation 4096-batch random-action rollout',
+            'value': value, 'unit': 'env steps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 32 else 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: 4096 batched walk_imitation envs per GPU, random-action rollout, '
+                                   'physics kernels + obs/reward/termination epilogue, no learner',
+                       'envs_per_gpu': n_env, 'global_envs': n_env * world, 'substeps_per_step': model.dim('nsubstep'),
+                       'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite},
+            'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
+                         'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
+                         'note': 'SURVEY 8(d): the path is vector-ALU/latency bound, not HBM bound; '
+                                 'valu_frac uses the provisional 9 MFLOP/env-step estimate',
+                         'valu_achieved_tflops': ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12,
+                         'valu_peak_tflops': VALU_PEAK_TFLOPS[args.precision],
+                         'valu_frac': ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12 / VALU_PEAK_TFLOPS[args.precision]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,376 @@
+// Wavefront-cooperative collision detection: 64 lanes sweep the precomputed geom-pair list
+// (bounding-sphere mid-phase), survivors are compacted with ballots and each lane runs the
+// narrow phase of one candidate pair.  Contact order (pair order, then per-pair order) is
+// preserved by prefix sums so the constraint rows come out in a deterministic order.
+#pragma once
+#include "fb_types.hpp"
+#include "fb_math.hpp"
+
+#define MPR_TOL ((real)1e-6)
+#define MPR_ITER 50
+#define MPR_EPS ((real)1e-14)
+
+template <typename real>
+struct CGeom { const real *pos, *mat, *size; int type; real margin; };
+
+template <typename real>
+FBD void support(const CGeom<real>& g, const real* dir, real* out) {
+  real l[3], p[3];
+  mulmatT3(l, g.mat, dir);
+  if (g.type == GEOM_SPHERE) { scl3(p, l, g.size[0]); }
+  else if (g.type == GEOM_CAPSULE) {
+    scl3(p, l, g.size[0]);
+    p[2] += (l[2] >= 0 ? g.size[1] : -g.size[1]);
+  } else if (g.type == GEOM_ELLIPSOID) {
+    real s[3] = {g.size[0]*l[0], g.size[1]*l[1], g.size[2]*l[2]};
+    real n = norm3(s);
+    if (n < FB_MINV) { p[0] = g.size[0]; p[1] = 0; p[2] = 0; }
+    else { p[0] = g.size[0]*s[0]/n; p[1] = g.size[1]*s[1]/n; p[2] = g.size[2]*s[2]/n; }
+  } else if (g.type == GEOM_CYLINDER) {
+    real n = sqrt(l[0]*l[0] + l[1]*l[1]);
+    if (n < FB_MINV) { p[0] = 0; p[1] = 0; }
+    else { p[0] = g.size[0]*l[0]/n; p[1] = g.size[0]*l[1]/n; }
+    p[2] = (l[2] >= 0 ? g.size[1] : -g.size[1]);
+  } else { p[0] = p[1] = p[2] = 0; }
+  addscl3(p, l, (real)0.5*g.margin);
+  mulmat3(out, g.mat, p);
+  add3(out, out, g.pos);
+}
+
+template <typename real> struct MprPt { real v[3], v1[3], v2[3]; };
+
+template <typename real>
+FBD void md_support(const CGeom<real>& a, const CGeom<real>& b, const real* dir, MprPt<real>& s) {
+  real nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support(a, dir, s.v1);
+  support(b, nd, s.v2);
+  sub3(s.v, s.v1, s.v2);
+}
+template <typename real>
+FBD void portal_dir(const MprPt<real>* p, real* dir) {
+  real a[3], b[3];
+  sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v);
+  cross3(dir, a, b); normalize3(dir);
+}
+template <typename real>
+FBD bool reach_tol(const MprPt<real>* p, const MprPt<real>& v4, const real* dir) {
+  real dv4 = dot3(v4.v, dir);
+  real d1 = dv4 - dot3(p[1].v, dir), d2 = dv4 - dot3(p[2].v, dir), d3 = dv4 - dot3(p[3].v, dir);
+  real dm = fmin(d1, fmin(d2, d3));
+  return dm <= MPR_TOL;
+}
+template <typename real>
+FBD void expand_portal(MprPt<real>* p, const MprPt<real>& v4) {
+  real v4v0[3];
+  cross3(v4v0, v4.v, p[0].v);
+  if (dot3(p[1].v, v4v0) > 0) {
+    if (dot3(p[2].v, v4v0) > 0) p[1] = v4; else p[3] = v4;
+  } else {
+    if (dot3(p[3].v, v4v0) > 0) p[2] = v4; else p[1] = v4;
+  }
+}
+template <typename real>
+FBD real origin_tri_dist2(const real* a, const real* b, const real* c, real* wit) {
+  real ab[3], ac[3], ap[3] = {-a[0], -a[1], -a[2]};
+  sub3(ab, b, a); sub3(ac, c, a);
+  real d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { copy3(wit, a); return dot3(a, a); }
+  real bp[3] = {-b[0], -b[1], -b[2]};
+  real d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { copy3(wit, b); return dot3(b, b); }
+  real vc = d1*d4 - d3*d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { real v = d1/(d1 - d3); copy3(wit, a); addscl3(wit, ab, v); return dot3(wit, wit); }
+  real cp[3] = {-c[0], -c[1], -c[2]};
+  real d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { copy3(wit, c); return dot3(c, c); }
+  real vb = d5*d2 - d1*d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { real w_ = d2/(d2 - d6); copy3(wit, a); addscl3(wit, ac, w_); return dot3(wit, wit); }
+  real va = d3*d6 - d5*d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    real w_ = (d4 - d3)/((d4 - d3) + (d5 - d6));
+    real bc[3]; sub3(bc, c, b); copy3(wit, b); addscl3(wit, bc, w_); return dot3(wit, wit);
+  }
+  real den = (real)1/(va + vb + vc);
+  real v = vb*den, w_ = vc*den;
+  copy3(wit, a); addscl3(wit, ab, v); addscl3(wit, ac, w_);
+  return dot3(wit, wit);
+}
+template <typename real>
+FBD void find_pos(const MprPt<real>* p, real* pos) {
+  real dir[3], t[3], b[4];
+  portal_dir(p, dir);
+  cross3(t, p[1].v, p[2].v); b[0] = dot3(t, p[3].v);
+  cross3(t, p[3].v, p[2].v); b[1] = dot3(t, p[0].v);
+  cross3(t, p[0].v, p[1].v); b[2] = dot3(t, p[3].v);
+  cross3(t, p[2].v, p[1].v); b[3] = dot3(t, p[0].v);
+  real sum = b[0] + b[1] + b[2] + b[3];
+  if (sum <= MPR_EPS) {
+    b[0] = 0;
+    cross3(t, p[2].v, p[3].v); b[1] = dot3(t, dir);
+    cross3(t, p[3].v, p[1].v); b[2] = dot3(t, dir);
+    cross3(t, p[1].v, p[2].v); b[3] = dot3(t, dir);
+    sum = b[1] + b[2] + b[3];
+  }
+  real inv = (real)1/sum, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+  for (int i = 0; i < 4; i++) { addscl3(p1, p[i].v1, b[i]); addscl3(p2, p[i].v2, b[i]); }
+  for (int k = 0; k < 3; k++) pos[k] = (real)0.5*inv*(p1[k] + p2[k]);
+}
+
+// Minkowski portal refinement on the margin-inflated shapes; returns penetration depth >= 0
+template <typename real>
+__device__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos) {
+  MprPt<real> p[4], v4;
+  real d[3], va[3], vb[3];
+  copy3(p[0].v1, a.pos); copy3(p[0].v2, b.pos); sub3(p[0].v, a.pos, b.pos);
+  if (dot3(p[0].v, p[0].v) < MPR_EPS*MPR_EPS) p[0].v[0] += (real)1e-9;
+  scl3(d, p[0].v, (real)-1); normalize3(d);
+  md_support(a, b, d, p[1]);
+  if (dot3(p[1].v, d) < 0) return false;
+  cross3(d, p[0].v, p[1].v);
+  if (dot3(d, d) < MPR_EPS*MPR_EPS) {
+    if (dot3(p[1].v, p[1].v) < MPR_EPS*MPR_EPS) { *depth = 0; dir[0] = 1; dir[1] = 0; dir[2] = 0; }
+    else { *depth = norm3(p[1].v); copy3(dir, p[1].v); normalize3(dir); }
+    for (int k = 0; k < 3; k++) pos[k] = (real)0.5*(p[1].v1[k] + p[1].v2[k]);
+    return true;
+  }
+  normalize3(d);
+  md_support(a, b, d, p[2]);
+  if (dot3(p[2].v, d) < 0) return false;
+  sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+  cross3(d, va, vb); normalize3(d);
+  if (dot3(d, p[0].v) > 0) { MprPt<real> t = p[1]; p[1] = p[2]; p[2] = t; scl3(d, d, (real)-1); }
+  for (int it = 0;; it++) {
+    if (it > 4*MPR_ITER) return false;
+    md_support(a, b, d, p[3]);
+    if (dot3(p[3].v, d) < 0) return false;
+    bool cont = false;
+    cross3(va, p[1].v, p[3].v);
+    if (dot3(va, p[0].v) < -MPR_EPS) { p[2] = p[3]; cont = true; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v);
+      if (dot3(va, p[0].v) < -MPR_EPS) { p[1] = p[3]; cont = true; }
+    }
+    if (!cont) break;
+    sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+    cross3(d, va, vb); normalize3(d);
+  }
+  for (int it = 0;; it++) {
+    portal_dir(p, d);
+    if (dot3(d, p[1].v) >= 0) break;
+    md_support(a, b, d, v4);
+    if (dot3(v4.v, d) < 0 || reach_tol(p, v4, d) || it > MPR_ITER) return false;
+    expand_portal(p, v4);
+  }
+  for (int it = 0;; it++) {
+    portal_dir(p, d);
+    md_support(a, b, d, v4);
+    if (reach_tol(p, v4, d) || it > MPR_ITER) {
+      real wit[3];
+      real d2 = origin_tri_dist2(p[1].v, p[2].v, p[3].v, wit);
+      *depth = sqrt(d2);
+      if (*depth < MPR_EPS) copy3(dir, d); else { copy3(dir, wit); normalize3(dir); }
+      find_pos(p, pos);
+      return true;
+    }
+    expand_portal(p, v4);
+  }
+}
+
+// ---- per-lane narrow phase: up to 4 contacts (dist, pos, normal) for one pair
+template <typename real>
+struct LaneContacts { real dist[4], pos[12], nrm[12]; int n; };
+
+template <typename real>
+FBD void lc_add(LaneContacts<real>& lc, real dist, const real* pos, const real* n) {
+  if (lc.n >= 4) return;
+  lc.dist[lc.n] = dist; copy3(lc.pos + 3*lc.n, pos); copy3(lc.nrm + 3*lc.n, n); lc.n++;
+}
+template <typename real>
+FBD void c_sphere_sphere(LaneContacts<real>& lc, const real* p1, real r1, const real* p2, real r2, real margin) {
+  real n[3]; sub3(n, p2, p1);
+  real len = norm3(n);
+  real dist = len - r1 - r2;
+  if (dist > margin) return;
+  if (len < FB_MINV) { n[0] = 1; n[1] = 0; n[2] = 0; } else scl3(n, n, (real)1/len);
+  real pos[3]; copy3(pos, p1); addscl3(pos, n, r1 + (real)0.5*dist);
+  lc_add(lc, dist, pos, n);
+}
+template <typename real>
+FBD void c_plane_sphere(LaneContacts<real>& lc, const real* ppos, const real* n, const real* spos, real r, real margin) {
+  real dif[3]; sub3(dif, spos, ppos);
+  real dist = dot3(dif, n) - r;
+  if (dist > margin) return;
+  real pos[3]; copy3(pos, spos); addscl3(pos, n, -(r + (real)0.5*dist));
+  lc_add(lc, dist, pos, n);
+}
+template <typename real>
+FBD void c_capsule_capsule(LaneContacts<real>& lc, const real* p1, const real* m1, const real* s1,
+                           const real* p2, const real* m2, const real* s2, real margin) {
+  real a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+  real dif[3]; sub3(dif, p1, p2);
+  real ma = 1, mb = -dot3(a1, a2), mc = 1;
+  real u = -dot3(a1, dif), v = dot3(a2, dif);
+  real det = ma*mc - mb*mb;
+  real l1 = s1[1], l2 = s2[1];
+  if (fabs(det) >= (real)1e-12) {
+    real x1 = (mc*u - mb*v)/det, x2 = (ma*v - mb*u)/det;
+    if (x1 > l1) { x1 = l1; x2 = (v - mb*l1)/mc; }
+    else if (x1 < -l1) { x1 = -l1; x2 = (v + mb*l1)/mc; }
+    if (x2 > l2) { x2 = l2; x1 = clampr((u - mb*l2)/ma, -l1, l1); }
+    else if (x2 < -l2) { x2 = -l2; x1 = clampr((u + mb*l2)/ma, -l1, l1); }
+    real v1[3], v2[3];
+    copy3(v1, p1); addscl3(v1, a1, x1);
+    copy3(v2, p2); addscl3(v2, a2, x2);
+    c_sphere_sphere(lc, v1, s1[0], v2, s2[0], margin);
+    return;
+  }
+  int n0 = lc.n, n = 0;
+  real last[3] = {(real)1e30, (real)1e30, (real)1e30};
+  for (int sgn = 1; sgn >= -1; sgn -= 2) {
+    real x1 = sgn*l1;
+    real x2 = clampr((v - mb*x1)/mc, -l2, l2);
+    real v1[3], v2[3], t[3];
+    copy3(v1, p1); addscl3(v1, a1, x1);
+    copy3(v2, p2); addscl3(v2, a2, x2);
+    sub3(t, v2, last);
+    if (n && dot3(t, t) < (real)1e-20) {
+      x1 = clampr((u - mb*x2)/ma, -l1, l1);
+      copy3(v1, p1); addscl3(v1, a1, x1);
+      lc.n = n0; n = 0;
+    }
+    copy3(last, v2);
+    int before = lc.n;
+    c_sphere_sphere(lc, v1, s1[0], v2, s2[0], margin);
+    n += lc.n - before;
+  }
+}
+template <typename real>
+FBD void c_plane_cylinder(LaneContacts<real>& lc, const real* ppos, const real* n, const real* cpos, const real* cmat, const real* size, real margin) {
+  real ax[3] = {cmat[2], cmat[5], cmat[8]};
+  real dif[3]; sub3(dif, cpos, ppos);
+  real dist0 = dot3(dif, n);
+  real prjaxis = dot3(n, ax);
+  if (prjaxis > 0) { scl3(ax, ax, (real)-1); prjaxis = -prjaxis; }
+  real vec[3] = {ax[0]*prjaxis - n[0], ax[1]*prjaxis - n[1], ax[2]*prjaxis - n[2]};
+  real len = norm3(vec);
+  if (len < (real)1e-12) { vec[0] = cmat[0]*size[0]; vec[1] = cmat[3]*size[0]; vec[2] = cmat[6]*size[0]; }
+  else scl3(vec, vec, size[0]/len);
+  real prjvec = dot3(vec, n);
+  scl3(ax, ax, size[1]); prjaxis *= size[1];
+  real dist = dist0 + prjaxis + prjvec;
+  if (dist > margin) return;
+  real pos[3];
+  for (int k = 0; k < 3; k++) pos[k] = cpos[k] + vec[k] + ax[k] - n[k]*dist*(real)0.5;
+  lc_add(lc, dist, pos, n);
+  dist = dist0 - prjaxis + prjvec;
+  if (dist <= margin) {
+    for (int k = 0; k < 3; k++) pos[k] = cpos[k] + vec[k] - ax[k] - n[k]*dist*(real)0.5;
+    lc_add(lc, dist, pos, n);
+  }
+  dist = dist0 + prjaxis - (real)0.5*prjvec;
+  if (dist <= margin) {
+    real v1[3]; cross3(v1, vec, ax); normalize3(v1); scl3(v1, v1, size[0]*(real)0.86602540378443865);
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      for (int k = 0; k < 3; k++) pos[k] = cpos[k] + sgn*v1[k] + ax[k] - (real)0.5*vec[k] - n[k]*dist*(real)0.5;
+      lc_add(lc, dist, pos, n);
+    }
+  }
+}
+
+template <typename real>
+__device__ void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
+  int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+  int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  real margin = M.pair_margin[p];
+  const real *p1 = w.gxpos + 3*g1, *p2 = w.gxpos + 3*g2;
+  const real *m1 = w.gxmat + 9*g1, *m2 = w.gxmat + 9*g2;
+  const real *s1 = M.geom_size + 3*g1, *s2 = M.geom_size + 3*g2;
+  if (t1 == GEOM_PLANE) {
+    real n[3] = {m1[2], m1[5], m1[8]};
+    if (t2 == GEOM_SPHERE) c_plane_sphere(lc, p1, n, p2, s2[0], margin);
+    else if (t2 == GEOM_CAPSULE) {
+      real ax[3] = {m2[2], m2[5], m2[8]};
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        real e[3]; copy3(e, p2); addscl3(e, ax, sgn*s2[1]);
+        c_plane_sphere(lc, p1, n, e, s2[0], margin);
+      }
+    } else if (t2 == GEOM_ELLIPSOID) {
+      real nl[3]; mulmatT3(nl, m2, n);
+      real s[3] = {s2[0]*nl[0], s2[1]*nl[1], s2[2]*nl[2]};
+      real len = norm3(s);
+      real loc[3] = {-s2[0]*s[0]/len, -s2[1]*s[1]/len, -s2[2]*s[2]/len};
+      real pt[3], dif[3]; mulmat3(pt, m2, loc); add3(pt, pt, p2);
+      sub3(dif, pt, p1);
+      real dist = dot3(dif, n);
+      if (dist <= margin) { real pos[3]; copy3(pos, pt); addscl3(pos, n, -(real)0.5*dist); lc_add(lc, dist, pos, n); }
+    } else if (t2 == GEOM_CYLINDER) c_plane_cylinder(lc, p1, n, p2, m2, s2, margin);
+    return;
+  }
+  if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) c_sphere_sphere(lc, p1, s1[0], p2, s2[0], margin);
+  else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
+    real ax[3] = {m2[2], m2[5], m2[8]}, dif[3];
+    sub3(dif, p1, p2);
+    real x = clampr(dot3(ax, dif), -s2[1], s2[1]);
+    real v[3]; copy3(v, p2); addscl3(v, ax, x);
+    c_sphere_sphere(lc, p1, s1[0], v, s2[0], margin);
+  } else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) c_capsule_capsule(lc, p1, m1, s1, p2, m2, s2, margin);
+  else {
+    CGeom<real> A = {p1, m1, s1, t1, margin}, B = {p2, m2, s2, t2, margin};
+    real depth, dir[3], pos[3];
+    if (mpr_penetration(A, B, &depth, dir, pos)) lc_add(lc, margin - depth, pos, dir);
+  }
+}
+
+template <typename real>
+__device__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // ---- mid phase: bounding spheres
+  int ncand = 0;
+  const int maxcand = 2*FB_MAXCON_ + 64;
+  for (int base = 0; base < M.npair; base += FB_WAVE) {
+    int p = base + lane;
+    bool hit = false;
+    if (p < M.npair) {
+      int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+      real margin = M.pair_margin[p];
+      real dif[3]; sub3(dif, w.gxpos + 3*g2, w.gxpos + 3*g1);
+      if (M.geom_type[g1] == GEOM_PLANE) {
+        const real* m1 = w.gxmat + 9*g1;
+        real n[3] = {m1[2], m1[5], m1[8]};
+        hit = dot3(dif, n) <= M.geom_rbound[g2] + margin;
+      } else {
+        real bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+        hit = dot3(dif, dif) <= bound*bound;
+      }
+    }
+    unsigned long long bal = __ballot(hit);
+    int idx = ncand + __popcll(bal & lt_mask);
+    if (hit && idx < maxcand) w.cand[idx] = p;
+    ncand += __popcll(bal);
+  }
+  if (ncand > maxcand) ncand = maxcand;
+  SYNC();
+  // ---- narrow phase
+  int ncon = 0;
+  for (int base = 0; base < ncand; base += FB_WAVE) {
+    LaneContacts<real> lc; lc.n = 0;
+    int c = base + lane, p = -1;
+    if (c < ncand) { p = w.cand[c]; narrow_phase(M, w, p, lc); }
+    int off = ncon + wave_excl_scan(lc.n, lane);
+    for (int k = 0; k < lc.n; k++) {
+      int ci = off + k;
+      if (ci >= FB_MAXCON_) break;
+      w.con_dist[ci] = lc.dist[k];
+      copy3(w.con_pos + 3*ci, lc.pos + 3*k);
+      real f[9];
+      copy3(f, lc.nrm + 3*k); f[3] = f[4] = f[5] = f[6] = f[7] = f[8] = 0;
+      makeframe(f);
+      for (int q = 0; q < 9; q++) w.con_frame[9*ci + q] = f[q];
+      w.con_pair[ci] = p;
+    }
+    ncon += wave_sum_i(lc.n);
+  }
+  if (ncon > FB_MAXCON_) ncon = FB_MAXCON_;
+  if (lane == 0) { w.istate[IS_NCON] = ncon; w.istate[IS_NCAND] = ncand; }
+  SYNC();
+}

@@ -1,0 +1,510 @@
+// Wavefront-cooperative constraint construction and the PGS / noslip solvers.
+//
+// Every constraint row touches at most two root->leaf dof chains (the chains of the two bodies
+// in contact, or of the limited joint).  Rows are therefore stored "chain-compressed":
+//   J[side][slot][row], side in {A,B}, slot < FB_MAXCH  (slot s == the dof at depth s on the chain)
+// laid out row-minor so that lane == row accesses are coalesced.  With the mass matrix factored
+// as M = L^T D L the half-solve Y = J L^-1 D^-1/2 keeps exactly the same sparsity, and the
+// Delassus matrix A = Y Y^T needs only the common prefix of two chains per entry.
+#pragma once
+#include "fb_types.hpp"
+#include "fb_math.hpp"
+#include "fb_smooth.hpp"
+
+#define JIDX(side, s, r) (((side)*FB_MAXCH + (s))*FB_MAXEFC_ + (r))
+#define MINIMP ((real)0.0001)
+#define MAXIMP ((real)0.9999)
+
+template <typename real>
+FBD real get_impedance(const real* si, real pos, real margin) {
+  real s0 = fmin(MAXIMP, fmax(MINIMP, si[0])), s1 = fmin(MAXIMP, fmax(MINIMP, si[1]));
+  real s2 = fmax((real)0, si[2]), s3 = fmin(MAXIMP, fmax(MINIMP, si[3])), s4 = fmax((real)1, si[4]);
+  if (s0 == s1 || s2 <= FB_MINV) return (real)0.5*(s0 + s1);
+  real x = fabs((pos - margin)/s2);
+  if (x >= 1) return s1;
+  if (x <= 0) return s0;
+  real y;
+  if (s4 == 1) y = x;
+  else if (x <= s3) y = pow(x, s4) / pow(s3, s4 - 1);
+  else y = 1 - pow(1 - x, s4) / pow(1 - s3, s4 - 1);
+  return s0 + y*(s1 - s0);
+}
+
+template <typename real>
+FBD void kbi(const DevModel<real>& M, const real* solref, const real* solimp, real pos, real margin, bool friction_row,
+             real& K, real& B, real& imp) {
+  imp = get_impedance(solimp, pos, margin);
+  real dmax = fmin(MAXIMP, fmax(MINIMP, solimp[1]));
+  if (solref[0] > 0) {
+    real tc = fmax(solref[0], 2*M.timestep);
+    K = (real)1 / fmax(FB_MINV, dmax*dmax*tc*tc*solref[1]*solref[1]);
+    B = (real)2 / fmax(FB_MINV, dmax*tc);
+  } else {
+    K = -solref[0] / fmax(FB_MINV, dmax*dmax);
+    B = -solref[1] / fmax(FB_MINV, dmax);
+  }
+  if (friction_row) K = 0;
+}
+
+// ------------------------------------------------------------------ rows
+template <typename real>
+__device__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
+  // ---- joint limits (row order: joint order)
+  int nlimit = 0;
+  for (int base = 0; base < M.njnt; base += FB_WAVE) {
+    int j = base + lane;
+    int side = 0; real dist = 0;
+    if (j < M.njnt && M.jnt_limited[j] && M.jnt_type[j] == JNT_HINGE) {
+      real value = w.qpos[M.jnt_qposadr[j]];
+      real dlo = value - M.jnt_range[2*j], dhi = M.jnt_range[2*j+1] - value;
+      if (dlo < M.jnt_margin[j]) { side = -1; dist = dlo; }
+      else if (dhi < M.jnt_margin[j]) { side = 1; dist = dhi; }
+    }
+    int has = side != 0;
+    int r = nlimit + wave_excl_scan(has, lane);
+    if (has) {
+      int dof = M.jnt_dofadr[j];
+      int len = M.dof_depth[dof] + 1;
+      w.efc_type[r] = CN_LIMIT; w.efc_id[r] = j;
+      w.efc_bA[r] = M.jnt_bodyid[j]; w.efc_lA[r] = len; w.efc_bB[r] = 0; w.efc_lB[r] = 0;
+      w.efc_pos[r] = dist; w.efc_margin[r] = M.jnt_margin[j];
+      for (int s = 0; s < FB_MAXCH; s++) { w.efc_J[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0; w.efc_J[JIDX(1, s, r)] = 0; }
+      real K, B, imp;
+      kbi(M, M.jnt_solref + 2*j, M.jnt_solimp + 5*j, dist, M.jnt_margin[j], false, K, B, imp);
+      w.efc_K[r] = K; w.efc_B[r] = B; w.efc_imp[r] = imp; w.efc_mu[r] = 0;
+      w.efc_R[r] = fmax(FB_MINV, (1 - imp)*M.dof_invweight0[dof]/imp);
+    }
+    nlimit += wave_sum_i(has);
+  }
+  // ---- contacts: lane == contact
+  int ncon = w.istate[IS_NCON];
+  int dim = 0, p = 0; real dist = 0, incl = 0;
+  if (lane < ncon) {
+    p = w.con_pair[lane];
+    dist = w.con_dist[lane];
+    incl = M.pair_margin[p] - M.pair_gap[p];
+    if (dist < incl) dim = (M.pair_condim[p] == 1) ? 1 : 3;
+  }
+  int adr = nlimit + wave_excl_scan(dim, lane);
+  bool over = dim > 0 && adr + dim > FB_MAXEFC_;
+  unsigned long long ob = __ballot(over);
+  int nefc = nlimit + wave_sum_i(dim);
+  if (ob) {
+    int first = __ffsll((long long)ob) - 1;
+    nefc = __shfl(adr, first, 64);
+    if (lane >= first) dim = 0;
+  }
+  if (lane < ncon) { w.con_efc[lane] = dim ? adr : -1; w.con_dim[lane] = dim; }
+  if (dim) {
+    int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+    int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+    const real* pos = w.con_pos + 3*lane;
+    const real* frame = w.con_frame + 9*lane;
+    real off[3]; sub3(off, pos, w.com);
+    real K, B, imp;
+    kbi(M, M.pair_solref + 2*p, M.pair_solimp + 5*p, dist, incl, false, K, B, imp);
+    real tran = M.body_invweight0[2*b1] + M.body_invweight0[2*b2];
+    real R0 = fmax(FB_MINV, (1 - imp)*tran/imp);
+    const real* fr = M.pair_friction + 5*p;
+    real R1 = R0 / fmax(FB_MINV, M.impratio);
+    real mu = fr[0]*sqrt(R1/R0);
+    real R2 = R1*fr[0]*fr[0]/(fr[1]*fr[1]);
+    for (int k = 0; k < dim; k++) {
+      int r = adr + k;
+      w.efc_type[r] = (dim == 1) ? CN_FRICTIONLESS : CN_ELLIPTIC; w.efc_id[r] = lane;
+      w.efc_bA[r] = b1; w.efc_bB[r] = b2;
+      w.efc_lA[r] = M.body_chlen[b1]; w.efc_lB[r] = M.body_chlen[b2];
+      w.efc_pos[r] = dist; w.efc_margin[r] = incl;
+      w.efc_K[r] = (k == 0) ? K : (real)0; w.efc_B[r] = B; w.efc_imp[r] = imp;
+      w.efc_R[r] = (k == 0) ? R0 : (k == 1 ? R1 : R2);
+      w.efc_mu[r] = mu;
+    }
+    for (int side = 0; side < 2; side++) {
+      int body = side ? b2 : b1;
+      real sgn = side ? (real)1 : (real)-1;
+      int len = M.body_chlen[body];
+      const int* chain = M.body_chain + body*FB_MAXCH;
+      for (int s = 0; s < FB_MAXCH; s++) {
+        real jp[3] = {0, 0, 0};
+        if (s < len) {
+          const real* c = w.cdof + 6*chain[s];
+          real t[3]; cross3(t, c, off);
+          jp[0] = c[3] + t[0]; jp[1] = c[4] + t[1]; jp[2] = c[5] + t[2];
+        }
+        for (int k = 0; k < dim; k++) w.efc_J[JIDX(side, s, adr + k)] = sgn*dot3(frame + 3*k, jp);
+      }
+    }
+  }
+  if (lane == 0) { w.istate[IS_NEFC] = nefc; w.istate[IS_NLIMIT] = nlimit; }
+  SYNC();
+  for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D[r] = (real)1 / w.efc_R[r];
+}
+
+// ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
+template <typename real>
+__device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
+  int nefc = w.istate[IS_NEFC];
+  if (nefc == 0) return;
+  for (int base = 0; base < nefc; base += FB_WAVE) {
+    int r = base + lane;
+    if (r < nefc) {
+      for (int side = 0; side < 2; side++) {
+        int body = side ? w.efc_bB[r] : w.efc_bA[r];
+        int len = side ? w.efc_lB[r] : w.efc_lA[r];
+        const int* chain = M.body_chain + body*FB_MAXCH;
+        real y[FB_MAXCH];
+#pragma unroll
+        for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0;
+#pragma unroll
+        for (int s = FB_MAXCH - 1; s >= 1; s--) {
+          if (s < len && y[s] != 0) {
+            int adr = M.dof_Madr[chain[s]];
+#pragma unroll
+            for (int t = 0; t < s; t++) y[t] -= w.qLD[adr + (s - t)] * y[s];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < FB_MAXCH; s++) {
+          real v = 0;
+          if (s < len) v = y[s] * sqrt(w.qLDinv[chain[s]]);
+          w.efc_Y[JIDX(side, s, r)] = v;
+        }
+      }
+    }
+  }
+  SYNC();
+  // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
+  for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
+    int c = cbase + lane;
+    bool valid = c < nefc;
+    real yA[FB_MAXCH], yB[FB_MAXCH];
+    int bA = 0, bB = 0, lA = 0, lB = 0;
+    if (valid) { bA = w.efc_bA[c]; bB = w.efc_bB[c]; lA = w.efc_lA[c]; lB = w.efc_lB[c]; }
+#pragma unroll
+    for (int s = 0; s < FB_MAXCH; s++) {
+      yA[s] = valid ? w.efc_Y[JIDX(0, s, c)] : (real)0;
+      yB[s] = valid ? w.efc_Y[JIDX(1, s, c)] : (real)0;
+    }
+    for (int r = 0; r < nefc; r++) {
+      real acc = 0;
+      for (int side = 0; side < 2; side++) {
+        int rb = side ? w.efc_bB[r] : w.efc_bA[r];
+        int rl = side ? w.efc_lB[r] : w.efc_lA[r];
+        if (rl == 0) continue;
+        int cmA = min(min(M.body_common[rb*M.nbody + bA], lA), rl);
+        int cmB = min(min(M.body_common[rb*M.nbody + bB], lB), rl);
+#pragma unroll
+        for (int s = 0; s < FB_MAXCH; s++) {
+          if (s < rl) {
+            real yr = w.efc_Y[JIDX(side, s, r)];
+            if (s < cmA) acc += yr*yA[s];
+            if (s < cmB) acc += yr*yB[s];
+          }
+        }
+      }
+      if (valid) {
+        if (c == r) acc += w.efc_R[r];
+        w.AR[r*nefc + c] = acc;
+      }
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ adhesion + actuator forces
+template <typename real>
+__device__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
+  SYNC();
+  for (int i = lane; i < M.nu; i += FB_WAVE) {
+    real ctrl = w.ctrl[i];
+    if (M.act_ctrllimited[i]) ctrl = clampr(ctrl, M.act_ctrlrange[2*i], M.act_ctrlrange[2*i+1]);
+    real input = ctrl;
+    int aa = M.act_actadr[i];
+    if (aa >= 0) {
+      w.act_dot[aa] = (ctrl - w.act[aa]) / fmax(FB_MINV, M.act_dynprm[i]);
+      input = w.act[aa];
+    }
+    real length = 0, vel = 0;
+    int tt = M.act_trntype[i], id = M.act_trnid[i];
+    if (tt == TRN_JOINT) { length = w.qpos[M.jnt_qposadr[id]]; vel = w.qvel[M.jnt_dofadr[id]]; }
+    else if (tt == TRN_TENDON) {
+      length = w.ten_length[id];
+      for (int k = M.tendon_adr[id]; k < M.tendon_adr[id] + M.tendon_num[id]; k++) vel += M.wrap_coef[k]*w.qvel[M.wrap_dofid[k]];
+    }
+    real force = M.act_gainprm[3*i]*input;
+    if (M.act_biastype[i] == 1) force += M.act_biasprm[3*i] + M.act_biasprm[3*i+1]*length + M.act_biasprm[3*i+2]*vel;
+    if (M.act_forcelimited[i]) force = clampr(force, M.act_forcerange[2*i], M.act_forcerange[2*i+1]);
+    w.act_force[i] = force;
+    // joint / tendon transmissions touch disjoint dofs: plain stores
+    if (tt == TRN_JOINT) w.qfrc_actuator[M.jnt_dofadr[id]] += force;
+    else if (tt == TRN_TENDON)
+      for (int k = M.tendon_adr[id]; k < M.tendon_adr[id] + M.tendon_num[id]; k++) w.qfrc_actuator[M.wrap_dofid[k]] += M.wrap_coef[k]*force;
+  }
+  SYNC();
+  // adhesion (body transmission): pull along the mean contact normal of the body's contacts.
+  // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
+  int ncon = w.istate[IS_NCON];
+  for (int a = 0; a < M.nadh; a++) {
+    int ai = M.adh_act[a];
+    int id = M.act_trnid[ai];
+    real force = w.act_force[ai];
+    bool mine = false; int b1 = 0, b2 = 0;
+    if (lane < ncon) {
+      int p = w.con_pair[lane];
+      b1 = M.geom_bodyid[M.pair_geom1[p]]; b2 = M.geom_bodyid[M.pair_geom2[p]];
+      mine = (b1 == id || b2 == id);
+    }
+    unsigned long long bal = __ballot(mine);
+    int cnt = __popcll(bal);
+    if (cnt == 0 || force == 0) continue;
+    real scale = -force / (real)cnt;
+    while (bal) {
+      int c = __ffsll((long long)bal) - 1;
+      bal &= bal - 1;
+      int p = w.con_pair[c];
+      int cb1 = M.geom_bodyid[M.pair_geom1[p]], cb2 = M.geom_bodyid[M.pair_geom2[p]];
+      real off[3]; sub3(off, w.con_pos + 3*c, w.com);
+      const real* nrm = w.con_frame + 9*c;
+      for (int side = 0; side < 2; side++) {
+        int body = side ? cb2 : cb1;
+        if (body <= 0) continue;
+        if (lane < M.body_chlen[body]) {
+          int dof = M.body_chain[body*FB_MAXCH + lane];
+          const real* cd = w.cdof + 6*dof;
+          real t[3]; cross3(t, cd, off);
+          real jp[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+          w.qfrc_actuator[dof] += (side ? scale : -scale)*dot3(nrm, jp);
+        }
+      }
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ QCQP for the 2 friction dims
+template <typename real>
+FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real r) {
+  real A11 = Ain[0]*dd[0]*dd[0], A22 = Ain[3]*dd[1]*dd[1], A12 = Ain[1]*dd[0]*dd[1];
+  real b1 = bin[0]*dd[0], b2 = bin[1]*dd[1];
+  real la = 0, v1 = 0, v2 = 0;
+  for (int it = 0; it < 20; it++) {
+    real det = (A11 + la)*(A22 + la) - A12*A12;
+    if (det < (real)1e-10) { res[0] = 0; res[1] = 0; return false; }
+    real detinv = (real)1/det;
+    real P11 = (A22 + la)*detinv, P22 = (A11 + la)*detinv, P12 = -A12*detinv;
+    v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
+    real val = v1*v1 + v2*v2 - r*r;
+    if (val < (real)1e-10) break;
+    real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
+    real delta = -val/deriv;
+    if (delta < (real)1e-10) break;
+    la += delta;
+  }
+  res[0] = v1*dd[0]; res[1] = v2*dd[1];
+  return la != 0;
+}
+
+// lane k holds force entries k, k+64, k+128 in registers
+template <typename real> struct FReg { real f0, f1, f2; };
+template <typename real> FBD real freg_get(const FReg<real>& f, int i, int lane) {
+  // uniform index i -> broadcast the owning lane's register
+  real v = (i < 64) ? f.f0 : (i < 128 ? f.f1 : f.f2);
+  return __shfl(v, i & 63, 64);
+}
+template <typename real> FBD void freg_set(FReg<real>& f, int i, int lane, real v) {
+  if (lane == (i & 63)) { if (i < 64) f.f0 = v; else if (i < 128) f.f1 = v; else f.f2 = v; }
+}
+template <typename real> FBD real row_dot(const real* row, int n, const FReg<real>& f, int lane) {
+  real s = 0;
+  if (lane < n) s += row[lane]*f.f0;
+  if (lane + 64 < n) s += row[lane + 64]*f.f1;
+  if (lane + 128 < n) s += row[lane + 128]*f.f2;
+  return wave_sum(s);
+}
+
+template <typename real>
+__device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, int lane) {
+  int nefc = w.istate[IS_NEFC];
+  int nv = M.nv;
+  if (nefc == 0) {
+    for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i]; w.qacc[i] = a; w.qacc_ws[i] = a; w.qfrc_constraint[i] = 0; }
+    if (lane == 0) w.istate[IS_NITER] = 0;
+    SYNC();
+    return;
+  }
+  // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
+  for (int r = lane; r < nefc; r += FB_WAVE) {
+    real vel = 0, ja = 0, jw = 0;
+    for (int side = 0; side < 2; side++) {
+      int body = side ? w.efc_bB[r] : w.efc_bA[r];
+      int len = side ? w.efc_lB[r] : w.efc_lA[r];
+      const int* chain = M.body_chain + body*FB_MAXCH;
+      for (int s = 0; s < len; s++) {
+        real j = w.efc_J[JIDX(side, s, r)];
+        int dof = chain[s];
+        vel += j*w.qvel[dof]; ja += j*w.qacc_smooth[dof]; jw += j*w.qacc_ws[dof];
+      }
+    }
+    real aref = -w.efc_B[r]*vel - w.efc_K[r]*w.efc_imp[r]*(w.efc_pos[r] - w.efc_margin[r]);
+    w.efc_vel[r] = vel; w.efc_aref[r] = aref; w.efc_b[r] = ja - aref; w.efc_jar[r] = jw - aref;
+  }
+  SYNC();
+  // ---- warm start: force implied by the previous acceleration (primal map)
+  for (int r = lane; r < nefc; r += FB_WAVE) {
+    int type = w.efc_type[r];
+    if (type != CN_ELLIPTIC) { real jar = w.efc_jar[r]; w.efc_force[r] = jar < 0 ? -w.efc_D[r]*jar : (real)0; }
+    else {
+      int c = w.efc_id[r];
+      if (w.con_efc[c] != r) continue;        // first row of the contact handles the block
+      const real* fr = M.pair_friction + 5*w.con_pair[c];
+      real mu = w.efc_mu[r];
+      real j0 = w.efc_jar[r], j1 = w.efc_jar[r+1], j2 = w.efc_jar[r+2];
+      real U0 = j0*mu, U1 = j1*fr[0], U2 = j2*fr[1];
+      real N = U0, T = sqrt(U1*U1 + U2*U2);
+      real f0, f1, f2;
+      if (N >= mu*T || (T <= 0 && N >= 0)) { f0 = f1 = f2 = 0; }
+      else if (mu*N + T <= 0 || (T <= 0 && N < 0)) { f0 = -w.efc_D[r]*j0; f1 = -w.efc_D[r+1]*j1; f2 = -w.efc_D[r+2]*j2; }
+      else {
+        real Dm = w.efc_D[r] / fmax(FB_MINV, mu*mu*(1 + mu*mu));
+        real NT = N - mu*T;
+        f0 = -Dm*NT*mu;
+        f1 = -f0/T*U1*fr[0];
+        f2 = -f0/T*U2*fr[1];
+      }
+      w.efc_force[r] = f0; w.efc_force[r+1] = f1; w.efc_force[r+2] = f2;
+    }
+  }
+  SYNC();
+  FReg<real> f;
+  f.f0 = (lane < nefc) ? w.efc_force[lane] : (real)0;
+  f.f1 = (lane + 64 < nefc) ? w.efc_force[lane + 64] : (real)0;
+  f.f2 = (lane + 128 < nefc) ? w.efc_force[lane + 128] : (real)0;
+  {
+    // dual cost of the warm start; fall back to zero if it is worse than zero force
+    real cost = 0;
+    for (int r = 0; r < nefc; r++) {
+      real s = row_dot(w.AR + r*nefc, nefc, f, lane);
+      real fr = freg_get(f, r, lane);
+      cost += fr*((real)0.5*s + w.efc_b[r]);
+    }
+    if (cost > 0) { f.f0 = 0; f.f1 = 0; f.f2 = 0; }
+  }
+  // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
+  real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
+  int niter = 0;
+  for (int it = 0; it < M.iterations; it++) {
+    real improvement = 0;
+    for (int i = 0; i < nefc;) {
+      int type = w.efc_type[i];
+      if (type != CN_ELLIPTIC) {
+        real res = w.efc_b[i] + row_dot(w.AR + i*nefc, nefc, f, lane);
+        real a = w.AR[i*nefc + i];
+        real old = freg_get(f, i, lane);
+        real fn = old - res/a;
+        if (fn < 0) fn = 0;
+        real del = fn - old;
+        improvement -= (real)0.5*del*del*a + del*res;
+        freg_set(f, i, lane, fn);
+        i += 1;
+      } else {
+        real res[3], old[3], A[9];
+        for (int j = 0; j < 3; j++) {
+          res[j] = w.efc_b[i+j] + row_dot(w.AR + (i+j)*nefc, nefc, f, lane);
+          old[j] = freg_get(f, i+j, lane);
+          for (int k = 0; k < 3; k++) A[3*j+k] = w.AR[(i+j)*nefc + i + k];
+        }
+        const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[i]];
+        real bc[3], fo[3] = {old[0], old[1], old[2]};
+        for (int j = 0; j < 3; j++) bc[j] = res[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
+        real v[3];
+        if (fo[0] < FB_MINV) { v[0] = 1; v[1] = 0; v[2] = 0; } else { v[0] = old[0]; v[1] = old[1]; v[2] = old[2]; }
+        real Av[3] = {A[0]*v[0] + A[1]*v[1] + A[2]*v[2], A[3]*v[0] + A[4]*v[1] + A[5]*v[2], A[6]*v[0] + A[7]*v[1] + A[8]*v[2]};
+        real denom = v[0]*Av[0] + v[1]*Av[1] + v[2]*Av[2];
+        if (denom >= FB_MINV) {
+          real x = -(v[0]*res[0] + v[1]*res[1] + v[2]*res[2])/denom;
+          if (fo[0] + x*v[0] < 0) x = -fo[0]/v[0];
+          for (int k = 0; k < 3; k++) fo[k] += x*v[k];
+        }
+        if (fo[0] < FB_MINV) { fo[0] = 0; fo[1] = 0; fo[2] = 0; }
+        else {
+          real Ac[4] = {A[4], A[5], A[7], A[8]};
+          real bf[2] = {bc[1] + A[3]*fo[0], bc[2] + A[6]*fo[0]};
+          real fq[2];
+          bool active = qcqp2(fq, Ac, bf, fr, fo[0]);
+          if (active) {
+            real s = sqrt((fq[0]/fr[0])*(fq[0]/fr[0]) + (fq[1]/fr[1])*(fq[1]/fr[1]));
+            if (s > FB_MINV) { fq[0] *= fo[0]/s; fq[1] *= fo[0]/s; }
+          }
+          fo[1] = fq[0]; fo[2] = fq[1];
+        }
+        real del[3] = {fo[0] - old[0], fo[1] - old[1], fo[2] - old[2]};
+        real q = 0, l = 0;
+        for (int j = 0; j < 3; j++) { l += del[j]*res[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
+        improvement -= (real)0.5*q + l;
+        freg_set(f, i, lane, fo[0]); freg_set(f, i+1, lane, fo[1]); freg_set(f, i+2, lane, fo[2]);
+        i += 3;
+      }
+    }
+    niter = it + 1;
+    if (improvement*scale < M.tolerance) break;
+  }
+  // ---- noslip: friction dims only, regularisation removed
+  int ncon = w.istate[IS_NCON];
+  for (int it = 0; it < M.noslip_iterations; it++) {
+    real improvement = 0;
+    for (int c = 0; c < ncon; c++) {
+      int i = w.con_efc[c];
+      if (i < 0 || w.con_dim[c] == 1) continue;
+      const real* fr = M.pair_friction + 5*w.con_pair[c];
+      real res[2], old[2];
+      real fnrm = freg_get(f, i, lane);
+      for (int j = 0; j < 2; j++) {
+        old[j] = freg_get(f, i+1+j, lane);
+        res[j] = w.efc_b[i+1+j] + row_dot(w.AR + (i+1+j)*nefc, nefc, f, lane) - w.efc_R[i+1+j]*old[j];
+      }
+      real Ac[4] = {w.AR[(i+1)*nefc + i+1] - w.efc_R[i+1], w.AR[(i+1)*nefc + i+2],
+                    w.AR[(i+2)*nefc + i+1], w.AR[(i+2)*nefc + i+2] - w.efc_R[i+2]};
+      real bc[2] = {res[0] - (Ac[0]*old[0] + Ac[1]*old[1]), res[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
+      real fq[2] = {0, 0};
+      if (fnrm >= FB_MINV) {
+        bool active = qcqp2(fq, Ac, bc, fr, fnrm);
+        if (active) {
+          real s = sqrt((fq[0]/fr[0])*(fq[0]/fr[0]) + (fq[1]/fr[1])*(fq[1]/fr[1]));
+          if (s > FB_MINV) { fq[0] *= fnrm/s; fq[1] *= fnrm/s; }
+        }
+      }
+      real del[2] = {fq[0] - old[0], fq[1] - old[1]};
+      improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*res[0] + del[1]*res[1];
+      freg_set(f, i+1, lane, fq[0]); freg_set(f, i+2, lane, fq[1]);
+    }
+    if (improvement*scale < M.noslip_tolerance) break;
+  }
+  if (lane < nefc) w.efc_force[lane] = f.f0;
+  if (lane + 64 < nefc) w.efc_force[lane + 64] = f.f1;
+  if (lane + 128 < nefc) w.efc_force[lane + 128] = f.f2;
+  for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
+  if (lane == 0) w.istate[IS_NITER] = niter;
+  SYNC();
+  // ---- qfrc_constraint = J^T f : lane == chain slot, a dof is owned by the lane of its depth
+  if (lane < FB_MAXCH) {
+    for (int r = 0; r < nefc; r++) {
+      real fr = w.efc_force[r];
+      if (fr == 0) continue;
+      for (int side = 0; side < 2; side++) {
+        int len = side ? w.efc_lB[r] : w.efc_lA[r];
+        if (lane < len) {
+          int body = side ? w.efc_bB[r] : w.efc_bA[r];
+          int dof = M.body_chain[body*FB_MAXCH + lane];
+          w.qfrc_constraint[dof] += w.efc_J[JIDX(side, lane, r)]*fr;
+        }
+      }
+    }
+  }
+  SYNC();
+  for (int i = lane; i < nv; i += FB_WAVE) w.tmpv[i] = w.qfrc_constraint[i];
+  SYNC();
+  d_solve(M, w.qLD, w.qLDinv, w.tmpv, lane);
+  for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.tmpv[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
+  SYNC();
+}

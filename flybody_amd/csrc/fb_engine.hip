@@ -1,0 +1,532 @@
+// libflybody_hip.so -- host side of the batched fly-physics engine and its C-ABI
+// (include/flybody_engine.h).  One HIP workgroup of 64 threads (one CDNA4 wavefront) owns one
+// environment; a single kernel launch advances every environment by one control step
+// (nsubstep physics steps + observation/reward/termination epilogue).
+#ifdef FB_EMULATE
+#include "emu/hip_emu.hpp"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/flybody_engine.h"
+#include "fb_step.hpp"
+
+static thread_local std::string g_err;
+static int fail(const std::string& s) { g_err = s; return -1; }
+extern "C" const char* fb_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------ blob
+struct BlobEntry { char name[40]; uint32_t dtype, ndim, shape[4]; uint64_t offset, nbytes; };
+
+struct fb_model {
+  std::vector<char> blob;
+  std::map<std::string, const BlobEntry*> idx;
+  // host-side derived tables
+  int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
+  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, tri_a, tri_e, adh_act;
+  std::vector<double> body_box;
+  double totalmass;
+  const double* d(const char* n, size_t* cnt = nullptr) const {
+    auto it = idx.find(n);
+    if (it == idx.end() || it->second->dtype != 0) { fprintf(stderr, "flybody_engine: missing f64 array %s\n", n); abort(); }
+    if (cnt) *cnt = it->second->nbytes/8;
+    return (const double*)(blob.data() + it->second->offset);
+  }
+  const int* i(const char* n, size_t* cnt = nullptr) const {
+    auto it = idx.find(n);
+    if (it == idx.end() || it->second->dtype != 1) { fprintf(stderr, "flybody_engine: missing i32 array %s\n", n); abort(); }
+    if (cnt) *cnt = it->second->nbytes/4;
+    return (const int*)(blob.data() + it->second->offset);
+  }
+};
+
+extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
+  if (!blob || n < 8 || memcmp(blob, "FBM1", 4) != 0) return fail("fb_model_load: bad blob magic");
+  fb_model* m = new fb_model();
+  m->blob.assign((const char*)blob, (const char*)blob + n);
+  uint32_t narr; memcpy(&narr, m->blob.data() + 4, 4);
+  const BlobEntry* e = (const BlobEntry*)(m->blob.data() + 8);
+  for (uint32_t k = 0; k < narr; k++) m->idx[std::string(e[k].name)] = e + k;
+  size_t c;
+  m->d("qpos0", &c); m->nq = (int)c;
+  m->i("dof_bodyid", &c); m->nv = (int)c;
+  m->i("body_parent", &c); m->nbody = (int)c;
+  m->i("jnt_type", &c); m->njnt = (int)c;
+  m->i("geom_type", &c); m->ngeom = (int)c;
+  m->i("site_bodyid", &c); m->nsite = (int)c;
+  m->i("actuator_trntype", &c); m->nu = (int)c;
+  m->i("tendon_adr", &c); m->ntendon = (int)c;
+  m->i("pair_geom1", &c); m->npair = (int)c;
+  m->i("observable_joints", &c); m->nobsjnt = (int)c;
+  m->i("appendage_sites", &c); m->napp = (int)c;
+  m->i("sensor_force_sites", &c); m->nforce = (int)c;
+  m->i("sensor_touch_sites", &c); m->ntouch = (int)c;
+  m->nM = m->i("dof_Madr")[m->nv];
+  m->nsubstep = (int)floor(m->d("opt_control_timestep")[0] / m->d("opt_timestep")[0] + 0.5);
+  const int* actadr = m->i("actuator_actadr");
+  m->na = 0; for (int k = 0; k < m->nu; k++) if (actadr[k] >= 0) m->na++;
+  // ---- derived topology tables
+  int nb = m->nbody, nv = m->nv;
+  const int* parent = m->i("body_parent"); const int* dofadr = m->i("body_dofadr"); const int* dofnum = m->i("body_dofnum");
+  const int* dofpar = m->i("dof_parentid"); const int* dofbody = m->i("dof_bodyid");
+  m->body_depth.assign(nb, 0); m->body_nsub.assign(nb, 1);
+  for (int b = 1; b < nb; b++) m->body_depth[b] = m->body_depth[parent[b]] + 1;
+  for (int b = nb - 1; b > 0; b--) m->body_nsub[parent[b]] += m->body_nsub[b];
+  for (int b = 1; b < nb; b++) {
+    if (m->body_depth[b] > FB_MAXDEPTH) { delete m; return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
+    // DFS contiguity: every body in (b, b+nsub) must descend from b
+    for (int d = b + 1; d < b + m->body_nsub[b]; d++) {
+      int a = d; while (a > b) a = parent[a];
+      if (a != b) { delete m; return fail("fb_model_load: bodies are not in DFS order"); }
+    }
+    if (parent[b] == 0 && b != 1) { delete m; return fail("fb_model_load: more than one kinematic tree"); }
+  }
+  m->body_path.assign((size_t)nb*FB_MAXDEPTH, 0);
+  for (int b = 1; b < nb; b++) { int a = b; for (int d = m->body_depth[b] - 1; d >= 0; d--) { m->body_path[(size_t)b*FB_MAXDEPTH + d] = a; a = parent[a]; } }
+  m->dof_depth.assign(nv, 0);
+  for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { n_++; a = dofpar[a]; } m->dof_depth[k] = n_; }
+  m->body_chlen.assign(nb, 0); m->body_chain.assign((size_t)nb*FB_MAXCH, 0);
+  for (int b = 1; b < nb; b++) {
+    int a = b; while (a > 0 && dofnum[a] == 0) a = parent[a];
+    if (a <= 0) continue;
+    int last = dofadr[a] + dofnum[a] - 1;
+    int len = m->dof_depth[last] + 1;
+    if (len > FB_MAXCH) { delete m; return fail("fb_model_load: dof chain longer than FB_MAXCH"); }
+    m->body_chlen[b] = len;
+    for (int k = last, s = len - 1; k >= 0; k = dofpar[k], s--) m->body_chain[(size_t)b*FB_MAXCH + s] = k;
+  }
+  m->body_common.assign((size_t)nb*nb, 0);
+  for (int a = 0; a < nb; a++) for (int b = 0; b < nb; b++) {
+    int n_ = 0, la = m->body_chlen[a], lb = m->body_chlen[b];
+    while (n_ < la && n_ < lb && m->body_chain[(size_t)a*FB_MAXCH + n_] == m->body_chain[(size_t)b*FB_MAXCH + n_]) n_++;
+    m->body_common[(size_t)a*nb + b] = n_;
+  }
+  for (int e_ = 0; e_ < FB_MAXCH + 1; e_++) for (int a = 0; a <= e_; a++) { m->tri_a.push_back(a); m->tri_e.push_back(e_); }
+  const int* trn = m->i("actuator_trntype");
+  for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
+  const double* mass = m->d("body_mass"); const double* inert = m->d("body_inertia");
+  m->body_box.assign((size_t)nb*3, 0); m->totalmass = 0;
+  for (int b = 1; b < nb; b++) {
+    m->totalmass += mass[b];
+    if (mass[b] < 1e-15) continue;
+    const double* I = inert + 3*b;
+    m->body_box[3*b+0] = sqrt(fmax(1e-15, I[1] + I[2] - I[0]) / mass[b] * 6.0);
+    m->body_box[3*b+1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass[b] * 6.0);
+    m->body_box[3*b+2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass[b] * 6.0);
+  }
+  (void)dofbody;
+  *out = m;
+  return 0;
+}
+
+extern "C" void fb_model_destroy(fb_model* m) { delete m; }
+
+extern "C" int fb_model_dim(const fb_model* m, const char* name) {
+#define X(f) if (!strcmp(name, #f)) return m->f
+  X(nq); X(nv); X(nbody); X(njnt); X(ngeom); X(nsite); X(nu); X(na); X(ntendon); X(npair); X(nM); X(nsubstep);
+  X(nobsjnt); X(napp); X(nforce); X(ntouch);
+#undef X
+  if (!strcmp(name, "nobs_base")) return 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + m->ntouch + 3 + 3;
+  return -1;
+}
+
+// ------------------------------------------------------------------ kernels
+template <typename real>
+struct Batch {
+  real* rarena; int* iarena; WSOff off;
+  float *obs, *reward, *discount; int* step_type;
+  int n_env, nobs;
+};
+
+enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
+
+template <typename real>
+__global__ void __launch_bounds__(FB_WAVE) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub) {
+  int slot = blockIdx.x;
+  int env = env_ids ? env_ids[slot] : slot;
+  int lane = threadIdx.x;
+  WS<real> w;
+  ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
+  float* obs = B.obs + (size_t)env*B.nobs;
+  if (mode == MODE_STEP) d_env_step(M, w, action + (size_t)env*M.nu, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  else if (mode == MODE_RESET) d_env_reset(M, w, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  else if (mode == MODE_SUBSTEP) { for (int s = 0; s < nsub; s++) d_substep(M, w, lane); }
+  else { d_step1(M, w, lane); d_step2(M, w, lane, true); }
+}
+
+// ------------------------------------------------------------------ batch
+struct fb_batch {
+  const fb_model* m;
+  int n_env, device, precision, nobs;
+  WSOff off;
+  void* rarena = nullptr; int* iarena = nullptr;
+  float *obs = nullptr, *reward = nullptr, *discount = nullptr; int* step_type = nullptr;
+  int* d_ids = nullptr;
+  std::vector<void*> allocs;          // model tables on the device
+  DevModel<double> M64; DevModel<float> M32;
+  void *ref_qpos = nullptr, *ref_qvel = nullptr;
+  bool have_ref = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; int timed_launches = 0; bool timing = false;
+};
+
+template <typename real, typename T>
+static int upload(fb_batch* b, const T* src, size_t n, const real** dst) {
+  std::vector<real> tmp(n ? n : 1);
+  for (size_t k = 0; k < n; k++) tmp[k] = (real)src[k];
+  void* p;
+  HIPCHK(hipMalloc(&p, tmp.size()*sizeof(real)));
+  HIPCHK(hipMemcpy(p, tmp.data(), tmp.size()*sizeof(real), hipMemcpyHostToDevice));
+  b->allocs.push_back(p);
+  *dst = (const real*)p;
+  return 0;
+}
+static int upload_i(fb_batch* b, const int* src, size_t n, const int** dst) {
+  void* p;
+  HIPCHK(hipMalloc(&p, (n ? n : 1)*sizeof(int)));
+  if (n) HIPCHK(hipMemcpy(p, src, n*sizeof(int), hipMemcpyHostToDevice));
+  b->allocs.push_back(p);
+  *dst = (const int*)p;
+  return 0;
+}
+
+template <typename real>
+static int build_devmodel(fb_batch* b, DevModel<real>& M) {
+  const fb_model* m = b->m;
+  memset(&M, 0, sizeof(M));
+  M.nq = m->nq; M.nv = m->nv; M.nbody = m->nbody; M.njnt = m->njnt; M.ngeom = m->ngeom; M.nsite = m->nsite;
+  M.nu = m->nu; M.na = m->na; M.ntendon = m->ntendon; M.npair = m->npair; M.nM = m->nM; M.nsubstep = m->nsubstep;
+  M.nobsjnt = m->nobsjnt; M.napp = m->napp; M.nforce = m->nforce; M.ntouch = m->ntouch;
+  M.site_thorax = m->i("sensor_site_thorax")[0]; M.nadh = (int)m->adh_act.size();
+  M.iterations = m->i("opt_iterations")[0]; M.noslip_iterations = m->i("opt_noslip_iterations")[0];
+  M.timestep = (real)m->d("opt_timestep")[0]; M.control_timestep = (real)m->d("opt_control_timestep")[0];
+  for (int k = 0; k < 3; k++) M.grav[k] = (real)m->d("opt_gravity")[k];
+  M.density = (real)m->d("opt_density")[0]; M.viscosity = (real)m->d("opt_viscosity")[0];
+  M.impratio = (real)m->d("opt_impratio")[0]; M.tolerance = (real)m->d("opt_tolerance")[0];
+  M.noslip_tolerance = (real)m->d("opt_noslip_tolerance")[0]; M.meaninertia = (real)m->d("stat_meaninertia")[0];
+  M.totalmass = (real)m->totalmass;
+  size_t c;
+#define UI(field, name) { const int* s_ = m->i(name, &c); if (upload_i(b, s_, c, &M.field)) return -1; }
+#define UV(field, vec) { if (upload_i(b, m->vec.data(), m->vec.size(), &M.field)) return -1; }
+#define UD(field, name) { const double* s_ = m->d(name, &c); if (upload<real>(b, s_, c, &M.field)) return -1; }
+  UI(body_parent, "body_parent") UI(body_jntadr, "body_jntadr") UI(body_jntnum, "body_jntnum") UI(body_dofadr, "body_dofadr") UI(body_dofnum, "body_dofnum")
+  UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
+  UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
+  UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
+  UV(tri_a, tri_a) UV(tri_e, tri_e)
+  UI(geom_type, "geom_type") UI(geom_bodyid, "geom_bodyid") UI(site_bodyid, "site_bodyid") UI(site_type, "site_type")
+  UI(tendon_adr, "tendon_adr") UI(tendon_num, "tendon_num") UI(wrap_dofid, "wrap_dofid")
+  UI(act_trntype, "actuator_trntype") UI(act_trnid, "actuator_trnid") UI(act_dyntype, "actuator_dyntype") UI(act_biastype, "actuator_biastype")
+  UI(act_ctrllimited, "actuator_ctrllimited") UI(act_forcelimited, "actuator_forcelimited") UI(act_actadr, "actuator_actadr")
+  UV(adh_act, adh_act) UI(action_to_ctrl, "action_to_ctrl")
+  UI(pair_geom1, "pair_geom1") UI(pair_geom2, "pair_geom2") UI(pair_condim, "pair_condim")
+  UI(obs_jnt, "observable_joints") UI(app_sites, "appendage_sites") UI(force_sites, "sensor_force_sites") UI(touch_sites, "sensor_touch_sites") UI(wing_jnt, "wing_jnt")
+  UD(body_pos, "body_pos") UD(body_quat, "body_quat") UD(body_ipos, "body_ipos") UD(body_iquat, "body_iquat") UD(body_mass, "body_mass")
+  UD(body_inertia, "body_inertia") UD(body_invweight0, "body_invweight0")
+  if (upload<real>(b, m->body_box.data(), m->body_box.size(), &M.body_box)) return -1;
+  UD(jnt_pos, "jnt_pos") UD(jnt_axis, "jnt_axis") UD(jnt_stiffness, "jnt_stiffness") UD(jnt_range, "jnt_range") UD(jnt_solref, "jnt_solref")
+  UD(jnt_solimp, "jnt_solimp") UD(jnt_margin, "jnt_margin") UD(qpos0, "qpos0") UD(qpos_spring, "qpos_spring")
+  UD(dof_armature, "dof_armature") UD(dof_damping, "dof_damping") UD(dof_invweight0, "dof_invweight0")
+  UD(geom_pos, "geom_pos") UD(geom_quat, "geom_quat") UD(geom_size, "geom_size") UD(geom_rbound, "geom_rbound") UD(geom_fluid, "geom_fluid")
+  UD(site_pos, "site_pos") UD(site_quat, "site_quat") UD(site_size, "site_size") UD(wrap_coef, "wrap_coef")
+  UD(act_dynprm, "actuator_dynprm") UD(act_gainprm, "actuator_gainprm") UD(act_biasprm, "actuator_biasprm") UD(act_ctrlrange, "actuator_ctrlrange") UD(act_forcerange, "actuator_forcerange")
+  UD(pair_friction, "pair_friction") UD(pair_solref, "pair_solref") UD(pair_solimp, "pair_solimp") UD(pair_margin, "pair_margin") UD(pair_gap, "pair_gap")
+#undef UI
+#undef UV
+#undef UD
+  return 0;
+}
+
+template <typename real>
+static void compute_offsets(const DevModel<real>& M, WSOff& o) {
+  uint32_t r = 0, i = 0;
+  auto al = [](uint32_t v) { return (v + 3u) & ~3u; };   // keep every array 16/32-byte aligned
+#define X(name, n) o.name = r; r = al(r + (uint32_t)(n));
+  FB_WS_REAL(X)
+#undef X
+#define X(name, n) o.name = i; i = al(i + (uint32_t)(n));
+  FB_WS_INT(X)
+#undef X
+  o.nreal = (r + 15u) & ~15u; o.nint = (i + 15u) & ~15u;
+}
+
+extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int precision, fb_batch** out) {
+  if (!m || n_env <= 0) return fail("fb_batch_create: bad arguments");
+  if (precision != 32 && precision != 64) return fail("fb_batch_create: precision must be 32 or 64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("fb_batch_create: no HIP device available (the engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail("fb_batch_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+  fb_batch* b = new fb_batch();
+  b->m = m; b->n_env = n_env; b->device = device; b->precision = precision;
+  if (precision == 64) { if (build_devmodel<double>(b, b->M64)) return -1; compute_offsets(b->M64, b->off); }
+  else { if (build_devmodel<float>(b, b->M32)) return -1; compute_offsets(b->M32, b->off); }
+  size_t rs = precision == 64 ? 8 : 4;
+  HIPCHK(hipMalloc(&b->rarena, (size_t)n_env*b->off.nreal*rs));
+  HIPCHK(hipMemset(b->rarena, 0, (size_t)n_env*b->off.nreal*rs));
+  HIPCHK(hipMalloc((void**)&b->iarena, (size_t)n_env*b->off.nint*sizeof(int)));
+  HIPCHK(hipMemset(b->iarena, 0, (size_t)n_env*b->off.nint*sizeof(int)));
+  HIPCHK(hipMalloc((void**)&b->reward, n_env*sizeof(float)));
+  HIPCHK(hipMalloc((void**)&b->discount, n_env*sizeof(float)));
+  HIPCHK(hipMalloc((void**)&b->step_type, n_env*sizeof(int)));
+  HIPCHK(hipMalloc((void**)&b->d_ids, n_env*sizeof(int)));
+  HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));
+  HIPCHK(hipMemset(b->discount, 0, n_env*sizeof(float)));
+  HIPCHK(hipMemset(b->step_type, 0, n_env*sizeof(int)));
+  // initial state: qpos0 everywhere (fb_batch_reset overrides it once a reference is set)
+  {
+    std::vector<char> rows((size_t)n_env*m->nq*rs);
+    const double* q0 = m->d("qpos0");
+    for (int e = 0; e < n_env; e++)
+      for (int k = 0; k < m->nq; k++) {
+        if (rs == 8) ((double*)rows.data())[(size_t)e*m->nq + k] = q0[k]; else ((float*)rows.data())[(size_t)e*m->nq + k] = (float)q0[k];
+      }
+    HIPCHK(hipMemcpy2D((char*)b->rarena + (size_t)b->off.qpos*rs, (size_t)b->off.nreal*rs, rows.data(), (size_t)m->nq*rs, (size_t)m->nq*rs, n_env, hipMemcpyHostToDevice));
+  }
+  b->nobs = 0;
+  *out = b;
+  return 0;
+}
+
+extern "C" void fb_batch_destroy(fb_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* p : b->allocs) (void)hipFree(p);
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->ref_qpos, b->ref_qvel};
+  for (void* p : frees_) (void)hipFree(p);
+
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const double* ref_qvel, int T,
+                                      int future_steps, double terminal_com_dist, double time_limit) {
+  if (!b || !ref_qpos || !ref_qvel || T < 2) return fail("fb_batch_set_reference: bad arguments");
+  if (T - future_steps - 1 < 1) return fail("fb_batch_set_reference: trajectory shorter than future_steps + 2");
+  HIPCHK(hipSetDevice(b->device));
+  (void)hipFree(b->ref_qpos); (void)hipFree(b->ref_qvel); (void)hipFree(b->obs);
+  const fb_model* m = b->m;
+  int nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
+  int max_steps = (int)floor(time_limit / m->d("opt_control_timestep")[0] + 0.5) + 1;
+  int snippet = T - future_steps - 1;
+  int episode_steps = max_steps < snippet ? max_steps : snippet;
+  size_t rs = b->precision == 64 ? 8 : 4;
+  HIPCHK(hipMalloc(&b->ref_qpos, (size_t)T*7*rs));
+  HIPCHK(hipMalloc(&b->ref_qvel, (size_t)T*6*rs));
+  if (rs == 8) {
+    HIPCHK(hipMemcpy(b->ref_qpos, ref_qpos, (size_t)T*7*8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->ref_qvel, ref_qvel, (size_t)T*6*8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> a((size_t)T*7), v((size_t)T*6);
+    for (size_t k = 0; k < a.size(); k++) a[k] = (float)ref_qpos[k];
+    for (size_t k = 0; k < v.size(); k++) v[k] = (float)ref_qvel[k];
+    HIPCHK(hipMemcpy(b->ref_qpos, a.data(), a.size()*4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->ref_qvel, v.data(), v.size()*4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
+  HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
+  b->nobs = nobs;
+#define SETREF(M) M.ref_qpos = (decltype(M.ref_qpos))b->ref_qpos; M.ref_qvel = (decltype(M.ref_qvel))b->ref_qvel; M.T = T; \
+  M.future_steps = future_steps; M.episode_steps = episode_steps; M.nobs = nobs; \
+  M.terminal_com_dist = (decltype(M.terminal_com_dist))terminal_com_dist; M.time_limit = (decltype(M.time_limit))time_limit;
+  SETREF(b->M64) SETREF(b->M32)
+#undef SETREF
+  b->have_ref = true;
+  return 0;
+}
+
+static int launch(fb_batch* b, int mode, const float* action, const int* ids, int n, int nsub, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (b->precision == 64) {
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    hipLaunchKernelGGL((k_fly<double>), dim3(n), dim3(FB_WAVE), 0, st, b->M64, B, action, ids, mode, nsub);
+  } else {
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    hipLaunchKernelGGL((k_fly<float>), dim3(n), dim3(FB_WAVE), 0, st, b->M32, B, action, ids, mode, nsub);
+  }
+  HIPCHK(hipGetLastError());
+  if (b->timing) b->timed_launches++;
+  return 0;
+}
+
+extern "C" int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* stream) {
+  if (!b) return fail("fb_batch_reset: null batch");
+  if (!b->have_ref) return fail("fb_batch_reset: call fb_batch_set_reference first");
+  HIPCHK(hipSetDevice(b->device));
+  if (env_ids) {
+    if (n <= 0 || n > b->n_env) return fail("fb_batch_reset: bad n");
+    for (int k = 0; k < n; k++) if (env_ids[k] < 0 || env_ids[k] >= b->n_env) return fail("fb_batch_reset: env id out of range");
+    HIPCHK(hipMemcpyAsync(b->d_ids, env_ids, n*sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+    return launch(b, MODE_RESET, nullptr, b->d_ids, n, 0, stream);
+  }
+  return launch(b, MODE_RESET, nullptr, nullptr, b->n_env, 0, stream);
+}
+
+extern "C" int fb_batch_step(fb_batch* b, const float* action, void* stream) {
+  if (!b || !action) return fail("fb_batch_step: null argument");
+  if (!b->have_ref) return fail("fb_batch_step: call fb_batch_set_reference first");
+  HIPCHK(hipSetDevice(b->device));
+  return launch(b, MODE_STEP, action, nullptr, b->n_env, 0, stream);
+}
+
+extern "C" int fb_batch_substep(fb_batch* b, int nsub, void* stream) {
+  if (!b || nsub < 0) return fail("fb_batch_substep: bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  return launch(b, MODE_SUBSTEP, nullptr, nullptr, b->n_env, nsub, stream);
+}
+
+extern "C" int fb_batch_forward(fb_batch* b, void* stream) {
+  if (!b) return fail("fb_batch_forward: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  return launch(b, MODE_FORWARD, nullptr, nullptr, b->n_env, 0, stream);
+}
+
+extern "C" int fb_batch_synchronize(fb_batch* b, void* stream) {
+  if (!b) return fail("fb_batch_synchronize: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------ field access
+struct FieldDesc { int kind; /*0 real arena, 1 int arena, 2 f32 array, 3 i32 array*/ size_t off, width; void* base; };
+
+static int field_desc(fb_batch* b, int field, FieldDesc* f) {
+  const fb_model* m = b->m; const WSOff& o = b->off;
+  switch (field) {
+    case FB_QPOS: *f = {0, o.qpos, (size_t)m->nq, nullptr}; break;
+    case FB_QVEL: *f = {0, o.qvel, (size_t)m->nv, nullptr}; break;
+    case FB_ACT: *f = {0, o.act, (size_t)m->na, nullptr}; break;
+    case FB_CTRL: *f = {0, o.ctrl, (size_t)m->nu, nullptr}; break;
+    case FB_QACC: *f = {0, o.qacc, (size_t)m->nv, nullptr}; break;
+    case FB_XPOS: *f = {0, o.xpos, (size_t)3*m->nbody, nullptr}; break;
+    case FB_XQUAT: *f = {0, o.xquat, (size_t)4*m->nbody, nullptr}; break;
+    case FB_SENSORDATA: *f = {0, o.sens, FB_NSENS, nullptr}; break;
+    case FB_QFRC_BIAS: *f = {0, o.qfrc_bias, (size_t)m->nv, nullptr}; break;
+    case FB_QFRC_PASSIVE: *f = {0, o.qfrc_passive, (size_t)m->nv, nullptr}; break;
+    case FB_QACC_SMOOTH: *f = {0, o.qacc_smooth, (size_t)m->nv, nullptr}; break;
+    case FB_QM: *f = {0, o.qM, (size_t)m->nM, nullptr}; break;
+    case FB_EFC_FORCE: *f = {0, o.efc_force, FB_MAXEFC_, nullptr}; break;
+    case FB_QFRC_ACTUATOR: *f = {0, o.qfrc_actuator, (size_t)m->nv, nullptr}; break;
+    case FB_QFRC_CONSTRAINT: *f = {0, o.qfrc_constraint, (size_t)m->nv, nullptr}; break;
+    case FB_SUBTREE_COM: *f = {0, o.com, 3, nullptr}; break;
+    case FB_NCON: *f = {1, o.istate + IS_NCON, 1, nullptr}; break;
+    case FB_NEFC: *f = {1, o.istate + IS_NEFC, 1, nullptr}; break;
+    case FB_SOLVER_NITER: *f = {1, o.istate + IS_NITER, 1, nullptr}; break;
+    case FB_STEP_COUNT: *f = {1, o.istate + IS_STEP, 1, nullptr}; break;
+    case FB_OBS: *f = {2, 0, (size_t)b->nobs, b->obs}; break;
+    case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
+    case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;
+    case FB_STEP_TYPE: *f = {3, 0, 1, b->step_type}; break;
+    default: return fail("unknown field");
+  }
+  return 0;
+}
+
+extern "C" int fb_batch_get(fb_batch* b, int field, void* dst, size_t bytes) {
+  if (!b || !dst) return fail("fb_batch_get: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  int n = b->n_env;
+  if (field == FB_CONTACT) {
+    // [n_env][64][8]: dist, pos3, normal3, pair id  (FP64)
+    if (bytes != (size_t)n*FB_MAXCON_*8*sizeof(double)) return fail("fb_batch_get: size mismatch");
+    size_t rs = b->precision == 64 ? 8 : 4;
+    std::vector<char> rr((size_t)n*b->off.nreal*rs);
+    std::vector<int> ii((size_t)n*b->off.nint);
+    HIPCHK(hipMemcpy(rr.data(), b->rarena, rr.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ii.data(), b->iarena, ii.size()*sizeof(int), hipMemcpyDeviceToHost));
+    double* out = (double*)dst;
+    auto rd = [&](size_t env, size_t off) { return rs == 8 ? ((double*)rr.data())[env*b->off.nreal + off] : (double)((float*)rr.data())[env*b->off.nreal + off]; };
+    for (int e = 0; e < n; e++) for (int c = 0; c < FB_MAXCON_; c++) {
+      double* o = out + ((size_t)e*FB_MAXCON_ + c)*8;
+      o[0] = rd(e, b->off.con_dist + c);
+      for (int k = 0; k < 3; k++) { o[1+k] = rd(e, b->off.con_pos + 3*c + k); o[4+k] = rd(e, b->off.con_frame + 9*c + k); }
+      o[7] = ii[(size_t)e*b->off.nint + b->off.con_pair + c];
+    }
+    return 0;
+  }
+  FieldDesc f;
+  if (field_desc(b, field, &f)) return -1;
+  if (f.kind == 0) {
+    if (bytes != (size_t)n*f.width*sizeof(double)) return fail("fb_batch_get: size mismatch (physics fields are returned as FP64)");
+    size_t rs = b->precision == 64 ? 8 : 4;
+    std::vector<char> tmp((size_t)n*f.width*rs);
+    HIPCHK(hipMemcpy2D(tmp.data(), f.width*rs, (char*)b->rarena + f.off*rs, (size_t)b->off.nreal*rs, f.width*rs, n, hipMemcpyDeviceToHost));
+    double* out = (double*)dst;
+    if (rs == 8) memcpy(out, tmp.data(), tmp.size());
+    else for (size_t k = 0; k < (size_t)n*f.width; k++) out[k] = ((float*)tmp.data())[k];
+  } else if (f.kind == 1) {
+    if (bytes != (size_t)n*f.width*sizeof(int)) return fail("fb_batch_get: size mismatch");
+    HIPCHK(hipMemcpy2D(dst, f.width*4, (char*)b->iarena + f.off*4, (size_t)b->off.nint*4, f.width*4, n, hipMemcpyDeviceToHost));
+  } else {
+    if (!f.base) return fail("fb_batch_get: field not allocated yet (set a reference first)");
+    if (bytes != (size_t)n*f.width*4) return fail("fb_batch_get: size mismatch");
+    HIPCHK(hipMemcpy(dst, f.base, bytes, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+extern "C" int fb_batch_set(fb_batch* b, int field, const void* src, size_t bytes) {
+  if (!b || !src) return fail("fb_batch_set: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  FieldDesc f;
+  if (field_desc(b, field, &f)) return -1;
+  int n = b->n_env;
+  if (f.kind == 0) {
+    if (bytes != (size_t)n*f.width*sizeof(double)) return fail("fb_batch_set: size mismatch (physics fields are passed as FP64)");
+    size_t rs = b->precision == 64 ? 8 : 4;
+    std::vector<char> tmp((size_t)n*f.width*rs);
+    const double* in = (const double*)src;
+    if (rs == 8) memcpy(tmp.data(), in, tmp.size());
+    else for (size_t k = 0; k < (size_t)n*f.width; k++) ((float*)tmp.data())[k] = (float)in[k];
+    HIPCHK(hipMemcpy2D((char*)b->rarena + f.off*rs, (size_t)b->off.nreal*rs, tmp.data(), f.width*rs, f.width*rs, n, hipMemcpyHostToDevice));
+  } else if (f.kind == 1) {
+    if (bytes != (size_t)n*f.width*sizeof(int)) return fail("fb_batch_set: size mismatch");
+    HIPCHK(hipMemcpy2D((char*)b->iarena + f.off*4, (size_t)b->off.nint*4, src, f.width*4, f.width*4, n, hipMemcpyHostToDevice));
+  } else return fail("fb_batch_set: field is read-only");
+  return 0;
+}
+
+extern "C" void* fb_batch_device_ptr(fb_batch* b, int field) {
+  if (!b) return nullptr;
+  switch (field) {
+    case FB_OBS: return b->obs;
+    case FB_REWARD: return b->reward;
+    case FB_DISCOUNT: return b->discount;
+    case FB_STEP_TYPE: return b->step_type;
+    default: return nullptr;
+  }
+}
+
+extern "C" int fb_batch_timing_begin(fb_batch* b, void* stream) {
+  if (!b) return fail("fb_batch_timing_begin: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->ev0) { HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); }
+  b->timed_launches = 0; b->timing = true;
+  HIPCHK(hipEventRecord(b->ev0, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launches) {
+  if (!b || !b->timing) return fail("fb_batch_timing_end: timing not started");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipEventRecord(b->ev1, (hipStream_t)stream));
+  HIPCHK(hipEventSynchronize(b->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+  if (total_ms) *total_ms = ms;
+  if (n_launches) *n_launches = b->timed_launches;
+  b->timing = false;
+  return 0;
+}

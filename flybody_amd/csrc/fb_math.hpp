@@ -1,0 +1,129 @@
+// Small per-lane vector / quaternion / spatial algebra for the HIP physics kernels.
+// Conventions: quaternions (w,x,y,z); 3x3 row-major; spatial vectors [rot(3); lin(3)].
+#pragma once
+#ifdef FB_EMULATE
+#include "emu/hip_emu.hpp"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#define FBD __device__ __forceinline__
+#define FB_MINV ((real)1e-15)
+
+template <typename real> FBD real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+template <typename real> FBD void cross3(real* r, const real* a, const real* b) {
+  real x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename real> FBD void copy3(real* r, const real* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+template <typename real> FBD void sub3(real* r, const real* a, const real* b) { r[0] = a[0]-b[0]; r[1] = a[1]-b[1]; r[2] = a[2]-b[2]; }
+template <typename real> FBD void add3(real* r, const real* a, const real* b) { r[0] = a[0]+b[0]; r[1] = a[1]+b[1]; r[2] = a[2]+b[2]; }
+template <typename real> FBD void scl3(real* r, const real* a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
+template <typename real> FBD void addscl3(real* r, const real* a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
+template <typename real> FBD real norm3(const real* a) { return sqrt(dot3(a, a)); }
+template <typename real> FBD real normalize3(real* a) {
+  real n = norm3(a);
+  if (n < FB_MINV) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
+  real inv = (real)1 / n;
+  a[0] *= inv; a[1] *= inv; a[2] *= inv;
+  return n;
+}
+template <typename real> FBD real dot6(const real* a, const real* b) {
+  return a[0]*b[0] + a[1]*b[1] + a[2]*b[2] + a[3]*b[3] + a[4]*b[4] + a[5]*b[5];
+}
+template <typename real> FBD void mulmat3(real* r, const real* m, const real* v) {
+  real x = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  real y = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  real z = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename real> FBD void mulmatT3(real* r, const real* m, const real* v) {
+  real x = m[0]*v[0] + m[3]*v[1] + m[6]*v[2];
+  real y = m[1]*v[0] + m[4]*v[1] + m[7]*v[2];
+  real z = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename real> FBD void mulquat(real* r, const real* a, const real* b) {
+  real w = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
+  real x = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+  real y = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1];
+  real z = a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+template <typename real> FBD void normquat(real* q) {
+  real n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  if (n < FB_MINV) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { real inv = (real)1 / n; q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv; }
+}
+template <typename real> FBD void quat2mat(real* m, const real* q) {
+  real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+  real q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3];
+  real q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02);
+  m[3] = 2*(q12 + q03); m[5] = 2*(q23 - q01);
+  m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
+}
+template <typename real> FBD void rotvecquat(real* r, const real* v, const real* q) {
+  real m[9]; quat2mat(m, q); mulmat3(r, m, v);
+}
+template <typename real> FBD void axisangle2quat(real* q, const real* axis, real ang) {
+  real s = sin((real)0.5*ang);
+  q[0] = cos((real)0.5*ang); q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+}
+template <typename real> FBD void mulinertvec(real* r, const real* i, const real* v) {
+  r[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
+  r[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
+  r[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
+  r[3] = i[8]*v[1] - i[7]*v[2] + i[9]*v[3];
+  r[4] = i[6]*v[2] - i[8]*v[0] + i[9]*v[4];
+  r[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
+}
+template <typename real> FBD void crossmotion(real* r, const real* vel, const real* v) {
+  r[0] = -vel[2]*v[1] + vel[1]*v[2];
+  r[1] =  vel[2]*v[0] - vel[0]*v[2];
+  r[2] = -vel[1]*v[0] + vel[0]*v[1];
+  r[3] = -vel[2]*v[4] + vel[1]*v[5] - vel[5]*v[1] + vel[4]*v[2];
+  r[4] =  vel[2]*v[3] - vel[0]*v[5] + vel[5]*v[0] - vel[3]*v[2];
+  r[5] = -vel[1]*v[3] + vel[0]*v[4] - vel[4]*v[0] + vel[3]*v[1];
+}
+template <typename real> FBD void crossforce(real* r, const real* vel, const real* f) {
+  r[0] = -vel[2]*f[1] + vel[1]*f[2] - vel[5]*f[4] + vel[4]*f[5];
+  r[1] =  vel[2]*f[0] - vel[0]*f[2] + vel[5]*f[3] - vel[3]*f[5];
+  r[2] = -vel[1]*f[0] + vel[0]*f[1] - vel[4]*f[3] + vel[3]*f[4];
+  r[3] = -vel[2]*f[4] + vel[1]*f[5];
+  r[4] =  vel[2]*f[3] - vel[0]*f[5];
+  r[5] = -vel[1]*f[3] + vel[0]*f[4];
+}
+template <typename real> FBD void makeframe(real* f) {
+  real* x = f; real* y = f + 3; real* z = f + 6;
+  normalize3(x);
+  if (x[1] > (real)0.5 || x[1] < (real)-0.5) { y[0] = 0; y[1] = 0; y[2] = 1; }
+  else { y[0] = 0; y[1] = 1; y[2] = 0; }
+  real d = dot3(x, y);
+  addscl3(y, x, -d);
+  normalize3(y);
+  cross3(z, x, y);
+}
+template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ---- wavefront (64-lane) collectives -------------------------------------------------
+FBD double shfl_xor_r(double v, int m) { return __shfl_xor(v, m, 64); }
+FBD float shfl_xor_r(float v, int m) { return __shfl_xor(v, m, 64); }
+template <typename real> FBD real wave_sum(real v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_r(v, m);
+  return v;
+}
+FBD int wave_sum_i(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// exclusive prefix sum of a small per-lane integer
+FBD int wave_excl_scan(int v, int lane) {
+  int s = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
+  return s - v;
+}

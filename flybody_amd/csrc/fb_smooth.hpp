@@ -1,0 +1,383 @@
+// Wavefront-cooperative smooth-dynamics stages: one environment per 64-lane wavefront.
+//
+// Parallelisation idioms used throughout (chosen for CDNA4's 64-wide waves):
+//  * "chain walk": a lane that owns a body/dof recomputes what it needs along its own
+//    root->leaf chain (<= FB_MAXDEPTH bodies / FB_MAXCH dofs) in registers instead of
+//    synchronising tree levels through memory -- redundant FLOPs are cheap, barriers are not;
+//  * "subtree pull": bodies are stored in DFS order, so a subtree is a contiguous index range and
+//    backward (leaf->root) accumulations become independent per-lane range sums;
+//  * sequential-in-dof / parallel-in-ancestor loops for the sparse L^T D L factorisation and
+//    solves (the elimination order is inherently serial along a chain).
+#pragma once
+#include "fb_types.hpp"
+#include "fb_math.hpp"
+
+#define SYNC() __syncthreads()
+
+// ------------------------------------------------------------------ kinematics (chain walk)
+template <typename real>
+__device__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+    int depth = M.body_depth[b];
+    for (int d = 0; d < depth; d++) {
+      int bb = M.body_path[b*FB_MAXDEPTH + d];
+      int ja = M.body_jntadr[bb], jn = M.body_jntnum[bb];
+      if (jn > 0 && M.jnt_type[ja] == JNT_FREE) {
+        const real* q = w.qpos + M.jnt_qposadr[ja];
+        pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
+        quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
+        normquat(quat);
+        if (bb == b) {
+          copy3(w.xanchor + 3*ja, pos);
+          real ax[3] = {0, 0, 1};
+          rotvecquat(w.xaxis + 3*ja, ax, quat);
+        }
+        ja++; jn--;
+      } else {
+        real t[3], qn[4];
+        rotvecquat(t, M.body_pos + 3*bb, quat);
+        add3(pos, pos, t);
+        mulquat(qn, quat, M.body_quat + 4*bb);
+        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+      }
+      for (int j = ja; j < ja + jn; j++) {
+        real anc[3], t[3], qloc[4], qn[4];
+        rotvecquat(t, M.jnt_pos + 3*j, quat);
+        add3(anc, t, pos);
+        if (bb == b) {
+          copy3(w.xanchor + 3*j, anc);
+          rotvecquat(w.xaxis + 3*j, M.jnt_axis + 3*j, quat);
+        }
+        int qa = M.jnt_qposadr[j];
+        axisangle2quat(qloc, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]);
+        mulquat(qn, quat, qloc);
+        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+        rotvecquat(t, M.jnt_pos + 3*j, quat);
+        sub3(pos, anc, t);
+      }
+      normquat(quat);
+    }
+    real mat[9], t[3], qi[4];
+    quat2mat(mat, quat);
+    copy3(w.xpos + 3*b, pos);
+    for (int k = 0; k < 4; k++) w.xquat[4*b + k] = quat[k];
+    for (int k = 0; k < 9; k++) w.xmat[9*b + k] = mat[k];
+    mulmat3(t, mat, M.body_ipos + 3*b);
+    add3(w.xipos + 3*b, pos, t);
+    mulquat(qi, quat, M.body_iquat + 4*b);
+    quat2mat(w.ximat + 9*b, qi);
+  }
+  SYNC();
+  // geoms and sites hang off their body frames
+  for (int g = lane; g < M.ngeom; g += FB_WAVE) {
+    int b = M.geom_bodyid[g];
+    real t[3], q[4];
+    mulmat3(t, w.xmat + 9*b, M.geom_pos + 3*g);
+    add3(w.gxpos + 3*g, w.xpos + 3*b, t);
+    mulquat(q, w.xquat + 4*b, M.geom_quat + 4*g);
+    quat2mat(w.gxmat + 9*g, q);
+  }
+  for (int s = lane; s < M.nsite; s += FB_WAVE) {
+    int b = M.site_bodyid[s];
+    real t[3], q[4];
+    mulmat3(t, w.xmat + 9*b, M.site_pos + 3*s);
+    add3(w.sxpos + 3*s, w.xpos + 3*b, t);
+    mulquat(q, w.xquat + 4*b, M.site_quat + 4*s);
+    quat2mat(w.sxmat + 9*s, q);
+  }
+  // centre of mass of the (single) kinematic tree
+  real c[3] = {0, 0, 0};
+  for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos + 3*b, M.body_mass[b]);
+  c[0] = wave_sum(c[0]); c[1] = wave_sum(c[1]); c[2] = wave_sum(c[2]);
+  if (lane == 0) { real inv = (real)1 / M.totalmass; w.com[0] = c[0]*inv; w.com[1] = c[1]*inv; w.com[2] = c[2]*inv; }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ cinert, cdof, tendons
+template <typename real>
+__device__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
+  const real com[3] = {w.com[0], w.com[1], w.com[2]};
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real* c = w.cinert + 10*b;
+    if (b == 0) { for (int k = 0; k < 10; k++) c[k] = 0; continue; }
+    const real* R = w.ximat + 9*b; const real* I = M.body_inertia + 3*b;
+    real mass = M.body_mass[b];
+    real dif[3]; sub3(dif, w.xipos + 3*b, com);
+    real t00 = 0, t11 = 0, t22 = 0, t01 = 0, t02 = 0, t12 = 0;
+    for (int k = 0; k < 3; k++) {
+      t00 += R[0+k]*I[k]*R[0+k]; t11 += R[3+k]*I[k]*R[3+k]; t22 += R[6+k]*I[k]*R[6+k];
+      t01 += R[0+k]*I[k]*R[3+k]; t02 += R[0+k]*I[k]*R[6+k]; t12 += R[3+k]*I[k]*R[6+k];
+    }
+    c[0] = t00 + mass*(dif[1]*dif[1] + dif[2]*dif[2]);
+    c[1] = t11 + mass*(dif[0]*dif[0] + dif[2]*dif[2]);
+    c[2] = t22 + mass*(dif[0]*dif[0] + dif[1]*dif[1]);
+    c[3] = t01 - mass*dif[0]*dif[1];
+    c[4] = t02 - mass*dif[0]*dif[2];
+    c[5] = t12 - mass*dif[1]*dif[2];
+    c[6] = mass*dif[0]; c[7] = mass*dif[1]; c[8] = mass*dif[2]; c[9] = mass;
+  }
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    int j = M.dof_jntid[i], b = M.dof_bodyid[i];
+    real off[3]; sub3(off, com, w.xanchor + 3*j);
+    real* c = w.cdof + 6*i;
+    if (M.jnt_type[j] == JNT_FREE) {
+      int k = i - M.jnt_dofadr[j];
+      if (k < 3) { for (int q = 0; q < 6; q++) c[q] = 0; c[3 + k] = 1; }
+      else {
+        const real* R = w.xmat + 9*b;
+        real ax[3] = {R[k-3], R[3+k-3], R[6+k-3]};
+        copy3(c, ax); cross3(c + 3, ax, off);
+      }
+    } else {
+      copy3(c, w.xaxis + 3*j); cross3(c + 3, w.xaxis + 3*j, off);
+    }
+  }
+  for (int t = lane; t < M.ntendon; t += FB_WAVE) {
+    real L = 0;
+    for (int k = M.tendon_adr[t]; k < M.tendon_adr[t] + M.tendon_num[t]; k++)
+      L += M.wrap_coef[k] * w.qpos[M.jnt_qposadr[M.dof_jntid[M.wrap_dofid[k]]]];
+    w.ten_length[t] = L;
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ composite inertia + mass matrix
+template <typename real>
+__device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
+  // subtree pull: crb[b] = sum of cinert over the DFS-contiguous subtree of b
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real acc[10];
+    for (int k = 0; k < 10; k++) acc[k] = 0;
+    int n = (b == 0) ? 0 : M.body_nsub[b];
+    for (int d = n - 1; d >= 0; d--) {
+      const real* c = w.cinert + 10*(b + d);
+      for (int k = 0; k < 10; k++) acc[k] += c[k];
+    }
+    for (int k = 0; k < 10; k++) w.crb[10*b + k] = acc[k];
+  }
+  SYNC();
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    int adr = M.dof_Madr[i];
+    real buf[6];
+    mulinertvec(buf, w.crb + 10*M.dof_bodyid[i], w.cdof + 6*i);
+    real arm = M.dof_armature[i];
+    for (int j = i; j >= 0; j = M.dof_parentid[j]) {
+      real v = dot6(w.cdof + 6*j, buf);
+      if (j == i) v += arm;
+      w.qM[adr++] = v;
+    }
+  }
+  SYNC();
+}
+
+// In-place sparse L^T D L of a mass-matrix-shaped array (dof_Madr layout).  Serial over dofs
+// (leaf -> root), parallel over the (ancestor, ancestor) update pairs of each eliminated dof.
+template <typename real>
+__device__ void d_factor(const DevModel<real>& M, real* LD, real* Dinv, int lane) {
+  for (int k = M.nv - 1; k >= 0; k--) {
+    int na = M.dof_depth[k];
+    if (na == 0) continue;
+    int Mkk = M.dof_Madr[k];
+    int b = M.dof_bodyid[k];
+    const int* chain = M.body_chain + b*FB_MAXCH;
+    int sk = na;   // slot of dof k on its chain
+    // body chains list every dof of the body; dof k sits at slot = its depth
+    real dkk = LD[Mkk];
+    int npair = na*(na + 1)/2;
+    real upd[3]; int tgt[3]; int cnt = 0;
+    for (int p = lane; p < npair; p += FB_WAVE) {
+      int a = M.tri_a[p], e = M.tri_e[p];
+      int i = chain[sk - 1 - a];
+      real tmp = LD[Mkk + 1 + a] / dkk;
+      tgt[cnt] = M.dof_Madr[i] + (e - a);
+      upd[cnt] = tmp * LD[Mkk + 1 + e];
+      cnt++;
+    }
+    SYNC();
+    for (int c = 0; c < cnt; c++) LD[tgt[c]] -= upd[c];
+    if (lane < na) LD[Mkk + 1 + lane] = LD[Mkk + 1 + lane] / dkk;
+    SYNC();
+  }
+  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / LD[M.dof_Madr[i]];
+  SYNC();
+}
+
+// x <- M^-1 x using the factorisation (x is an nv-vector in the environment workspace)
+template <typename real>
+__device__ void d_solve(const DevModel<real>& M, const real* LD, const real* Dinv, real* x, int lane) {
+  // x <- L^-T x : push each dof's value to its ancestors, leaf -> root
+  for (int i = M.nv - 1; i >= 0; i--) {
+    int na = M.dof_depth[i];
+    if (na == 0) continue;
+    if (lane < na) {
+      const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
+      int j = chain[na - 1 - lane];
+      x[j] -= LD[M.dof_Madr[i] + 1 + lane] * x[i];
+    }
+    SYNC();
+  }
+  for (int i = lane; i < M.nv; i += FB_WAVE) x[i] *= Dinv[i];
+  SYNC();
+  // x <- L^-1 x : pull from ancestors, root -> leaf
+  for (int i = 0; i < M.nv; i++) {
+    int na = M.dof_depth[i];
+    if (na == 0) continue;
+    real s = 0;
+    if (lane < na) {
+      const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
+      int j = chain[na - 1 - lane];
+      s = LD[M.dof_Madr[i] + 1 + lane] * x[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) x[i] -= s;
+    SYNC();
+  }
+}
+
+// ------------------------------------------------------------------ velocity stage
+// cvel per body and cdof_dot per dof by walking the owning chain (no tree-level barriers)
+template <typename real>
+__device__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real v[6] = {0, 0, 0, 0, 0, 0};
+    int n = M.body_chlen[b];
+    const int* chain = M.body_chain + b*FB_MAXCH;
+    for (int s = 0; s < n; s++) {
+      int i = chain[s];
+      real qv = w.qvel[i];
+      const real* c = w.cdof + 6*i;
+      for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
+    }
+    for (int k = 0; k < 6; k++) w.cvel[6*b + k] = v[k];
+  }
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    int j = M.dof_jntid[i];
+    real* cd = w.cdof_dot + 6*i;
+    int nprev;   // number of leading chain dofs whose velocity precedes this dof's axis
+    if (M.jnt_type[j] == JNT_FREE) {
+      int k = i - M.jnt_dofadr[j];
+      if (k < 3) { for (int q = 0; q < 6; q++) cd[q] = 0; continue; }
+      nprev = 3;             // all three rotational axes see parent + translational velocity only
+    } else nprev = M.dof_depth[i];
+    const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
+    real v[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nprev; s++) {
+      int a = chain[s];
+      real qv = w.qvel[a];
+      const real* c = w.cdof + 6*a;
+      for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
+    }
+    crossmotion(cd, v, w.cdof + 6*i);
+  }
+  SYNC();
+}
+
+// 6-D velocity of a frame (pos, rot) rigidly attached to `body`, expressed in that frame
+template <typename real>
+FBD void object_velocity(const WS<real>& w, int body, const real* pos, const real* rot, real* lvel) {
+  const real* cv = w.cvel + 6*body;
+  real dif[3], lin[3], t[3];
+  sub3(dif, pos, w.com);
+  cross3(t, dif, cv);
+  sub3(lin, cv + 3, t);
+  mulmatT3(lvel, rot, cv);
+  mulmatT3(lvel + 3, rot, lin);
+}
+
+// passive forces: joint springs/dampers + per-body inertia-box fluid drag (density, viscosity)
+template <typename real>
+__device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) {
+  // per-body fluid wrench about the tree CoM, stored in cfrc_ext as [torque; force] (scratch use)
+  bool fluid = (M.density > 0 || M.viscosity > 0);
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real* out = w.cfrc_ext + 6*b;
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    if (!fluid || b == 0 || M.body_mass[b] < FB_MINV) continue;
+    const real* box = M.body_box + 3*b;
+    real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+    object_velocity(w, b, w.xipos + 3*b, w.ximat + 9*b, lvel);
+    if (M.viscosity > 0) {
+      real diam = (box[0] + box[1] + box[2]) / (real)3;
+      for (int k = 0; k < 3; k++) {
+        lfrc[k] = -(real)3.14159265358979323846 * diam*diam*diam * M.viscosity * lvel[k];
+        lfrc[3+k] = -(real)3 * (real)3.14159265358979323846 * diam * M.viscosity * lvel[3+k];
+      }
+    }
+    if (M.density > 0) {
+      real b0 = box[0], b1 = box[1], b2 = box[2];
+      real b04 = b0*b0*b0*b0, b14 = b1*b1*b1*b1, b24 = b2*b2*b2*b2;
+      lfrc[3] -= (real)0.5*M.density*b1*b2*fabs(lvel[3])*lvel[3];
+      lfrc[4] -= (real)0.5*M.density*b0*b2*fabs(lvel[4])*lvel[4];
+      lfrc[5] -= (real)0.5*M.density*b0*b1*fabs(lvel[5])*lvel[5];
+      lfrc[0] -= M.density*b0*(b14 + b24)*fabs(lvel[0])*lvel[0]/(real)64;
+      lfrc[1] -= M.density*b1*(b04 + b24)*fabs(lvel[1])*lvel[1]/(real)64;
+      lfrc[2] -= M.density*b2*(b04 + b14)*fabs(lvel[2])*lvel[2]/(real)64;
+    }
+    real trq[3], frc[3], off[3], t[3];
+    mulmat3(trq, w.ximat + 9*b, lfrc);
+    mulmat3(frc, w.ximat + 9*b, lfrc + 3);
+    // move the wrench to the CoM reference point: torque += off x force
+    sub3(off, w.xipos + 3*b, w.com);
+    cross3(t, off, frc);
+    out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
+    out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
+  }
+  SYNC();
+  // qfrc_passive[i] = spring + damper + cdof_i . (sum of fluid wrenches over the dof's subtree)
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    int j = M.dof_jntid[i];
+    real f = -M.dof_damping[i]*w.qvel[i];
+    if (M.jnt_type[j] == JNT_HINGE && M.jnt_stiffness[j] != 0) {
+      int qa = M.jnt_qposadr[j];
+      f -= M.jnt_stiffness[j]*(w.qpos[qa] - M.qpos_spring[qa]);
+    }
+    if (fluid) {
+      int b = M.dof_bodyid[i];
+      real acc[6] = {0, 0, 0, 0, 0, 0};
+      int n = M.body_nsub[b];
+      for (int d = 0; d < n; d++) {
+        const real* c = w.cfrc_ext + 6*(b + d);
+        for (int k = 0; k < 6; k++) acc[k] += c[k];
+      }
+      f += dot6(w.cdof + 6*i, acc);
+    }
+    w.qfrc_passive[i] = f;
+  }
+  SYNC();
+}
+
+// bias forces by RNE: chain walk for the body accelerations, subtree pull for the forces
+template <typename real>
+__device__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
+    real* out = w.cfrc + 6*b;
+    if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
+    int n = M.body_chlen[b];
+    const int* chain = M.body_chain + b*FB_MAXCH;
+    for (int s = 0; s < n; s++) {
+      int i = chain[s];
+      real qv = w.qvel[i];
+      const real* c = w.cdof_dot + 6*i;
+      for (int k = 0; k < 6; k++) a[k] += c[k]*qv;
+    }
+    real t[6], t1[6], t2[6];
+    mulinertvec(t, w.cinert + 10*b, a);
+    mulinertvec(t1, w.cinert + 10*b, w.cvel + 6*b);
+    crossforce(t2, w.cvel + 6*b, t1);
+    for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k];
+  }
+  SYNC();
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    int b = M.dof_bodyid[i];
+    real acc[6] = {0, 0, 0, 0, 0, 0};
+    int n = M.body_nsub[b];
+    for (int d = n - 1; d >= 0; d--) {
+      const real* c = w.cfrc + 6*(b + d);
+      for (int k = 0; k < 6; k++) acc[k] += c[k];
+    }
+    w.qfrc_bias[i] = dot6(w.cdof + 6*i, acc);
+  }
+  SYNC();
+}

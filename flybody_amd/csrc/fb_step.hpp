@@ -1,0 +1,351 @@
+// Substep driver, sensors, integrator and the walk_imitation environment epilogue
+// (observations, reward, termination, auto-reset) fused behind the physics.
+#pragma once
+#include "fb_types.hpp"
+#include "fb_math.hpp"
+#include "fb_smooth.hpp"
+#include "fb_collide.hpp"
+#include "fb_constraint.hpp"
+
+// ------------------------------------------------------------------ sensors
+template <typename real>
+__device__ void d_sensor_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
+  if (lane == 0) {
+    int s = M.site_thorax;
+    real lvel[6];
+    object_velocity(w, M.site_bodyid[s], w.sxpos + 3*s, w.sxmat + 9*s, lvel);
+    for (int k = 0; k < 3; k++) { w.sens[3 + k] = lvel[k]; w.sens[6 + k] = lvel[3 + k]; }
+  }
+  SYNC();
+}
+
+template <typename real>
+FBD real ray_quad(real a, real b, real c, real* x) {
+  real det = b*b - a*c;
+  if (det < FB_MINV || a < FB_MINV) { x[0] = -1; x[1] = -1; return -1; }
+  det = sqrt(det);
+  x[0] = (-b - det)/a; x[1] = (-b + det)/a;
+  if (x[0] >= 0) return x[0];
+  if (x[1] >= 0) return x[1];
+  return -1;
+}
+template <typename real>
+FBD real ray_site(const real* pos, const real* mat, const real* size, int type, const real* pnt, const real* vec) {
+  real dif[3], lp[3], lv[3], xx[2];
+  sub3(dif, pnt, pos);
+  mulmatT3(lp, mat, dif); mulmatT3(lv, mat, vec);
+  if (type == GEOM_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0]*size[0], xx);
+  if (type == GEOM_CAPSULE) {
+    real best = -1;
+    real a = lv[0]*lv[0] + lv[1]*lv[1], b = lv[0]*lp[0] + lv[1]*lp[1], c = lp[0]*lp[0] + lp[1]*lp[1] - size[0]*size[0];
+    ray_quad(a, b, c, xx);
+    for (int k = 0; k < 2; k++) if (xx[k] >= 0 && fabs(lp[2] + xx[k]*lv[2]) <= size[1] && (best < 0 || xx[k] < best)) best = xx[k];
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      real lq[3] = {lp[0], lp[1], lp[2] - sgn*size[1]};
+      ray_quad(dot3(lv, lv), dot3(lv, lq), dot3(lq, lq) - size[0]*size[0], xx);
+      for (int k = 0; k < 2; k++) if (xx[k] >= 0 && sgn*(lq[2] + xx[k]*lv[2]) >= 0 && (best < 0 || xx[k] < best)) best = xx[k];
+    }
+    return best;
+  }
+  if (type == GEOM_ELLIPSOID) {
+    real sp[3] = {lp[0]/size[0], lp[1]/size[1], lp[2]/size[2]}, sv[3] = {lv[0]/size[0], lv[1]/size[1], lv[2]/size[2]};
+    return ray_quad(dot3(sv, sv), dot3(sv, sp), dot3(sp, sp) - 1, xx);
+  }
+  return -1;
+}
+
+// acceleration-stage sensors: accelerometer (thorax site), 6 force sensors, 6 touch sensors
+template <typename real>
+__device__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
+  int ncon = w.istate[IS_NCON];
+  // external (contact) wrench per body about the tree CoM: lane == body pulls from the contact list
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real acc[6] = {0, 0, 0, 0, 0, 0};
+    if (b > 0) {
+      for (int c = 0; c < ncon; c++) {
+        int adr = w.con_efc[c];
+        if (adr < 0) continue;
+        int p = w.con_pair[c];
+        int b1 = M.geom_bodyid[M.pair_geom1[p]], b2 = M.geom_bodyid[M.pair_geom2[p]];
+        if (b != b1 && b != b2) continue;
+        real lf[3] = {w.efc_force[adr], 0, 0};
+        if (w.con_dim[c] > 1) { lf[1] = w.efc_force[adr+1]; lf[2] = w.efc_force[adr+2]; }
+        real f[3], r[3], tq[3];
+        mulmatT3(f, w.con_frame + 9*c, lf);
+        sub3(r, w.con_pos + 3*c, w.com);
+        cross3(tq, r, f);
+        real sgn = (b == b2) ? (real)1 : (real)-1;
+        if (b1 == b2) sgn = 0;
+        for (int k = 0; k < 3; k++) { acc[k] += sgn*tq[k]; acc[3+k] += sgn*f[k]; }
+      }
+    }
+    for (int k = 0; k < 6; k++) w.cfrc_ext[6*b + k] = acc[k];
+  }
+  SYNC();
+  // body accelerations (chain walk, now including qacc) and body forces
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
+    real* out = w.cfrc + 6*b;
+    if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc[k] = a[k]; } continue; }
+    int n = M.body_chlen[b];
+    const int* chain = M.body_chain + b*FB_MAXCH;
+    for (int s = 0; s < n; s++) {
+      int i = chain[s];
+      real qv = w.qvel[i], qa = w.qacc[i];
+      const real* cd = w.cdof_dot + 6*i; const real* c = w.cdof + 6*i;
+      for (int k = 0; k < 6; k++) a[k] += cd[k]*qv + c[k]*qa;
+    }
+    for (int k = 0; k < 6; k++) w.cacc[6*b + k] = a[k];
+    real t[6], t1[6], t2[6];
+    mulinertvec(t, w.cinert + 10*b, a);
+    mulinertvec(t1, w.cinert + 10*b, w.cvel + 6*b);
+    crossforce(t2, w.cvel + 6*b, t1);
+    for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k] - w.cfrc_ext[6*b + k];
+  }
+  SYNC();
+  if (lane == 0) {
+    int s = M.site_thorax, b = M.site_bodyid[s];
+    const real* ca = w.cacc + 6*b;
+    real dif[3], t[3], lin[3], la[3], lvel[6], cor[3];
+    sub3(dif, w.sxpos + 3*s, w.com);
+    cross3(t, dif, ca);
+    sub3(lin, ca + 3, t);
+    mulmatT3(la, w.sxmat + 9*s, lin);
+    object_velocity(w, b, w.sxpos + 3*s, w.sxmat + 9*s, lvel);
+    cross3(cor, lvel, lvel + 3);
+    for (int k = 0; k < 3; k++) w.sens[k] = la[k] + cor[k];
+  }
+  // force sensors: interaction force of the site's body = subtree sum of body forces
+  if (lane >= 8 && lane < 8 + M.nforce) {
+    int k = lane - 8;
+    int s = M.force_sites[k], b = M.site_bodyid[s];
+    real acc[3] = {0, 0, 0};
+    int n = M.body_nsub[b];
+    for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
+    mulmatT3(w.sens + 9 + 3*k, w.sxmat + 9*s, acc);
+  }
+  if (lane >= 16 && lane < 16 + M.ntouch) {
+    int k = lane - 16;
+    int s = M.touch_sites[k], b = M.site_bodyid[s];
+    real sum = 0;
+    for (int c = 0; c < ncon; c++) {
+      int adr = w.con_efc[c];
+      if (adr < 0) continue;
+      int p = w.con_pair[c];
+      int b1 = M.geom_bodyid[M.pair_geom1[p]], b2 = M.geom_bodyid[M.pair_geom2[p]];
+      if (b != b1 && b != b2) continue;
+      real fn = w.efc_force[adr];
+      if (fn <= 0) continue;
+      real ray[3]; copy3(ray, w.con_frame + 9*c);
+      if (b == b2) scl3(ray, ray, (real)-1);
+      if (ray_site(w.sxpos + 3*s, w.sxmat + 9*s, M.site_size + 3*s, M.site_type[s], w.con_pos + 3*c, ray) >= 0) sum += fn;
+    }
+    w.sens[9 + 3*M.nforce + k] = sum;
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ integrator
+template <typename real>
+__device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
+  real h = M.timestep;
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.qH[i] = w.qM[i];
+  SYNC();
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    w.qH[M.dof_Madr[i]] += h*M.dof_damping[i];
+    w.tmpv2[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
+  }
+  SYNC();
+  d_factor(M, w.qH, w.qHinv, lane);
+  d_solve(M, w.qH, w.qHinv, w.tmpv2, lane);
+  for (int i = lane; i < M.nu; i += FB_WAVE) {
+    int aa = M.act_actadr[i];
+    if (aa < 0) continue;
+    if (M.act_dyntype[i] == DYN_FILTEREXACT) {
+      real tau = fmax(FB_MINV, M.act_dynprm[i]);
+      w.act[aa] += w.act_dot[aa]*tau*(1 - exp(-h/tau));
+    } else w.act[aa] += h*w.act_dot[aa];
+  }
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel[i] += h*w.tmpv2[i];
+  SYNC();
+  for (int j = lane; j < M.njnt; j += FB_WAVE) {
+    int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+    if (M.jnt_type[j] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) w.qpos[qa+k] += h*w.qvel[da+k];
+      real ax[3] = {w.qvel[da+3], w.qvel[da+4], w.qvel[da+5]};
+      real n = normalize3(ax);
+      real q[4] = {w.qpos[qa+3], w.qpos[qa+4], w.qpos[qa+5], w.qpos[qa+6]}, qr[4], res[4];
+      axisangle2quat(qr, ax, n*h);
+      normquat(q);
+      mulquat(res, q, qr);
+      normquat(res);
+      for (int k = 0; k < 4; k++) w.qpos[qa+3+k] = res[k];
+    } else w.qpos[qa] += h*w.qvel[da];
+  }
+  if (lane == 0) w.simtime[0] += h;
+  SYNC();
+}
+
+// ------------------------------------------------------------------ stages
+template <typename real>
+__device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
+  d_kinematics(M, w, lane);
+  d_com_pos(M, w, lane);
+  d_crb(M, w, lane);
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.qM[i];
+  SYNC();
+  d_factor(M, w.qLD, w.qLDinv, lane);
+  d_collision(M, w, lane);
+  d_make_constraint(M, w, lane);
+  d_project_constraint(M, w, lane);
+  d_com_vel(M, w, lane);
+  d_passive(M, w, lane);
+  d_rne_bias(M, w, lane);
+  d_sensor_vel(M, w, lane);
+}
+
+template <typename real>
+__device__ void d_acceleration(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
+    w.qfrc_smooth[i] = f; w.qacc_smooth[i] = f;
+  }
+  SYNC();
+  d_solve(M, w.qLD, w.qLDinv, w.qacc_smooth, lane);
+}
+
+template <typename real>
+__device__ void d_step2(const DevModel<real>& M, const WS<real>& w, int lane, bool actuate) {
+  if (actuate) d_actuation(M, w, lane);
+  else {
+    for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
+    for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
+    SYNC();
+  }
+  d_acceleration(M, w, lane);
+  d_solve_constraints(M, w, lane);
+  d_sensor_acc(M, w, lane);
+}
+
+// ------------------------------------------------------------------ environment epilogue
+template <typename real>
+__device__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
+  int thorax = M.site_bodyid[M.site_thorax];
+  const real* R = w.xmat + 9*thorax;
+  const real* tp = w.xpos + 3*thorax;
+  int step = w.istate[IS_STEP];
+  int o = 0;
+  if (lane < 3) obs[o + lane] = (float)sm[lane];
+  o += 3;
+  for (int i = lane; i < M.na; i += FB_WAVE) obs[o + i] = (float)w.act[i];
+  o += M.na;
+  for (int k = lane; k < M.napp; k += FB_WAVE) {
+    real dif[3], e[3]; sub3(dif, w.sxpos + 3*M.app_sites[k], tp);
+    mulmatT3(e, R, dif);
+    for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
+  }
+  o += 3*M.napp;
+  for (int k = lane; k < 3*M.nforce; k += FB_WAVE) obs[o + k] = (float)sm[9 + k];
+  o += 3*M.nforce;
+  if (lane < 3) obs[o + lane] = (float)sm[3 + lane];
+  o += 3;
+  for (int k = lane; k < M.nobsjnt; k += FB_WAVE) {
+    int j = M.obs_jnt[k];
+    obs[o + k] = (float)w.qpos[M.jnt_qposadr[j]];
+    obs[o + M.nobsjnt + k] = (float)w.qvel[M.jnt_dofadr[j]];
+  }
+  o += 2*M.nobsjnt;
+  int nf = M.future_steps + 1;
+  for (int k = lane; k < nf; k += FB_WAVE) {
+    int idx = step + k; if (idx >= M.T) idx = M.T - 1;
+    real dif[3], e[3]; sub3(dif, M.ref_qpos + 7*idx, w.qpos);
+    mulmatT3(e, R, dif);
+    for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
+  }
+  o += 3*nf;
+  {
+    const real* q = w.qpos + 3;
+    real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
+    real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2};
+    for (int k = lane; k < nf; k += FB_WAVE) {
+      int idx = step + k; if (idx >= M.T) idx = M.T - 1;
+      real e[4]; mulquat(e, qi, M.ref_qpos + 7*idx + 3);
+      for (int c = 0; c < 4; c++) obs[o + 4*k + c] = (float)e[c];
+    }
+  }
+  o += 4*nf;
+  for (int k = lane; k < M.ntouch; k += FB_WAVE) obs[o + k] = (float)sm[9 + 3*M.nforce + k];
+  o += M.ntouch;
+  if (lane < 3) { obs[o + lane] = (float)sm[6 + lane]; obs[o + 3 + lane] = (float)R[6 + lane]; }
+}
+
+// env.reset(): walk_imitation.py:112-136 + fruitfly.py:390-405, then a forward pass with
+// actuation disabled (dm_control Physics.after_reset)
+template <typename real>
+__device__ void d_env_reset(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  SYNC();
+  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
+  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
+  SYNC();
+  d_step1(M, w, lane);
+  d_step2(M, w, lane, false);
+  d_pack_obs(M, w, w.sens, obs, lane);
+  if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
+  SYNC();
+}
+
+template <typename real>
+__device__ void d_substep(const DevModel<real>& M, const WS<real>& w, int lane) {
+  d_step2(M, w, lane, true);
+  d_euler(M, w, lane);
+  d_step1(M, w, lane);
+}
+
+// env.step(action): before_step hooks, nsubstep physics steps, reward/termination/observation
+template <typename real>
+__device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward,
+                           float* discount, int* step_type, int lane) {
+  if (w.istate[IS_RESET_NEXT]) { d_env_reset(M, w, obs, reward, discount, step_type, lane); return; }
+  for (int k = lane; k < M.nu; k += FB_WAVE) {
+    float a = action[k];
+    if (a != a) a = 0.f;
+    w.ctrl[M.action_to_ctrl[k]] = (real)a;
+  }
+  if (lane < FB_NSENS) w.sens_acc[lane] = 0;
+  SYNC();
+  for (int s = 0; s < M.nsubstep; s++) {
+    d_substep(M, w, lane);
+    if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane];
+    SYNC();
+  }
+  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
+  int stepc = w.istate[IS_STEP] + 1;
+  SYNC();
+  if (lane == 0) w.istate[IS_STEP] = stepc;
+  real qn = 0;
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  qn = wave_sum(qn);
+  SYNC();
+  real linvel = norm3(w.sens + 6), angvel = norm3(w.sens + 3);
+  int tstep = (int)floor(w.simtime[0] / M.control_timestep + (real)0.5);
+  int idx = stepc < M.T ? stepc : M.T - 1;
+  real dif[3]; sub3(dif, M.ref_qpos + 7*idx, w.qpos);
+  real com_dist = norm3(dif);
+  bool traj_end = (tstep == M.episode_steps);
+  bool term = (linvel > (real)50) || (angvel > (real)200) || traj_end || (com_dist > M.terminal_com_dist) ||
+              (sqrt(qn) > (real)1e14) || (qn != qn);
+  bool terminating = term || (w.simtime[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  if (lane == 0) {
+    *reward = 1.0f;
+    *discount = (term && !traj_end) ? 0.0f : 1.0f;
+    *step_type = terminating ? 2 : 1;
+    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+  }
+  SYNC();
+}

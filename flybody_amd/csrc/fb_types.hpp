@@ -1,0 +1,114 @@
+// Device-side model/workspace descriptors for the batched fly-physics engine (gfx950).
+// One environment is owned by one 64-lane wavefront.  All per-environment arrays of one
+// environment live in one contiguous row of the batch arena, so the owning wavefront streams
+// them coalesced (lane k touches element k of the array).
+#pragma once
+#ifdef FB_EMULATE
+#include "emu/hip_emu.hpp"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#define FB_WAVE 64
+#define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
+#define FB_MAXDEPTH 10     // deepest body (claw: 9)
+#define FB_MAXCON_ 64
+#define FB_MAXEFC_ 192
+#define FB_NSENS 33
+
+enum { JNT_FREE = 0, JNT_HINGE = 3 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
+enum { TRN_JOINT = 0, TRN_TENDON = 3, TRN_BODY = 5 };
+enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
+enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
+// istate slots
+enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7, IS_N = 8 };
+
+// Constant tables shared by all environments (device pointers).
+template <typename real>
+struct DevModel {
+  int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep;
+  int nobsjnt, napp, nforce, ntouch, site_thorax, nadh;
+  int iterations, noslip_iterations;
+  real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
+  // topology
+  const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub, *body_depth;
+  const int *body_path;      // [nbody][FB_MAXDEPTH] ancestors from the tree root down to the body
+  const int *body_chlen;     // [nbody] number of dofs on the root->body chain
+  const int *body_chain;     // [nbody][FB_MAXCH] dof ids on that chain, root first
+  const int *body_common;    // [nbody][nbody] number of shared chain dofs
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
+  const int *tri_a, *tri_e;  // triangular index tables for the LDL update pairs
+  const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
+  const int *tendon_adr, *tendon_num, *wrap_dofid;
+  const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
+  const int *adh_act;        // [nadh] actuator ids with body transmission
+  const int *action_to_ctrl;
+  const int *pair_geom1, *pair_geom2, *pair_condim;
+  const int *obs_jnt, *app_sites, *force_sites, *touch_sites, *wing_jnt;
+  // constants
+  const real *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_box;
+  const real *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_solref, *jnt_solimp, *jnt_margin;
+  const real *qpos0, *qpos_spring, *dof_armature, *dof_damping, *dof_invweight0;
+  const real *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_fluid;
+  const real *site_pos, *site_quat, *site_size;
+  const real *wrap_coef;
+  const real *act_dynprm, *act_gainprm, *act_biasprm, *act_ctrlrange, *act_forcerange;
+  const real *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  // env-level (walk_imitation)
+  const real *ref_qpos, *ref_qvel;
+  int T, future_steps, episode_steps, nobs;
+  real terminal_com_dist, time_limit;
+};
+
+// Per-environment real arrays: X(name, element count expression in terms of DevModel M)
+#define FB_WS_REAL(X) \
+  X(qpos, M.nq) X(qvel, M.nv) X(act, M.na + 1) X(ctrl, M.nu) X(qacc, M.nv) X(qacc_ws, M.nv) X(act_dot, M.na + 1) \
+  X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) \
+  X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) X(xmat, 9*M.nbody) X(xipos, 3*M.nbody) X(ximat, 9*M.nbody) \
+  X(xanchor, 3*M.njnt) X(xaxis, 3*M.njnt) X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
+  X(cinert, 10*M.nbody) X(crb, 10*M.nbody) X(cdof, 6*M.nv) X(cdof_dot, 6*M.nv) X(cvel, 6*M.nbody) \
+  X(qM, M.nM) X(qLD, M.nM) X(qLDinv, M.nv) X(qH, M.nM) X(qHinv, M.nv) \
+  X(qfrc_bias, M.nv) X(qfrc_passive, M.nv) X(qfrc_actuator, M.nv) X(qfrc_smooth, M.nv) X(qacc_smooth, M.nv) \
+  X(qfrc_constraint, M.nv) X(tmpv, M.nv) X(tmpv2, M.nv) X(ten_length, M.ntendon + 1) X(act_force, M.nu) \
+  X(con_dist, FB_MAXCON_) X(con_pos, 3*FB_MAXCON_) X(con_frame, 9*FB_MAXCON_) \
+  X(efc_J, 2*FB_MAXCH*FB_MAXEFC_) X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) \
+  X(efc_pos, FB_MAXEFC_) X(efc_margin, FB_MAXEFC_) X(efc_R, FB_MAXEFC_) X(efc_D, FB_MAXEFC_) X(efc_K, FB_MAXEFC_) \
+  X(efc_B, FB_MAXEFC_) X(efc_imp, FB_MAXEFC_) X(efc_aref, FB_MAXEFC_) X(efc_b, FB_MAXEFC_) X(efc_force, FB_MAXEFC_) \
+  X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) \
+  X(AR, FB_MAXEFC_*FB_MAXEFC_) \
+  X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody)
+
+#define FB_WS_INT(X) \
+  X(istate, IS_N) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
+  X(efc_type, FB_MAXEFC_) X(efc_id, FB_MAXEFC_) X(efc_bA, FB_MAXEFC_) X(efc_bB, FB_MAXEFC_) X(efc_lA, FB_MAXEFC_) X(efc_lB, FB_MAXEFC_)
+
+struct WSOff {
+#define X(name, n) uint32_t name;
+  FB_WS_REAL(X)
+  FB_WS_INT(X)
+#undef X
+  uint32_t nreal, nint;
+};
+
+template <typename real>
+struct WS {
+#define X(name, n) real* name;
+  FB_WS_REAL(X)
+#undef X
+#define X(name, n) int* name;
+  FB_WS_INT(X)
+#undef X
+};
+
+template <typename real>
+__device__ __forceinline__ void ws_bind(WS<real>& w, const WSOff& o, real* rbase, int* ibase) {
+#define X(name, n) w.name = rbase + o.name;
+  FB_WS_REAL(X)
+#undef X
+#define X(name, n) w.name = ibase + o.name;
+  FB_WS_INT(X)
+#undef X
+}

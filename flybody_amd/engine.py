@@ -1,0 +1,176 @@
+"""Thin ctypes shim over the C-ABI of libflybody_hip.so (include/flybody_engine.h).
+
+The product path is HIP only: `load_library()` opens ``flybody_amd/libflybody_hip.so`` and every
+entry point fails loudly if the library or a GPU is missing -- there is no CPU fallback.
+(`lib_path` exists so the test-suite can point the same shim at the kernel-emulation build under
+tests/_emu; nothing in the package does that.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from .model_blob import load_npz, pack_model
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, 'libflybody_hip.so')
+ASSETS = os.path.join(_HERE, 'assets')
+
+# field ids (include/flybody_engine.h)
+FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA=7, OBS=8, REWARD=9,
+              DISCOUNT=10, STEP_TYPE=11, NCON=12, NEFC=13, SOLVER_NITER=14, QFRC_BIAS=15, QFRC_PASSIVE=16,
+              QACC_SMOOTH=17, QM=18, CONTACT=19, EFC_FORCE=20, QFRC_ACTUATOR=21, QFRC_CONSTRAINT=22,
+              STEP_COUNT=23, SUBTREE_COM=24)
+_INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT'}
+_F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
+MAXCON, MAXEFC, NSENSOR = 64, 192, 33
+
+_libs: Dict[str, C.CDLL] = {}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(lib_path: Optional[str] = None) -> C.CDLL:
+    path = lib_path or HIP_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise EngineError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    L = C.CDLL(path)
+    L.fb_last_error.restype = C.c_char_p
+    L.fb_model_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.fb_model_destroy.argtypes = [C.c_void_p]; L.fb_model_destroy.restype = None
+    L.fb_model_dim.argtypes = [C.c_void_p, C.c_char_p]
+    L.fb_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.fb_batch_destroy.argtypes = [C.c_void_p]; L.fb_batch_destroy.restype = None
+    L.fb_batch_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.fb_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.fb_batch_forward.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.fb_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p
+    L.fb_batch_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_timing_begin.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    _libs[path] = L
+    return L
+
+
+def _check(L, rc):
+    if rc != 0:
+        raise EngineError(L.fb_last_error().decode())
+
+
+class Model:
+    """Compiled model handle (fb_model)."""
+
+    def __init__(self, arrays: Dict[str, np.ndarray], lib_path: Optional[str] = None):
+        self.L = load_library(lib_path)
+        self.arrays = arrays
+        self.blob = pack_model(arrays)
+        h = C.c_void_p()
+        _check(self.L, self.L.fb_model_load(self.blob, len(self.blob), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_asset(cls, name: str = 'walk_imitation', lib_path: Optional[str] = None) -> 'Model':
+        return cls(load_npz(os.path.join(ASSETS, name + '.npz')), lib_path)
+
+    def dim(self, name: str) -> int:
+        return self.L.fb_model_dim(self.h, name.encode())
+
+    def __del__(self):
+        try:
+            self.L.fb_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Batch:
+    """n_env environments on one device (fb_batch)."""
+
+    def __init__(self, model: Model, n_env: int, device: int = 0, precision: int = 64):
+        self.model = model; self.L = model.L; self.n_env = n_env; self.precision = precision
+        h = C.c_void_p()
+        _check(self.L, self.L.fb_batch_create(model.h, n_env, device, precision, C.byref(h)))
+        self.h = h
+        self.nobs = 0
+
+    def set_reference(self, ref_qpos, ref_qvel, future_steps=64, terminal_com_dist=0.3, time_limit=10.0):
+        rq = np.ascontiguousarray(ref_qpos, np.float64); rv = np.ascontiguousarray(ref_qvel, np.float64)
+        assert rq.ndim == 2 and rq.shape[1] == 7 and rv.shape == (rq.shape[0], 6)
+        _check(self.L, self.L.fb_batch_set_reference(self.h, rq.ctypes.data, rv.ctypes.data, rq.shape[0],
+                                                     int(future_steps), float(terminal_com_dist), float(time_limit)))
+        m = self.model
+        self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
+                     7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
+
+    def reset(self, env_ids=None, stream=None):
+        if env_ids is None:
+            _check(self.L, self.L.fb_batch_reset(self.h, None, 0, stream))
+        else:
+            ids = np.ascontiguousarray(env_ids, np.int32)
+            _check(self.L, self.L.fb_batch_reset(self.h, ids.ctypes.data, len(ids), stream))
+
+    def step_ptr(self, action_dev_ptr: int, stream=None):
+        """action_dev_ptr: device pointer to float32 [n_env][nu]."""
+        _check(self.L, self.L.fb_batch_step(self.h, C.c_void_p(action_dev_ptr), stream))
+
+    def substep(self, n=1, stream=None):
+        _check(self.L, self.L.fb_batch_substep(self.h, n, stream))
+
+    def forward(self, stream=None):
+        _check(self.L, self.L.fb_batch_forward(self.h, stream))
+
+    def synchronize(self, stream=None):
+        _check(self.L, self.L.fb_batch_synchronize(self.h, stream))
+
+    def _width(self, name):
+        m = self.model
+        return dict(QPOS=m.dim('nq'), QVEL=m.dim('nv'), ACT=m.dim('na'), CTRL=m.dim('nu'), QACC=m.dim('nv'),
+                    XPOS=3*m.dim('nbody'), XQUAT=4*m.dim('nbody'), SENSORDATA=NSENSOR, OBS=self.nobs, REWARD=1,
+                    DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
+                    QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
+                    EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
+                    SUBTREE_COM=3)[name]
+
+    def get(self, name: str) -> np.ndarray:
+        w = self._width(name)
+        dt = np.int32 if name in _INT_FIELDS else (np.float32 if name in _F32_FIELDS else np.float64)
+        out = np.zeros((self.n_env, w), dt)
+        _check(self.L, self.L.fb_batch_get(self.h, FIELDS[name], out.ctypes.data, out.nbytes))
+        return out
+
+    def set(self, name: str, value):
+        w = self._width(name)
+        dt = np.int32 if name in _INT_FIELDS else np.float64
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dt), (self.n_env, w)))
+        _check(self.L, self.L.fb_batch_set(self.h, FIELDS[name], v.ctypes.data, v.nbytes))
+
+    def device_ptr(self, name: str) -> int:
+        p = self.L.fb_batch_device_ptr(self.h, FIELDS[name])
+        if not p:
+            raise EngineError(f'no device pointer for {name}')
+        return p
+
+    def timing_begin(self, stream=None):
+        _check(self.L, self.L.fb_batch_timing_begin(self.h, stream))
+
+    def timing_end(self, stream=None):
+        ms = C.c_float(); n = C.c_int()
+        _check(self.L, self.L.fb_batch_timing_end(self.h, stream, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            self.L.fb_batch_destroy(self.h)
+        except Exception:
+            pass

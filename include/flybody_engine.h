@@ -1,0 +1,117 @@
+/* flybody_engine.h -- C-ABI of the MI355X-native batched fly-physics engine (libflybody_hip.so).
+ *
+ * WHAT THIS BOUNDARY REPLACES.  The reference has no FFI of its own: its hot path is
+ *   env.step(action)  ->  dm_control composer.Environment.step  ->  10 x mujoco mj_step
+ * created at flybody/fly_envs.py:152 (walk_imitation) / :94 (flight_imitation) and driven by the
+ * task hooks flybody/tasks/walk_imitation.py:92-203, tasks/base.py:197-268 and
+ * fruitfly/fruitfly.py:390-405,532-544,594-684.  The entry points below are what a maintainer
+ * would bind (ctypes) behind `fly_envs.walk_imitation()` to step thousands of flies in lock-step
+ * on one GPU; see INTEGRATION.md for the binding stub.
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure, the message
+ * is available from fb_last_error() (thread local).  The caller owns all buffers it passes in;
+ * the library owns the handles.  One fb_batch is bound to one device; it is not thread-safe,
+ * distinct batches may be driven from distinct host threads / processes (one process per GPU).
+ * Batched arrays are row-major [n_env][width]: one environment's row is contiguous, so the
+ * wavefront that owns the environment reads it coalesced.
+ */
+#ifndef FLYBODY_ENGINE_H
+#define FLYBODY_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fb_model fb_model;
+typedef struct fb_batch fb_batch;
+
+/* fields for fb_batch_get / fb_batch_set / fb_batch_device_ptr */
+enum {
+  FB_QPOS = 0,        /* [n_env][nq]   physics real   */
+  FB_QVEL = 1,        /* [n_env][nv]                  */
+  FB_ACT = 2,         /* [n_env][na]                  */
+  FB_CTRL = 3,        /* [n_env][nu]                  */
+  FB_QACC = 4,        /* [n_env][nv]                  */
+  FB_XPOS = 5,        /* [n_env][nbody][3]            */
+  FB_XQUAT = 6,       /* [n_env][nbody][4]            */
+  FB_SENSORDATA = 7,  /* [n_env][33]                  */
+  FB_OBS = 8,         /* [n_env][nobs]   float32      */
+  FB_REWARD = 9,      /* [n_env]         float32      */
+  FB_DISCOUNT = 10,   /* [n_env]         float32      */
+  FB_STEP_TYPE = 11,  /* [n_env]         int32  0 FIRST 1 MID 2 LAST (dm_env.StepType) */
+  FB_NCON = 12,       /* [n_env]         int32        */
+  FB_NEFC = 13,       /* [n_env]         int32        */
+  FB_SOLVER_NITER = 14, /* [n_env]       int32        */
+  FB_QFRC_BIAS = 15,  /* [n_env][nv]                  */
+  FB_QFRC_PASSIVE = 16,
+  FB_QACC_SMOOTH = 17,
+  FB_QM = 18,         /* [n_env][nM] sparse mass matrix (dof_Madr layout) */
+  FB_CONTACT = 19,    /* [n_env][64][8] dist,pos3,normal3,pairid      */
+  FB_EFC_FORCE = 20,  /* [n_env][FB_MAXEFC]           */
+  FB_QFRC_ACTUATOR = 21,
+  FB_QFRC_CONSTRAINT = 22,
+  FB_STEP_COUNT = 23, /* [n_env] int32 control steps since reset */
+  FB_SUBTREE_COM = 24,/* [n_env][3] */
+  FB_NFIELD
+};
+
+enum { FB_MAXCON = 64, FB_MAXEFC = 192, FB_NSENSOR = 33 };
+
+/* model dimensions by name: "nq","nv","nu","na","nbody","nobs","nsubstep", ... ; -1 if unknown */
+int fb_model_dim(const fb_model* m, const char* name);
+
+/* Load a compiled-model blob (flybody_amd/model_blob.py: "FBM1"). */
+int fb_model_load(const void* blob, size_t nbytes, fb_model** out);
+void fb_model_destroy(fb_model* m);
+
+/* Create n_env environments on HIP device `device`.  precision is 64 (FP64 physics) or
+ * 32 (FP32 physics).  Fails (never falls back to a CPU path) if no GPU is present. */
+int fb_batch_create(const fb_model* m, int n_env, int device, int precision, fb_batch** out);
+void fb_batch_destroy(fb_batch* b);
+
+/* Reference trajectory shared by all environments (host pointers, FP64), as produced by the
+ * reference's trajectory loaders (tasks/trajectory_loaders.py:267-309):
+ * ref_qpos[T][7] root position+quaternion, ref_qvel[T][6].  Mirrors
+ * `env.task._traj_generator.set_next_trajectory` (tests/test_walking_env.py:43-44) plus the
+ * walk_imitation() kwargs future_steps / terminal_com_dist / time_limit (fly_envs.py:100-155). */
+int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const double* ref_qvel, int T,
+                           int future_steps, double terminal_com_dist, double time_limit);
+
+/* env.reset() for the listed environments (env_ids == NULL: all).  `stream` is a hipStream_t
+ * (NULL = default stream).  Asynchronous. */
+int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* stream);
+
+/* env.step(action) for every environment: `action` is a DEVICE pointer to float32
+ * [n_env][nu] in the reference's action order (fruitfly.py:342-379).  Environments whose
+ * previous step returned LAST are reset instead (dm_env auto-reset convention).
+ * Asynchronous on `stream`; results land in FB_OBS/FB_REWARD/FB_DISCOUNT/FB_STEP_TYPE. */
+int fb_batch_step(fb_batch* b, const float* action, void* stream);
+
+/* Debug / parity entry points: run one physics substep (mj_step2 then mj_step1 order, as
+ * dm_control's legacy step does) with the current FB_CTRL, or only re-evaluate the
+ * position/velocity stage at the current state. */
+int fb_batch_substep(fb_batch* b, int nsub, void* stream);
+int fb_batch_forward(fb_batch* b, void* stream);
+
+/* Synchronous host copies (physics-real fields are converted to/from FP64; FB_OBS/REWARD/
+ * DISCOUNT are float32, the int fields int32).  `bytes` must match exactly. */
+int fb_batch_get(fb_batch* b, int field, void* dst_host, size_t bytes);
+int fb_batch_set(fb_batch* b, int field, const void* src_host, size_t bytes);
+
+/* Device pointer of a field (e.g. to wrap FB_OBS in a torch tensor without a copy). */
+void* fb_batch_device_ptr(fb_batch* b, int field);
+int fb_batch_synchronize(fb_batch* b, void* stream);
+
+/* Average duration (ms) of the last `fb_batch_step` launches, measured with HIP events on the
+ * launch stream between fb_batch_timing_begin / fb_batch_timing_end. */
+int fb_batch_timing_begin(fb_batch* b, void* stream);
+int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launches);
+
+const char* fb_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
