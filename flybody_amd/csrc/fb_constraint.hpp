@@ -333,6 +333,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     SYNC();
     return;
   }
+  PROF_BEGIN();
   // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
   for (int r = lane; r < nefc; r += FB_WAVE) {
     real vel = 0, ja = 0, jw = 0;
@@ -390,6 +391,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     }
     if (cost > 0) { f.f0 = 0; f.f1 = 0; f.f2 = 0; }
   }
+  PROF(P_CSETUP);
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
   real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
   int niter = 0;
@@ -449,6 +451,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     niter = it + 1;
     if (improvement*scale < M.tolerance) break;
   }
+  PROF(P_PGS);
   // ---- noslip: friction dims only, regularisation removed
   int ncon = w.istate[IS_NCON];
   for (int it = 0; it < M.noslip_iterations; it++) {
@@ -480,6 +483,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     }
     if (improvement*scale < M.noslip_tolerance) break;
   }
+  PROF(P_NOSLIP);
   if (lane < nefc) w.efc_force[lane] = f.f0;
   if (lane + 64 < nefc) w.efc_force[lane + 64] = f.f1;
   if (lane + 128 < nefc) w.efc_force[lane + 128] = f.f2;
@@ -507,4 +511,5 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   d_solve(M, w.qLD, w.qLDinv, w.tmpv, lane);
   for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.tmpv[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
   SYNC();
+  PROF(P_CFIN);
 }

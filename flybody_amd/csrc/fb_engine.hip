@@ -423,6 +423,7 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_NEFC: *f = {1, o.istate + IS_NEFC, 1, nullptr}; break;
     case FB_SOLVER_NITER: *f = {1, o.istate + IS_NITER, 1, nullptr}; break;
     case FB_STEP_COUNT: *f = {1, o.istate + IS_STEP, 1, nullptr}; break;
+    case FB_PROF: *f = {1, o.prof, 2*FB_NPROF, nullptr}; break;
     case FB_OBS: *f = {2, 0, (size_t)b->nobs, b->obs}; break;
     case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
     case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;

@@ -189,19 +189,20 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
 // ------------------------------------------------------------------ stages
 template <typename real>
 __device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
-  d_kinematics(M, w, lane);
-  d_com_pos(M, w, lane);
-  d_crb(M, w, lane);
+  PROF_BEGIN();
+  d_kinematics(M, w, lane); PROF(P_KIN);
+  d_com_pos(M, w, lane); PROF(P_COMPOS);
+  d_crb(M, w, lane); PROF(P_CRB);
   for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.qM[i];
   SYNC();
-  d_factor(M, w.qLD, w.qLDinv, lane);
-  d_collision(M, w, lane);
-  d_make_constraint(M, w, lane);
-  d_project_constraint(M, w, lane);
+  d_factor(M, w.qLD, w.qLDinv, lane); PROF(P_FACTOR);
+  d_collision(M, w, lane); PROF(P_COLL);
+  d_make_constraint(M, w, lane); PROF(P_MAKEC);
+  d_project_constraint(M, w, lane); PROF(P_PROJ);
   d_com_vel(M, w, lane);
   d_passive(M, w, lane);
   d_rne_bias(M, w, lane);
-  d_sensor_vel(M, w, lane);
+  d_sensor_vel(M, w, lane); PROF(P_VEL);
 }
 
 template <typename real>
@@ -216,15 +217,17 @@ __device__ void d_acceleration(const DevModel<real>& M, const WS<real>& w, int l
 
 template <typename real>
 __device__ void d_step2(const DevModel<real>& M, const WS<real>& w, int lane, bool actuate) {
-  if (actuate) d_actuation(M, w, lane);
-  else {
+  { PROF_BEGIN(); if (actuate) d_actuation(M, w, lane); PROF(P_ACT); }
+  if (!actuate) {
     for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
     for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
     SYNC();
   }
-  d_acceleration(M, w, lane);
+  PROF_BEGIN();
+  d_acceleration(M, w, lane); PROF(P_ACC);
   d_solve_constraints(M, w, lane);
-  d_sensor_acc(M, w, lane);
+  PROF_BEGIN();
+  d_sensor_acc(M, w, lane); PROF(P_SENS);
 }
 
 // ------------------------------------------------------------------ environment epilogue
@@ -301,7 +304,7 @@ __device__ void d_env_reset(const DevModel<real>& M, const WS<real>& w, float* o
 template <typename real>
 __device__ void d_substep(const DevModel<real>& M, const WS<real>& w, int lane) {
   d_step2(M, w, lane, true);
-  d_euler(M, w, lane);
+  { PROF_BEGIN(); d_euler(M, w, lane); PROF(P_EULER); }
   d_step1(M, w, lane);
 }
 

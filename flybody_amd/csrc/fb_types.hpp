@@ -16,6 +16,7 @@
 #define FB_MAXCON_ 64
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
+#define FB_NPROF 24
 
 enum { JNT_FREE = 0, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -82,7 +83,7 @@ struct DevModel {
   X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody)
 
 #define FB_WS_INT(X) \
-  X(istate, IS_N) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
+  X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
   X(efc_type, FB_MAXEFC_) X(efc_id, FB_MAXEFC_) X(efc_bA, FB_MAXEFC_) X(efc_bB, FB_MAXEFC_) X(efc_lA, FB_MAXEFC_) X(efc_lB, FB_MAXEFC_)
 
 struct WSOff {

@@ -23,8 +23,8 @@ ASSETS = os.path.join(_HERE, 'assets')
 FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA=7, OBS=8, REWARD=9,
               DISCOUNT=10, STEP_TYPE=11, NCON=12, NEFC=13, SOLVER_NITER=14, QFRC_BIAS=15, QFRC_PASSIVE=16,
               QACC_SMOOTH=17, QM=18, CONTACT=19, EFC_FORCE=20, QFRC_ACTUATOR=21, QFRC_CONSTRAINT=22,
-              STEP_COUNT=23, SUBTREE_COM=24)
-_INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT'}
+              STEP_COUNT=23, SUBTREE_COM=24, PROF=25)
+_INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF'}
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
 MAXCON, MAXEFC, NSENSOR = 64, 192, 33
 
@@ -42,6 +42,13 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(path):
         raise EngineError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    if lib_path is None:
+        # torch bundles its own libamdhip64; it must be the first HIP runtime loaded into the
+        # process, otherwise torch.cuda later fails with "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     L.fb_last_error.restype = C.c_char_p
     L.fb_model_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -140,7 +147,7 @@ class Batch:
                     DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
-                    SUBTREE_COM=3)[name]
+                    SUBTREE_COM=3, PROF=48)[name]
 
     def get(self, name: str) -> np.ndarray:
         w = self._width(name)

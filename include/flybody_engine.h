@@ -54,6 +54,7 @@ enum {
   FB_QFRC_CONSTRAINT = 22,
   FB_STEP_COUNT = 23, /* [n_env] int32 control steps since reset */
   FB_SUBTREE_COM = 24,/* [n_env][3] */
+  FB_PROF = 25,       /* [n_env][48] int32 pairs = 24 int64 per-phase cycle counters (profiling builds) */
   FB_NFIELD
 };
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the step kernel (needs a build with -DFB_PROFILE)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import numpy as np, torch
+from flybody_amd import engine
+from flybody_amd.reference import default_walking_reference
+lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(engine.HIP_LIB), 'libflybody_hip_prof.so')
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+M = engine.Model.from_asset('walk_imitation', lib_path=lib)
+B = engine.Batch(M, n, precision=prec)
+qp, qv = default_walking_reference(); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+a = torch.empty(n, 59, device='cuda')
+for _ in range(5):
+    a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+B.set('PROF', np.zeros(48, np.int32))
+K = 10
+import time; t0 = time.time()
+for _ in range(K):
+    a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize(); dt = time.time() - t0
+p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][24]
+names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'epi']
+tot = p.sum(1).mean()
+print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step; mean cycles per env-step {tot/K:.0f}; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
+for i, nm in enumerate(names):
+    print(f'  {nm:8s} {p[:, i].mean()/K:12.0f} cycles/env-step  {100*p[:, i].mean()/tot:5.1f}%')
