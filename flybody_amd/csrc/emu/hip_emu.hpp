@@ -26,6 +26,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ static
 
 using std::min;
 using std::max;

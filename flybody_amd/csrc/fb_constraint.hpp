@@ -160,19 +160,21 @@ __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w,
           if (s < len && y[s] != 0) {
             int adr = M.dof_Madr[chain[s]];
 #pragma unroll
-            for (int t = 0; t < s; t++) y[t] -= w.qLD[adr + (s - t)] * y[s];
+            for (int t = 0; t < s; t++) y[t] -= w.lLD[adr + (s - t)] * y[s];
           }
         }
 #pragma unroll
         for (int s = 0; s < FB_MAXCH; s++) {
           real v = 0;
-          if (s < len) v = y[s] * sqrt(w.qLDinv[chain[s]]);
+          if (s < len) v = y[s] * sqrt(w.lDinv[chain[s]]);
           w.efc_Y[JIDX(side, s, r)] = v;
         }
       }
     }
   }
   SYNC();
+  // AR lives in LDS when it fits, otherwise in the environment's global workspace
+  real* AR = (nefc <= LdsCfg<real>::AR_ROWS) ? w.lAR : w.AR;
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;
@@ -204,7 +206,7 @@ __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w,
       }
       if (valid) {
         if (c == r) acc += w.efc_R[r];
-        w.AR[r*nefc + c] = acc;
+        AR[r*nefc + c] = acc;
       }
     }
   }
@@ -377,6 +379,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     }
   }
   SYNC();
+  const real* AR = (nefc <= LdsCfg<real>::AR_ROWS) ? w.lAR : w.AR;
   FReg<real> f;
   f.f0 = (lane < nefc) ? w.efc_force[lane] : (real)0;
   f.f1 = (lane + 64 < nefc) ? w.efc_force[lane + 64] : (real)0;
@@ -385,7 +388,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     // dual cost of the warm start; fall back to zero if it is worse than zero force
     real cost = 0;
     for (int r = 0; r < nefc; r++) {
-      real s = row_dot(w.AR + r*nefc, nefc, f, lane);
+      real s = row_dot(AR + r*nefc, nefc, f, lane);
       real fr = freg_get(f, r, lane);
       cost += fr*((real)0.5*s + w.efc_b[r]);
     }
@@ -400,8 +403,8 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     for (int i = 0; i < nefc;) {
       int type = w.efc_type[i];
       if (type != CN_ELLIPTIC) {
-        real res = w.efc_b[i] + row_dot(w.AR + i*nefc, nefc, f, lane);
-        real a = w.AR[i*nefc + i];
+        real res = w.efc_b[i] + row_dot(AR + i*nefc, nefc, f, lane);
+        real a = AR[i*nefc + i];
         real old = freg_get(f, i, lane);
         real fn = old - res/a;
         if (fn < 0) fn = 0;
@@ -412,9 +415,9 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
       } else {
         real res[3], old[3], A[9];
         for (int j = 0; j < 3; j++) {
-          res[j] = w.efc_b[i+j] + row_dot(w.AR + (i+j)*nefc, nefc, f, lane);
+          res[j] = w.efc_b[i+j] + row_dot(AR + (i+j)*nefc, nefc, f, lane);
           old[j] = freg_get(f, i+j, lane);
-          for (int k = 0; k < 3; k++) A[3*j+k] = w.AR[(i+j)*nefc + i + k];
+          for (int k = 0; k < 3; k++) A[3*j+k] = AR[(i+j)*nefc + i + k];
         }
         const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[i]];
         real bc[3], fo[3] = {old[0], old[1], old[2]};
@@ -464,10 +467,10 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
       real fnrm = freg_get(f, i, lane);
       for (int j = 0; j < 2; j++) {
         old[j] = freg_get(f, i+1+j, lane);
-        res[j] = w.efc_b[i+1+j] + row_dot(w.AR + (i+1+j)*nefc, nefc, f, lane) - w.efc_R[i+1+j]*old[j];
+        res[j] = w.efc_b[i+1+j] + row_dot(AR + (i+1+j)*nefc, nefc, f, lane) - w.efc_R[i+1+j]*old[j];
       }
-      real Ac[4] = {w.AR[(i+1)*nefc + i+1] - w.efc_R[i+1], w.AR[(i+1)*nefc + i+2],
-                    w.AR[(i+2)*nefc + i+1], w.AR[(i+2)*nefc + i+2] - w.efc_R[i+2]};
+      real Ac[4] = {AR[(i+1)*nefc + i+1] - w.efc_R[i+1], AR[(i+1)*nefc + i+2],
+                    AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - w.efc_R[i+2]};
       real bc[2] = {res[0] - (Ac[0]*old[0] + Ac[1]*old[1]), res[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
       real fq[2] = {0, 0};
       if (fnrm >= FB_MINV) {
@@ -506,10 +509,10 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     }
   }
   SYNC();
-  for (int i = lane; i < nv; i += FB_WAVE) w.tmpv[i] = w.qfrc_constraint[i];
+  for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint[i];
   SYNC();
-  d_solve(M, w.qLD, w.qLDinv, w.tmpv, lane);
-  for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.tmpv[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
+  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
+  for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.lx[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
   SYNC();
   PROF(P_CFIN);
 }

@@ -101,6 +101,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     int last = dofadr[a] + dofnum[a] - 1;
     int len = m->dof_depth[last] + 1;
     if (len > FB_MAXCH) { delete m; return fail("fb_model_load: dof chain longer than FB_MAXCH"); }
+    if (m->nM > FB_MAXNM || m->nv > FB_MAXNV) { delete m; return fail("fb_model_load: model exceeds the LDS capacity constants FB_MAXNM / FB_MAXNV"); }
     m->body_chlen[b] = len;
     for (int k = last, s = len - 1; k >= 0; k = dofpar[k], s--) m->body_chain[(size_t)b*FB_MAXCH + s] = k;
   }
@@ -154,13 +155,21 @@ __global__ void __launch_bounds__(FB_WAVE) k_fly(DevModel<real> M, Batch<real> B
   int slot = blockIdx.x;
   int env = env_ids ? env_ids[slot] : slot;
   int lane = threadIdx.x;
+  __shared__ real s_LD[FB_MAXNM];
+  __shared__ real s_Dinv[FB_MAXNV];
+  __shared__ real s_x[FB_MAXNV];
+  __shared__ real s_AR[LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
   WS<real> w;
   ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
+  w.lLD = s_LD; w.lDinv = s_Dinv; w.lx = s_x; w.lAR = s_AR;
   float* obs = B.obs + (size_t)env*B.nobs;
-  if (mode == MODE_STEP) d_env_step(M, w, action + (size_t)env*M.nu, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
-  else if (mode == MODE_RESET) d_env_reset(M, w, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
-  else if (mode == MODE_SUBSTEP) { for (int s = 0; s < nsub; s++) d_substep(M, w, lane); }
+  if (mode == MODE_STEP) {
+    if (!w.istate[IS_RESET_NEXT]) d_lds_load(M, w, lane);
+    d_env_step(M, w, action + (size_t)env*M.nu, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  } else if (mode == MODE_RESET) d_env_reset(M, w, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  else if (mode == MODE_SUBSTEP) { d_lds_load(M, w, lane); for (int s = 0; s < nsub; s++) d_substep(M, w, lane); }
   else { d_step1(M, w, lane); d_step2(M, w, lane, true); }
+  d_lds_store(M, w, lane);
 }
 
 // ------------------------------------------------------------------ batch

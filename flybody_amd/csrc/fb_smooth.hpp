@@ -16,9 +16,11 @@
 // optional per-phase cycle accounting (build with -DFB_PROFILE): lane 0 accumulates s_memtime deltas
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
 #define PROF_BEGIN() long long prof_t_ = clock64()
+#define PROF_RESET() prof_t_ = clock64()
 #define PROF(id) do { long long now_ = clock64(); if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[id] += now_ - prof_t_; } prof_t_ = clock64(); } while (0)
 #else
 #define PROF_BEGIN() do {} while (0)
+#define PROF_RESET() do {} while (0)
 #define PROF(id) do {} while (0)
 #endif
 enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_ACT, P_ACC, P_CSETUP, P_PGS, P_NOSLIP, P_CFIN, P_SENS, P_EULER, P_EPI };

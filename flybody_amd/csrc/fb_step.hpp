@@ -149,15 +149,16 @@ __device__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lan
 template <typename real>
 __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
   real h = M.timestep;
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.qH[i] = w.qM[i];
+  // the factor of M is dead after the constraint solve: reuse its LDS slot for M + h*D
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qM[i];
   SYNC();
   for (int i = lane; i < M.nv; i += FB_WAVE) {
-    w.qH[M.dof_Madr[i]] += h*M.dof_damping[i];
-    w.tmpv2[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
+    w.lLD[M.dof_Madr[i]] += h*M.dof_damping[i];
+    w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
   }
   SYNC();
-  d_factor(M, w.qH, w.qHinv, lane);
-  d_solve(M, w.qH, w.qHinv, w.tmpv2, lane);
+  d_factor(M, w.lLD, w.lDinv, lane);
+  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < M.nu; i += FB_WAVE) {
     int aa = M.act_actadr[i];
     if (aa < 0) continue;
@@ -166,7 +167,7 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
       w.act[aa] += w.act_dot[aa]*tau*(1 - exp(-h/tau));
     } else w.act[aa] += h*w.act_dot[aa];
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel[i] += h*w.tmpv2[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel[i] += h*w.lx[i];
   SYNC();
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
     int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
@@ -186,6 +187,26 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
   SYNC();
 }
 
+// LDS does not survive a kernel boundary: the factor of M, its inverse diagonal and the Delassus
+// matrix produced by the position stage are parked in the environment's global row at the end of
+// a launch and reloaded at the start of the next one (once per control step, not per substep).
+template <typename real>
+__device__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.lLD[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
+  int nefc = w.istate[IS_NEFC];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.AR[i] = w.lAR[i];
+  SYNC();
+}
+template <typename real>
+__device__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
+  int nefc = w.istate[IS_NEFC];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.lAR[i] = w.AR[i];
+  SYNC();
+}
+
 // ------------------------------------------------------------------ stages
 template <typename real>
 __device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
@@ -193,9 +214,9 @@ __device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
   d_kinematics(M, w, lane); PROF(P_KIN);
   d_com_pos(M, w, lane); PROF(P_COMPOS);
   d_crb(M, w, lane); PROF(P_CRB);
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.qM[i];
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qM[i];
   SYNC();
-  d_factor(M, w.qLD, w.qLDinv, lane); PROF(P_FACTOR);
+  d_factor(M, w.lLD, w.lDinv, lane); PROF(P_FACTOR);
   d_collision(M, w, lane); PROF(P_COLL);
   d_make_constraint(M, w, lane); PROF(P_MAKEC);
   d_project_constraint(M, w, lane); PROF(P_PROJ);
@@ -209,24 +230,28 @@ template <typename real>
 __device__ void d_acceleration(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
-    w.qfrc_smooth[i] = f; w.qacc_smooth[i] = f;
+    w.qfrc_smooth[i] = f; w.lx[i] = f;
   }
   SYNC();
-  d_solve(M, w.qLD, w.qLDinv, w.qacc_smooth, lane);
+  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
+  SYNC();
 }
 
 template <typename real>
 __device__ void d_step2(const DevModel<real>& M, const WS<real>& w, int lane, bool actuate) {
-  { PROF_BEGIN(); if (actuate) d_actuation(M, w, lane); PROF(P_ACT); }
+  PROF_BEGIN();
+  if (actuate) d_actuation(M, w, lane);
+  PROF(P_ACT);
   if (!actuate) {
     for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
     for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
     SYNC();
   }
-  PROF_BEGIN();
+  PROF_RESET();
   d_acceleration(M, w, lane); PROF(P_ACC);
   d_solve_constraints(M, w, lane);
-  PROF_BEGIN();
+  PROF_RESET();
   d_sensor_acc(M, w, lane); PROF(P_SENS);
 }
 

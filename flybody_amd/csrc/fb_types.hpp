@@ -17,6 +17,8 @@
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
 #define FB_NPROF 24
+#define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
+#define FB_MAXNV 128
 
 enum { JNT_FREE = 0, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -94,8 +96,12 @@ struct WSOff {
   uint32_t nreal, nint;
 };
 
+template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 64 : 40; };
+
 template <typename real>
 struct WS {
+  // LDS-resident hot arrays (per workgroup == per environment)
+  real *lLD, *lDinv, *lx, *lAR;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X
