@@ -307,21 +307,26 @@ FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real
   return la != 0;
 }
 
-// lane k holds force entries k, k+64, k+128 in registers
-template <typename real> struct FReg { real f0, f1, f2; };
-template <typename real> FBD real freg_get(const FReg<real>& f, int i, int lane) {
-  // uniform index i -> broadcast the owning lane's register
-  real v = (i < 64) ? f.f0 : (i < 128 ? f.f1 : f.f2);
-  return __shfl(v, i & 63, 64);
+// lane k holds per-row quantities of rows k, k+64, k+128 in registers; a wave-uniform row index is
+// served by v_readlane (no memory traffic inside the Gauss-Seidel sweep)
+template <typename T> struct R3 { T v0, v1, v2; };
+template <typename T> FBD T r3_get(const R3<T>& f, int i) {
+  T v = (i < 64) ? f.v0 : (i < 128 ? f.v1 : f.v2);
+  return rdlane(v, i & 63);
 }
-template <typename real> FBD void freg_set(FReg<real>& f, int i, int lane, real v) {
-  if (lane == (i & 63)) { if (i < 64) f.f0 = v; else if (i < 128) f.f1 = v; else f.f2 = v; }
+template <typename T> FBD void r3_set(R3<T>& f, int i, int lane, T v) {
+  if (lane == (i & 63)) { if (i < 64) f.v0 = v; else if (i < 128) f.v1 = v; else f.v2 = v; }
 }
-template <typename real> FBD real row_dot(const real* row, int n, const FReg<real>& f, int lane) {
+template <typename T> FBD void r3_load(R3<T>& f, const T* p, int n, int lane, T dflt) {
+  f.v0 = (lane < n) ? p[lane] : dflt;
+  f.v1 = (lane + 64 < n) ? p[lane + 64] : dflt;
+  f.v2 = (lane + 128 < n) ? p[lane + 128] : dflt;
+}
+template <typename real> FBD real row_dot(const real* row, int n, const R3<real>& f, int lane) {
   real s = 0;
-  if (lane < n) s += row[lane]*f.f0;
-  if (lane + 64 < n) s += row[lane + 64]*f.f1;
-  if (lane + 128 < n) s += row[lane + 128]*f.f2;
+  if (lane < n) s += row[lane]*f.v0;
+  if (lane + 64 < n) s += row[lane + 64]*f.v1;
+  if (lane + 128 < n) s += row[lane + 128]*f.v2;
   return wave_sum(s);
 }
 
@@ -380,19 +385,31 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   }
   SYNC();
   const real* AR = (nefc <= LdsCfg<real>::AR_ROWS) ? w.lAR : w.AR;
-  FReg<real> f;
-  f.f0 = (lane < nefc) ? w.efc_force[lane] : (real)0;
-  f.f1 = (lane + 64 < nefc) ? w.efc_force[lane + 64] : (real)0;
-  f.f2 = (lane + 128 < nefc) ? w.efc_force[lane + 128] : (real)0;
+  R3<real> f, rb, rR, rfr0, rfr1;
+  R3<int> rtype;
+  r3_load(f, w.efc_force, nefc, lane, (real)0);
+  r3_load(rb, w.efc_b, nefc, lane, (real)0);
+  r3_load(rR, w.efc_R, nefc, lane, (real)0);
+  r3_load(rtype, w.efc_type, nefc, lane, 0);
+  {
+    // friction coefficients of the contact a row belongs to
+    real a0[3], a1[3];
+    for (int q = 0; q < 3; q++) {
+      int r = lane + 64*q;
+      a0[q] = 1; a1[q] = 1;
+      if (r < nefc && w.efc_type[r] == CN_ELLIPTIC) { const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[r]]; a0[q] = fr[0]; a1[q] = fr[1]; }
+    }
+    rfr0.v0 = a0[0]; rfr0.v1 = a0[1]; rfr0.v2 = a0[2]; rfr1.v0 = a1[0]; rfr1.v1 = a1[1]; rfr1.v2 = a1[2];
+  }
   {
     // dual cost of the warm start; fall back to zero if it is worse than zero force
     real cost = 0;
     for (int r = 0; r < nefc; r++) {
       real s = row_dot(AR + r*nefc, nefc, f, lane);
-      real fr = freg_get(f, r, lane);
-      cost += fr*((real)0.5*s + w.efc_b[r]);
+      real fr = r3_get(f, r);
+      cost += fr*((real)0.5*s + r3_get(rb, r));
     }
-    if (cost > 0) { f.f0 = 0; f.f1 = 0; f.f2 = 0; }
+    if (cost > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; }
   }
   PROF(P_CSETUP);
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
@@ -401,25 +418,25 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   for (int it = 0; it < M.iterations; it++) {
     real improvement = 0;
     for (int i = 0; i < nefc;) {
-      int type = w.efc_type[i];
+      int type = r3_get(rtype, i);
       if (type != CN_ELLIPTIC) {
-        real res = w.efc_b[i] + row_dot(AR + i*nefc, nefc, f, lane);
+        real res = r3_get(rb, i) + row_dot(AR + i*nefc, nefc, f, lane);
         real a = AR[i*nefc + i];
-        real old = freg_get(f, i, lane);
+        real old = r3_get(f, i);
         real fn = old - res/a;
         if (fn < 0) fn = 0;
         real del = fn - old;
         improvement -= (real)0.5*del*del*a + del*res;
-        freg_set(f, i, lane, fn);
+        r3_set(f, i, lane, fn);
         i += 1;
       } else {
         real res[3], old[3], A[9];
         for (int j = 0; j < 3; j++) {
-          res[j] = w.efc_b[i+j] + row_dot(AR + (i+j)*nefc, nefc, f, lane);
-          old[j] = freg_get(f, i+j, lane);
+          res[j] = r3_get(rb, i+j) + row_dot(AR + (i+j)*nefc, nefc, f, lane);
+          old[j] = r3_get(f, i+j);
           for (int k = 0; k < 3; k++) A[3*j+k] = AR[(i+j)*nefc + i + k];
         }
-        const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[i]];
+        real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
         real bc[3], fo[3] = {old[0], old[1], old[2]};
         for (int j = 0; j < 3; j++) bc[j] = res[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
         real v[3];
@@ -447,7 +464,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
         real q = 0, l = 0;
         for (int j = 0; j < 3; j++) { l += del[j]*res[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
         improvement -= (real)0.5*q + l;
-        freg_set(f, i, lane, fo[0]); freg_set(f, i+1, lane, fo[1]); freg_set(f, i+2, lane, fo[2]);
+        r3_set(f, i, lane, fo[0]); r3_set(f, i+1, lane, fo[1]); r3_set(f, i+2, lane, fo[2]);
         i += 3;
       }
     }
@@ -455,22 +472,24 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
     if (improvement*scale < M.tolerance) break;
   }
   PROF(P_PGS);
-  // ---- noslip: friction dims only, regularisation removed
+  // ---- noslip: friction dims only, regularisation removed; lane == contact keeps its row address
   int ncon = w.istate[IS_NCON];
+  int my_efc = (lane < ncon && w.con_dim[lane] > 1) ? w.con_efc[lane] : -1;
   for (int it = 0; it < M.noslip_iterations; it++) {
     real improvement = 0;
     for (int c = 0; c < ncon; c++) {
-      int i = w.con_efc[c];
-      if (i < 0 || w.con_dim[c] == 1) continue;
-      const real* fr = M.pair_friction + 5*w.con_pair[c];
-      real res[2], old[2];
-      real fnrm = freg_get(f, i, lane);
+      int i = rdlane(my_efc, c);
+      if (i < 0) continue;
+      real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
+      real res[2], old[2], Rj[2];
+      real fnrm = r3_get(f, i);
       for (int j = 0; j < 2; j++) {
-        old[j] = freg_get(f, i+1+j, lane);
-        res[j] = w.efc_b[i+1+j] + row_dot(AR + (i+1+j)*nefc, nefc, f, lane) - w.efc_R[i+1+j]*old[j];
+        old[j] = r3_get(f, i+1+j);
+        Rj[j] = r3_get(rR, i+1+j);
+        res[j] = r3_get(rb, i+1+j) + row_dot(AR + (i+1+j)*nefc, nefc, f, lane) - Rj[j]*old[j];
       }
-      real Ac[4] = {AR[(i+1)*nefc + i+1] - w.efc_R[i+1], AR[(i+1)*nefc + i+2],
-                    AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - w.efc_R[i+2]};
+      real Ac[4] = {AR[(i+1)*nefc + i+1] - Rj[0], AR[(i+1)*nefc + i+2],
+                    AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - Rj[1]};
       real bc[2] = {res[0] - (Ac[0]*old[0] + Ac[1]*old[1]), res[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
       real fq[2] = {0, 0};
       if (fnrm >= FB_MINV) {
@@ -482,14 +501,14 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
       }
       real del[2] = {fq[0] - old[0], fq[1] - old[1]};
       improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*res[0] + del[1]*res[1];
-      freg_set(f, i+1, lane, fq[0]); freg_set(f, i+2, lane, fq[1]);
+      r3_set(f, i+1, lane, fq[0]); r3_set(f, i+2, lane, fq[1]);
     }
     if (improvement*scale < M.noslip_tolerance) break;
   }
   PROF(P_NOSLIP);
-  if (lane < nefc) w.efc_force[lane] = f.f0;
-  if (lane + 64 < nefc) w.efc_force[lane + 64] = f.f1;
-  if (lane + 128 < nefc) w.efc_force[lane + 128] = f.f2;
+  if (lane < nefc) w.efc_force[lane] = f.v0;
+  if (lane + 64 < nefc) w.efc_force[lane + 64] = f.v1;
+  if (lane + 128 < nefc) w.efc_force[lane + 128] = f.v2;
   for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
   if (lane == 0) w.istate[IS_NITER] = niter;
   SYNC();
@@ -511,7 +530,7 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   SYNC();
   for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint[i];
   SYNC();
-  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
+  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.lx[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
   SYNC();
   PROF(P_CFIN);

@@ -108,22 +108,45 @@ template <typename real> FBD void makeframe(real* f) {
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // ---- wavefront (64-lane) collectives -------------------------------------------------
+#ifdef FB_EMULATE
+template <typename T> FBD T rdlane(T v, int src) { return __shfl(v, src, 64); }
 FBD double shfl_xor_r(double v, int m) { return __shfl_xor(v, m, 64); }
 FBD float shfl_xor_r(float v, int m) { return __shfl_xor(v, m, 64); }
 template <typename real> FBD real wave_sum(real v) {
-#pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_r(v, m);
   return v;
 }
+#else
+// broadcast from a wave-uniform source lane: v_readlane, no LDS crossbar round trip
+FBD int rdlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+FBD float rdlane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+FBD double rdlane(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> FBD float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> FBD double dpp_mov(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// full-wave sum in every lane: DPP butterflies inside each row of 16 lanes, then 4 readlanes.
+// Must be called with all 64 lanes active.
+template <typename real> FBD real wave_sum(real v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+#endif
 FBD int wave_sum_i(int v) {
-#pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
 // exclusive prefix sum of a small per-lane integer
 FBD int wave_excl_scan(int v, int lane) {
   int s = v;
-#pragma unroll
   for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
   return s - v;
 }

@@ -182,26 +182,23 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
   SYNC();
 }
 
-// In-place sparse L^T D L of a mass-matrix-shaped array (dof_Madr layout).  Serial over dofs
-// (leaf -> root), parallel over the (ancestor, ancestor) update pairs of each eliminated dof.
+// In-place sparse L^T D L of a mass-matrix-shaped array (dof_Madr layout) held in LDS.  Serial over
+// dofs (leaf -> root), parallel over the (ancestor, ancestor) update pairs of each eliminated
+// dof.  All index tables are LDS copies: the loop carries no global-memory dependency.
 template <typename real>
-__device__ void d_factor(const DevModel<real>& M, real* LD, real* Dinv, int lane) {
+__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, real* LD, real* Dinv, int lane) {
   for (int k = M.nv - 1; k >= 0; k--) {
-    int na = M.dof_depth[k];
+    int na = w.ldepth[k];
     if (na == 0) continue;
-    int Mkk = M.dof_Madr[k];
-    int b = M.dof_bodyid[k];
-    const int* chain = M.body_chain + b*FB_MAXCH;
-    int sk = na;   // slot of dof k on its chain
-    // body chains list every dof of the body; dof k sits at slot = its depth
+    int Mkk = w.lmadr[k];
     real dkk = LD[Mkk];
     int npair = na*(na + 1)/2;
     real upd[3]; int tgt[3]; int cnt = 0;
     for (int p = lane; p < npair; p += FB_WAVE) {
-      int a = M.tri_a[p], e = M.tri_e[p];
-      int i = chain[sk - 1 - a];
+      int a = w.ltri_a[p], e = w.ltri_e[p];
+      int i = w.lanc[k*FB_MAXCH + a];
       real tmp = LD[Mkk + 1 + a] / dkk;
-      tgt[cnt] = M.dof_Madr[i] + (e - a);
+      tgt[cnt] = w.lmadr[i] + (e - a);
       upd[cnt] = tmp * LD[Mkk + 1 + e];
       cnt++;
     }
@@ -210,21 +207,20 @@ __device__ void d_factor(const DevModel<real>& M, real* LD, real* Dinv, int lane
     if (lane < na) LD[Mkk + 1 + lane] = LD[Mkk + 1 + lane] / dkk;
     SYNC();
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / LD[M.dof_Madr[i]];
+  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / LD[w.lmadr[i]];
   SYNC();
 }
 
-// x <- M^-1 x using the factorisation (x is an nv-vector in the environment workspace)
+// x <- M^-1 x using the factorisation (x, LD, Dinv in LDS)
 template <typename real>
-__device__ void d_solve(const DevModel<real>& M, const real* LD, const real* Dinv, real* x, int lane) {
+__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const real* LD, const real* Dinv, real* x, int lane) {
   // x <- L^-T x : push each dof's value to its ancestors, leaf -> root
   for (int i = M.nv - 1; i >= 0; i--) {
-    int na = M.dof_depth[i];
+    int na = w.ldepth[i];
     if (na == 0) continue;
     if (lane < na) {
-      const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
-      int j = chain[na - 1 - lane];
-      x[j] -= LD[M.dof_Madr[i] + 1 + lane] * x[i];
+      int j = w.lanc[i*FB_MAXCH + lane];
+      x[j] -= LD[w.lmadr[i] + 1 + lane] * x[i];
     }
     SYNC();
   }
@@ -232,13 +228,12 @@ __device__ void d_solve(const DevModel<real>& M, const real* LD, const real* Din
   SYNC();
   // x <- L^-1 x : pull from ancestors, root -> leaf
   for (int i = 0; i < M.nv; i++) {
-    int na = M.dof_depth[i];
+    int na = w.ldepth[i];
     if (na == 0) continue;
     real s = 0;
     if (lane < na) {
-      const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
-      int j = chain[na - 1 - lane];
-      s = LD[M.dof_Madr[i] + 1 + lane] * x[j];
+      int j = w.lanc[i*FB_MAXCH + lane];
+      s = LD[w.lmadr[i] + 1 + lane] * x[j];
     }
     s = wave_sum(s);
     if (lane == 0) x[i] -= s;

@@ -157,8 +157,8 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
     w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
   }
   SYNC();
-  d_factor(M, w.lLD, w.lDinv, lane);
-  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
+  d_factor(M, w, w.lLD, w.lDinv, lane);
+  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < M.nu; i += FB_WAVE) {
     int aa = M.act_actadr[i];
     if (aa < 0) continue;
@@ -216,7 +216,7 @@ __device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
   d_crb(M, w, lane); PROF(P_CRB);
   for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qM[i];
   SYNC();
-  d_factor(M, w.lLD, w.lDinv, lane); PROF(P_FACTOR);
+  d_factor(M, w, w.lLD, w.lDinv, lane); PROF(P_FACTOR);
   d_collision(M, w, lane); PROF(P_COLL);
   d_make_constraint(M, w, lane); PROF(P_MAKEC);
   d_project_constraint(M, w, lane); PROF(P_PROJ);
@@ -233,7 +233,7 @@ __device__ void d_acceleration(const DevModel<real>& M, const WS<real>& w, int l
     w.qfrc_smooth[i] = f; w.lx[i] = f;
   }
   SYNC();
-  d_solve(M, w.lLD, w.lDinv, w.lx, lane);
+  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
   SYNC();
 }

@@ -19,6 +19,7 @@
 #define FB_NPROF 24
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
+#define FB_NTRI 232         // (FB_MAXCH+1)(FB_MAXCH+2)/2 rounded up
 
 enum { JNT_FREE = 0, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -44,6 +45,7 @@ struct DevModel {
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
   const int *tri_a, *tri_e;  // triangular index tables for the LDL update pairs
+  const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
@@ -102,6 +104,8 @@ template <typename real>
 struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
   real *lLD, *lDinv, *lx, *lAR;
+  // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
+  const uint8_t *lanc, *ldepth, *ltri_a, *ltri_e; const uint16_t *lmadr;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X
