@@ -140,6 +140,9 @@ __device__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, in
   for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D[r] = (real)1 / w.efc_R[r];
 }
 
+template <typename real, typename ARP>
+__device__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
+
 // ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
 template <typename real>
 __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
@@ -174,7 +177,12 @@ __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w,
   }
   SYNC();
   // AR lives in LDS when it fits, otherwise in the environment's global workspace
-  real* AR = (nefc <= LdsCfg<real>::AR_ROWS) ? w.lAR : w.AR;
+  if (nefc <= LdsCfg<real>::AR_ROWS) d_build_AR(M, w, w.lAR, nefc, lane);
+  else d_build_AR(M, w, w.AR, nefc, lane);
+}
+
+template <typename real, typename ARP>
+__device__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;
@@ -322,7 +330,7 @@ template <typename T> FBD void r3_load(R3<T>& f, const T* p, int n, int lane, T 
   f.v1 = (lane + 64 < n) ? p[lane + 64] : dflt;
   f.v2 = (lane + 128 < n) ? p[lane + 128] : dflt;
 }
-template <typename real> FBD real row_dot(const real* row, int n, const R3<real>& f, int lane) {
+template <typename real, typename RP> FBD real row_dot(RP row, int n, const R3<real>& f, int lane) {
   real s = 0;
   if (lane < n) s += row[lane]*f.v0;
   if (lane + 64 < n) s += row[lane + 64]*f.v1;
@@ -330,61 +338,11 @@ template <typename real> FBD real row_dot(const real* row, int n, const R3<real>
   return wave_sum(s);
 }
 
-template <typename real>
-__device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, int lane) {
-  int nefc = w.istate[IS_NEFC];
+// PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix
+template <typename real, typename ARP>
+__device__ int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
-  if (nefc == 0) {
-    for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i]; w.qacc[i] = a; w.qacc_ws[i] = a; w.qfrc_constraint[i] = 0; }
-    if (lane == 0) w.istate[IS_NITER] = 0;
-    SYNC();
-    return;
-  }
   PROF_BEGIN();
-  // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
-  for (int r = lane; r < nefc; r += FB_WAVE) {
-    real vel = 0, ja = 0, jw = 0;
-    for (int side = 0; side < 2; side++) {
-      int body = side ? w.efc_bB[r] : w.efc_bA[r];
-      int len = side ? w.efc_lB[r] : w.efc_lA[r];
-      const int* chain = M.body_chain + body*FB_MAXCH;
-      for (int s = 0; s < len; s++) {
-        real j = w.efc_J[JIDX(side, s, r)];
-        int dof = chain[s];
-        vel += j*w.qvel[dof]; ja += j*w.qacc_smooth[dof]; jw += j*w.qacc_ws[dof];
-      }
-    }
-    real aref = -w.efc_B[r]*vel - w.efc_K[r]*w.efc_imp[r]*(w.efc_pos[r] - w.efc_margin[r]);
-    w.efc_vel[r] = vel; w.efc_aref[r] = aref; w.efc_b[r] = ja - aref; w.efc_jar[r] = jw - aref;
-  }
-  SYNC();
-  // ---- warm start: force implied by the previous acceleration (primal map)
-  for (int r = lane; r < nefc; r += FB_WAVE) {
-    int type = w.efc_type[r];
-    if (type != CN_ELLIPTIC) { real jar = w.efc_jar[r]; w.efc_force[r] = jar < 0 ? -w.efc_D[r]*jar : (real)0; }
-    else {
-      int c = w.efc_id[r];
-      if (w.con_efc[c] != r) continue;        // first row of the contact handles the block
-      const real* fr = M.pair_friction + 5*w.con_pair[c];
-      real mu = w.efc_mu[r];
-      real j0 = w.efc_jar[r], j1 = w.efc_jar[r+1], j2 = w.efc_jar[r+2];
-      real U0 = j0*mu, U1 = j1*fr[0], U2 = j2*fr[1];
-      real N = U0, T = sqrt(U1*U1 + U2*U2);
-      real f0, f1, f2;
-      if (N >= mu*T || (T <= 0 && N >= 0)) { f0 = f1 = f2 = 0; }
-      else if (mu*N + T <= 0 || (T <= 0 && N < 0)) { f0 = -w.efc_D[r]*j0; f1 = -w.efc_D[r+1]*j1; f2 = -w.efc_D[r+2]*j2; }
-      else {
-        real Dm = w.efc_D[r] / fmax(FB_MINV, mu*mu*(1 + mu*mu));
-        real NT = N - mu*T;
-        f0 = -Dm*NT*mu;
-        f1 = -f0/T*U1*fr[0];
-        f2 = -f0/T*U2*fr[1];
-      }
-      w.efc_force[r] = f0; w.efc_force[r+1] = f1; w.efc_force[r+2] = f2;
-    }
-  }
-  SYNC();
-  const real* AR = (nefc <= LdsCfg<real>::AR_ROWS) ? w.lAR : w.AR;
   R3<real> f, rb, rR, rfr0, rfr1;
   R3<int> rtype;
   r3_load(f, w.efc_force, nefc, lane, (real)0);
@@ -509,6 +467,64 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   if (lane < nefc) w.efc_force[lane] = f.v0;
   if (lane + 64 < nefc) w.efc_force[lane + 64] = f.v1;
   if (lane + 128 < nefc) w.efc_force[lane + 128] = f.v2;
+  return niter;
+}
+
+template <typename real>
+__device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, int lane) {
+  int nefc = w.istate[IS_NEFC];
+  int nv = M.nv;
+  if (nefc == 0) {
+    for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i]; w.qacc[i] = a; w.qacc_ws[i] = a; w.qfrc_constraint[i] = 0; }
+    if (lane == 0) w.istate[IS_NITER] = 0;
+    SYNC();
+    return;
+  }
+  PROF_BEGIN();
+  // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
+  for (int r = lane; r < nefc; r += FB_WAVE) {
+    real vel = 0, ja = 0, jw = 0;
+    for (int side = 0; side < 2; side++) {
+      int body = side ? w.efc_bB[r] : w.efc_bA[r];
+      int len = side ? w.efc_lB[r] : w.efc_lA[r];
+      const int* chain = M.body_chain + body*FB_MAXCH;
+      for (int s = 0; s < len; s++) {
+        real j = w.efc_J[JIDX(side, s, r)];
+        int dof = chain[s];
+        vel += j*w.qvel[dof]; ja += j*w.qacc_smooth[dof]; jw += j*w.qacc_ws[dof];
+      }
+    }
+    real aref = -w.efc_B[r]*vel - w.efc_K[r]*w.efc_imp[r]*(w.efc_pos[r] - w.efc_margin[r]);
+    w.efc_vel[r] = vel; w.efc_aref[r] = aref; w.efc_b[r] = ja - aref; w.efc_jar[r] = jw - aref;
+  }
+  SYNC();
+  // ---- warm start: force implied by the previous acceleration (primal map)
+  for (int r = lane; r < nefc; r += FB_WAVE) {
+    int type = w.efc_type[r];
+    if (type != CN_ELLIPTIC) { real jar = w.efc_jar[r]; w.efc_force[r] = jar < 0 ? -w.efc_D[r]*jar : (real)0; }
+    else {
+      int c = w.efc_id[r];
+      if (w.con_efc[c] != r) continue;        // first row of the contact handles the block
+      const real* fr = M.pair_friction + 5*w.con_pair[c];
+      real mu = w.efc_mu[r];
+      real j0 = w.efc_jar[r], j1 = w.efc_jar[r+1], j2 = w.efc_jar[r+2];
+      real U0 = j0*mu, U1 = j1*fr[0], U2 = j2*fr[1];
+      real N = U0, T = sqrt(U1*U1 + U2*U2);
+      real f0, f1, f2;
+      if (N >= mu*T || (T <= 0 && N >= 0)) { f0 = f1 = f2 = 0; }
+      else if (mu*N + T <= 0 || (T <= 0 && N < 0)) { f0 = -w.efc_D[r]*j0; f1 = -w.efc_D[r+1]*j1; f2 = -w.efc_D[r+2]*j2; }
+      else {
+        real Dm = w.efc_D[r] / fmax(FB_MINV, mu*mu*(1 + mu*mu));
+        real NT = N - mu*T;
+        f0 = -Dm*NT*mu;
+        f1 = -f0/T*U1*fr[0];
+        f2 = -f0/T*U2*fr[1];
+      }
+      w.efc_force[r] = f0; w.efc_force[r+1] = f1; w.efc_force[r+2] = f2;
+    }
+  }
+  SYNC();
+  int niter = (nefc <= LdsCfg<real>::AR_ROWS) ? d_pgs(M, w, (const FB_LDS real*)w.lAR, nefc, lane) : d_pgs(M, w, (const real*)w.AR, nefc, lane);
   for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
   if (lane == 0) w.istate[IS_NITER] = niter;
   SYNC();

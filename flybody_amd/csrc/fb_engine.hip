@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(FB_WAVE) k_fly(DevModel<real> M, Batch<real> B
   __shared__ uint8_t s_tri_a[FB_NTRI];
   __shared__ uint8_t s_tri_e[FB_NTRI];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
-  w.lLD = s_LD; w.lDinv = s_Dinv; w.lx = s_x; w.lAR = s_AR;
-  w.lanc = s_anc; w.ldepth = s_depth; w.ltri_a = s_tri_a; w.ltri_e = s_tri_e; w.lmadr = s_madr;
+  w.lLD = (FB_LDS real*)s_LD; w.lDinv = (FB_LDS real*)s_Dinv; w.lx = (FB_LDS real*)s_x; w.lAR = (FB_LDS real*)s_AR;
+  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.ltri_a = (FB_LDS uint8_t*)s_tri_a; w.ltri_e = (FB_LDS uint8_t*)s_tri_e; w.lmadr = (FB_LDS uint16_t*)s_madr;
   // stage the elimination-tree tables in LDS (shared by every factor / solve of this launch)
   for (int i = lane; i < M.nv*FB_MAXCH; i += FB_WAVE) s_anc[i] = (uint8_t)M.dof_anc[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) s_depth[i] = (uint8_t)M.dof_depth[i];

@@ -186,7 +186,7 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
 // dofs (leaf -> root), parallel over the (ancestor, ancestor) update pairs of each eliminated
 // dof.  All index tables are LDS copies: the loop carries no global-memory dependency.
 template <typename real>
-__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, real* LD, real* Dinv, int lane) {
+__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, FB_LDS real* LD, FB_LDS real* Dinv, int lane) {
   for (int k = M.nv - 1; k >= 0; k--) {
     int na = w.ldepth[k];
     if (na == 0) continue;
@@ -213,7 +213,7 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, real* LD, r
 
 // x <- M^-1 x using the factorisation (x, LD, Dinv in LDS)
 template <typename real>
-__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const real* LD, const real* Dinv, real* x, int lane) {
+__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LD, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
   // x <- L^-T x : push each dof's value to its ancestors, leaf -> root
   for (int i = M.nv - 1; i >= 0; i--) {
     int na = w.ldepth[i];

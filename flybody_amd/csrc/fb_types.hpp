@@ -98,14 +98,22 @@ struct WSOff {
   uint32_t nreal, nint;
 };
 
+// LDS pointers carry their address space in the type so that every access compiles to ds_read /
+// ds_write (a generic pointer would fall back to flat_* instructions and their global-class latency)
+#ifdef FB_EMULATE
+#define FB_LDS
+#else
+#define FB_LDS __attribute__((address_space(3)))
+#endif
+
 template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 64 : 40; };
 
 template <typename real>
 struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
-  real *lLD, *lDinv, *lx, *lAR;
+  FB_LDS real *lLD, *lDinv, *lx, *lAR;
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
-  const uint8_t *lanc, *ldepth, *ltri_a, *ltri_e; const uint16_t *lmadr;
+  const FB_LDS uint8_t *lanc, *ldepth, *ltri_a, *ltri_e; const FB_LDS uint16_t *lmadr;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X
