@@ -32,7 +32,8 @@ struct fb_model {
   std::map<std::string, const BlobEntry*> idx;
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
-  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, tri_a, tri_e, adh_act;
+  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, tri_a, tri_e, adh_act;
+  int nlevel;
   std::vector<double> body_box;
   double totalmass;
   const double* d(const char* n, size_t* cnt = nullptr) const {
@@ -113,6 +114,23 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   }
   for (int e_ = 0; e_ < FB_MAXCH + 1; e_++) for (int a = 0; a <= e_; a++) { m->tri_a.push_back(a); m->tri_e.push_back(e_); }
   m->tri_a.resize(FB_NTRI, 0); m->tri_e.resize(FB_NTRI, 0);
+  // descendant ranges (dofs are in DFS order) and depth levels
+  m->dof_ndesc.assign(nv, 0);
+  for (int k = nv - 1; k >= 0; k--) if (dofpar[k] >= 0) m->dof_ndesc[dofpar[k]] += m->dof_ndesc[k] + 1;
+  for (int k = 0; k < nv; k++)
+    for (int q = k + 1; q <= k + m->dof_ndesc[k]; q++) {
+      int a = q; while (a > k) a = dofpar[a];
+      if (a != k) { delete m; return fail("fb_model_load: dofs are not in DFS order"); }
+    }
+  m->nlevel = 0;
+  for (int k = 0; k < nv; k++) if (m->dof_depth[k] + 1 > m->nlevel) m->nlevel = m->dof_depth[k] + 1;
+  m->lvl_start.assign(m->nlevel + 1, 0);
+  for (int d = 0; d < m->nlevel; d++) {
+    m->lvl_start[d] = (int)m->lvl_dof.size();
+    for (int k = 0; k < nv; k++) if (m->dof_depth[k] == d) m->lvl_dof.push_back(k);
+    if ((int)m->lvl_dof.size() - m->lvl_start[d] > FB_WAVE) { delete m; return fail("fb_model_load: more than 64 dofs on one depth level"); }
+  }
+  m->lvl_start[m->nlevel] = (int)m->lvl_dof.size();
   m->dof_anc.assign((size_t)nv*FB_MAXCH, 0);
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
@@ -166,16 +184,18 @@ __global__ void __launch_bounds__(FB_WAVE) k_fly(DevModel<real> M, Batch<real> B
   ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
   __shared__ uint8_t s_anc[FB_MAXNV*FB_MAXCH];
   __shared__ uint8_t s_depth[FB_MAXNV];
-  __shared__ uint8_t s_tri_a[FB_NTRI];
-  __shared__ uint8_t s_tri_e[FB_NTRI];
+  __shared__ uint8_t s_ndesc[FB_MAXNV];
+  __shared__ uint8_t s_lvl_dof[FB_MAXNV];
+  __shared__ uint8_t s_lvl_start[FB_MAXCH + 4];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
   w.lLD = (FB_LDS real*)s_LD; w.lDinv = (FB_LDS real*)s_Dinv; w.lx = (FB_LDS real*)s_x; w.lAR = (FB_LDS real*)s_AR;
-  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.ltri_a = (FB_LDS uint8_t*)s_tri_a; w.ltri_e = (FB_LDS uint8_t*)s_tri_e; w.lmadr = (FB_LDS uint16_t*)s_madr;
+  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc; w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.nlevel = M.nlevel; w.lmadr = (FB_LDS uint16_t*)s_madr;
   // stage the elimination-tree tables in LDS (shared by every factor / solve of this launch)
   for (int i = lane; i < M.nv*FB_MAXCH; i += FB_WAVE) s_anc[i] = (uint8_t)M.dof_anc[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) s_depth[i] = (uint8_t)M.dof_depth[i];
   for (int i = lane; i <= M.nv; i += FB_WAVE) s_madr[i] = (uint16_t)M.dof_Madr[i];
-  for (int i = lane; i < FB_NTRI; i += FB_WAVE) { s_tri_a[i] = (uint8_t)M.tri_a[i]; s_tri_e[i] = (uint8_t)M.tri_e[i]; }
+  for (int i = lane; i < M.nv; i += FB_WAVE) { s_ndesc[i] = (uint8_t)M.dof_ndesc[i]; s_lvl_dof[i] = (uint8_t)M.lvl_dof[i]; }
+  for (int i = lane; i <= M.nlevel; i += FB_WAVE) s_lvl_start[i] = (uint8_t)M.lvl_start[i];
   __syncthreads();
   float* obs = B.obs + (size_t)env*B.nobs;
   if (mode == MODE_STEP) {
@@ -245,7 +265,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc)
+  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start)
+  M.nlevel = m->nlevel;
   UI(geom_type, "geom_type") UI(geom_bodyid, "geom_bodyid") UI(site_bodyid, "site_bodyid") UI(site_type, "site_type")
   UI(tendon_adr, "tendon_adr") UI(tendon_num, "tendon_num") UI(wrap_dofid, "wrap_dofid")
   UI(act_trntype, "actuator_trntype") UI(act_trnid, "actuator_trnid") UI(act_dyntype, "actuator_dyntype") UI(act_biastype, "actuator_biastype")

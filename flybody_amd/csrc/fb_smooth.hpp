@@ -182,29 +182,59 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
   SYNC();
 }
 
-// In-place sparse L^T D L of a mass-matrix-shaped array (dof_Madr layout) held in LDS.  Serial over
-// dofs (leaf -> root), parallel over the (ancestor, ancestor) update pairs of each eliminated
-// dof.  All index tables are LDS copies: the loop carries no global-memory dependency.
+// Sparse L^T D L factorisation / solves of the joint-space inertia matrix, LDS resident.
+//
+// The elimination order of a kinematic tree is serial along a chain but the dofs of one *depth
+// level* are independent once every deeper level is final.  Both kernels are written in "pull"
+// form over depth levels: a row (or solution entry) gathers the contributions of its descendant
+// dofs -- a DFS-contiguous index range -- so no two lanes ever write the same address and the
+// dependency chain is ~20 levels long instead of ~2*nv steps.  Rows with many descendants (the 6
+// free-joint dofs) are reduced across the whole wavefront instead.
+#define FB_BIGROW 24
+
 template <typename real>
 __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, FB_LDS real* LD, FB_LDS real* Dinv, int lane) {
-  for (int k = M.nv - 1; k >= 0; k--) {
-    int na = w.ldepth[k];
-    if (na == 0) continue;
-    int Mkk = w.lmadr[k];
-    real dkk = LD[Mkk];
-    int npair = na*(na + 1)/2;
-    real upd[3]; int tgt[3]; int cnt = 0;
+  for (int d = w.nlevel - 1; d >= 0; d--) {
+    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
+    int width = d + 1, npair = n*width;
+    real val[4]; int adr[4]; int cnt = 0;
     for (int p = lane; p < npair; p += FB_WAVE) {
-      int a = w.ltri_a[p], e = w.ltri_e[p];
-      int i = w.lanc[k*FB_MAXCH + a];
-      real tmp = LD[Mkk + 1 + a] / dkk;
-      tgt[cnt] = w.lmadr[i] + (e - a);
-      upd[cnt] = tmp * LD[Mkk + 1 + e];
-      cnt++;
+      int t = p / width, e = p - t*width;
+      int i = w.llvl_dof[s0 + t];
+      int nd = w.lndesc[i];
+      if (nd > FB_BIGROW) continue;
+      int mi = w.lmadr[i];
+      real acc = LD[mi + e];
+      for (int k = i + 1; k <= i + nd; k++) {
+        int mk = w.lmadr[k], dk = w.ldepth[k] - d;
+        acc -= LD[mk + dk] * LD[mk + dk + e] * LD[mk];
+      }
+      val[cnt] = acc; adr[cnt] = mi + e; cnt++;
+    }
+    for (int t = 0; t < n; t++) {
+      int i = w.llvl_dof[s0 + t];
+      int nd = w.lndesc[i];
+      if (nd <= FB_BIGROW) continue;
+      int mi = w.lmadr[i];
+      for (int e = 0; e < width; e++) {
+        real part = 0;
+        for (int k = i + 1 + lane; k <= i + nd; k += FB_WAVE) {
+          int mk = w.lmadr[k], dk = w.ldepth[k] - d;
+          part += LD[mk + dk] * LD[mk + dk + e] * LD[mk];
+        }
+        part = wave_sum(part);
+        if (lane == 0) LD[mi + e] -= part;
+      }
     }
     SYNC();
-    for (int c = 0; c < cnt; c++) LD[tgt[c]] -= upd[c];
-    if (lane < na) LD[Mkk + 1 + lane] = LD[Mkk + 1 + lane] / dkk;
+    for (int c = 0; c < cnt; c++) LD[adr[c]] = val[c];
+    SYNC();
+    for (int p = lane; p < npair; p += FB_WAVE) {
+      int t = p / width, e = p - t*width;
+      if (e == 0) continue;
+      int mi = w.lmadr[w.llvl_dof[s0 + t]];
+      LD[mi + e] = LD[mi + e] / LD[mi];
+    }
     SYNC();
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / LD[w.lmadr[i]];
@@ -214,29 +244,41 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, FB_LDS real
 // x <- M^-1 x using the factorisation (x, LD, Dinv in LDS)
 template <typename real>
 __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LD, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
-  // x <- L^-T x : push each dof's value to its ancestors, leaf -> root
-  for (int i = M.nv - 1; i >= 0; i--) {
-    int na = w.ldepth[i];
-    if (na == 0) continue;
-    if (lane < na) {
-      int j = w.lanc[i*FB_MAXCH + lane];
-      x[j] -= LD[w.lmadr[i] + 1 + lane] * x[i];
+  // x <- L^-T x, deepest level first: each dof pulls from its (already final) descendants
+  for (int d = w.nlevel - 1; d >= 0; d--) {
+    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
+    if (lane < n) {
+      int j = w.llvl_dof[s0 + lane];
+      int nd = w.lndesc[j];
+      if (nd <= FB_BIGROW) {
+        real acc = 0;
+        for (int k = j + 1; k <= j + nd; k++) acc += LD[w.lmadr[k] + w.ldepth[k] - d] * x[k];
+        x[j] -= acc;
+      }
+    }
+    for (int t = 0; t < n; t++) {
+      int j = w.llvl_dof[s0 + t];
+      int nd = w.lndesc[j];
+      if (nd <= FB_BIGROW) continue;
+      real part = 0;
+      for (int k = j + 1 + lane; k <= j + nd; k += FB_WAVE) part += LD[w.lmadr[k] + w.ldepth[k] - d] * x[k];
+      part = wave_sum(part);
+      if (lane == 0) x[j] -= part;
     }
     SYNC();
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) x[i] *= Dinv[i];
   SYNC();
-  // x <- L^-1 x : pull from ancestors, root -> leaf
-  for (int i = 0; i < M.nv; i++) {
-    int na = w.ldepth[i];
-    if (na == 0) continue;
-    real s = 0;
-    if (lane < na) {
-      int j = w.lanc[i*FB_MAXCH + lane];
-      s = LD[w.lmadr[i] + 1 + lane] * x[j];
+  // x <- L^-1 x, shallowest level first: each dof pulls from its ancestors
+  for (int d = 1; d < w.nlevel; d++) {
+    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
+    if (lane < n) {
+      int i = w.llvl_dof[s0 + lane];
+      int mi = w.lmadr[i];
+      real acc = 0;
+      for (int a = 0; a < d; a++) acc += LD[mi + 1 + a] * x[w.lanc[i*FB_MAXCH + a]];
+      x[i] -= acc;
     }
-    s = wave_sum(s);
-    if (lane == 0) x[i] -= s;
     SYNC();
   }
 }

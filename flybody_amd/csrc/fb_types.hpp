@@ -46,6 +46,8 @@ struct DevModel {
   const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
   const int *tri_a, *tri_e;  // triangular index tables for the LDL update pairs
   const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
+  const int *dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
+  const int *lvl_dof, *lvl_start; int nlevel;   // dofs grouped by depth
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
@@ -113,7 +115,7 @@ struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
   FB_LDS real *lLD, *lDinv, *lx, *lAR;
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
-  const FB_LDS uint8_t *lanc, *ldepth, *ltri_a, *ltri_e; const FB_LDS uint16_t *lmadr;
+  const FB_LDS uint8_t *lanc, *ldepth, *lndesc, *llvl_dof, *llvl_start; const FB_LDS uint16_t *lmadr; int nlevel;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X

@@ -1,8 +1,9 @@
 """GPU parity: the HIP engine (through the C-ABI) against the FP64 CPU oracle on identical inputs.
 
 Tolerances (written here, as the task statement requires):
-  * FP64 kernel vs FP64 oracle, single forward evaluation:  1e-9 relative on every stage output
-    (different summation orders only);
+  * FP64 kernel vs FP64 oracle, single forward evaluation:  1e-9 relative on every smooth-dynamics
+    stage output (different summation orders only) and 1e-6 on solver-dependent outputs (the PGS
+    sweep stops on a 1e-8 improvement threshold, so the last iteration may differ);
   * FP64 kernel vs oracle over 20 control steps (200 physics steps, contacts, PGS):  1e-6 relative
     on qpos / qvel (contact-rich dynamics amplify rounding differences);
   * FP32 kernel vs oracle, single forward evaluation:  2e-3 relative on accelerations.
@@ -45,13 +46,14 @@ def test_forward_stage_parity_fp64(gpu_model, oracle_model, walk_arrays, seed):
     assert int(B.get('NCON')[0, 0]) == int(od.scalar('ncon'))
     assert int(B.get('NEFC')[0, 0]) == int(od.scalar('nefc'))
     n = int(od.scalar('nefc'))
-    for name, of in [('XPOS', 'xpos'), ('XQUAT', 'xquat'), ('QM', 'qM'), ('QFRC_BIAS', 'qfrc_bias'),
-                     ('QFRC_PASSIVE', 'qfrc_passive'), ('QFRC_ACTUATOR', 'qfrc_actuator'), ('QACC_SMOOTH', 'qacc_smooth'),
-                     ('QFRC_CONSTRAINT', 'qfrc_constraint'), ('QACC', 'qacc'), ('SENSORDATA', 'sensordata')]:
+    for name, of, tol in [('XPOS', 'xpos', 1e-9), ('XQUAT', 'xquat', 1e-9), ('QM', 'qM', 1e-9), ('QFRC_BIAS', 'qfrc_bias', 1e-9),
+                          ('QFRC_PASSIVE', 'qfrc_passive', 1e-9), ('QFRC_ACTUATOR', 'qfrc_actuator', 1e-9),
+                          ('QACC_SMOOTH', 'qacc_smooth', 1e-9), ('QFRC_CONSTRAINT', 'qfrc_constraint', 1e-6),
+                          ('QACC', 'qacc', 1e-6), ('SENSORDATA', 'sensordata', 1e-6)]:
         g = B.get(name)
-        assert _rel(g[0], od.field(of)) < 1e-9, name
+        assert _rel(g[0], od.field(of)) < tol, name
         assert np.array_equal(g[0], g[-1]), name + ' differs between identical environments'
-    assert _rel(B.get('EFC_FORCE')[0][:n], od.field('efc_force')[:n]) < 1e-8
+    assert _rel(B.get('EFC_FORCE')[0][:n], od.field('efc_force')[:n]) < 1e-6
     oc = od.contacts(); gc = B.get('CONTACT')[0].reshape(64, 8)[:len(oc)]
     assert _rel(gc[:, :7], oc[:, :7]) < 1e-9
 
