@@ -36,15 +36,16 @@ typedef emu_dim3 dim3;
 static emu_dim3 threadIdx, blockIdx;     // single OS thread: plain globals, swapped per fiber
 
 // ---- fibers -------------------------------------------------------------------------
-#define EMU_LANES 64
+#define EMU_MAXLANES 256
+static int EMU_LANES = 64;          // threads per block of the current launch
 #define EMU_STACK (512*1024)
 struct EmuFiber { void* sp; char* stack; bool done; };
-static EmuFiber emu_fib[EMU_LANES];
+static EmuFiber emu_fib[EMU_MAXLANES];
 static void* emu_main_sp;
 static int emu_cur = -1, emu_ndone = 0, emu_dir = 1;
 static void (*emu_entry_fn)(void*);
 static void* emu_entry_arg;
-static uint64_t emu_exch[EMU_LANES];
+static uint64_t emu_exch[EMU_MAXLANES];
 
 extern "C" void emu_ctx_switch(void** from_sp, void* to_sp);
 __asm__(
@@ -106,19 +107,19 @@ template <typename T> static inline T emu_exchange(T v, int src) {
   uint64_t bits = 0; memcpy(&bits, &v, sizeof(T));
   emu_exch[me] = bits;
   emu_yield();                       // everyone has published
-  T r; uint64_t rb = emu_exch[src & 63]; memcpy(&r, &rb, sizeof(T));
+  T r; uint64_t rb = emu_exch[(me & ~63) + (src & 63)]; memcpy(&r, &rb, sizeof(T));
   emu_yield();                       // everyone has read
   return r;
 }
-template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return emu_exchange(v, (int)threadIdx.x ^ m); }
-template <typename T> static inline T __shfl_up(T v, int d, int = 64) { int me = threadIdx.x; return emu_exchange(v, me >= d ? me - d : me); }
+template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return emu_exchange(v, ((int)threadIdx.x & 63) ^ m); }
+template <typename T> static inline T __shfl_up(T v, int d, int = 64) { int me = threadIdx.x & 63; return emu_exchange(v, me >= d ? me - d : me); }
 template <typename T> static inline T __shfl(T v, int src, int = 64) { return emu_exchange(v, src); }
 static inline unsigned long long __ballot(int pred) {
   int me = threadIdx.x;
   emu_exch[me] = pred ? 1 : 0;
   emu_yield();
   unsigned long long r = 0;
-  for (int i = 0; i < EMU_LANES; i++) if (emu_exch[i]) r |= (1ull << i);
+  for (int i = 0; i < 64; i++) if (emu_exch[(me & ~63) + i]) r |= (1ull << i);
   emu_yield();
   return r;
 }
@@ -163,7 +164,8 @@ template <typename F, typename Tup, size_t... I>
 static inline void emu_apply(F f, Tup& t, std::index_sequence<I...>) { f(std::get<I>(t)...); }
 template <typename F, typename... Args>
 static inline void emu_launch(F kernel, dim3 grid, dim3 block, Args... args) {
-  if (block.x != EMU_LANES) { fprintf(stderr, "hip_emu: only 64-thread blocks are supported\n"); abort(); }
+  if (block.x % 64 != 0 || block.x > EMU_MAXLANES) { fprintf(stderr, "hip_emu: block size must be a multiple of 64 and <= 256\n"); abort(); }
+  EMU_LANES = (int)block.x;
   auto tup = std::make_tuple(args...);
   struct Ctx { F k; decltype(tup)* t; } ctx = {kernel, &tup};
   auto thunk = [](void* p) { Ctx* c = (Ctx*)p; emu_apply(c->k, *c->t, std::index_sequence_for<Args...>{}); };

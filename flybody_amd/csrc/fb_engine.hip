@@ -172,31 +172,34 @@ struct Batch {
 enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
 
 template <typename real>
-__global__ void __launch_bounds__(FB_WAVE) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub) {
-  int slot = blockIdx.x;
-  int env = env_ids ? env_ids[slot] : slot;
-  int lane = threadIdx.x;
-  __shared__ real s_LD[FB_MAXNM];
-  __shared__ real s_Dinv[FB_MAXNV];
-  __shared__ real s_x[FB_MAXNV];
-  __shared__ real s_AR[LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
-  WS<real> w;
-  ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
+__global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+  // per-wave (per-environment) hot arrays
+  __shared__ real s_LD[FB_EPB][FB_MAXNM];
+  __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
+  __shared__ real s_x[FB_EPB][FB_MAXNV];
+  __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
+  // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
   __shared__ uint8_t s_anc[FB_MAXNV*FB_MAXCH];
   __shared__ uint8_t s_depth[FB_MAXNV];
   __shared__ uint8_t s_ndesc[FB_MAXNV];
   __shared__ uint8_t s_lvl_dof[FB_MAXNV];
   __shared__ uint8_t s_lvl_start[FB_MAXCH + 4];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
-  w.lLD = (FB_LDS real*)s_LD; w.lDinv = (FB_LDS real*)s_Dinv; w.lx = (FB_LDS real*)s_x; w.lAR = (FB_LDS real*)s_AR;
-  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc; w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.nlevel = M.nlevel; w.lmadr = (FB_LDS uint16_t*)s_madr;
-  // stage the elimination-tree tables in LDS (shared by every factor / solve of this launch)
-  for (int i = lane; i < M.nv*FB_MAXCH; i += FB_WAVE) s_anc[i] = (uint8_t)M.dof_anc[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) s_depth[i] = (uint8_t)M.dof_depth[i];
-  for (int i = lane; i <= M.nv; i += FB_WAVE) s_madr[i] = (uint16_t)M.dof_Madr[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { s_ndesc[i] = (uint8_t)M.dof_ndesc[i]; s_lvl_dof[i] = (uint8_t)M.lvl_dof[i]; }
-  for (int i = lane; i <= M.nlevel; i += FB_WAVE) s_lvl_start[i] = (uint8_t)M.lvl_start[i];
-  __syncthreads();
+  int tid = threadIdx.x;
+  for (int i = tid; i < M.nv*FB_MAXCH; i += FB_WAVE*FB_EPB) s_anc[i] = (uint8_t)M.dof_anc[i];
+  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) { s_depth[i] = (uint8_t)M.dof_depth[i]; s_ndesc[i] = (uint8_t)M.dof_ndesc[i]; s_lvl_dof[i] = (uint8_t)M.lvl_dof[i]; }
+  for (int i = tid; i <= M.nv; i += FB_WAVE*FB_EPB) s_madr[i] = (uint16_t)M.dof_Madr[i];
+  for (int i = tid; i <= M.nlevel; i += FB_WAVE*FB_EPB) s_lvl_start[i] = (uint8_t)M.lvl_start[i];
+  __syncthreads();                       // the only workgroup-wide barrier of the kernel
+  int wave = tid / FB_WAVE, lane = tid % FB_WAVE;
+  int slot = blockIdx.x*FB_EPB + wave;
+  if (slot >= nslot) return;
+  int env = env_ids ? env_ids[slot] : slot;
+  WS<real> w;
+  ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
+  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
+  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc;
+  w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.lmadr = (FB_LDS uint16_t*)s_madr; w.nlevel = M.nlevel;
   float* obs = B.obs + (size_t)env*B.nobs;
   if (mode == MODE_STEP) {
     if (!w.istate[IS_RESET_NEXT]) d_lds_load(M, w, lane);
@@ -393,10 +396,10 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   hipStream_t st = (hipStream_t)stream;
   if (b->precision == 64) {
     Batch<double> B = {(double*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
-    hipLaunchKernelGGL((k_fly<double>), dim3(n), dim3(FB_WAVE), 0, st, b->M64, B, action, ids, mode, nsub);
+    hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, b->M64, B, action, ids, mode, nsub, n);
   } else {
     Batch<float> B = {(float*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
-    hipLaunchKernelGGL((k_fly<float>), dim3(n), dim3(FB_WAVE), 0, st, b->M32, B, action, ids, mode, nsub);
+    hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, b->M32, B, action, ids, mode, nsub, n);
   }
   HIPCHK(hipGetLastError());
   if (b->timing) b->timed_launches++;

@@ -12,7 +12,15 @@
 #include "fb_types.hpp"
 #include "fb_math.hpp"
 
+// Wavefront-level synchronisation.  A workgroup holds FB_EPB independent environments (one per
+// wave); the lanes of one wave exchange data through LDS / the environment's global row, so only a
+// memory fence is needed (a wave executes its own memory instructions in order) -- never an
+// s_barrier, which would couple unrelated environments.
+#ifdef FB_EMULATE
 #define SYNC() __syncthreads()
+#else
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 // optional per-phase cycle accounting (build with -DFB_PROFILE): lane 0 accumulates s_memtime deltas
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
 #define PROF_BEGIN() long long prof_t_ = clock64()

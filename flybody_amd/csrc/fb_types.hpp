@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #define FB_WAVE 64
+#define FB_EPB 4            // environments (wavefronts) per workgroup; they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
 #define FB_MAXDEPTH 10     // deepest body (claw: 9)
 #define FB_MAXCON_ 64
@@ -108,7 +109,7 @@ struct WSOff {
 #define FB_LDS __attribute__((address_space(3)))
 #endif
 
-template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 64 : 40; };
+template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 24 : 16; };
 
 template <typename real>
 struct WS {

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Time K control steps of n_env envs with a given engine build: quick_bench.py LIB PRECISION [N] [K]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import torch
+from flybody_amd import engine
+from flybody_amd.reference import default_walking_reference
+lib = os.path.abspath(sys.argv[1]); prec = int(sys.argv[2]); n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096; K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+M = engine.Model.from_asset('walk_imitation', lib_path=lib)
+B = engine.Batch(M, n, precision=prec)
+qp, qv = default_walking_reference(); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+a = torch.empty(n, 59, device='cuda')
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(5):
+    a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), st)
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(K):
+    a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), st)
+torch.cuda.synchronize(); dt = time.time() - t0
+print(f'{os.path.basename(lib)} prec {prec} n {n}: {dt/K*1e3:.2f} ms/step  {n*K/dt:.0f} env-steps/s  nefc {B.get("NEFC").mean():.1f}')
