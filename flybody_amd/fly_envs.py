@@ -1,0 +1,218 @@
+"""dm_env-compatible fly environments backed by the batched HIP engine.
+
+Mirrors the public surface of the reference's ``flybody/fly_envs.py`` for the hot-path task:
+``walk_imitation(...)`` (fly_envs.py:100-155) returns an object with ``reset() / step(action) /
+action_spec() / observation_spec() / control_timestep() / physics.timestep() /
+task._traj_generator.set_next_trajectory(qpos, qvel)`` -- the members the reference's tests use
+(tests/test_walking_env.py:37-72).  dm_env itself is not a dependency: `TimeStep`, `StepType`
+and the specs below are attribute-compatible stand-ins.
+
+`BatchedFlyEnv` is the native interface (thousands of environments in lock-step on one GPU,
+observations/rewards as torch tensors that alias the engine's device buffers); `walk_imitation`
+with ``n_env=1`` wraps one of them as a single dm_env-style environment.
+"""
+from __future__ import annotations
+
+import collections
+import enum
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import engine
+from .reference import default_walking_reference
+
+
+class StepType(enum.IntEnum):
+    FIRST = 0
+    MID = 1
+    LAST = 2
+
+
+class TimeStep(collections.namedtuple('TimeStep', ['step_type', 'reward', 'discount', 'observation'])):
+    __slots__ = ()
+
+    def first(self): return self.step_type == StepType.FIRST
+    def mid(self): return self.step_type == StepType.MID
+    def last(self): return self.step_type == StepType.LAST
+
+
+class Array:
+    def __init__(self, shape, dtype, name=None):
+        self.shape = tuple(shape); self.dtype = np.dtype(dtype); self.name = name
+
+
+class BoundedArray(Array):
+    def __init__(self, shape, dtype, minimum, maximum, name=None):
+        super().__init__(shape, dtype, name)
+        self.minimum = np.asarray(minimum, dtype); self.maximum = np.asarray(maximum, dtype)
+
+
+# observation layout: packed buffer is in sorted-key order (tasks/task_utils.py:12); the dict the
+# reference returns lists the walker observables first and the two task observables last
+# (tests/test_walking_env.py:11-23)
+_DICT_ORDER = ['accelerometer', 'actuator_activation', 'appendages_pos', 'force', 'gyro', 'joints_pos', 'joints_vel',
+               'touch', 'velocimeter', 'world_zaxis', 'ref_displacement', 'ref_root_quat']
+
+
+def observation_layout(model: engine.Model, future_steps: int):
+    na, napp, nforce, nobsj, ntouch = (model.dim(k) for k in ('na', 'napp', 'nforce', 'nobsjnt', 'ntouch'))
+    nf = future_steps + 1
+    sizes = collections.OrderedDict([
+        ('accelerometer', (3,)), ('actuator_activation', (na,)), ('appendages_pos', (3*napp,)), ('force', (3*nforce,)),
+        ('gyro', (3,)), ('joints_pos', (nobsj,)), ('joints_vel', (nobsj,)), ('ref_displacement', (nf, 3)),
+        ('ref_root_quat', (nf, 4)), ('touch', (ntouch,)), ('velocimeter', (3,)), ('world_zaxis', (3,))])
+    layout = collections.OrderedDict(); off = 0
+    for k, shp in sizes.items():
+        n = int(np.prod(shp)); layout[k] = (off, n, shp); off += n
+    return layout, off
+
+
+class _TrajGenerator:
+    """Stand-in for InferenceWalkingTrajectoryLoader (tasks/trajectory_loaders.py:267-309)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self._snippet = None
+
+    def set_next_trajectory(self, qpos, qvel):
+        self._snippet = {'qpos': np.asarray(qpos, float), 'qvel': np.asarray(qvel, float)}
+        self._owner._apply_reference()
+
+    def get_trajectory(self, traj_idx=None):
+        return self._snippet
+
+    def get_joint_names(self): return []
+    def get_site_names(self): return []
+
+
+class _Task:
+    def __init__(self, owner):
+        self._traj_generator = _TrajGenerator(owner)
+
+
+class _Physics:
+    def __init__(self, owner): self._owner = owner
+    def timestep(self): return float(self._owner.model.arrays['opt_timestep'])
+    def time(self): return self._owner._time
+
+
+class BatchedFlyEnv:
+    """n_env walk_imitation environments stepped in lock-step by one kernel launch per control step."""
+
+    def __init__(self, n_env: int = 1, device: int = 0, precision: int = 32, terminal_com_dist: float = 0.3,
+                 joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation'):
+        arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
+        if joint_filter <= 0:
+            raise NotImplementedError('joint_filter=0 changes the activation layout: recompile the model with '
+                                      'tools/compile_models.py (needs the reference fruitfly.xml)')
+        if joint_filter != 0.01:
+            arrays = dict(arrays)
+            dyn = arrays['actuator_dynprm'].copy()
+            dyn[arrays['actuator_trntype'] != 5] = joint_filter       # fruitfly.py:330-335
+            arrays['actuator_dynprm'] = dyn
+        self.model = engine.Model(arrays)
+        self.n_env = n_env; self.device = device
+        self.batch = engine.Batch(self.model, n_env, device=device, precision=precision)
+        self.future_steps = future_steps; self.terminal_com_dist = terminal_com_dist; self.time_limit = time_limit
+        self.task = _Task(self); self.physics = _Physics(self)
+        self._time = 0.0
+        qp, qv = default_walking_reference()
+        self.task._traj_generator.set_next_trajectory(qp, qv)
+        self.layout, self.nobs = observation_layout(self.model, future_steps)
+        self._torch_views = None
+
+    def _apply_reference(self):
+        s = self.task._traj_generator._snippet
+        self.batch.set_reference(s['qpos'], s['qvel'], future_steps=self.future_steps,
+                                 terminal_com_dist=self.terminal_com_dist, time_limit=self.time_limit)
+        self._torch_views = None
+
+    # ---- specs --------------------------------------------------------------------------------
+    def action_spec(self) -> BoundedArray:
+        a = self.model.arrays
+        idx = a['action_to_ctrl']
+        rng = a['actuator_ctrlrange'][idx]
+        names = [str(a['names_actuator'][i]) for i in idx]
+        return BoundedArray((len(idx),), float, rng[:, 0], rng[:, 1], name='\t'.join(names))
+
+    def observation_spec(self):
+        return collections.OrderedDict(('walker/' + k, Array(self.layout[k][2], np.float32, 'walker/' + k)) for k in _DICT_ORDER)
+
+    def control_timestep(self) -> float:
+        return float(self.model.arrays['opt_control_timestep'])
+
+    # ---- torch interface (zero-copy views of the engine's device buffers) -----------------------
+    def torch_views(self):
+        if self._torch_views is None:
+            import torch
+
+            def view(name, shape, dtype):
+                nbytes = int(np.prod(shape)) * torch.tensor([], dtype=dtype).element_size()
+                ptr = self.batch.device_ptr(name)
+                iface = {'shape': tuple(shape), 'typestr': {torch.float32: '<f4', torch.int32: '<i4'}[dtype],
+                         'data': (ptr, False), 'version': 2}
+                holder = type('DevBuf', (), {'__cuda_array_interface__': iface})()
+                t = torch.as_tensor(holder, device=f'cuda:{self.device}')
+                assert t.numel() * t.element_size() == nbytes
+                return t
+            self._torch_views = dict(obs=view('OBS', (self.n_env, self.nobs), torch.float32),
+                                     reward=view('REWARD', (self.n_env,), torch.float32),
+                                     discount=view('DISCOUNT', (self.n_env,), torch.float32),
+                                     step_type=view('STEP_TYPE', (self.n_env,), torch.int32))
+        return self._torch_views
+
+    def reset_all(self):
+        import torch
+        self.batch.reset(stream=torch.cuda.current_stream().cuda_stream)
+        self._time = 0.0
+        return self.torch_views()
+
+    def step_tensor(self, action):
+        """action: float32 CUDA tensor [n_env, nu] (contiguous).  Asynchronous on torch's current stream."""
+        import torch
+        assert action.is_cuda and action.dtype == torch.float32 and action.is_contiguous()
+        assert tuple(action.shape) == (self.n_env, self.model.dim('nu'))
+        self.batch.step_ptr(action.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self._time += self.control_timestep()
+        return self.torch_views()
+
+    # ---- dm_env-style host interface ----------------------------------------------------------
+    def _timestep(self, env: int = 0) -> TimeStep:
+        obs = self.batch.get('OBS')[env]
+        st = StepType(int(self.batch.get('STEP_TYPE')[env, 0]))
+        od = collections.OrderedDict()
+        for k in _DICT_ORDER:
+            off, n, shp = self.layout[k]
+            od['walker/' + k] = obs[off:off + n].reshape(shp).copy()
+        if st == StepType.FIRST:
+            return TimeStep(st, None, None, od)
+        return TimeStep(st, float(self.batch.get('REWARD')[env, 0]), float(self.batch.get('DISCOUNT')[env, 0]), od)
+
+    def reset(self) -> TimeStep:
+        self.batch.reset(); self.batch.synchronize()
+        self._time = 0.0
+        return self._timestep()
+
+    def step(self, action) -> TimeStep:
+        import torch
+        a = np.broadcast_to(np.asarray(action, np.float32), (self.n_env, self.model.dim('nu')))
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(f'cuda:{self.device}')
+        self.batch.step_ptr(t.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ts = self._timestep()
+        self._time = 0.0 if ts.first() else self._time + self.control_timestep()
+        return ts
+
+
+def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False, disable_wings: bool = True,
+                   traj_indices: Optional[Sequence[int]] = None, random_state=None, terminal_com_dist: float = 0.3,
+                   joint_filter: float = 0.01, n_env: int = 1, device: int = 0, precision: int = 32) -> BatchedFlyEnv:
+    """Same keyword surface as flybody/fly_envs.py:100-106, plus n_env / device / precision."""
+    if ref_path is not None:
+        raise NotImplementedError('HDF5 reference datasets (training-mode reward) are a "next" row of SURVEY.md 8(f); '
+                                  'inference mode (ref_path=None) is implemented')
+    if force_actuators or not disable_wings:
+        raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
+    return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
+                         joint_filter=joint_filter, future_steps=64, time_limit=10.0)

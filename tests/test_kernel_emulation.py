@@ -1,0 +1,96 @@
+"""The HIP kernel SOURCE, compiled for the host with tests/../csrc/emu/hip_emu.hpp (64 fibers per
+wavefront), against the CPU oracle.  This exercises the kernels' indexing, chain-compressed
+constraint algebra, level-parallel LDL and the C-ABI on a GPU-less box.  It is test infrastructure:
+the product path never loads the emulation library (see test_abi.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, random_state
+
+_rel = lambda a, b: np.abs(np.asarray(a).ravel() - np.asarray(b).ravel()).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def emu_lib():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    return g.build_emu()
+
+
+@pytest.fixture(scope='module')
+def emu_model(walk_arrays, emu_lib):
+    from flybody_amd import engine
+    return engine.Model(walk_arrays, lib_path=emu_lib)
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 5e-3)])
+def test_forward_stage_parity(emu_model, oracle_model, walk_arrays, precision, tol):
+    from flybody_amd import engine
+    from oracle import fbo
+    rng = np.random.default_rng(1)
+    B = engine.Batch(emu_model, 5, precision=precision)      # 5: exercises a partially filled workgroup
+    od = fbo.OracleData(oracle_model)
+    q, v = random_state(walk_arrays, rng, z=0.13 if precision == 32 else 0.125)
+    if precision == 32:
+        q = q.astype(np.float32).astype(float); v = v.astype(np.float32).astype(float)
+    ctrl = rng.uniform(-0.3, 0.3, 59); act = rng.uniform(-0.2, 0.2, 59)
+    for name, val in (('QPOS', q), ('QVEL', v), ('CTRL', ctrl), ('ACT', act)):
+        B.set(name, val)
+    od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.field('ctrl')[:] = ctrl; od.field('act')[:] = act
+    B.forward(); od.call('forward')
+    for name, of in [('XPOS', 'xpos'), ('XQUAT', 'xquat'), ('QM', 'qM'), ('QFRC_BIAS', 'qfrc_bias'),
+                     ('QFRC_PASSIVE', 'qfrc_passive'), ('QFRC_ACTUATOR', 'qfrc_actuator'), ('QACC_SMOOTH', 'qacc_smooth')]:
+        assert _rel(B.get(name)[0], od.field(of)) < tol, name
+    if precision == 64:
+        assert int(B.get('NCON')[0, 0]) == int(od.scalar('ncon')) and int(B.get('NEFC')[0, 0]) == int(od.scalar('nefc'))
+        n = int(od.scalar('nefc'))
+        assert _rel(B.get('EFC_FORCE')[0][:n], od.field('efc_force')[:n]) < 1e-6
+        assert _rel(B.get('QACC')[0], od.field('qacc')) < 1e-6
+        assert _rel(B.get('SENSORDATA')[0], od.field('sensordata')) < 1e-6
+        oc = od.contacts(); gc = B.get('CONTACT')[0].reshape(64, 8)[:len(oc)]
+        assert _rel(gc[:, :7], oc[:, :7]) < 1e-9
+    q4 = B.get('QACC')
+    assert np.array_equal(q4[0], q4[4])
+
+
+def test_env_steps_match_oracle_and_golden(emu_model, oracle_model, reference_traj):
+    from flybody_amd import engine
+    from oracle import fbo
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'oracle_walk_rollout.npz'))
+    qp, qv = reference_traj
+    B = engine.Batch(emu_model, 2, precision=64)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    od = fbo.OracleData(oracle_model); od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
+    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-5, atol=1e-4)
+    for k in range(3):
+        a = np.ascontiguousarray(np.tile(g['actions'][k], (2, 1)))
+        B.step_ptr(a.ctypes.data)
+        od.env_step(g['actions'][k].astype(np.float64))
+    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-9
+    assert _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-8
+    assert np.allclose(B.get('QPOS')[0], g['qpos'][3], rtol=1e-8, atol=1e-10)
+    assert np.allclose(B.get('OBS')[0], g['obs'][3], rtol=1e-4, atol=1e-3)
+    assert B.get('REWARD')[0, 0] == 1.0 and B.get('STEP_TYPE')[0, 0] == 1
+
+
+def test_lane_order_independence(emu_lib):
+    """Running the 64 lanes in reverse order between barriers must not change a single bit:
+    a cheap detector for missing synchronisation."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from flybody_amd import engine\n"
+        "from flybody_amd.reference import default_walking_reference\n"
+        "M = engine.Model.from_asset('walk_imitation', lib_path=%r); B = engine.Batch(M, 1, precision=64)\n"
+        "qp, qv = default_walking_reference(); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()\n"
+        "a = np.random.default_rng(0).uniform(-0.5, 0.5, (1, 59)).astype(np.float32)\n"
+        "B.step_ptr(a.ctypes.data)\n"
+        "sys.stdout.write(B.get('QPOS').tobytes().hex() + B.get('QVEL').tobytes().hex())\n" % (ROOT, emu_lib))
+    outs = []
+    for rev in ('0', '1'):
+        env = dict(os.environ, FB_EMU_REVERSE=rev)
+        outs.append(subprocess.check_output([sys.executable, '-c', code], env=env))
+    assert outs[0] == outs[1] and len(outs[0]) > 1000

@@ -1,0 +1,147 @@
+"""The CPU oracle pinned against physical invariants and its own golden rollout
+(no reference trajectory exists: "parity unpinned")."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_state
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _data(oracle_model):
+    from oracle import fbo
+    return fbo.OracleData(oracle_model)
+
+
+def test_equation_of_motion_residual(oracle_model, walk_arrays):
+    """M qacc + bias = passive + actuator + constraint at a random contact-rich state."""
+    d = _data(oracle_model); rng = np.random.default_rng(0)
+    q, v = random_state(walk_arrays, rng)
+    d.field('qpos')[:] = q; d.field('qvel')[:] = v; d.field('ctrl')[:] = rng.uniform(-0.3, 0.3, 59)
+    d.call('forward')
+    assert d.scalar('ncon') > 0 and d.scalar('nefc') > 0
+    qacc = d.field('qacc').copy()
+    res = d.mul_m(qacc) + d.field('qfrc_bias') - d.field('qfrc_passive') - d.field('qfrc_actuator') - d.field('qfrc_constraint')
+    assert np.abs(res).max() < 1e-9 * max(1.0, np.abs(d.field('qfrc_constraint')).max())
+    # RNE with accelerations reproduces M qacc + bias minus the armature term
+    assert np.allclose(d.rne(1), d.mul_m(qacc) + d.field('qfrc_bias') - walk_arrays['dof_armature']*qacc, rtol=1e-9, atol=1e-9)
+
+
+def test_mass_matrix_symmetric_positive_definite(oracle_model, walk_arrays):
+    d = _data(oracle_model); rng = np.random.default_rng(1)
+    q, v = random_state(walk_arrays, rng)
+    d.field('qpos')[:] = q
+    d.call('kinematics'); d.call('com_pos'); d.call('crb')
+    nv = 108
+    M = np.array([d.mul_m(np.eye(nv)[i]) for i in range(nv)])
+    assert np.abs(M - M.T).max() < 1e-18
+    assert np.linalg.eigvalsh(M).min() > 0
+    # at qpos0 the compiled reference-configuration matrix is reproduced
+    d.field('qpos')[:] = walk_arrays['qpos0']
+    d.call('kinematics'); d.call('com_pos'); d.call('crb')
+    M0 = np.array([d.mul_m(np.eye(nv)[i]) for i in range(nv)])
+    assert np.abs(M0 - walk_arrays['M0_full']).max() < 1e-16
+    # factorisation: solve(M x) == x
+    d.call('factor_m')
+    x = rng.normal(size=nv)
+    from oracle.fbo import lib
+    import ctypes as C
+    y = d.mul_m(x).copy()
+    lib().fbo_solve_m.argtypes = [C.c_void_p] * 4
+    lib().fbo_solve_m(d.h, y.ctypes.data, d.field('qLD').ctypes.data, d.field('qLDiagInv').ctypes.data)
+    assert np.allclose(y, x, rtol=1e-8, atol=1e-10)
+
+
+def test_jacobian_matches_finite_differences(oracle_model, walk_arrays):
+    d = _data(oracle_model); rng = np.random.default_rng(2)
+    q0, _ = random_state(walk_arrays, rng, spread=0.3)
+    names = list(walk_arrays['names_body']); body = names.index('claw_T2_left'); nv = 108
+
+    def integrate(q, v, h):
+        q = q.copy(); q[0:3] += h*v[0:3]
+        w = v[3:6]*h; ang = np.linalg.norm(w)
+        if ang > 0:
+            ax = w/ang; b = np.concatenate([[np.cos(ang/2)], np.sin(ang/2)*ax]); a = q[3:7].copy()
+            q[3:7] = [a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
+                      a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0]]
+        q[7:] += h*v[6:]
+        return q
+    d.field('qpos')[:] = q0; d.call('kinematics'); d.call('com_pos')
+    p0 = d.field('xpos').reshape(-1, 3)[body].copy()
+    jp, _ = d.jac(p0, body)
+    eps = 1e-6; jfd = np.zeros((3, nv))
+    for i in range(nv):
+        e = np.zeros(nv); e[i] = 1
+        d.field('qpos')[:] = integrate(q0, e, eps); d.call('kinematics'); pp = d.field('xpos').reshape(-1, 3)[body].copy()
+        d.field('qpos')[:] = integrate(q0, e, -eps); d.call('kinematics'); pm = d.field('xpos').reshape(-1, 3)[body].copy()
+        jfd[:, i] = (pp - pm)/(2*eps)
+    assert np.abs(jfd - jp).max() < 1e-7
+
+
+def test_free_fall_and_constraint_signs(oracle_model, walk_arrays):
+    """High above the floor no contact enters the solver and the tree's centre of mass falls with g
+    (semi-implicit Euler: z_n = -g h^2 n(n+1)/2, internal spring/actuator forces cancel);
+    resting on the floor the normal forces are non-negative and inside the friction cone."""
+    d = _data(oracle_model)
+    q = walk_arrays['qpos0'].copy(); q[2] = 5.0
+    d.field('qpos')[:] = q; d.call('step1')
+    assert all(c[10] < 0 for c in d.contacts())
+    z0 = d.field('subtree_com')[5]
+    n = 5; h = float(walk_arrays['opt_timestep'])
+    for _ in range(n):
+        d.call('step')
+    dz = d.field('subtree_com')[5] - z0
+    assert np.isclose(dz, -981.0*h*h*n*(n + 1)/2, rtol=2e-3)
+    d.call('reset_state'); d.call('forward')
+    c = d.contacts(); f = d.field('efc_force')
+    assert sum(1 for row in c if row[10] >= 0) >= 6
+    for row in c:
+        adr = int(row[10])
+        if adr < 0:
+            continue
+        assert f[adr] >= 0
+        if int(row[9]) == 3:
+            assert np.hypot(f[adr+1], f[adr+2]) <= 1.0*f[adr] + 1e-9    # claw-floor friction coefficient 1.0
+
+
+def test_env_semantics(oracle_model, reference_traj):
+    """reward == 1 in inference mode (tests/test_walking_env.py:72), FIRST/MID/LAST bookkeeping,
+    episode length min(5001, T - 65) = 235 (walk_imitation.py:104-105), auto-reset."""
+    d = _data(oracle_model); qp, qv = reference_traj
+    d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset()
+    assert d.scalar('step_type') == 0 and d.scalar('nobs') == 741 and d.scalar('episode_steps') == 235
+    rng = np.random.default_rng(0); last_at = None
+    for k in range(240):
+        d.env_step(rng.uniform(-0.5, 0.5, 59))
+        if d.scalar('step_type') == 0:
+            assert last_at == k - 1                      # the step after LAST is a reset (FIRST)
+            break
+        assert d.scalar('reward') == 1.0
+        if d.scalar('step_type') == 2:
+            last_at = k
+            assert d.scalar('discount') == 1.0 and k == 234   # good termination at the trajectory end
+    assert last_at == 234
+    # NaN actions are zeroed (walk_imitation.py:148)
+    a = np.full(59, np.nan); d.env_step(a)
+    assert np.isfinite(d.field('qpos')).all()
+    # falling far behind the ghost terminates with discount 0
+    d2 = _data(oracle_model); d2.configure_env(qp, qv, terminal_com_dist=0.05); d2.env_reset()
+    for k in range(60):
+        d2.env_step(np.zeros(59))
+        if d2.scalar('step_type') == 2:
+            break
+    assert d2.scalar('step_type') == 2 and d2.scalar('discount') == 0.0
+
+
+def test_golden_rollout_regression(oracle_model, reference_traj):
+    g = np.load(os.path.join(HERE, 'golden', 'oracle_walk_rollout.npz'))
+    d = _data(oracle_model); qp, qv = reference_traj
+    d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset()
+    assert np.allclose(d.field('obs'), g['obs'][0], rtol=1e-5, atol=1e-4)
+    for k in range(20):
+        d.env_step(g['actions'][k].astype(np.float64))
+    assert np.allclose(d.field('qpos'), g['qpos'][20], rtol=1e-7, atol=1e-9)
+    assert np.allclose(d.field('qvel'), g['qvel'][20], rtol=1e-6, atol=1e-7)
+    assert np.allclose(d.field('obs'), g['obs'][20], rtol=1e-4, atol=1e-3)
