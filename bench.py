@@ -126,6 +126,11 @@ def main():
         dt = float(t.item())
     q = batch.get('QPOS')
     finite = bool(np.isfinite(q).all())
+    traffic = None
+    tr_path = os.path.join(ROOT, 'profiles', f'pmc_traffic_f{args.precision}.json')
+    if os.path.exists(tr_path):
+        # recorded by tools/collect_profiles.sh with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)
+        traffic = json.load(open(tr_path))
     if rank == 0:
         total_env_steps = n_env * world * args.steps
         value = total_env_steps / dt
@@ -141,7 +146,8 @@ def main():
                        'envs_per_gpu': n_env, 'global_envs': n_env * world, 'substeps_per_step': model.dim('nsubstep'),
                        'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': (traffic or {}).get('bytes_per_launch'),
+                         'traffic_source': (traffic or {}).get('source'),
                          'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
                          'note': 'SURVEY 8(d): the path is vector-ALU/latency bound, not HBM bound; '

@@ -1,0 +1,57 @@
+"""The dm_env surface of fly_envs.walk_imitation(), mirroring the reference's own env tests
+(tests/test_walking_env.py:37-72) on the HIP engine."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+expect_obs_names = ['walker/' + s for s in ['accelerometer', 'actuator_activation', 'appendages_pos', 'force', 'gyro',
+                                            'joints_pos', 'joints_vel', 'touch', 'velocimeter', 'world_zaxis',
+                                            'ref_displacement', 'ref_root_quat']]
+n_steps = 200
+qpos = np.zeros((n_steps, 7)); qpos[:, 0] = np.arange(0, n_steps*0.002, 0.002); qpos[:, [2, 3]] = [0.14355, 1.]
+qvel = np.zeros((n_steps, 6)); qvel[:, 0] = 1.
+
+
+def test_can_create_env_inference_mode():
+    from flybody_amd.fly_envs import walk_imitation
+    env = walk_imitation(terminal_com_dist=float('inf'), precision=64)
+    assert list(env.observation_spec()) == expect_obs_names
+    spec = env.action_spec()
+    assert spec.shape == (59,) and (spec.minimum < spec.maximum).all() and len(spec.name.split('\t')) == 59
+    env.task._traj_generator.set_next_trajectory(qpos, qvel)
+    ts = env.reset()
+    assert ts.first() and ts.reward is None
+    for name in expect_obs_names:
+        assert isinstance(ts.observation[name], np.ndarray)
+    assert ts.observation['walker/ref_displacement'].shape == (65, 3) and ts.observation['walker/ref_root_quat'].shape == (65, 4)
+    assert np.isclose(env.control_timestep(), 2e-3) and np.isclose(env.physics.timestep(), 2e-4)
+
+
+def test_can_step_env_inference_mode():
+    from flybody_amd.fly_envs import walk_imitation
+    env = walk_imitation(terminal_com_dist=float('inf'), precision=64)
+    env.task._traj_generator.set_next_trajectory(qpos, qvel)
+    env.reset()
+    for _ in range(100):
+        ts = env.step(np.random.uniform(-0.5, 0.5, 59))
+        assert ts.reward == 1.        # at test time the reward is 1
+    assert ts.mid() and ts.discount == 1.0
+    # episode ends after min(5001, 200 - 65) = 135 steps, then the next step() is a reset
+    for _ in range(35):
+        ts = env.step(np.zeros(59))
+    assert ts.last() and ts.discount == 1.0
+    ts = env.step(np.zeros(59))
+    assert ts.first()
+
+
+def test_batched_tensor_interface():
+    import torch
+    from flybody_amd.fly_envs import walk_imitation
+    env = walk_imitation(n_env=256, precision=32, terminal_com_dist=float('inf'))
+    v = env.reset_all()
+    assert v['obs'].shape == (256, 741) and v['obs'].is_cuda
+    a = torch.zeros(256, 59, device='cuda')
+    v = env.step_tensor(a); torch.cuda.synchronize()
+    assert torch.isfinite(v['obs']).all() and (v['reward'] == 1).all() and (v['step_type'] == 1).all()
+    assert torch.equal(v['obs'][0], v['obs'][255])
