@@ -1,0 +1,113 @@
+"""DMPO learner step (flybody/agents/learning_dmpo.py:169-317) in PyTorch, with one flat-buffer
+gradient all-reduce per step for multi-GPU data parallelism (RCCL over xGMI via torch.distributed)."""
+from __future__ import annotations
+
+import copy
+import dataclasses
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .losses import MPOLoss, categorical_td_loss
+from .networks import DMPONetworks
+
+
+@dataclasses.dataclass
+class DMPOConfig:
+    """Defaults of flybody/train_dmpo_ray.py:107-137 / agents/ray_distributed_dmpo.py:33-64."""
+    batch_size: int = 256
+    num_samples: int = 20
+    n_step: int = 5
+    discount: float = 0.99
+    min_replay_size: int = 10_000
+    max_replay_size: int = 4_000_000
+    samples_per_insert: float = 15.0
+    target_policy_update_period: int = 101
+    target_critic_update_period: int = 107
+    policy_lr: float = 1e-4
+    critic_lr: float = 1e-4
+    dual_lr: float = 1e-3
+    clipping: bool = True
+    max_grad_norm: float = 40.0
+
+
+class DMPOLearner:
+    def __init__(self, networks: DMPONetworks, loss: MPOLoss, config: DMPOConfig = DMPOConfig(), device='cpu'):
+        self.cfg = config; self.device = torch.device(device)
+        self.online = networks.to(self.device)
+        self.target = copy.deepcopy(self.online).requires_grad_(False)
+        self.loss = loss.to(self.device)
+        self.policy_params = list(self.online.policy.parameters())
+        self.critic_params = list(self.online.critic.parameters())
+        self.dual_params = list(self.loss.parameters())
+        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr)
+        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr)
+        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr)
+        self.num_steps = 0
+        # one flat gradient buffer; every parameter's .grad is a view into it
+        allp = self.policy_params + self.critic_params + self.dual_params
+        self.flat_grad = torch.zeros(sum(p.numel() for p in allp), device=self.device)
+        off = 0
+        for p in allp:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p); off += p.numel()
+
+    def broadcast_parameters(self):
+        """Make every rank start from rank 0's weights (replicas then stay identical deterministically)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for t in list(self.online.state_dict().values()) + list(self.loss.state_dict().values()):
+                dist.broadcast(t, 0)
+            self.target.load_state_dict(self.online.state_dict())
+
+    def _sync_targets(self):
+        if self.num_steps % self.cfg.target_policy_update_period == 0:
+            self.target.policy.load_state_dict(self.online.policy.state_dict())
+        if self.num_steps % self.cfg.target_critic_update_period == 0:
+            self.target.critic.load_state_dict(self.online.critic.state_dict())
+
+    def step(self, batch) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        o_tm1, a_tm1, r_t, d_t, o_t = batch
+        self._sync_targets()
+        self.num_steps += 1
+        N, B = cfg.num_samples, o_t.shape[0]
+        with torch.no_grad():
+            t_mean, t_std = self.target.policy(o_t)
+            sampled = t_mean[None] + t_std[None] * torch.randn(N, B, t_mean.shape[-1], device=self.device)
+            tiled = o_t[None].expand(N, B, o_t.shape[-1]).reshape(N * B, -1)
+            q_t_logits = self.target.critic(tiled, sampled.reshape(N * B, -1))
+            logp = torch.log_softmax(q_t_logits.view(N, B, -1), dim=-1)
+            avg_logits = torch.logsumexp(logp, dim=0)
+            sampled_q = self.target.critic.mean_q(q_t_logits).view(N, B)
+        o_mean, o_std = self.online.policy(o_t)
+        q_tm1_logits = self.online.critic(o_tm1, a_tm1)
+        critic_loss = categorical_td_loss(q_tm1_logits, self.online.critic.values, r_t, cfg.discount * d_t, avg_logits).mean()
+        policy_loss, stats = self.loss(o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        self.flat_grad.zero_()
+        # critic loss trains the critic only; policy loss trains policy + duals (independent graphs)
+        (critic_loss + policy_loss).backward()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad)                  # ONE collective per learner step
+            self.flat_grad.div_(dist.get_world_size())
+        if cfg.clipping:
+            torch.nn.utils.clip_grad_norm_(self.policy_params, cfg.max_grad_norm)
+            torch.nn.utils.clip_grad_norm_(self.critic_params, cfg.max_grad_norm)
+        self.critic_opt.step(); self.policy_opt.step(); self.dual_opt.step()
+        stats = dict(stats); stats['critic_loss'] = critic_loss.detach(); stats['policy_loss'] = policy_loss.detach()
+        return stats
+
+    @torch.no_grad()
+    def act(self, obs, deterministic: bool = False):
+        mean, std = self.online.policy(obs)
+        a = mean if deterministic else mean + std * torch.randn_like(mean)
+        return a.clamp(-1.0, 1.0)
+
+    def state_dict(self):
+        return dict(online=self.online.state_dict(), target=self.target.state_dict(), duals=self.loss.state_dict(),
+                    policy_opt=self.policy_opt.state_dict(), critic_opt=self.critic_opt.state_dict(),
+                    dual_opt=self.dual_opt.state_dict(), num_steps=self.num_steps)
+
+    def load_state_dict(self, sd):
+        self.online.load_state_dict(sd['online']); self.target.load_state_dict(sd['target']); self.loss.load_state_dict(sd['duals'])
+        self.policy_opt.load_state_dict(sd['policy_opt']); self.critic_opt.load_state_dict(sd['critic_opt'])
+        self.dual_opt.load_state_dict(sd['dual_opt']); self.num_steps = sd['num_steps']

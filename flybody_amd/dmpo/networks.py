@@ -1,0 +1,98 @@
+"""Policy / critic networks of the DMPO agent (flybody/agents/network_factory.py:66-109).
+
+policy : concat(obs) -> LayerNormMLP(256,256,256, activate_final) -> diagonal Gaussian head
+         (init_scale 0.7, min_scale 1e-6)
+critic : concat(obs, clip(action)) -> LayerNormMLP(512,512,256, activate_final) -> 51-atom categorical
+         head on [-150, 150]
+LayerNormMLP = Linear -> LayerNorm -> tanh -> (Linear -> ELU)*  (Acme networks.LayerNormMLP).
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _uniform_fan_out_(w: torch.Tensor, scale: float = 0.333):
+    # VarianceScaling(scale, mode='fan_out', distribution='uniform'); torch weight is [out, in]
+    limit = math.sqrt(3.0 * scale / w.shape[0])
+    with torch.no_grad():
+        w.uniform_(-limit, limit)
+
+
+class LayerNormMLP(nn.Module):
+    def __init__(self, in_dim: int, sizes: Sequence[int], activate_final: bool = True):
+        super().__init__()
+        self.first = nn.Linear(in_dim, sizes[0])
+        self.norm = nn.LayerNorm(sizes[0])
+        self.rest = nn.ModuleList(nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:]))
+        self.activate_final = activate_final
+        for lin in [self.first, *self.rest]:
+            _uniform_fan_out_(lin.weight); nn.init.zeros_(lin.bias)
+
+    def forward(self, x):
+        h = torch.tanh(self.norm(self.first(x)))
+        for i, lin in enumerate(self.rest):
+            h = lin(h)
+            if self.activate_final or i < len(self.rest) - 1:
+                h = F.elu(h)
+        return h
+
+
+class GaussianHead(nn.Module):
+    """MultivariateNormalDiagHead: mean = Linear, stddev = softplus(Linear) * init_scale/softplus(0) + min_scale."""
+
+    def __init__(self, in_dim: int, action_dim: int, init_scale: float = 0.7, min_scale: float = 1e-6):
+        super().__init__()
+        self.mean = nn.Linear(in_dim, action_dim)
+        self.scale = nn.Linear(in_dim, action_dim)
+        for lin in (self.mean, self.scale):
+            nn.init.normal_(lin.weight, std=math.sqrt(1e-4 / in_dim)); nn.init.zeros_(lin.bias)
+        self.init_scale = init_scale; self.min_scale = min_scale
+
+    def forward(self, h):
+        mean = self.mean(h)
+        std = F.softplus(self.scale(h)) * (self.init_scale / math.log(2.0)) + self.min_scale
+        return mean, std
+
+
+class Policy(nn.Module):
+    def __init__(self, obs_dim, action_dim, sizes=(256, 256, 256)):
+        super().__init__()
+        self.torso = LayerNormMLP(obs_dim, sizes, activate_final=True)
+        self.head = GaussianHead(sizes[-1], action_dim)
+
+    def forward(self, obs):
+        return self.head(self.torso(obs))
+
+
+class Critic(nn.Module):
+    def __init__(self, obs_dim, action_dim, sizes=(512, 512, 256), vmin=-150.0, vmax=150.0, num_atoms=51):
+        super().__init__()
+        self.torso = LayerNormMLP(obs_dim + action_dim, sizes, activate_final=True)
+        self.logits = nn.Linear(sizes[-1], num_atoms)
+        nn.init.normal_(self.logits.weight, std=math.sqrt(1e-5 / sizes[-1])); nn.init.zeros_(self.logits.bias)
+        self.register_buffer('values', torch.linspace(vmin, vmax, num_atoms))
+
+    def forward(self, obs, action):
+        # ClipToSpec on canonical actions ([-1, 1] after CanonicalSpecWrapper, train_dmpo_ray.py:89)
+        x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
+        return self.logits(self.torso(x))
+
+    def mean_q(self, logits):
+        return (F.softmax(logits, dim=-1) * self.values).sum(-1)
+
+
+class DMPONetworks(nn.Module):
+    def __init__(self, obs_dim: int, action_dim: int, policy_sizes=(256, 256, 256), critic_sizes=(512, 512, 256),
+                 vmin=-150.0, vmax=150.0, num_atoms=51):
+        super().__init__()
+        self.policy = Policy(obs_dim, action_dim, policy_sizes)
+        self.critic = Critic(obs_dim, action_dim, critic_sizes, vmin, vmax, num_atoms)
+
+
+def make_networks(obs_dim: int, action_dim: int, **kw) -> DMPONetworks:
+    return DMPONetworks(obs_dim, action_dim, **kw)

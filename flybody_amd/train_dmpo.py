@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""On-GPU DMPO training loop for walk_imitation (BASELINE configs[2] and [4]).
+
+Replaces the reference's Ray topology (flybody/train_dmpo_ray.py: 32 CPU actors + Reverb + 1 GPU learner)
+with: batched rollouts of thousands of environments on the same GPU as the learner, an on-GPU n-step replay,
+and -- for N GPUs -- one process per GPU (torchrun), environment shards per rank and one flat gradient
+all-reduce per learner step over RCCL.
+
+    python -m flybody_amd.train_dmpo --envs 4096 --iters 200
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m flybody_amd.train_dmpo --envs 4096
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, make_networks
+from .dmpo.losses import PenalizationCostRealActions
+from .fly_envs import BatchedFlyEnv
+
+
+class Trainer:
+    def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=1, seed=0,
+                 config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3):
+        self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device('cuda', self.local_rank)
+        if self.world > 1 and not dist.is_initialized():
+            dist.init_process_group('nccl', device_id=self.device)
+        self.env = BatchedFlyEnv(n_env=n_env, device=self.local_rank, precision=precision, terminal_com_dist=terminal_com_dist)
+        spec = self.env.action_spec()
+        self.a_min = torch.as_tensor(spec.minimum, dtype=torch.float32, device=self.device)
+        self.a_scale = torch.as_tensor(spec.maximum - spec.minimum, dtype=torch.float32, device=self.device)
+        nu, nobs = spec.shape[0], self.env.nobs
+        torch.manual_seed(seed)                       # identical initial weights on every rank
+        nets = make_networks(nobs, nu)
+        loss = MPOLoss(nu, epsilon=0.1, epsilon_mean=0.0025, epsilon_stddev=1e-7, action_penalization=True, epsilon_penalty=0.1,
+                       penalization_cost=PenalizationCostRealActions(spec.minimum, spec.maximum, self.device))
+        self.cfg = config
+        self.learner = DMPOLearner(nets, loss, config, device=self.device)
+        self.learner.broadcast_parameters()
+        torch.manual_seed(seed + 1000 * (self.rank + 1))   # per-rank exploration / replay sampling noise
+        self.replay = NStepReplay(n_env, nobs, nu, min(replay_capacity, config.max_replay_size), config.n_step, config.discount,
+                                  device=self.device, seed=seed + self.rank)
+        self.lsteps_per = learner_steps_per_env_step
+        self.views = self.env.reset_all()
+        self.obs = self.views['obs'].clone()
+        self.env_steps = 0; self.learner_steps = 0
+
+    def iterate(self, learn=True):
+        """One control step of every environment, replay insertion, and the scheduled learner steps."""
+        canon = self.learner.act(self.obs)
+        real = (self.a_min + 0.5 * (canon + 1.0) * self.a_scale).contiguous()       # CanonicalSpecWrapper inverse
+        v = self.env.step_tensor(real)
+        st = v['step_type']
+        first, last = st == 0, st == 2
+        nxt = v['obs'].clone()
+        self.replay.add(self.obs, canon, v['reward'], v['discount'], nxt, first, last)
+        self.obs = nxt
+        self.env_steps += self.env.n_env
+        stats = None
+        if learn and self.replay.size >= min(self.cfg.min_replay_size, self.replay.capacity // 2):
+            for _ in range(self.lsteps_per):
+                stats = self.learner.step(self.replay.sample(self.cfg.batch_size)); self.learner_steps += 1
+        return stats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--iters', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10); ap.add_argument('--precision', type=int, default=32)
+    ap.add_argument('--learner-steps', type=int, default=1, help='learner steps per control step of the batch')
+    ap.add_argument('--min-replay', type=int, default=10_000)
+    a = ap.parse_args()
+    tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
+                 config=DMPOConfig(min_replay_size=a.min_replay), terminal_com_dist=float('inf'))
+    for _ in range(a.warmup):
+        tr.iterate()
+    torch.cuda.synchronize()
+    if tr.world > 1:
+        dist.barrier()
+    e0, l0 = tr.env_steps, tr.learner_steps
+    t0 = time.perf_counter(); stats = None
+    for _ in range(a.iters):
+        stats = tr.iterate() or stats
+    torch.cuda.synchronize()
+    if tr.world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if tr.rank == 0:
+        out = {'metric': 'env steps/sec + learner steps/sec, walk_imitation DMPO on-GPU training', 'n_gpus': tr.world,
+               'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
+               'envs_per_gpu': a.envs, 'learner_steps_per_env_step': a.learner_steps, 'batch_size': tr.cfg.batch_size,
+               'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'dtype': f'f{a.precision} physics / f32 learner',
+               'reward': 'inference mode (== 1): synthetic reference, throughput run',
+               'stats': {k: float(v) for k, v in (stats or {}).items() if k in ('critic_loss', 'policy_loss', 'dual_temperature', 'kl_q_rel')}}
+        print(json.dumps(out))
+    if tr.world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,194 @@
+"""DMPO pieces on CPU tensors: losses against independent numpy restatements, the n-step replay
+against a per-environment Python reference, learner mechanics, and the 2-rank gradient all-reduce."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, categorical_td_loss, l2_project, make_networks
+
+
+def test_network_shapes_and_sizes():
+    nets = make_networks(741, 59)
+    assert sum(p.numel() for p in nets.policy.parameters()) == 352_374      # ~0.35 M
+    assert sum(p.numel() for p in nets.critic.parameters()) == 818_227      # ~0.82 M
+    mean, std = nets.policy(torch.randn(7, 741))
+    assert mean.shape == (7, 59) and (std > 0).all()
+    assert abs(float(std.mean()) - 0.7) < 0.05                               # init_scale 0.7
+    logits = nets.critic(torch.randn(7, 741), torch.randn(7, 59) * 3)
+    assert logits.shape == (7, 51)
+    assert torch.allclose(nets.critic.values, torch.linspace(-150, 150, 51))
+
+
+def test_l2_projection_properties():
+    z = torch.linspace(-150, 150, 51)
+    p = torch.softmax(torch.randn(5, 51), -1)
+    # identity when the support is unchanged
+    assert torch.allclose(l2_project(z.expand(5, 51), p, z), p, atol=1e-6)
+    # mass is conserved and the mean is preserved for an in-range affine shift
+    zt = 3.0 + 0.9 * z
+    q = l2_project(zt.expand(5, 51), p, z)
+    assert torch.allclose(q.sum(-1), torch.ones(5), atol=1e-5)
+    assert torch.allclose((q * z).sum(-1), (p * zt).sum(-1), atol=1e-3)
+    # a point mass between two atoms splits linearly
+    pm = torch.zeros(1, 51); pm[0, 0] = 1.0
+    zt = torch.full((1, 51), -150 + 6 * 0.25)
+    q = l2_project(zt, pm, z)
+    assert abs(float(q[0, 0]) - 0.75) < 1e-6 and abs(float(q[0, 1]) - 0.25) < 1e-6
+
+
+def test_categorical_td_loss_minimum_at_target():
+    z = torch.linspace(-150, 150, 51)
+    tgt_logits = torch.randn(4, 51)
+    r = torch.zeros(4); d = torch.ones(4)
+    loss_same = categorical_td_loss(tgt_logits, z, r, d, tgt_logits)
+    loss_other = categorical_td_loss(torch.randn(4, 51), z, r, d, tgt_logits)
+    assert (loss_same <= loss_other + 1e-6).all()
+
+
+def test_mpo_loss_against_numpy():
+    torch.manual_seed(0)
+    N, B, D = 6, 5, 4
+    om, os_, tm, ts = torch.randn(B, D), torch.rand(B, D) + 0.3, torch.randn(B, D), torch.rand(B, D) + 0.3
+    acts = tm[None] + ts[None] * torch.randn(N, B, D); q = torch.randn(N, B)
+    loss_mod = MPOLoss(D, action_penalization=False, init_log_temperature=1.0, init_log_alpha_mean=1.0, init_log_alpha_stddev=2.0)
+    loss, stats = loss_mod(om, os_, tm, ts, acts, q)
+    sp = lambda x: math.log1p(math.exp(x))
+    T, am, asd = sp(1.0) + 1e-8, sp(1.0) + 1e-8, sp(2.0) + 1e-8
+    qn = q.numpy(); tq = qn / T
+    w = np.exp(tq - tq.max(0)) / np.exp(tq - tq.max(0)).sum(0)
+    lse = np.log(np.exp(tq - tq.max(0)).sum(0)) + tq.max(0)
+    loss_T = T * (0.1 + lse.mean() - math.log(N))
+    lp = lambda x, m, s: (-0.5 * ((x - m) / s) ** 2 - np.log(s) - 0.5 * math.log(2 * math.pi)).sum(-1)
+    A = acts.numpy()
+    l_mean = -(lp(A, om.numpy(), ts.numpy()) * w).sum(0).mean()
+    l_std = -(lp(A, tm.numpy(), os_.numpy()) * w).sum(0).mean()
+    kl = lambda m0, s0, m1, s1: np.log(s1 / s0) + (s0 ** 2 + (m0 - m1) ** 2) / (2 * s1 ** 2) - 0.5
+    klm = kl(tm.numpy(), ts.numpy(), om.numpy(), ts.numpy()).mean(0); kls = kl(tm.numpy(), ts.numpy(), tm.numpy(), os_.numpy()).mean(0)
+    total = l_mean + l_std + (am * klm).sum() + (asd * kls).sum() + (am * (0.0025 - klm)).sum() + (asd * (1e-7 - kls)).sum() + loss_T
+    assert abs(float(loss) - total) < 1e-3 * max(1.0, abs(total))
+    # gradient routing: E-step weights and KL regularisers are stop-gradiented where the reference does
+    loss.backward()
+    assert loss_mod.log_temperature.grad is not None and loss_mod.log_penalty_temperature.grad is None
+
+
+def _naive_nstep(episode, n, gamma):
+    """episode: list of (obs, act, rew, disc, next_obs, last); returns list of transitions (Acme NStepTransitionAdder order)."""
+    out = []; hist = []
+    for (o, a, r, d, no, last) in episode:
+        hist.append((o, a, r, d))
+        starts = [max(0, len(hist) - n)]
+        if last:
+            starts += list(range(starts[0] + 1, len(hist)))
+        for s in starts:
+            R, D = 0.0, 1.0
+            for (_, _, rr, dd) in hist[s:]:
+                R += D * rr; D *= dd * gamma
+            out.append((hist[s][0], hist[s][1], R, D / gamma, no))
+        if last:
+            hist = []
+    return out
+
+
+def test_nstep_replay_matches_reference_adder():
+    rng = np.random.default_rng(0)
+    n_env, n, gamma, T = 3, 5, 0.99, 23
+    rep = NStepReplay(n_env, 2, 1, capacity=1000, n_step=n, discount=gamma)
+    naive = [[] for _ in range(n_env)]; episodes = [[] for _ in range(n_env)]
+    obs = rng.normal(size=(n_env, 2)).astype(np.float32)
+    for t in range(T):
+        act = rng.normal(size=(n_env, 1)).astype(np.float32); rew = rng.normal(size=n_env).astype(np.float32)
+        last = np.array([(t + 1) % (7 + e) == 0 for e in range(n_env)])
+        first = np.array([(t % (7 + e) == 0) and t > 0 and False for e in range(n_env)])
+        disc = np.where(last, rng.integers(0, 2, n_env), 1).astype(np.float32)
+        nxt = rng.normal(size=(n_env, 2)).astype(np.float32)
+        rep.add(*(torch.from_numpy(x) for x in (obs, act, rew, disc, nxt)), torch.from_numpy(first), torch.from_numpy(last))
+        for e in range(n_env):
+            episodes[e].append((obs[e].copy(), act[e].copy(), float(rew[e]), float(disc[e]), nxt[e].copy(), bool(last[e])))
+        obs = np.where(last[:, None], rng.normal(size=(n_env, 2)).astype(np.float32), nxt)
+    want = [tr for e in range(n_env) for tr in _naive_nstep(episodes[e], n, gamma)]
+    assert rep.size == len(want)
+    got = sorted((tuple(np.round(rep.obs[i].numpy(), 4)), round(float(rep.reward[i]), 3), round(float(rep.discount[i]), 4),
+                  tuple(np.round(rep.next_obs[i].numpy(), 4))) for i in range(rep.size))
+    exp = sorted((tuple(np.round(w[0], 4)), round(w[2], 3), round(w[3], 4), tuple(np.round(w[4], 4))) for w in want)
+    assert got == exp
+    # FIFO overwrite and uniform sampling
+    small = NStepReplay(2, 2, 1, capacity=8, n_step=1, discount=gamma)
+    for t in range(10):
+        small.add(torch.full((2, 2), float(t)), torch.zeros(2, 1), torch.ones(2), torch.ones(2), torch.zeros(2, 2),
+                  torch.zeros(2, dtype=torch.bool), torch.zeros(2, dtype=torch.bool))
+    assert small.size == 8 and float(small.obs.min()) == 6.0
+    o, a, r, d, no = small.sample(64)
+    assert o.shape == (64, 2) and float(o.min()) >= 6.0
+
+
+def test_learner_step_mechanics():
+    torch.manual_seed(0)
+    nets = make_networks(20, 4, policy_sizes=(32, 32), critic_sizes=(32, 32))
+    cfg = DMPOConfig(batch_size=16, num_samples=5, target_policy_update_period=3, target_critic_update_period=2)
+    L = DMPOLearner(nets, MPOLoss(4), cfg)
+    batch = (torch.randn(16, 20), torch.rand(16, 4) * 2 - 1, torch.ones(16), torch.ones(16), torch.randn(16, 20))
+    losses = []
+    for _ in range(30):
+        s = L.step(batch); losses.append(float(s['critic_loss']))
+    assert losses[-1] < losses[0]                           # the critic fits the fixed batch
+    assert all(torch.isfinite(p).all() for p in nets.parameters())
+    # target networks trail the online ones and are synchronised on their periods
+    assert L.num_steps == 30
+    sd = L.state_dict(); L2 = DMPOLearner(make_networks(20, 4, policy_sizes=(32, 32), critic_sizes=(32, 32)), MPOLoss(4), cfg)
+    L2.load_state_dict(sd)
+    a1 = L.act(batch[0], deterministic=True); a2 = L2.act(batch[0], deterministic=True)
+    assert torch.equal(a1, a2) and a1.abs().max() <= 1.0
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, make_networks
+dist.init_process_group('gloo'); rank = dist.get_rank(); world = dist.get_world_size()
+torch.manual_seed(1234)                                  # identical initial weights on every rank
+L = DMPOLearner(make_networks(12, 3, policy_sizes=(16, 16), critic_sizes=(16, 16)), MPOLoss(3), DMPOConfig(num_samples=4))
+L.broadcast_parameters()
+g = torch.Generator().manual_seed(100 + rank)            # different data shard per rank
+batch = (torch.randn(8, 12, generator=g), torch.rand(8, 3, generator=g) * 2 - 1, torch.ones(8), torch.ones(8), torch.randn(8, 12, generator=g))
+torch.manual_seed(7)                                     # same action-sampling noise on both ranks
+L.step(batch)
+flat = torch.cat([p.detach().flatten() for p in L.online.parameters()])
+out = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(out, flat)
+if rank == 0:
+    assert torch.equal(out[0], out[1]), 'replicas diverged after the all-reduced step'
+    torch.save(L.flat_grad.clone(), %(out)r)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    out = str(tmp_path / 'grad.pt'); script = tmp_path / 'w.py'
+    script.write_text(WORKER % dict(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29544')
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+                           '127.0.0.1', '--master-port', '29544', str(script)], env=env, timeout=600)
+    # single-process reference: mean of the two ranks' gradients
+    grads = []
+    for rank in range(2):
+        torch.manual_seed(1234)
+        L = DMPOLearner(make_networks(12, 3, policy_sizes=(16, 16), critic_sizes=(16, 16)), MPOLoss(3), DMPOConfig(num_samples=4))
+        g = torch.Generator().manual_seed(100 + rank)
+        batch = (torch.randn(8, 12, generator=g), torch.rand(8, 3, generator=g) * 2 - 1, torch.ones(8), torch.ones(8), torch.randn(8, 12, generator=g))
+        torch.manual_seed(7)
+        L.cfg.clipping = False
+        # reproduce backward without the optimizer step
+        for opt in (L.policy_opt, L.critic_opt, L.dual_opt):
+            for grp in opt.param_groups:
+                grp['lr'] = 0.0
+        L.step(batch); grads.append(L.flat_grad.clone())
+    want = (grads[0] + grads[1]) / 2
+    got = torch.load(out)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)

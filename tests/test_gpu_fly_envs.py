@@ -55,3 +55,19 @@ def test_batched_tensor_interface():
     v = env.step_tensor(a); torch.cuda.synchronize()
     assert torch.isfinite(v['obs']).all() and (v['reward'] == 1).all() and (v['step_type'] == 1).all()
     assert torch.equal(v['obs'][0], v['obs'][255])
+
+
+def test_dmpo_training_loop_smoke():
+    """BASELINE configs[2] plumbing: on-GPU rollout -> n-step replay -> DMPO learner step."""
+    import torch
+    from flybody_amd.dmpo import DMPOConfig
+    from flybody_amd.train_dmpo import Trainer
+    tr = Trainer(n_env=256, precision=32, replay_capacity=20_000, config=DMPOConfig(min_replay_size=1000, batch_size=64, num_samples=8),
+                 terminal_com_dist=float('inf'))
+    stats = None
+    for _ in range(12):
+        stats = tr.iterate() or stats
+    torch.cuda.synchronize()
+    assert tr.replay.size > 1000 and tr.learner_steps > 0 and stats is not None
+    assert all(torch.isfinite(v).all() for v in stats.values())
+    assert torch.isfinite(tr.obs).all()
