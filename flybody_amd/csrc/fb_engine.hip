@@ -35,6 +35,7 @@ struct fb_model {
   std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, tri_a, tri_e, adh_act;
   int nlevel;
   std::vector<double> body_box;
+  std::vector<int> body_fluid_geom;
   double totalmass;
   const double* d(const char* n, size_t* cnt = nullptr) const {
     auto it = idx.find(n);
@@ -145,6 +146,9 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     m->body_box[3*b+1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass[b] * 6.0);
     m->body_box[3*b+2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass[b] * 6.0);
   }
+  m->body_fluid_geom.assign(nb, -1);
+  { const double* gfl = m->d("geom_fluid"); const int* gb = m->i("geom_bodyid");
+    for (int g = 0; g < m->ngeom; g++) if (gfl[12*g] > 0) m->body_fluid_geom[gb[g]] = g; }
   (void)dofbody;
   *out = m;
   return 0;
@@ -157,6 +161,8 @@ extern "C" int fb_model_dim(const fb_model* m, const char* name) {
   X(nq); X(nv); X(nbody); X(njnt); X(ngeom); X(nsite); X(nu); X(na); X(ntendon); X(npair); X(nM); X(nsubstep);
   X(nobsjnt); X(napp); X(nforce); X(ntouch);
 #undef X
+  if (!strcmp(name, "nact")) return m->nu + (m->i("user_action_idx")[0] >= 0 ? 1 : 0);
+  if (!strcmp(name, "task_id")) return m->i("task_id")[0];
   if (!strcmp(name, "nobs_base")) return 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + m->ntouch + 3 + 3;
   return -1;
 }
@@ -203,8 +209,8 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   float* obs = B.obs + (size_t)env*B.nobs;
   if (mode == MODE_STEP) {
     if (!w.istate[IS_RESET_NEXT]) d_lds_load(M, w, lane);
-    d_env_step(M, w, action + (size_t)env*M.nu, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
-  } else if (mode == MODE_RESET) d_env_reset(M, w, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+    d_env_step(M, w, env, action + (size_t)env*M.nact, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  } else if (mode == MODE_RESET) d_env_reset(M, w, env, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
   else if (mode == MODE_SUBSTEP) { d_lds_load(M, w, lane); for (int s = 0; s < nsub; s++) d_substep(M, w, lane); }
   else { d_step1(M, w, lane); d_step2(M, w, lane, true); }
   d_lds_store(M, w, lane);
@@ -221,7 +227,7 @@ struct fb_batch {
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   void *ref_qpos = nullptr, *ref_qvel = nullptr;
-  bool have_ref = false;
+  bool have_ref = false, have_wbpg = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; int timed_launches = 0; bool timing = false;
 };
 
@@ -268,7 +274,10 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start)
+  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
+  UI(wing_act_idx, "wing_action_idx")
+  M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
+  for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];
   M.nlevel = m->nlevel;
   UI(geom_type, "geom_type") UI(geom_bodyid, "geom_bodyid") UI(site_bodyid, "site_bodyid") UI(site_type, "site_type")
   UI(tendon_adr, "tendon_adr") UI(tendon_num, "tendon_num") UI(wrap_dofid, "wrap_dofid")
@@ -367,6 +376,10 @@ extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const
   int max_steps = (int)floor(time_limit / m->d("opt_control_timestep")[0] + 0.5) + 1;
   int snippet = T - future_steps - 1;
   int episode_steps = max_steps < snippet ? max_steps : snippet;
+  if (m->i("task_id")[0] == 1) {          // flight_imitation.py:101-105
+    int lim = max_steps - 1;
+    episode_steps = (T < lim ? T : lim) - (future_steps + 1);
+  }
   size_t rs = b->precision == 64 ? 8 : 4;
   HIPCHK(hipMalloc(&b->ref_qpos, (size_t)T*7*rs));
   HIPCHK(hipMalloc(&b->ref_qvel, (size_t)T*6*rs));
@@ -392,6 +405,22 @@ extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const
   return 0;
 }
 
+extern "C" int fb_batch_set_wbpg(fb_batch* b, const double* traj, const double* phase, const int32_t* offset, const double* freqs,
+                                 int nfreq, double base_freq, double rel_range, double rate, uint32_t seed) {
+  if (!b || !traj || !phase || !offset || !freqs || nfreq <= 0) return fail("fb_batch_set_wbpg: bad arguments");
+  HIPCHK(hipSetDevice(b->device));
+  int rows = offset[nfreq];
+#define SETWB(M, real) { const real *t_, *p_, *f_; const int* o_; \
+    if (upload<real>(b, traj, (size_t)rows*6, &t_) || upload<real>(b, phase, (size_t)rows, &p_) || upload<real>(b, freqs, (size_t)nfreq, &f_) || \
+        upload_i(b, offset, (size_t)nfreq + 1, &o_)) return -1; \
+    M.wb_traj = t_; M.wb_phase = p_; M.wb_freqs = f_; M.wb_offset = o_; M.wb_nfreq = nfreq; M.wb_base_freq = (real)base_freq; \
+    M.wb_rel_range = (real)rel_range; M.wb_rate = (real)rate; M.seed = seed; }
+  if (b->precision == 64) SETWB(b->M64, double) else SETWB(b->M32, float)
+#undef SETWB
+  b->have_wbpg = true;
+  return 0;
+}
+
 static int launch(fb_batch* b, int mode, const float* action, const int* ids, int n, int nsub, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (b->precision == 64) {
@@ -409,6 +438,7 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
 extern "C" int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* stream) {
   if (!b) return fail("fb_batch_reset: null batch");
   if (!b->have_ref) return fail("fb_batch_reset: call fb_batch_set_reference first");
+  if (b->m->i("task_id")[0] == 1 && !b->have_wbpg) return fail("fb_batch_reset: flight task needs fb_batch_set_wbpg first");
   HIPCHK(hipSetDevice(b->device));
   if (env_ids) {
     if (n <= 0 || n > b->n_env) return fail("fb_batch_reset: bad n");
@@ -422,6 +452,7 @@ extern "C" int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* 
 extern "C" int fb_batch_step(fb_batch* b, const float* action, void* stream) {
   if (!b || !action) return fail("fb_batch_step: null argument");
   if (!b->have_ref) return fail("fb_batch_step: call fb_batch_set_reference first");
+  if (b->m->i("task_id")[0] == 1 && !b->have_wbpg) return fail("fb_batch_step: flight task needs fb_batch_set_wbpg first");
   HIPCHK(hipSetDevice(b->device));
   return launch(b, MODE_STEP, action, nullptr, b->n_env, 0, stream);
 }

@@ -140,6 +140,8 @@ template <typename real> FBD real wave_sum(real v) {
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 #endif
+FBD double shfl_xor_any(double v, int m) { return __shfl_xor(v, m, 64); }
+FBD float shfl_xor_any(float v, int m) { return __shfl_xor(v, m, 64); }
 FBD int wave_sum_i(int v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;

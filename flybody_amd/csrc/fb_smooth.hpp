@@ -341,6 +341,61 @@ FBD void object_velocity(const WS<real>& w, int body, const real* pos, const rea
   mulmatT3(lvel + 3, rot, lin);
 }
 
+// Ellipsoid fluid model for one fluid geom (wing): added mass, Magnus and Kutta lift, blunt / slender /
+// angular drag, Stokes terms.  Follows the reference's restatement flybody/ellipsoid_fluid_model.py:88-310
+// (coefficient layout :229-237).  Writes the wrench about the tree CoM as [torque; force].
+template <typename real>
+__device__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& w, int b, int g, real* out) {
+  const real PI = (real)3.14159265358979323846;
+  const real* gf = M.geom_fluid + 12*g;
+  const real* size = M.geom_size + 3*g;
+  real blunt = gf[1], slender = gf[2], angc = gf[3], kutta = gf[4], magnus = gf[5];
+  const real* vmass = gf + 6; const real* vinert = gf + 9;
+  real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+  object_velocity(w, b, w.gxpos + 3*g, w.gxmat + 9*g, lvel);
+  const real* om = lvel; const real* v = lvel + 3;
+  real plin[3], pang[3], t[3];
+  for (int k = 0; k < 3; k++) { plin[k] = M.density*vmass[k]*v[k]; pang[k] = M.density*vinert[k]*om[k]; }
+  cross3(t, plin, om); add3(lfrc + 3, lfrc + 3, t);
+  cross3(t, plin, v); add3(lfrc, lfrc, t);
+  cross3(t, pang, om); add3(lfrc, lfrc, t);
+  real volume = (real)4/(real)3*PI*size[0]*size[1]*size[2];
+  real dmax = fmax(size[0], fmax(size[1], size[2])), dmin = fmin(size[0], fmin(size[1], size[2]));
+  real dmid = size[0] + size[1] + size[2] - dmax - dmin;
+  real Amax = PI*dmax*dmid;
+  real mag[3]; cross3(mag, om, v); scl3(mag, mag, magnus*M.density*volume);
+  real s12 = size[1]*size[2], s20 = size[2]*size[0], s01 = size[0]*size[1];
+  real pden = s12*s12*s12*s12*v[0]*v[0] + s20*s20*s20*s20*v[1]*v[1] + s01*s01*s01*s01*v[2]*v[2];
+  real pnum = (s12*v[0])*(s12*v[0]) + (s20*v[1])*(s20*v[1]) + (s01*v[2])*(s01*v[2]);
+  real Aproj = PI*sqrt(pden / fmax(FB_MINV, pnum));
+  real nrm[3] = {s12*s12*v[0], s20*s20*v[1], s01*s01*v[2]};
+  real speed = norm3(v);
+  real cosa = pnum / fmax(FB_MINV, speed*pden);
+  real circ[3]; cross3(circ, nrm, v); scl3(circ, circ, kutta*M.density*cosa*Aproj);
+  real kf[3]; cross3(kf, circ, v);
+  real eqD = (real)2/(real)3*(size[0] + size[1] + size[2]);
+  real linc = (real)3*PI*eqD, angcoef = PI*eqD*eqD*eqD;
+  real Imax = (real)8/(real)15*PI*dmid*dmax*dmax*dmax*dmax;
+  real mv[3];
+  for (int k = 0; k < 3; k++) {
+    real d0 = size[k], d1 = size[(k+1)%3], d2 = size[(k+2)%3];
+    real mx = fmax(d1, d2);
+    real II = (real)8/(real)15*PI*d0*mx*mx*mx*mx;
+    mv[k] = om[k]*(angc*II + slender*(Imax - II));
+  }
+  real dragl = M.viscosity*linc + M.density*speed*(Aproj*blunt + slender*(Amax - Aproj));
+  real draga = M.viscosity*angcoef + M.density*norm3(mv);
+  for (int k = 0; k < 3; k++) { lfrc[k] -= draga*om[k]; lfrc[3+k] += mag[k] + kf[k] - dragl*v[k]; }
+  for (int k = 0; k < 6; k++) lfrc[k] *= gf[0];
+  real trq[3], frc[3], off[3];
+  mulmat3(trq, w.gxmat + 9*g, lfrc);
+  mulmat3(frc, w.gxmat + 9*g, lfrc + 3);
+  sub3(off, w.gxpos + 3*g, w.com);
+  cross3(t, off, frc);
+  out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
+  out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
+}
+
 // passive forces: joint springs/dampers + per-body inertia-box fluid drag (density, viscosity)
 template <typename real>
 __device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) {
@@ -350,6 +405,8 @@ __device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) 
     real* out = w.cfrc_ext + 6*b;
     for (int k = 0; k < 6; k++) out[k] = 0;
     if (!fluid || b == 0 || M.body_mass[b] < FB_MINV) continue;
+    int fg = M.body_fluid_geom[b];
+    if (fg >= 0) { ellipsoid_fluid_wrench(M, w, b, fg, out); continue; }
     const real* box = M.body_box + 3*b;
     real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
     object_velocity(w, b, w.xipos + 3*b, w.ximat + 9*b, lvel);

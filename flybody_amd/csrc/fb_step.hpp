@@ -310,7 +310,13 @@ __device__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const rea
 // env.reset(): walk_imitation.py:112-136 + fruitfly.py:390-405, then a forward pass with
 // actuation disabled (dm_control Physics.after_reset)
 template <typename real>
-__device__ void d_env_reset(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
+__device__ void d_flight_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane);
+template <typename real>
+__device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward, float* discount, int* step_type, int lane);
+
+template <typename real>
+__device__ void d_env_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane) {
+  if (M.task == 1) { d_flight_reset(M, w, env, obs, reward, discount, step_type, lane); return; }
   for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
   for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
@@ -335,9 +341,10 @@ __device__ void d_substep(const DevModel<real>& M, const WS<real>& w, int lane) 
 
 // env.step(action): before_step hooks, nsubstep physics steps, reward/termination/observation
 template <typename real>
-__device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward,
+__device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, int env, const float* action, float* obs, float* reward,
                            float* discount, int* step_type, int lane) {
-  if (w.istate[IS_RESET_NEXT]) { d_env_reset(M, w, obs, reward, discount, step_type, lane); return; }
+  if (w.istate[IS_RESET_NEXT]) { d_env_reset(M, w, env, obs, reward, discount, step_type, lane); return; }
+  if (M.task == 1) { d_flight_step(M, w, action, obs, reward, discount, step_type, lane); return; }
   for (int k = lane; k < M.nu; k += FB_WAVE) {
     float a = action[k];
     if (a != a) a = 0.f;
@@ -370,6 +377,149 @@ __device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, const flo
   d_pack_obs(M, w, w.sens_acc, obs, lane);
   if (lane == 0) {
     *reward = 1.0f;
+    *discount = (term && !traj_end) ? 0.0f : 1.0f;
+    *step_type = terminating ? 2 : 1;
+    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ flight_imitation
+// Wing-beat pattern generator state machine (flybody/tasks/pattern_generators.py:131-203), one per
+// environment: the 64 lanes search the phase / frequency tables cooperatively (first-minimum argmin).
+template <typename real>
+__device__ int wave_argmin_absdiff(const real* v, int n, real x, bool mod1, int lane) {
+  real best = (real)1e30; int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += FB_WAVE) {
+    real a = v[i];
+    if (mod1) a = a - floor(a);
+    real e = fabs(x - a);
+    if (e < best) { best = e; bi = i; }
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    real ob = shfl_xor_any(best, m); int oi = __shfl_xor(bi, m, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  return bi;
+}
+
+FBD float hash_uniform(unsigned seed, unsigned env, unsigned episode) {
+  unsigned x = seed*0x9E3779B9u ^ (env*0x85EBCA6Bu) ^ (episode*0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f/16777216.0f);
+}
+
+template <typename real> FBD real tolerance_linear(real x, real margin) { real d = fabs(x)/margin; return d < 1 ? 1 - d : (real)0; }
+
+// env.reset(): flight_imitation.py:112-144 (root pose/velocity from the reference, wings from the WBPG at a
+// per-episode phase), then a forward pass with actuation disabled
+template <typename real>
+__device__ void d_flight_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane) {
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = (i < 3) ? M.ref_qvel[i] : (real)0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  int episode = w.istate[IS_EPISODE];
+  SYNC();
+  real phase0 = (real)hash_uniform(M.seed, (unsigned)env, (unsigned)episode);
+  int fidx = wave_argmin_absdiff(M.wb_freqs, M.wb_nfreq, M.wb_base_freq, false, lane);
+  int o = M.wb_offset[fidx], n = M.wb_offset[fidx + 1] - o;
+  int st = wave_argmin_absdiff(M.wb_phase + o, n, phase0, false, lane);
+  if (lane < 6) {
+    int j = M.wing_jnt[lane];
+    real q0 = M.wb_traj[6*(o + st) + lane], q1 = M.wb_traj[6*(o + st + 1) + lane];
+    w.qpos[M.jnt_qposadr[j]] = q0; w.qvel[M.jnt_dofadr[j]] = (q1 - q0)/M.control_timestep;
+  }
+  if (lane == 0) {
+    w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0;
+    w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.istate[IS_EPISODE] = episode + 1; w.wbfreq[0] = M.wb_base_freq;
+  }
+  SYNC();
+  d_step1(M, w, lane);
+  d_step2(M, w, lane, false);
+  d_pack_obs(M, w, w.sens, obs, lane);
+  if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
+  SYNC();
+}
+
+// env.step(): flight_imitation.py:146-212
+template <typename real>
+__device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward,
+                              float* discount, int* step_type, int lane) {
+  // ---- WBPG step at the frequency requested by the user action
+  float au = action[M.user_idx]; if (au != au) au = 0.f;
+  real ctrl_freq = M.wb_base_freq*(1 + M.wb_rel_range*(real)au);
+  int fidx = w.istate[IS_WB_FREQ], st = w.istate[IS_WB_STEP];
+  real filt = w.wbfreq[0];
+  int o = M.wb_offset[fidx], n = M.wb_offset[fidx + 1] - o;
+  st = (st + 1) % n;
+  filt = (M.wb_rate == 0) ? ctrl_freq : filt*M.wb_rate + ctrl_freq*(1 - M.wb_rate);
+  int fnew = wave_argmin_absdiff(M.wb_freqs, M.wb_nfreq, filt, false, lane);
+  if (fnew != fidx) {
+    real cur = M.wb_phase[o + st]; cur = cur - floor(cur);
+    int o2 = M.wb_offset[fnew], n2 = M.wb_offset[fnew + 1] - o2;
+    st = wave_argmin_absdiff(M.wb_phase + o2, n2, cur, true, lane);
+    fidx = fnew; o = o2;
+  }
+  int prev = w.istate[IS_STEP];
+  SYNC();
+  // ---- action -> ctrl, wing entries become position-error force commands (flight_imitation.py:156-158)
+  for (int k = lane; k < M.nu; k += FB_WAVE) {
+    float a = action[k]; if (a != a) a = 0.f;
+    real v = (real)a;
+    for (int q = 0; q < 6; q++) if (M.wing_act_idx[q] == k) v += M.wb_traj[6*(o + st) + q] - w.qpos[M.jnt_qposadr[M.wing_jnt[q]]];
+    w.ctrl[M.action_to_ctrl[k]] = v;
+  }
+  if (lane < FB_NSENS) w.sens_acc[lane] = 0;
+  if (lane == 0) { w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.wbfreq[0] = filt; }
+  SYNC();
+  for (int s = 0; s < M.nsubstep; s++) {
+    d_substep(M, w, lane);
+    if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane];
+    SYNC();
+  }
+  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
+  int stepc = prev + 1;
+  SYNC();
+  if (lane == 0) w.istate[IS_STEP] = stepc;
+  real qn = 0;
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  qn = wave_sum(qn);
+  SYNC();
+  // ---- reward: CoM distance to the ghost and orientation error (flight_imitation.py:170-201)
+  real gp[3], gq[4], qr[4], tmpq[4];
+  const real* rv = M.ref_qvel + 6*prev;
+  for (int k = 0; k < 3; k++) gp[k] = M.ref_qpos[7*prev + k] + M.control_timestep*rv[k];
+  for (int k = 0; k < 4; k++) gq[k] = M.ref_qpos[7*prev + 3 + k];
+  {
+    real ax[3] = {rv[3], rv[4], rv[5]};
+    real nn = normalize3(ax);
+    axisangle2quat(qr, ax, nn*M.control_timestep);
+    normquat(gq); mulquat(tmpq, gq, qr); normquat(tmpq);
+  }
+  real off[3], dif[3];
+  rotvecquat(off, M.com_offset, tmpq);
+  for (int k = 0; k < 3; k++) dif[k] = gp[k] + off[k] - w.com[k];
+  real r_disp = tolerance_linear((real)norm3(dif), (real)0.4);
+  int idx = stepc < M.T ? stepc : M.T - 1;
+  const real* q = w.qpos + 3;
+  real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
+  real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2}, dq[4];
+  mulquat(dq, qi, M.ref_qpos + 7*idx + 3);
+  real nq = sqrt(dq[0]*dq[0] + dq[1]*dq[1] + dq[2]*dq[2] + dq[3]*dq[3]);
+  real x = 2*(dq[0]/nq)*(dq[0]/nq) - 1; if (x > 1) x = 1;
+  real r_quat = tolerance_linear((real)acos(x), (real)3.14159265358979323846);
+  // ---- termination (flight_imitation.py:203-212)
+  int thorax = M.site_bodyid[M.site_thorax];
+  real height = w.xpos[3*thorax + 2];
+  real cd[3]; sub3(cd, M.ref_qpos + 7*idx, w.qpos);
+  int tstep = (int)floor(w.simtime[0] / M.control_timestep + (real)0.5);
+  bool traj_end = (tstep == M.episode_steps);
+  bool term = (height < (real)0.2) || (norm3(cd) > M.terminal_com_dist) || traj_end || (sqrt(qn) > (real)1e14) || (qn != qn);
+  bool terminating = term || (w.simtime[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  if (lane == 0) {
+    *reward = (float)(r_disp*r_quat);
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
     w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;

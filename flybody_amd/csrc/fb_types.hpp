@@ -28,7 +28,8 @@ enum { TRN_JOINT = 0, TRN_TENDON = 3, TRN_BODY = 5 };
 enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 // istate slots
-enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7, IS_N = 8 };
+enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
+       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_N = 12 };
 
 // Constant tables shared by all environments (device pointers).
 template <typename real>
@@ -69,12 +70,18 @@ struct DevModel {
   const real *ref_qpos, *ref_qvel;
   int T, future_steps, episode_steps, nobs;
   real terminal_com_dist, time_limit;
+  // flight task (task == 1): action layout, CoM offset, wing-beat pattern generator tables
+  int task, nact, user_idx; unsigned seed;
+  const int *wing_act_idx, *body_fluid_geom;
+  real com_offset[3];
+  const real *wb_traj, *wb_phase, *wb_freqs; const int* wb_offset; int wb_nfreq;
+  real wb_base_freq, wb_rel_range, wb_rate;
 };
 
 // Per-environment real arrays: X(name, element count expression in terms of DevModel M)
 #define FB_WS_REAL(X) \
   X(qpos, M.nq) X(qvel, M.nv) X(act, M.na + 1) X(ctrl, M.nu) X(qacc, M.nv) X(qacc_ws, M.nv) X(act_dot, M.na + 1) \
-  X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) \
+  X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) X(wbfreq, 1) \
   X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) X(xmat, 9*M.nbody) X(xipos, 3*M.nbody) X(ximat, 9*M.nbody) \
   X(xanchor, 3*M.njnt) X(xaxis, 3*M.njnt) X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
   X(cinert, 10*M.nbody) X(crb, 10*M.nbody) X(cdof, 6*M.nv) X(cdof_dot, 6*M.nv) X(cvel, 6*M.nbody) \

@@ -57,6 +57,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.fb_batch_destroy.argtypes = [C.c_void_p]; L.fb_batch_destroy.restype = None
     L.fb_batch_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.fb_batch_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32]
     L.fb_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -119,6 +120,12 @@ class Batch:
         m = self.model
         self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
                      7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
+
+    def set_wbpg(self, tables, seed: int = 0):
+        t = np.ascontiguousarray(tables['traj'], np.float64); p = np.ascontiguousarray(tables['phase'], np.float64)
+        o = np.ascontiguousarray(tables['offset'], np.int32); f = np.ascontiguousarray(tables['beat_freqs'], np.float64)
+        _check(self.L, self.L.fb_batch_set_wbpg(self.h, t.ctypes.data, p.ctypes.data, o.ctypes.data, f.ctypes.data, len(f),
+                                                float(tables['base_freq']), float(tables['rel_range']), float(tables['rate']), int(seed)))
 
     def reset(self, env_ids=None, stream=None):
         if env_ids is None:

@@ -20,7 +20,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import engine
-from .reference import default_walking_reference
+from .reference import constant_speed_trajectory, default_walking_reference
 
 
 class StepType(enum.IntEnum):
@@ -101,12 +101,15 @@ class BatchedFlyEnv:
     """n_env walk_imitation environments stepped in lock-step by one kernel launch per control step."""
 
     def __init__(self, n_env: int = 1, device: int = 0, precision: int = 32, terminal_com_dist: float = 0.3,
-                 joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation'):
+                 joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation',
+                 wbpg_tables=None, seed: int = 0):
         arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
-        if joint_filter <= 0:
-            raise NotImplementedError('joint_filter=0 changes the activation layout: recompile the model with '
-                                      'tools/compile_models.py (needs the reference fruitfly.xml)')
-        if joint_filter != 0.01:
+        self.task_name = task
+        compiled_filter = 0.01 if task == 'walk_imitation' else 0.0
+        if (joint_filter > 0) != (compiled_filter > 0):
+            raise NotImplementedError('switching the joint filter on/off changes the activation layout: recompile the model '
+                                      'with tools/compile_models.py (needs the reference fruitfly.xml)')
+        if joint_filter > 0 and joint_filter != compiled_filter:
             arrays = dict(arrays)
             dyn = arrays['actuator_dynprm'].copy()
             dyn[arrays['actuator_trntype'] != 5] = joint_filter       # fruitfly.py:330-335
@@ -117,13 +120,28 @@ class BatchedFlyEnv:
         self.future_steps = future_steps; self.terminal_com_dist = terminal_com_dist; self.time_limit = time_limit
         self.task = _Task(self); self.physics = _Physics(self)
         self._time = 0.0
-        qp, qv = default_walking_reference()
+        if task == 'flight_imitation':
+            from .wbpg import build_tables
+            self.batch.set_wbpg(wbpg_tables or build_tables(), seed=seed)
+            # InferenceFlightTrajectoryLoader default (trajectory_loaders.py:161-163): 200 steps, 20 cm/s, z = 1, pitch -47.5 deg
+            qp, qv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+        else:
+            qp, qv = default_walking_reference()
         self.task._traj_generator.set_next_trajectory(qp, qv)
         self.layout, self.nobs = observation_layout(self.model, future_steps)
         self._torch_views = None
 
     def _apply_reference(self):
         s = self.task._traj_generator._snippet
+        if self.task_name == 'flight_imitation':
+            # the flight loaders hand over a CoM trajectory; the task converts it to the root joint
+            # (set_next_trajectory re-centres x,y: trajectory_loaders.py:172-173; com2root: flight_imitation.py:93-99)
+            from .mjcf_compile import qrot
+            q = s['qpos'].copy(); q[:, :2] -= q[0, :2]
+            off = self.model.arrays['com_offset']
+            for i in range(len(q)):
+                q[i, :3] = q[i, :3] + qrot(q[i, 3:7] / np.linalg.norm(q[i, 3:7]), -off)
+            s = {'qpos': q, 'qvel': s['qvel']}
         self.batch.set_reference(s['qpos'], s['qvel'], future_steps=self.future_steps,
                                  terminal_com_dist=self.terminal_com_dist, time_limit=self.time_limit)
         self._torch_views = None
@@ -134,10 +152,16 @@ class BatchedFlyEnv:
         idx = a['action_to_ctrl']
         rng = a['actuator_ctrlrange'][idx]
         names = [str(a['names_actuator'][i]) for i in idx]
-        return BoundedArray((len(idx),), float, rng[:, 0], rng[:, 1], name='\t'.join(names))
+        lo, hi = list(rng[:, 0]), list(rng[:, 1])
+        for k in range(int(a['num_user_actions'])):          # fruitfly.py:571-576
+            lo.append(-1.0); hi.append(1.0); names.append(f'user_{k}')
+        return BoundedArray((len(names),), float, lo, hi, name='\t'.join(names))
 
     def observation_spec(self):
-        return collections.OrderedDict(('walker/' + k, Array(self.layout[k][2], np.float32, 'walker/' + k)) for k in _DICT_ORDER)
+        return collections.OrderedDict(('walker/' + k, Array(self.layout[k][2], np.float32, 'walker/' + k)) for k in self._keys())
+
+    def _keys(self):
+        return [k for k in _DICT_ORDER if self.layout[k][1] > 0 or k == 'actuator_activation']
 
     def control_timestep(self) -> float:
         return float(self.model.arrays['opt_control_timestep'])
@@ -172,7 +196,7 @@ class BatchedFlyEnv:
         """action: float32 CUDA tensor [n_env, nu] (contiguous).  Asynchronous on torch's current stream."""
         import torch
         assert action.is_cuda and action.dtype == torch.float32 and action.is_contiguous()
-        assert tuple(action.shape) == (self.n_env, self.model.dim('nu'))
+        assert tuple(action.shape) == (self.n_env, self.model.dim('nact'))
         self.batch.step_ptr(action.data_ptr(), torch.cuda.current_stream().cuda_stream)
         self._time += self.control_timestep()
         return self.torch_views()
@@ -182,7 +206,7 @@ class BatchedFlyEnv:
         obs = self.batch.get('OBS')[env]
         st = StepType(int(self.batch.get('STEP_TYPE')[env, 0]))
         od = collections.OrderedDict()
-        for k in _DICT_ORDER:
+        for k in self._keys():
             off, n, shp = self.layout[k]
             od['walker/' + k] = obs[off:off + n].reshape(shp).copy()
         if st == StepType.FIRST:
@@ -196,7 +220,7 @@ class BatchedFlyEnv:
 
     def step(self, action) -> TimeStep:
         import torch
-        a = np.broadcast_to(np.asarray(action, np.float32), (self.n_env, self.model.dim('nu')))
+        a = np.broadcast_to(np.asarray(action, np.float32), (self.n_env, self.model.dim('nact')))
         t = torch.from_numpy(np.ascontiguousarray(a)).to(f'cuda:{self.device}')
         self.batch.step_ptr(t.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -216,3 +240,21 @@ def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False
         raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
                          joint_filter=joint_filter, future_steps=64, time_limit=10.0)
+
+
+def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,
+                     disable_legs: bool = True, traj_indices: Optional[Sequence[int]] = None, randomize_start_step: bool = True,
+                     joint_filter: float = 0.0, future_steps: int = 5, random_state=None, terminal_com_dist: float = 2.0,
+                     n_env: int = 1, device: int = 0, precision: int = 32, seed: int = 0) -> BatchedFlyEnv:
+    """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed."""
+    if ref_path is not None:
+        raise NotImplementedError('HDF5 flight datasets are a "next" row (SURVEY.md 8f); inference mode is implemented')
+    if force_actuators or not disable_legs:
+        raise NotImplementedError('force_actuators / enabled legs need a recompiled model (tools/compile_models.py)')
+    tables = None
+    if wpg_pattern_path is not None:
+        from .wbpg import build_tables
+        tables = build_tables(np.load(wpg_pattern_path))
+    return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
+                         joint_filter=joint_filter, future_steps=future_steps, time_limit=0.6, task='flight_imitation',
+                         wbpg_tables=tables, seed=seed)

@@ -864,6 +864,13 @@ class FlyCompiler:
         for bi in range(1, nbody):
             rootid[bi] = bi if m['body_parent'][bi] == 0 else rootid[m['body_parent'][bi]]
         m['body_rootid'] = rootid
+        # task-level index tables (flight_imitation.py:60-63): positions of the wing / user entries in the action
+        names_act = [a['name'] for a in self.actuators]
+        act_order = [names_act[i] for i in self.action_to_ctrl]
+        m['wing_action_idx'] = np.array([k for k, n in enumerate(act_order) if 'wing' in n], int)
+        m['user_action_idx'] = np.array(len(act_order) if cfg.num_user_actions else -1)
+        m['task_id'] = np.array(1 if cfg.name == 'flight_imitation' else 0)
+        m['com_offset'] = np.array([-0.03697732, 0.00029205, -0.0142447])     # tasks/task_utils.py:237
         m['notes'] = np.array(self.notes)
         m['config_name'] = np.array(cfg.name)
         m['num_user_actions'] = np.array(cfg.num_user_actions)
@@ -1039,9 +1046,11 @@ class FlyCompiler:
         touch_sites = [sn[s[2]] for s in self.sensors if s[0] == 'touch']
         m['sensor_force_sites'] = np.array(force_sites, int); m['sensor_touch_sites'] = np.array(touch_sites, int)
         # appendages: end effectors (claw sites) + head site  (fruitfly.py:478-497)
+        # (enabled by Walking, base.py:425-428; Flying enables them only with legs, base.py:360-364)
         app = [sn[n] for n in ('claw_T1_left', 'claw_T1_right', 'claw_T2_left', 'claw_T2_right',
                                'claw_T3_left', 'claw_T3_right') if n in sn and self.cfg.use_legs]
-        app.append(sn['head'])
+        if self.cfg.use_legs:
+            app.append(sn['head'])
         m['appendage_sites'] = np.array(app, int)
         # wing joints (qpos addresses) and their springrefs
         wj = [j for j, n in enumerate(m['names_jnt']) if _any_in(['yaw', 'roll', 'pitch'], str(n))]

@@ -80,12 +80,19 @@ void fb_batch_destroy(fb_batch* b);
 int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const double* ref_qvel, int T,
                            int future_steps, double terminal_com_dist, double time_limit);
 
+/* flight_imitation only: wing-beat pattern generator tables (flybody/tasks/pattern_generators.py:17-129 builds them;
+ * flybody_amd/wbpg.py restates it).  traj[rows][6], phase[rows], offset[nfreq+1] (row range of each frequency's
+ * sequence), freqs[nfreq]; rate = exp(-dt_ctrl / ctrl_filter); seed keys the per-episode initial phase. */
+int fb_batch_set_wbpg(fb_batch* b, const double* traj, const double* phase, const int32_t* offset, const double* freqs,
+                      int nfreq, double base_freq, double rel_range, double rate, uint32_t seed);
+
 /* env.reset() for the listed environments (env_ids == NULL: all).  `stream` is a hipStream_t
  * (NULL = default stream).  Asynchronous. */
 int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* stream);
 
 /* env.step(action) for every environment: `action` is a DEVICE pointer to float32
- * [n_env][nu] in the reference's action order (fruitfly.py:342-379).  Environments whose
+ * [n_env][nact] in the reference's action order (fruitfly.py:342-379); nact = nu + user actions
+ * (59 for walk_imitation, 12 for flight_imitation; fb_model_dim(m, "nact")).  Environments whose
  * previous step returned LAST are reset instead (dm_env auto-reset convention).
  * Asynchronous on `stream`; results land in FB_OBS/FB_REWARD/FB_DISCOUNT/FB_STEP_TYPE. */
 int fb_batch_step(fb_batch* b, const float* action, void* stream);

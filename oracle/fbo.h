@@ -57,6 +57,7 @@ typedef struct {
   const int *observable_joints, *appendage_sites, *sensor_force_sites, *sensor_touch_sites, *wing_jnt;
   int sensor_site_thorax;
   int any_damping;
+  int task_id, user_action_idx; const int* wing_action_idx; const double* com_offset;
 } fbo_model;
 
 typedef struct {
@@ -96,6 +97,10 @@ typedef struct {
   int step_type;                  /* 0 FIRST, 1 MID, 2 LAST */
   int* scratch_i;
   double* scratch;
+  /* flight task: wing-beat pattern generator tables + per-episode state (tasks/pattern_generators.py) */
+  const double *wb_traj, *wb_phase, *wb_freqs; const int* wb_offset; int wb_nfreq;
+  double wb_base_freq, wb_rel_range, wb_rate, wb_ctrl_freq;
+  int wb_step, wb_freq_idx, episode_count; unsigned seed;
 } fbo_data;
 
 /* model / data lifetime */
@@ -138,6 +143,9 @@ void fbo_jac(const fbo_data* d, double* jacp, double* jacr, const double* point,
 void fbo_env_configure(fbo_data* d, const double* ref_qpos, const double* ref_qvel, int T,
                        int future_steps, double terminal_com_dist, double time_limit);
 void fbo_env_reset(fbo_data* d);
+void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, const int* offset, const double* freqs, int nfreq,
+                      double base_freq, double rel_range, double rate, unsigned seed);
+double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode);
 void fbo_env_step(fbo_data* d, const double* action);
 void fbo_env_step_batch(fbo_data** ds, int n, const double* actions, int nthreads);
 

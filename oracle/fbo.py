@@ -46,6 +46,8 @@ def lib():
         L.fbo_jac.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.fbo_env_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
         L.fbo_env_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.fbo_env_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint]
+        L.fbo_hash_uniform.argtypes = [C.c_uint, C.c_uint, C.c_uint]; L.fbo_hash_uniform.restype = C.c_double
         L.fbo_env_step_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     return _LIB
 
@@ -122,6 +124,12 @@ class OracleData:
         rq = np.ascontiguousarray(ref_qpos, float); rv = np.ascontiguousarray(ref_qvel, float)
         lib().fbo_env_configure(self.h, rq.ctypes.data, rv.ctypes.data, rq.shape[0], future_steps,
                                 float(terminal_com_dist), float(time_limit))
+
+    def set_wbpg(self, tables, seed=0):
+        t = np.ascontiguousarray(tables['traj'], float); p = np.ascontiguousarray(tables['phase'], float)
+        o = np.ascontiguousarray(tables['offset'], np.int32); f = np.ascontiguousarray(tables['beat_freqs'], float)
+        lib().fbo_env_set_wbpg(self.h, t.ctypes.data, p.ctypes.data, o.ctypes.data, f.ctypes.data, len(f),
+                               tables['base_freq'], tables['rel_range'], tables['rate'], seed)
 
     def env_reset(self):
         lib().fbo_env_reset(self.h)

@@ -83,8 +83,76 @@ static void pack_obs(fbo_data* d, const double* sens_mean) {
   o[0] = R[6]; o[1] = R[7]; o[2] = R[8]; o += 3;
 }
 
+/* counter-based uniform in [0,1): the per-episode initial wing-beat phase (flight_imitation.py:128-129 draws it
+ * from the task's RandomState; here it is a pure function of (seed, environment, episode) so that the oracle and
+ * the batched engine agree and results do not depend on the number of GPUs) */
+double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode) {
+  unsigned x = seed*0x9E3779B9u ^ (env*0x85EBCA6Bu) ^ (episode*0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (double)(x >> 8) * (1.0/16777216.0);
+}
+
+void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, const int* offset, const double* freqs, int nfreq,
+                      double base_freq, double rel_range, double rate, unsigned seed) {
+  int rows = offset[nfreq];
+  double* t = (double*)malloc(sizeof(double)*6*rows); memcpy(t, traj, sizeof(double)*6*rows);
+  double* p = (double*)malloc(sizeof(double)*rows); memcpy(p, phase, sizeof(double)*rows);
+  int* o = (int*)malloc(sizeof(int)*(nfreq + 1)); memcpy(o, offset, sizeof(int)*(nfreq + 1));
+  double* f = (double*)malloc(sizeof(double)*nfreq); memcpy(f, freqs, sizeof(double)*nfreq);
+  d->wb_traj = t; d->wb_phase = p; d->wb_offset = o; d->wb_freqs = f; d->wb_nfreq = nfreq;   /* leaked with the data: test infrastructure */
+  d->wb_base_freq = base_freq; d->wb_rel_range = rel_range; d->wb_rate = rate; d->seed = seed;
+}
+
+static int argmin_absdiff(const double* v, int n, double x, int mod1) {
+  int best = 0; double bv = 1e300;
+  for (int i = 0; i < n; i++) {
+    double a = mod1 ? fmod(v[i], 1.0) : v[i];
+    double e = fabs(x - a);
+    if (e < bv) { bv = e; best = i; }
+  }
+  return best;
+}
+
+/* WingBeatPatternGenerator.reset (pattern_generators.py:131-166) */
+static void wbpg_reset(fbo_data* d, double initial_phase, double* qpos6, double* qvel6) {
+  d->wb_ctrl_freq = d->wb_base_freq;
+  d->wb_freq_idx = argmin_absdiff(d->wb_freqs, d->wb_nfreq, d->wb_ctrl_freq, 0);
+  int o = d->wb_offset[d->wb_freq_idx], n = d->wb_offset[d->wb_freq_idx + 1] - o;
+  d->wb_step = argmin_absdiff(d->wb_phase + o, n, initial_phase, 0);
+  for (int k = 0; k < 6; k++) {
+    qpos6[k] = d->wb_traj[6*(o + d->wb_step) + k];
+    qvel6[k] = (d->wb_traj[6*(o + d->wb_step + 1) + k] - qpos6[k]) / d->m->control_timestep;
+  }
+}
+
+/* WingBeatPatternGenerator.step (pattern_generators.py:168-203) */
+static void wbpg_step(fbo_data* d, double ctrl_freq, double* out6) {
+  int o = d->wb_offset[d->wb_freq_idx], n = d->wb_offset[d->wb_freq_idx + 1] - o;
+  d->wb_step = (d->wb_step + 1) % n;
+  if (d->wb_rate == 0) d->wb_ctrl_freq = ctrl_freq;
+  else d->wb_ctrl_freq = d->wb_ctrl_freq*d->wb_rate + ctrl_freq*(1 - d->wb_rate);
+  int idx_new = argmin_absdiff(d->wb_freqs, d->wb_nfreq, d->wb_ctrl_freq, 0);
+  if (idx_new != d->wb_freq_idx) {
+    double cur = fmod(d->wb_phase[o + d->wb_step], 1.0);
+    int o2 = d->wb_offset[idx_new], n2 = d->wb_offset[idx_new + 1] - o2;
+    d->wb_step = argmin_absdiff(d->wb_phase + o2, n2, cur, 1);
+    d->wb_freq_idx = idx_new; o = o2;
+  }
+  for (int k = 0; k < 6; k++) out6[k] = d->wb_traj[6*(o + d->wb_step) + k];
+}
+
+static double tolerance_linear(double x, double margin) {
+  /* dm_control rewards.tolerance(bounds=(0,0), sigmoid='linear', value_at_margin=0) */
+  double dd = fabs(x)/margin;
+  return dd < 1.0 ? 1.0 - dd : 0.0;
+}
+
+static void flight_reset(fbo_data* d);
+static void flight_step(fbo_data* d, const double* action);
+
 void fbo_env_reset(fbo_data* d) {
   const fbo_model* m = d->m;
+  if (m->task_id == 1) { flight_reset(d); return; }
   fbo_reset_state(d);
   memcpy(d->qpos, d->ref_qpos, sizeof(double)*7);          /* root pose from the reference snippet */
   for (int k = 0; k < 6; k++) {                            /* wings to their retracted (springref) pose */
@@ -112,6 +180,7 @@ void fbo_env_reset(fbo_data* d) {
 void fbo_env_step(fbo_data* d, const double* action) {
   const fbo_model* m = d->m;
   if (d->reset_next) { fbo_env_reset(d); return; }
+  if (m->task_id == 1) { flight_step(d, action); return; }
   /* before_step */
   memset(d->ctrl, 0, sizeof(double)*m->nu);
   for (int k = 0; k < m->nu; k++) {
@@ -139,6 +208,85 @@ void fbo_env_step(fbo_data* d, const double* action) {
   d->should_terminate = (linvel > TERMINAL_LINVEL) || (angvel > TERMINAL_ANGVEL) || d->reached_traj_end ||
                         (com_dist > d->terminal_com_dist) || (sqrt(qn) > TERMINAL_QACC) || (qn != qn);
   d->reward = 1.0;    /* inference mode: walk_imitation.py:155-156 */
+  d->discount = (d->should_terminate && !d->reached_traj_end) ? 0.0 : 1.0;
+  int terminating = d->should_terminate || (d->time >= d->time_limit);
+  pack_obs(d, mean);
+  d->step_type = terminating ? 2 : 1;
+  d->reset_next = terminating;
+}
+
+/* ---- flight_imitation: flybody/tasks/flight_imitation.py:82-223, tasks/base.py:274-364 ---- */
+static void flight_reset(fbo_data* d) {
+  const fbo_model* m = d->m;
+  fbo_reset_state(d);
+  memcpy(d->qpos, d->ref_qpos, sizeof(double)*7);
+  double wq[6], wv[6];
+  wbpg_reset(d, fbo_hash_uniform(d->seed, 0u, (unsigned)d->episode_count), wq, wv);
+  d->episode_count++;
+  for (int k = 0; k < 6; k++) {
+    int j = m->wing_jnt[k];
+    d->qpos[m->jnt_qposadr[j]] = wq[k]; d->qvel[m->jnt_dofadr[j]] = wv[k];
+  }
+  for (int k = 0; k < 3; k++) d->qvel[k] = d->ref_qvel[k];     /* initialize_qvel: linear CoM velocity only */
+  d->step_counter = 0;
+  int lim = (int)floor(d->time_limit / m->control_timestep + 0.5);
+  d->episode_steps = (d->T < lim ? d->T : lim) - (d->future_steps + 1);
+  d->should_terminate = 0; d->reached_traj_end = 0; d->reset_next = 0;
+  fbo_fwd_position(d); fbo_fwd_velocity(d); fbo_sensor_vel(d);
+  memset(d->qfrc_actuator, 0, sizeof(double)*m->nv);
+  fbo_fwd_acceleration(d); fbo_fwd_constraint(d); fbo_sensor_acc(d);
+  pack_obs(d, d->sensordata);
+  d->reward = 0; d->discount = 1; d->step_type = 0;
+}
+
+static void flight_step(fbo_data* d, const double* action_in) {
+  const fbo_model* m = d->m;
+  double action[64];
+  int na_total = m->nu + 1;
+  for (int k = 0; k < na_total; k++) { action[k] = action_in[k]; if (action[k] != action[k]) action[k] = 0; }
+  double ctrl_freq = d->wb_base_freq*(1 + d->wb_rel_range*action[m->user_action_idx]);
+  double target[6];
+  wbpg_step(d, ctrl_freq, target);
+  for (int k = 0; k < 6; k++) action[m->wing_action_idx[k]] += target[k] - d->qpos[m->jnt_qposadr[m->wing_jnt[k]]];
+  int prev = d->step_counter;                       /* ghost is set from ref[step] before the physics */
+  memset(d->ctrl, 0, sizeof(double)*m->nu);
+  for (int k = 0; k < m->nu; k++) d->ctrl[m->action_to_ctrl[k]] = action[k];
+  d->step_counter++;
+  memset(d->sensor_acc, 0, sizeof(d->sensor_acc));
+  for (int s = 0; s < m->nsubstep; s++) {
+    fbo_step(d);
+    for (int k = 0; k < FBO_NSENSOR; k++) d->sensor_acc[k] += d->sensordata[k];
+  }
+  double mean[FBO_NSENSOR];
+  for (int k = 0; k < FBO_NSENSOR; k++) mean[k] = d->sensor_acc[k] / m->nsubstep;
+  /* ghost pose after the control step: set_pose/set_velocity from ref[prev], integrated over control_dt
+   * (its ~1e-8 cm gravity sag -- a 1 g-armature free body -- is neglected) */
+  double gp[3], gq[4];
+  for (int k = 0; k < 3; k++) gp[k] = d->ref_qpos[7*prev + k] + m->control_timestep*d->ref_qvel[6*prev + k];
+  memcpy(gq, d->ref_qpos + 7*prev + 3, sizeof(double)*4);
+  quatintegrate(gq, d->ref_qvel + 6*prev + 3, m->control_timestep);
+  double off[3], gcom[3], dif[3];
+  rotvecquat(off, m->com_offset, gq); add3(gcom, gp, off);
+  sub3(dif, gcom, d->subtree_com + 3);
+  double r_disp = tolerance_linear(norm3(dif), 0.4);
+  int idx = d->step_counter < d->T ? d->step_counter : d->T - 1;
+  const double* q = d->qpos + 3; const double* rq = d->ref_qpos + 7*idx + 3;
+  double n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
+  double qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2}, dq[4];
+  mulquat(dq, qi, rq);
+  double nq_ = sqrt(dq[0]*dq[0] + dq[1]*dq[1] + dq[2]*dq[2] + dq[3]*dq[3]);
+  double x = 2*(dq[0]/nq_)*(dq[0]/nq_) - 1; if (x > 1) x = 1;
+  double r_quat = tolerance_linear(acos(x), FBO_PI);
+  /* termination */
+  int thorax = m->site_bodyid[m->sensor_site_thorax];
+  double height = d->xpos[3*thorax + 2];
+  double cd[3]; sub3(cd, d->ref_qpos + 7*idx, d->qpos);
+  double com_dist = norm3(cd);
+  int step = (int)floor(d->time / m->control_timestep + 0.5);
+  double qn = 0; for (int i = 0; i < m->nv; i++) qn += d->qacc[i]*d->qacc[i];
+  d->reached_traj_end = (step == d->episode_steps);
+  d->should_terminate = (height < 0.2) || (com_dist > d->terminal_com_dist) || d->reached_traj_end || (sqrt(qn) > TERMINAL_QACC) || (qn != qn);
+  d->reward = r_disp*r_quat;
   d->discount = (d->should_terminate && !d->reached_traj_end) ? 0.0 : 1.0;
   int terminating = d->should_terminate || (d->time >= d->time_limit);
   pack_obs(d, mean);

@@ -74,6 +74,8 @@ int fbo_model_load(const void* blob_in, size_t n, fbo_model** out) {
   m->sensor_touch_sites = geti(b, "sensor_touch_sites", &m->ntouch);
   m->wing_jnt = geti(b, "wing_jnt", NULL);
   m->sensor_site_thorax = geti(b, "sensor_site_thorax", NULL)[0];
+  m->task_id = geti(b, "task_id", NULL)[0]; m->user_action_idx = geti(b, "user_action_idx", NULL)[0];
+  m->wing_action_idx = geti(b, "wing_action_idx", NULL); m->com_offset = getd(b, "com_offset", NULL);
   m->timestep = getd(b, "opt_timestep", NULL)[0];
   m->control_timestep = getd(b, "opt_control_timestep", NULL)[0];
   memcpy(m->gravity, getd(b, "opt_gravity", NULL), 24);
@@ -196,6 +198,7 @@ double* fbo_field(fbo_data* d, const char* name, int* n) {
 double fbo_scalar(const fbo_data* d, const char* name) {
 #define X(f) if (!strcmp(name, #f)) return (double)d->f
   X(ncon); X(nefc); X(solver_niter); X(noslip_niter); X(time); X(reward); X(discount); X(step_type);
+  X(wb_step); X(wb_freq_idx); X(wb_ctrl_freq); X(episode_count);
   X(step_counter); X(episode_steps); X(reset_next); X(should_terminate); X(reached_traj_end); X(nobs);
 #undef X
   return -1e300;

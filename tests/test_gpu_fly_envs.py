@@ -71,3 +71,28 @@ def test_dmpo_training_loop_smoke():
     assert tr.replay.size > 1000 and tr.learner_steps > 0 and stats is not None
     assert all(torch.isfinite(v).all() for v in stats.values())
     assert torch.isfinite(tr.obs).all()
+
+
+def test_flight_imitation_env():
+    """flight_imitation on the GPU: spec sizes (docs/sensory-input-tracking.ipynb cells 8-9: 104 obs floats, 12 actions),
+    reward in (0, 1], episode of 194 steps with a 'good' termination."""
+    import torch
+    from flybody_amd.fly_envs import flight_imitation
+    env = flight_imitation(precision=64)
+    assert env.action_spec().shape == (12,) and env.action_spec().name.split('\t')[-1] == 'user_0'
+    assert sum(int(np.prod(v.shape)) for v in env.observation_spec().values()) == 104
+    assert np.isclose(env.control_timestep(), 2e-4) and np.isclose(env.physics.timestep(), 5e-5)
+    ts = env.reset(); assert ts.first()
+    for k in range(194):
+        ts = env.step(np.zeros(12))
+        assert 0.0 <= ts.reward <= 1.0
+        if ts.last():
+            break
+    assert ts.last() and k == 193 and ts.discount == 1.0
+    venv = flight_imitation(n_env=512, precision=32)
+    v = venv.reset_all()
+    a = torch.rand(512, 12, device='cuda') * 2 - 1
+    for _ in range(5):
+        v = venv.step_tensor(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(v['obs']).all() and (v['reward'] > 0).all()

@@ -94,3 +94,37 @@ def test_lane_order_independence(emu_lib):
         env = dict(os.environ, FB_EMU_REVERSE=rev)
         outs.append(subprocess.check_output([sys.executable, '-c', code], env=env))
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+def test_flight_imitation_matches_oracle(emu_lib):
+    """flight_imitation: ellipsoid wing fluid forces, WBPG state machine, flight reward/termination."""
+    from flybody_amd import engine
+    from flybody_amd.mjcf_compile import qrot
+    from flybody_amd.model_blob import load_npz, pack_model
+    from flybody_amd.reference import constant_speed_trajectory
+    from flybody_amd.wbpg import HostWBPG, build_tables
+    from oracle import fbo
+    arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
+    M = engine.Model(arr, lib_path=emu_lib); B = engine.Batch(M, 2, precision=64)
+    od = fbo.OracleData(fbo.OracleModel(pack_model(arr)))
+    tabs = build_tables(); od.set_wbpg(tabs, seed=3); B.set_wbpg(tabs, seed=3)
+    cq, cv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+    root = cq.copy()
+    for i in range(len(root)):
+        root[i, :3] = cq[i, :3] + qrot(cq[i, 3:], -arr['com_offset'])
+    od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
+    B.set_reference(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
+    od.env_reset(); B.reset()
+    assert od.scalar('nobs') == 104 and od.scalar('episode_steps') == 194
+    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-5, atol=1e-3)
+    host = HostWBPG(tabs); host.reset(fbo.lib().fbo_hash_uniform(3, 0, 0))
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        a = rng.uniform(-1, 1, (1, 12)).astype(np.float32)
+        a2 = np.ascontiguousarray(np.tile(a, (2, 1)))
+        B.step_ptr(a2.ctypes.data); od.env_step(a[0].astype(np.float64)); host.step(218*(1 + 0.05*float(a[0, 11])))
+        assert host.step_i == int(od.scalar('wb_step')) and host.freq_idx == int(od.scalar('wb_freq_idx'))
+        assert abs(float(B.get('REWARD')[0, 0]) - od.scalar('reward')) < 1e-6 and 0 < od.scalar('reward') < 1
+    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-9 and _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-9
+    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-2)
+    assert not np.array_equal(B.get('QPOS')[0], B.get('QPOS')[1])       # a different initial wing phase per environment

@@ -6,11 +6,16 @@ import torch
 from flybody_amd import engine
 from flybody_amd.reference import default_walking_reference
 lib = os.path.abspath(sys.argv[1]); prec = int(sys.argv[2]); n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096; K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-M = engine.Model.from_asset('walk_imitation', lib_path=lib)
+task = os.environ.get('FB_TASK', 'walk_imitation'); M = engine.Model.from_asset(task, lib_path=lib)
 B = engine.Batch(M, n, precision=prec)
-qp, qv = default_walking_reference(); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+if task == 'flight_imitation':
+    from flybody_amd.fly_envs import BatchedFlyEnv
+    env = BatchedFlyEnv(n_env=n, precision=prec, terminal_com_dist=2.0, joint_filter=0.0, future_steps=5, time_limit=0.6, task=task)
+    B = env.batch; B.reset()
+else:
+    qp, qv = default_walking_reference(); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
 g = torch.Generator(device='cuda'); g.manual_seed(0)
-a = torch.empty(n, 59, device='cuda')
+a = torch.empty(n, M.dim('nact'), device='cuda')
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(5):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), st)
