@@ -158,12 +158,16 @@ __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w,
         real y[FB_MAXCH];
 #pragma unroll
         for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0;
+        // L[chain[s], chain[t]] lives in column chain[t] at offset chain[s] - chain[t] - 1
+        int cbase[FB_MAXCH];
+#pragma unroll
+        for (int t = 0; t < FB_MAXCH; t++) { int ct = (t < len) ? chain[t] : 0; cbase[t] = (int)w.lcadr[ct] - ct - 1; }
 #pragma unroll
         for (int s = FB_MAXCH - 1; s >= 1; s--) {
           if (s < len && y[s] != 0) {
-            int adr = M.dof_Madr[chain[s]];
+            int cs = chain[s];
 #pragma unroll
-            for (int t = 0; t < s; t++) y[t] -= w.lLD[adr + (s - t)] * y[s];
+            for (int t = 0; t < s; t++) y[t] -= w.lLD[cbase[t] + cs] * y[s];
           }
         }
 #pragma unroll

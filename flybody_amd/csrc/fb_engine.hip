@@ -32,7 +32,7 @@ struct fb_model {
   std::map<std::string, const BlobEntry*> idx;
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
-  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, tri_a, tri_e, adh_act;
+  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, dof_cadr, col_dof, lvl_cstart, tri_a, tri_e, adh_act;
   int nlevel;
   std::vector<double> body_box;
   std::vector<int> body_fluid_geom;
@@ -132,6 +132,22 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     if ((int)m->lvl_dof.size() - m->lvl_start[d] > FB_WAVE) { delete m; return fail("fb_model_load: more than 64 dofs on one depth level"); }
   }
   m->lvl_start[m->nlevel] = (int)m->lvl_dof.size();
+  // column-major factor layout: columns ordered level by level
+  m->dof_cadr.assign(nv + 1, 0); m->lvl_cstart.assign(m->nlevel + 1, 0);
+  for (int d = 0; d < m->nlevel; d++) {
+    m->lvl_cstart[d] = (int)m->col_dof.size();
+    int npair_max = (m->lvl_start[d + 1] - m->lvl_start[d])*(d + 1);
+    bool wide = false;
+    for (int t = m->lvl_start[d]; t < m->lvl_start[d + 1]; t++) {
+      int k = m->lvl_dof[t];
+      m->dof_cadr[k] = (int)m->col_dof.size();
+      for (int q = 0; q < m->dof_ndesc[k]; q++) m->col_dof.push_back(k);
+      if (m->dof_ndesc[k] > 24) wide = true;
+    }
+    if (npair_max > 4*FB_WAVE || (wide && npair_max > FB_WAVE)) { delete m; return fail("fb_model_load: elimination level too wide for the factor kernel"); }
+  }
+  m->lvl_cstart[m->nlevel] = (int)m->col_dof.size();
+  if ((int)m->col_dof.size() != m->nM - nv) { delete m; return fail("fb_model_load: inconsistent elimination tree"); }
   m->dof_anc.assign((size_t)nv*FB_MAXCH, 0);
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
@@ -181,6 +197,7 @@ template <typename real>
 __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
   __shared__ real s_LD[FB_EPB][FB_MAXNM];
+  __shared__ real s_Dg[FB_EPB][FB_MAXNV];
   __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
   __shared__ real s_x[FB_EPB][FB_MAXNV];
   __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
@@ -191,11 +208,16 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   __shared__ uint8_t s_lvl_dof[FB_MAXNV];
   __shared__ uint8_t s_lvl_start[FB_MAXCH + 4];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
+  __shared__ uint16_t s_cadr[FB_MAXNV + 1];
+  __shared__ uint16_t s_lvl_cstart[FB_MAXCH + 4];
+  __shared__ uint8_t s_col_dof[FB_MAXNM];
   int tid = threadIdx.x;
   for (int i = tid; i < M.nv*FB_MAXCH; i += FB_WAVE*FB_EPB) s_anc[i] = (uint8_t)M.dof_anc[i];
   for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) { s_depth[i] = (uint8_t)M.dof_depth[i]; s_ndesc[i] = (uint8_t)M.dof_ndesc[i]; s_lvl_dof[i] = (uint8_t)M.lvl_dof[i]; }
   for (int i = tid; i <= M.nv; i += FB_WAVE*FB_EPB) s_madr[i] = (uint16_t)M.dof_Madr[i];
-  for (int i = tid; i <= M.nlevel; i += FB_WAVE*FB_EPB) s_lvl_start[i] = (uint8_t)M.lvl_start[i];
+  for (int i = tid; i <= M.nlevel; i += FB_WAVE*FB_EPB) { s_lvl_start[i] = (uint8_t)M.lvl_start[i]; s_lvl_cstart[i] = (uint16_t)M.lvl_cstart[i]; }
+  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) s_cadr[i] = (uint16_t)M.dof_cadr[i];
+  for (int i = tid; i < M.ncol; i += FB_WAVE*FB_EPB) s_col_dof[i] = (uint8_t)M.col_dof[i];
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
   int wave = tid / FB_WAVE, lane = tid % FB_WAVE;
   int slot = blockIdx.x*FB_EPB + wave;
@@ -203,9 +225,10 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   int env = env_ids ? env_ids[slot] : slot;
   WS<real> w;
   ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
-  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
+  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDg = (FB_LDS real*)s_Dg[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
   w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc;
   w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.lmadr = (FB_LDS uint16_t*)s_madr; w.nlevel = M.nlevel;
+  w.lcadr = (FB_LDS uint16_t*)s_cadr; w.llvl_cstart = (FB_LDS uint16_t*)s_lvl_cstart; w.lcol_dof = (FB_LDS uint8_t*)s_col_dof;
   float* obs = B.obs + (size_t)env*B.nobs;
   if (mode == MODE_STEP) {
     if (!w.istate[IS_RESET_NEXT]) d_lds_load(M, w, lane);
@@ -274,7 +297,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
+  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom) UV(dof_cadr, dof_cadr) UV(col_dof, col_dof) UV(lvl_cstart, lvl_cstart)
+  M.ncol = (int)m->col_dof.size();
   UI(wing_act_idx, "wing_action_idx")
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];

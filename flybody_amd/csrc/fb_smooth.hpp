@@ -169,6 +169,7 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
     real acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
     int n = (b == 0) ? 0 : M.body_nsub[b];
+#pragma unroll 4
     for (int d = n - 1; d >= 0; d--) {
       const real* c = w.cinert + 10*(b + d);
       for (int k = 0; k < 10; k++) acc[k] += c[k];
@@ -181,6 +182,7 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
     real buf[6];
     mulinertvec(buf, w.crb + 10*M.dof_bodyid[i], w.cdof + 6*i);
     real arm = M.dof_armature[i];
+#pragma unroll 4
     for (int j = i; j >= 0; j = M.dof_parentid[j]) {
       real v = dot6(w.cdof + 6*j, buf);
       if (j == i) v += arm;
@@ -193,65 +195,80 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
 // Sparse L^T D L factorisation / solves of the joint-space inertia matrix, LDS resident.
 //
 // The elimination order of a kinematic tree is serial along a chain but the dofs of one *depth
-// level* are independent once every deeper level is final.  Both kernels are written in "pull"
-// form over depth levels: a row (or solution entry) gathers the contributions of its descendant
-// dofs -- a DFS-contiguous index range -- so no two lanes ever write the same address and the
-// dependency chain is ~20 levels long instead of ~2*nv steps.  Rows with many descendants (the 6
-// free-joint dofs) are reduced across the whole wavefront instead.
+// level* are independent once every deeper level is final.  Storage is COLUMN-major over the
+// elimination tree: column j holds L[k,j] for the descendants k = j+1 .. j+ndesc[j] of dof j -- a
+// DFS-contiguous range -- at LC[cadr[j] + (k-j-1)], D separately.  Every inner loop below is then a
+// unit-stride stream over k (no index-table lookup on the critical path):
+//   factor   U[i,e] = M[i,e] - sum_k L[k,i] L[k,anc_e(i)] D[k]        (pull, deepest level first)
+//   L^-T x   x[j] -= sum_k L[k,j] x[k]                                 (pull, deepest level first)
+//   L^-1 x   x[k] -= L[k,j] x[j]  for k in desc(j)                     (push, shallowest level first;
+//            subtrees of dofs on one level are disjoint, so no two lanes write the same entry)
+// Rows with many descendants (the 6 free-joint dofs) are reduced across the whole wavefront.
 #define FB_BIGROW 24
 
 template <typename real>
-__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, FB_LDS real* LD, FB_LDS real* Dinv, int lane) {
+__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
+                         FB_LDS real* LC, FB_LDS real* Dg, FB_LDS real* Dinv, int lane) {
   for (int d = w.nlevel - 1; d >= 0; d--) {
     int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
     int width = d + 1, npair = n*width;
-    real val[4]; int adr[4]; int cnt = 0;
+    real val[4]; int cnt = 0;
     for (int p = lane; p < npair; p += FB_WAVE) {
       int t = p / width, e = p - t*width;
       int i = w.llvl_dof[s0 + t];
       int nd = w.lndesc[i];
-      if (nd > FB_BIGROW) continue;
-      int mi = w.lmadr[i];
-      real acc = LD[mi + e];
-      for (int k = i + 1; k <= i + nd; k++) {
-        int mk = w.lmadr[k], dk = w.ldepth[k] - d;
-        acc -= LD[mk + dk] * LD[mk + dk + e] * LD[mk];
+      real acc = qM[w.lmadr[i] + e];
+      if (e == 0 && diag_add) acc += hscale*diag_add[i];
+      if (nd <= FB_BIGROW) {
+        int je = e ? w.lanc[i*FB_MAXCH + e - 1] : i;
+        const FB_LDS real* ci = LC + w.lcadr[i];                  // L[k,i],  k = i+1+q
+        const FB_LDS real* cj = LC + w.lcadr[je] + (i - je);      // L[k,je], k = i+1+q
+        const FB_LDS real* dk = Dg + i + 1;
+        for (int q = 0; q < nd; q++) acc -= ci[q]*cj[q]*dk[q];
       }
-      val[cnt] = acc; adr[cnt] = mi + e; cnt++;
+      val[cnt++] = acc;
     }
+    // wide rows: one (row, entry) at a time, descendants spread over the lanes
     for (int t = 0; t < n; t++) {
       int i = w.llvl_dof[s0 + t];
       int nd = w.lndesc[i];
       if (nd <= FB_BIGROW) continue;
-      int mi = w.lmadr[i];
       for (int e = 0; e < width; e++) {
+        int je = e ? w.lanc[i*FB_MAXCH + e - 1] : i;
+        const FB_LDS real* ci = LC + w.lcadr[i];
+        const FB_LDS real* cj = LC + w.lcadr[je] + (i - je);
         real part = 0;
-        for (int k = i + 1 + lane; k <= i + nd; k += FB_WAVE) {
-          int mk = w.lmadr[k], dk = w.ldepth[k] - d;
-          part += LD[mk + dk] * LD[mk + dk + e] * LD[mk];
-        }
+        for (int q = lane; q < nd; q += FB_WAVE) part += ci[q]*cj[q]*Dg[i + 1 + q];
         part = wave_sum(part);
-        if (lane == 0) LD[mi + e] -= part;
+        if (lane == t*width + e) val[0] -= part;                  // the lane that owns this pair (levels with wide rows have <= 64 pairs)
       }
     }
-    SYNC();
-    for (int c = 0; c < cnt; c++) LD[adr[c]] = val[c];
-    SYNC();
+    cnt = 0;
     for (int p = lane; p < npair; p += FB_WAVE) {
       int t = p / width, e = p - t*width;
-      if (e == 0) continue;
-      int mi = w.lmadr[w.llvl_dof[s0 + t]];
-      LD[mi + e] = LD[mi + e] / LD[mi];
+      if (e == 0) Dg[w.llvl_dof[s0 + t]] = val[cnt];
+      cnt++;
+    }
+    SYNC();
+    cnt = 0;
+    for (int p = lane; p < npair; p += FB_WAVE) {
+      int t = p / width, e = p - t*width;
+      if (e > 0) {
+        int i = w.llvl_dof[s0 + t];
+        int je = w.lanc[i*FB_MAXCH + e - 1];
+        LC[w.lcadr[je] + (i - je - 1)] = val[cnt] / Dg[i];
+      }
+      cnt++;
     }
     SYNC();
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / LD[w.lmadr[i]];
+  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / Dg[i];
   SYNC();
 }
 
-// x <- M^-1 x using the factorisation (x, LD, Dinv in LDS)
+// x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LD, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
   // x <- L^-T x, deepest level first: each dof pulls from its (already final) descendants
   for (int d = w.nlevel - 1; d >= 0; d--) {
     int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
@@ -259,8 +276,10 @@ __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS
       int j = w.llvl_dof[s0 + lane];
       int nd = w.lndesc[j];
       if (nd <= FB_BIGROW) {
+        const FB_LDS real* cj = LC + w.lcadr[j];
+        const FB_LDS real* xk = x + j + 1;
         real acc = 0;
-        for (int k = j + 1; k <= j + nd; k++) acc += LD[w.lmadr[k] + w.ldepth[k] - d] * x[k];
+        for (int q = 0; q < nd; q++) acc += cj[q]*xk[q];
         x[j] -= acc;
       }
     }
@@ -268,8 +287,9 @@ __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS
       int j = w.llvl_dof[s0 + t];
       int nd = w.lndesc[j];
       if (nd <= FB_BIGROW) continue;
+      const FB_LDS real* cj = LC + w.lcadr[j];
       real part = 0;
-      for (int k = j + 1 + lane; k <= j + nd; k += FB_WAVE) part += LD[w.lmadr[k] + w.ldepth[k] - d] * x[k];
+      for (int q = lane; q < nd; q += FB_WAVE) part += cj[q]*x[j + 1 + q];
       part = wave_sum(part);
       if (lane == 0) x[j] -= part;
     }
@@ -277,15 +297,13 @@ __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) x[i] *= Dinv[i];
   SYNC();
-  // x <- L^-1 x, shallowest level first: each dof pulls from its ancestors
-  for (int d = 1; d < w.nlevel; d++) {
-    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
-    if (lane < n) {
-      int i = w.llvl_dof[s0 + lane];
-      int mi = w.lmadr[i];
-      real acc = 0;
-      for (int a = 0; a < d; a++) acc += LD[mi + 1 + a] * x[w.lanc[i*FB_MAXCH + a]];
-      x[i] -= acc;
+  // x <- L^-1 x, shallowest level first: each dof pushes to its descendants (disjoint subtrees per level)
+  for (int d = 0; d < w.nlevel - 1; d++) {
+    // columns are laid out level by level, so the (dof, descendant) pairs of a level are one index range of LC
+    int p0 = w.llvl_cstart[d], p1 = w.llvl_cstart[d + 1];
+    for (int p = p0 + lane; p < p1; p += FB_WAVE) {
+      int j = w.lcol_dof[p];
+      x[j + 1 + (p - w.lcadr[j])] -= LC[p]*x[j];
     }
     SYNC();
   }
@@ -299,6 +317,7 @@ __device__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) 
     real v[6] = {0, 0, 0, 0, 0, 0};
     int n = M.body_chlen[b];
     const int* chain = M.body_chain + b*FB_MAXCH;
+#pragma unroll 4
     for (int s = 0; s < n; s++) {
       int i = chain[s];
       real qv = w.qvel[i];
@@ -318,6 +337,7 @@ __device__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) 
     } else nprev = M.dof_depth[i];
     const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
     real v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 4
     for (int s = 0; s < nprev; s++) {
       int a = chain[s];
       real qv = w.qvel[a];
@@ -449,6 +469,7 @@ __device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) 
       int b = M.dof_bodyid[i];
       real acc[6] = {0, 0, 0, 0, 0, 0};
       int n = M.body_nsub[b];
+#pragma unroll 4
       for (int d = 0; d < n; d++) {
         const real* c = w.cfrc_ext + 6*(b + d);
         for (int k = 0; k < 6; k++) acc[k] += c[k];
@@ -469,6 +490,7 @@ __device__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane)
     if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
     int n = M.body_chlen[b];
     const int* chain = M.body_chain + b*FB_MAXCH;
+#pragma unroll 4
     for (int s = 0; s < n; s++) {
       int i = chain[s];
       real qv = w.qvel[i];
@@ -486,6 +508,7 @@ __device__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane)
     int b = M.dof_bodyid[i];
     real acc[6] = {0, 0, 0, 0, 0, 0};
     int n = M.body_nsub[b];
+#pragma unroll 4
     for (int d = n - 1; d >= 0; d--) {
       const real* c = w.cfrc + 6*(b + d);
       for (int k = 0; k < 6; k++) acc[k] += c[k];

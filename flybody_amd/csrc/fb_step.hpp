@@ -150,14 +150,9 @@ template <typename real>
 __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
   real h = M.timestep;
   // the factor of M is dead after the constraint solve: reuse its LDS slot for M + h*D
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qM[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
   SYNC();
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    w.lLD[M.dof_Madr[i]] += h*M.dof_damping[i];
-    w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
-  }
-  SYNC();
-  d_factor(M, w, w.lLD, w.lDinv, lane);
+  d_factor(M, w, w.qM, M.dof_damping, h, w.lLD, w.lDg, w.lDinv, lane);
   d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < M.nu; i += FB_WAVE) {
     int aa = M.act_actadr[i];
@@ -192,7 +187,7 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
 // a launch and reloaded at the start of the next one (once per control step, not per substep).
 template <typename real>
 __device__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.lLD[i];
+  for (int i = lane; i < M.ncol; i += FB_WAVE) w.qLD[i] = w.lLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
   int nefc = w.istate[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.AR[i] = w.lAR[i];
@@ -200,7 +195,7 @@ __device__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane
 }
 template <typename real>
 __device__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD[i];
+  for (int i = lane; i < M.ncol; i += FB_WAVE) w.lLD[i] = w.qLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
   int nefc = w.istate[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.lAR[i] = w.AR[i];
@@ -214,9 +209,7 @@ __device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
   d_kinematics(M, w, lane); PROF(P_KIN);
   d_com_pos(M, w, lane); PROF(P_COMPOS);
   d_crb(M, w, lane); PROF(P_CRB);
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qM[i];
-  SYNC();
-  d_factor(M, w, w.lLD, w.lDinv, lane); PROF(P_FACTOR);
+  d_factor(M, w, w.qM, (const real*)nullptr, (real)0, w.lLD, w.lDg, w.lDinv, lane); PROF(P_FACTOR);
   d_collision(M, w, lane); PROF(P_COLL);
   d_make_constraint(M, w, lane); PROF(P_MAKEC);
   d_project_constraint(M, w, lane); PROF(P_PROJ);

@@ -50,6 +50,7 @@ struct DevModel {
   const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
   const int *dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
   const int *lvl_dof, *lvl_start; int nlevel;   // dofs grouped by depth
+  const int *dof_cadr, *col_dof, *lvl_cstart; int ncol;   // column-major factor layout (columns ordered by level)
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
@@ -121,9 +122,9 @@ template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(
 template <typename real>
 struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
-  FB_LDS real *lLD, *lDinv, *lx, *lAR;
+  FB_LDS real *lLD, *lDg, *lDinv, *lx, *lAR;     // lLD: column-major L (see fb_smooth.hpp)
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
-  const FB_LDS uint8_t *lanc, *ldepth, *lndesc, *llvl_dof, *llvl_start; const FB_LDS uint16_t *lmadr; int nlevel;
+  const FB_LDS uint8_t *lanc, *ldepth, *lndesc, *llvl_dof, *llvl_start, *lcol_dof; const FB_LDS uint16_t *lmadr, *lcadr, *llvl_cstart; int nlevel;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X
