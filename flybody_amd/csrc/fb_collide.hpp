@@ -118,7 +118,7 @@ FBD void find_pos(const MprPt<real>* p, real* pos) {
 
 // Minkowski portal refinement on the margin-inflated shapes; returns penetration depth >= 0
 template <typename real>
-__device__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos) {
+__device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos) {
   MprPt<real> p[4], v4;
   real d[3], va[3], vb[3];
   copy3(p[0].v1, a.pos); copy3(p[0].v2, b.pos); sub3(p[0].v, a.pos, b.pos);
@@ -278,7 +278,7 @@ FBD void c_plane_cylinder(LaneContacts<real>& lc, const real* ppos, const real* 
 }
 
 template <typename real>
-__device__ void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
+__device__ __forceinline__ void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
   int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   real margin = M.pair_margin[p];
@@ -322,7 +322,7 @@ __device__ void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, 
 }
 
 template <typename real>
-__device__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // ---- mid phase: bounding spheres
   int ncand = 0;

@@ -48,7 +48,7 @@ FBD void kbi(const DevModel<real>& M, const real* solref, const real* solimp, re
 
 // ------------------------------------------------------------------ rows
 template <typename real>
-__device__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
   // ---- joint limits (row order: joint order)
   int nlimit = 0;
   for (int base = 0; base < M.njnt; base += FB_WAVE) {
@@ -141,11 +141,11 @@ __device__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, in
 }
 
 template <typename real, typename ARP>
-__device__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
+__device__ __forceinline__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
 
 // ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
 template <typename real>
-__device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
   int nefc = w.istate[IS_NEFC];
   if (nefc == 0) return;
   for (int base = 0; base < nefc; base += FB_WAVE) {
@@ -186,7 +186,7 @@ __device__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w,
 }
 
 template <typename real, typename ARP>
-__device__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+__device__ __forceinline__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;
@@ -227,7 +227,7 @@ __device__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
 
 // ------------------------------------------------------------------ adhesion + actuator forces
 template <typename real>
-__device__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
   SYNC();
   for (int i = lane; i < M.nu; i += FB_WAVE) {
@@ -309,10 +309,13 @@ FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real
     real P11 = (A22 + la)*detinv, P22 = (A11 + la)*detinv, P12 = -A12*detinv;
     v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
     real val = v1*v1 + v2*v2 - r*r;
-    if (val < (real)1e-10) break;
+    // FP64: MuJoCo's absolute 1e-10 thresholds; FP32: the same test scaled to single-precision resolution
+    const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*r*r + (real)1e-10;
+    if (val < tolv) break;
     real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
     real delta = -val/deriv;
-    if (delta < (real)1e-10) break;
+    const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
+    if (delta < told) break;
     la += delta;
   }
   res[0] = v1*dd[0]; res[1] = v2*dd[1];
@@ -344,7 +347,7 @@ template <typename real, typename RP> FBD real row_dot(RP row, int n, const R3<r
 
 // PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix
 template <typename real, typename ARP>
-__device__ int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+__device__ __forceinline__ int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
   PROF_BEGIN();
   R3<real> f, rb, rR, rfr0, rfr1;
@@ -475,14 +478,15 @@ __device__ int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
 }
 
 template <typename real>
-__device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS<real>& w, int lane) {
+  // returns true when lx holds J^T f and the caller must run the M^-1 solve before d_constraint_b
   int nefc = w.istate[IS_NEFC];
   int nv = M.nv;
   if (nefc == 0) {
-    for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i]; w.qacc[i] = a; w.qacc_ws[i] = a; w.qfrc_constraint[i] = 0; }
+    for (int i = lane; i < nv; i += FB_WAVE) { w.lx[i] = 0; w.qfrc_constraint[i] = 0; }
     if (lane == 0) w.istate[IS_NITER] = 0;
     SYNC();
-    return;
+    return false;
   }
   PROF_BEGIN();
   // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
@@ -550,8 +554,13 @@ __device__ void d_solve_constraints(const DevModel<real>& M, const WS<real>& w, 
   SYNC();
   for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint[i];
   SYNC();
-  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
-  for (int i = lane; i < nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.lx[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
-  SYNC();
   PROF(P_CFIN);
+  return true;
+}
+
+// qacc = qacc_smooth + M^-1 J^T f (lx), also saved as the next warm start
+template <typename real>
+__device__ __forceinline__ void d_constraint_b(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.lx[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
+  SYNC();
 }

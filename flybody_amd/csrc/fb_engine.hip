@@ -191,7 +191,6 @@ struct Batch {
   int n_env, nobs;
 };
 
-enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
 
 template <typename real>
 __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
@@ -229,14 +228,8 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc;
   w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.lmadr = (FB_LDS uint16_t*)s_madr; w.nlevel = M.nlevel;
   w.lcadr = (FB_LDS uint16_t*)s_cadr; w.llvl_cstart = (FB_LDS uint16_t*)s_lvl_cstart; w.lcol_dof = (FB_LDS uint8_t*)s_col_dof;
-  float* obs = B.obs + (size_t)env*B.nobs;
-  if (mode == MODE_STEP) {
-    if (!w.istate[IS_RESET_NEXT]) d_lds_load(M, w, lane);
-    d_env_step(M, w, env, action + (size_t)env*M.nact, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
-  } else if (mode == MODE_RESET) d_env_reset(M, w, env, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
-  else if (mode == MODE_SUBSTEP) { d_lds_load(M, w, lane); for (int s = 0; s < nsub; s++) d_substep(M, w, lane); }
-  else { d_step1(M, w, lane); d_step2(M, w, lane, true); }
-  d_lds_store(M, w, lane);
+  float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
+  d_run(M, w, env, mode, nsub, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 }
 
 // ------------------------------------------------------------------ batch

@@ -35,7 +35,7 @@ enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_A
 
 // ------------------------------------------------------------------ kinematics (chain walk)
 template <typename real>
-__device__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
     int depth = M.body_depth[b];
@@ -115,7 +115,7 @@ __device__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lan
 
 // ------------------------------------------------------------------ cinert, cdof, tendons
 template <typename real>
-__device__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
   const real com[3] = {w.com[0], w.com[1], w.com[2]};
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real* c = w.cinert + 10*b;
@@ -163,7 +163,7 @@ __device__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) 
 
 // ------------------------------------------------------------------ composite inertia + mass matrix
 template <typename real>
-__device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
   // subtree pull: crb[b] = sum of cinert over the DFS-contiguous subtree of b
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real acc[10];
@@ -207,12 +207,14 @@ __device__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
 #define FB_BIGROW 24
 
 template <typename real>
-__device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
+__device__ __forceinline__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
                          FB_LDS real* LC, FB_LDS real* Dg, FB_LDS real* Dinv, int lane) {
+  PROF_BEGIN();
   for (int d = w.nlevel - 1; d >= 0; d--) {
     int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
     int width = d + 1, npair = n*width;
     real val[4]; int cnt = 0;
+    PROF_RESET();
     for (int p = lane; p < npair; p += FB_WAVE) {
       int t = p / width, e = p - t*width;
       int i = w.llvl_dof[s0 + t];
@@ -228,6 +230,7 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real*
       }
       val[cnt++] = acc;
     }
+    PROF(17);
     // wide rows: one (row, entry) at a time, descendants spread over the lanes
     for (int t = 0; t < n; t++) {
       int i = w.llvl_dof[s0 + t];
@@ -243,6 +246,7 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real*
         if (lane == t*width + e) val[0] -= part;                  // the lane that owns this pair (levels with wide rows have <= 64 pairs)
       }
     }
+    PROF(18);
     cnt = 0;
     for (int p = lane; p < npair; p += FB_WAVE) {
       int t = p / width, e = p - t*width;
@@ -261,6 +265,7 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real*
       cnt++;
     }
     SYNC();
+    PROF(19);
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / Dg[i];
   SYNC();
@@ -268,7 +273,8 @@ __device__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real*
 
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-__device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+__device__ __forceinline__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+  PROF_BEGIN();
   // x <- L^-T x, deepest level first: each dof pulls from its (already final) descendants
   for (int d = w.nlevel - 1; d >= 0; d--) {
     int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
@@ -297,6 +303,7 @@ __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) x[i] *= Dinv[i];
   SYNC();
+  PROF(20);
   // x <- L^-1 x, shallowest level first: each dof pushes to its descendants (disjoint subtrees per level)
   for (int d = 0; d < w.nlevel - 1; d++) {
     // columns are laid out level by level, so the (dof, descendant) pairs of a level are one index range of LC
@@ -307,12 +314,13 @@ __device__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS
     }
     SYNC();
   }
+  PROF(21);
 }
 
 // ------------------------------------------------------------------ velocity stage
 // cvel per body and cdof_dot per dof by walking the owning chain (no tree-level barriers)
 template <typename real>
-__device__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real v[6] = {0, 0, 0, 0, 0, 0};
     int n = M.body_chlen[b];
@@ -365,7 +373,7 @@ FBD void object_velocity(const WS<real>& w, int body, const real* pos, const rea
 // angular drag, Stokes terms.  Follows the reference's restatement flybody/ellipsoid_fluid_model.py:88-310
 // (coefficient layout :229-237).  Writes the wrench about the tree CoM as [torque; force].
 template <typename real>
-__device__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& w, int b, int g, real* out) {
+__device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& w, int b, int g, real* out) {
   const real PI = (real)3.14159265358979323846;
   const real* gf = M.geom_fluid + 12*g;
   const real* size = M.geom_size + 3*g;
@@ -418,7 +426,7 @@ __device__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& 
 
 // passive forces: joint springs/dampers + per-body inertia-box fluid drag (density, viscosity)
 template <typename real>
-__device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) {
   // per-body fluid wrench about the tree CoM, stored in cfrc_ext as [torque; force] (scratch use)
   bool fluid = (M.density > 0 || M.viscosity > 0);
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
@@ -483,7 +491,7 @@ __device__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) 
 
 // bias forces by RNE: chain walk for the body accelerations, subtree pull for the forces
 template <typename real>
-__device__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
     real* out = w.cfrc + 6*b;

@@ -9,7 +9,7 @@
 
 // ------------------------------------------------------------------ sensors
 template <typename real>
-__device__ void d_sensor_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_sensor_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
   if (lane == 0) {
     int s = M.site_thorax;
     real lvel[6];
@@ -56,7 +56,7 @@ FBD real ray_site(const real* pos, const real* mat, const real* size, int type, 
 
 // acceleration-stage sensors: accelerometer (thorax site), 6 force sensors, 6 touch sensors
 template <typename real>
-__device__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
   int ncon = w.istate[IS_NCON];
   // external (contact) wrench per body about the tree CoM: lane == body pulls from the contact list
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
@@ -145,15 +145,10 @@ __device__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lan
   SYNC();
 }
 
-// ------------------------------------------------------------------ integrator
+// ------------------------------------------------------------------ integrator (semi-implicit Euler, implicit joint damping)
 template <typename real>
-__device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<real>& w, int lane) {
   real h = M.timestep;
-  // the factor of M is dead after the constraint solve: reuse its LDS slot for M + h*D
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
-  SYNC();
-  d_factor(M, w, w.qM, M.dof_damping, h, w.lLD, w.lDg, w.lDinv, lane);
-  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
   for (int i = lane; i < M.nu; i += FB_WAVE) {
     int aa = M.act_actadr[i];
     if (aa < 0) continue;
@@ -186,7 +181,7 @@ __device__ void d_euler(const DevModel<real>& M, const WS<real>& w, int lane) {
 // matrix produced by the position stage are parked in the environment's global row at the end of
 // a launch and reloaded at the start of the next one (once per control step, not per substep).
 template <typename real>
-__device__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.ncol; i += FB_WAVE) w.qLD[i] = w.lLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
   int nefc = w.istate[IS_NEFC];
@@ -194,7 +189,7 @@ __device__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane
   SYNC();
 }
 template <typename real>
-__device__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.ncol; i += FB_WAVE) w.lLD[i] = w.qLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
   int nefc = w.istate[IS_NEFC];
@@ -202,55 +197,9 @@ __device__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane)
   SYNC();
 }
 
-// ------------------------------------------------------------------ stages
-template <typename real>
-__device__ void d_step1(const DevModel<real>& M, const WS<real>& w, int lane) {
-  PROF_BEGIN();
-  d_kinematics(M, w, lane); PROF(P_KIN);
-  d_com_pos(M, w, lane); PROF(P_COMPOS);
-  d_crb(M, w, lane); PROF(P_CRB);
-  d_factor(M, w, w.qM, (const real*)nullptr, (real)0, w.lLD, w.lDg, w.lDinv, lane); PROF(P_FACTOR);
-  d_collision(M, w, lane); PROF(P_COLL);
-  d_make_constraint(M, w, lane); PROF(P_MAKEC);
-  d_project_constraint(M, w, lane); PROF(P_PROJ);
-  d_com_vel(M, w, lane);
-  d_passive(M, w, lane);
-  d_rne_bias(M, w, lane);
-  d_sensor_vel(M, w, lane); PROF(P_VEL);
-}
-
-template <typename real>
-__device__ void d_acceleration(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
-    w.qfrc_smooth[i] = f; w.lx[i] = f;
-  }
-  SYNC();
-  d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
-  SYNC();
-}
-
-template <typename real>
-__device__ void d_step2(const DevModel<real>& M, const WS<real>& w, int lane, bool actuate) {
-  PROF_BEGIN();
-  if (actuate) d_actuation(M, w, lane);
-  PROF(P_ACT);
-  if (!actuate) {
-    for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
-    for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
-    SYNC();
-  }
-  PROF_RESET();
-  d_acceleration(M, w, lane); PROF(P_ACC);
-  d_solve_constraints(M, w, lane);
-  PROF_RESET();
-  d_sensor_acc(M, w, lane); PROF(P_SENS);
-}
-
 // ------------------------------------------------------------------ environment epilogue
 template <typename real>
-__device__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
+__device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
   int thorax = M.site_bodyid[M.site_thorax];
   const real* R = w.xmat + 9*thorax;
   const real* tp = w.xpos + 3*thorax;
@@ -302,42 +251,37 @@ __device__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const rea
 
 // env.reset(): walk_imitation.py:112-136 + fruitfly.py:390-405, then a forward pass with
 // actuation disabled (dm_control Physics.after_reset)
+// ------------------------------------------------------------------ flight_imitation
+// Wing-beat pattern generator state machine (flybody/tasks/pattern_generators.py:131-203), one per
+// environment: the 64 lanes search the phase / frequency tables cooperatively (first-minimum argmin).
 template <typename real>
-__device__ void d_flight_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane);
-template <typename real>
-__device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward, float* discount, int* step_type, int lane);
-
-template <typename real>
-__device__ void d_env_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane) {
-  if (M.task == 1) { d_flight_reset(M, w, env, obs, reward, discount, step_type, lane); return; }
-  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
-  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
-  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
-  SYNC();
-  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
-  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
-  SYNC();
-  d_step1(M, w, lane);
-  d_step2(M, w, lane, false);
-  d_pack_obs(M, w, w.sens, obs, lane);
-  if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
-  SYNC();
+__device__ __forceinline__ int wave_argmin_absdiff(const real* v, int n, real x, bool mod1, int lane) {
+  real best = (real)1e30; int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += FB_WAVE) {
+    real a = v[i];
+    if (mod1) a = a - floor(a);
+    real e = fabs(x - a);
+    if (e < best) { best = e; bi = i; }
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    real ob = shfl_xor_any(best, m); int oi = __shfl_xor(bi, m, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  return bi;
 }
 
-template <typename real>
-__device__ void d_substep(const DevModel<real>& M, const WS<real>& w, int lane) {
-  d_step2(M, w, lane, true);
-  { PROF_BEGIN(); d_euler(M, w, lane); PROF(P_EULER); }
-  d_step1(M, w, lane);
+FBD float hash_uniform(unsigned seed, unsigned env, unsigned episode) {
+  unsigned x = seed*0x9E3779B9u ^ (env*0x85EBCA6Bu) ^ (episode*0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f/16777216.0f);
 }
 
-// env.step(action): before_step hooks, nsubstep physics steps, reward/termination/observation
+template <typename real> FBD real tolerance_linear(real x, real margin) { real d = fabs(x)/margin; return d < 1 ? 1 - d : (real)0; }
+
+// ------------------------------------------------------------------ task pre / post hooks
+// walk_imitation before_step (walk_imitation.py:138-150, fruitfly.py:532-544)
 template <typename real>
-__device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, int env, const float* action, float* obs, float* reward,
-                           float* discount, int* step_type, int lane) {
-  if (w.istate[IS_RESET_NEXT]) { d_env_reset(M, w, env, obs, reward, discount, step_type, lane); return; }
-  if (M.task == 1) { d_flight_step(M, w, action, obs, reward, discount, step_type, lane); return; }
+__device__ __forceinline__ void d_walk_pre(const DevModel<real>& M, const WS<real>& w, const float* action, int lane) {
   for (int k = lane; k < M.nu; k += FB_WAVE) {
     float a = action[k];
     if (a != a) a = 0.f;
@@ -345,11 +289,11 @@ __device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, int env, 
   }
   if (lane < FB_NSENS) w.sens_acc[lane] = 0;
   SYNC();
-  for (int s = 0; s < M.nsubstep; s++) {
-    d_substep(M, w, lane);
-    if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane];
-    SYNC();
-  }
+}
+
+// walk_imitation reward / termination / observation (base.py:212-225, walk_imitation.py:152-203)
+template <typename real>
+__device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
   if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
   int stepc = w.istate[IS_STEP] + 1;
   SYNC();
@@ -378,37 +322,23 @@ __device__ void d_env_step(const DevModel<real>& M, const WS<real>& w, int env, 
   SYNC();
 }
 
-// ------------------------------------------------------------------ flight_imitation
-// Wing-beat pattern generator state machine (flybody/tasks/pattern_generators.py:131-203), one per
-// environment: the 64 lanes search the phase / frequency tables cooperatively (first-minimum argmin).
+// walk_imitation episode init (walk_imitation.py:112-136, fruitfly.py:390-405)
 template <typename real>
-__device__ int wave_argmin_absdiff(const real* v, int n, real x, bool mod1, int lane) {
-  real best = (real)1e30; int bi = 0x7fffffff;
-  for (int i = lane; i < n; i += FB_WAVE) {
-    real a = v[i];
-    if (mod1) a = a - floor(a);
-    real e = fabs(x - a);
-    if (e < best) { best = e; bi = i; }
-  }
-  for (int m = 32; m >= 1; m >>= 1) {
-    real ob = shfl_xor_any(best, m); int oi = __shfl_xor(bi, m, 64);
-    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
-  return bi;
+__device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  SYNC();
+  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
+  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
+  SYNC();
 }
 
-FBD float hash_uniform(unsigned seed, unsigned env, unsigned episode) {
-  unsigned x = seed*0x9E3779B9u ^ (env*0x85EBCA6Bu) ^ (episode*0xC2B2AE35u);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return (float)(x >> 8) * (1.0f/16777216.0f);
-}
-
-template <typename real> FBD real tolerance_linear(real x, real margin) { real d = fabs(x)/margin; return d < 1 ? 1 - d : (real)0; }
-
-// env.reset(): flight_imitation.py:112-144 (root pose/velocity from the reference, wings from the WBPG at a
-// per-episode phase), then a forward pass with actuation disabled
+// flight_imitation episode init (flight_imitation.py:112-144): root pose / linear velocity from the reference,
+// wings from the WBPG at a per-episode phase
 template <typename real>
-__device__ void d_flight_reset(const DevModel<real>& M, const WS<real>& w, int env, float* obs, float* reward, float* discount, int* step_type, int lane) {
+__device__ __forceinline__ void d_flight_init(const DevModel<real>& M, const WS<real>& w, int env, int lane) {
   for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = (i < 3) ? M.ref_qvel[i] : (real)0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
   for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
@@ -428,18 +358,12 @@ __device__ void d_flight_reset(const DevModel<real>& M, const WS<real>& w, int e
     w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.istate[IS_EPISODE] = episode + 1; w.wbfreq[0] = M.wb_base_freq;
   }
   SYNC();
-  d_step1(M, w, lane);
-  d_step2(M, w, lane, false);
-  d_pack_obs(M, w, w.sens, obs, lane);
-  if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
-  SYNC();
 }
 
-// env.step(): flight_imitation.py:146-212
+// flight_imitation before_step (flight_imitation.py:146-168): WBPG step at the requested frequency, wing action
+// entries become position-error force commands
 template <typename real>
-__device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const float* action, float* obs, float* reward,
-                              float* discount, int* step_type, int lane) {
-  // ---- WBPG step at the frequency requested by the user action
+__device__ __forceinline__ void d_flight_pre(const DevModel<real>& M, const WS<real>& w, const float* action, int lane) {
   float au = action[M.user_idx]; if (au != au) au = 0.f;
   real ctrl_freq = M.wb_base_freq*(1 + M.wb_rel_range*(real)au);
   int fidx = w.istate[IS_WB_FREQ], st = w.istate[IS_WB_STEP];
@@ -454,9 +378,7 @@ __device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const 
     st = wave_argmin_absdiff(M.wb_phase + o2, n2, cur, true, lane);
     fidx = fnew; o = o2;
   }
-  int prev = w.istate[IS_STEP];
   SYNC();
-  // ---- action -> ctrl, wing entries become position-error force commands (flight_imitation.py:156-158)
   for (int k = lane; k < M.nu; k += FB_WAVE) {
     float a = action[k]; if (a != a) a = 0.f;
     real v = (real)a;
@@ -466,12 +388,13 @@ __device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const 
   if (lane < FB_NSENS) w.sens_acc[lane] = 0;
   if (lane == 0) { w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.wbfreq[0] = filt; }
   SYNC();
-  for (int s = 0; s < M.nsubstep; s++) {
-    d_substep(M, w, lane);
-    if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane];
-    SYNC();
-  }
+}
+
+// flight_imitation reward / termination / observation (flight_imitation.py:170-212)
+template <typename real>
+__device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
   if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
+  int prev = w.istate[IS_STEP];
   int stepc = prev + 1;
   SYNC();
   if (lane == 0) w.istate[IS_STEP] = stepc;
@@ -479,7 +402,8 @@ __device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const 
   for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
   qn = wave_sum(qn);
   SYNC();
-  // ---- reward: CoM distance to the ghost and orientation error (flight_imitation.py:170-201)
+  // ghost pose: set from ref[prev] before the physics and advanced by its velocity over the control step
+  // (its ~1e-8 cm gravity sag is neglected)
   real gp[3], gq[4], qr[4], tmpq[4];
   const real* rv = M.ref_qvel + 6*prev;
   for (int k = 0; k < 3; k++) gp[k] = M.ref_qpos[7*prev + k] + M.control_timestep*rv[k];
@@ -502,7 +426,6 @@ __device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const 
   real nq = sqrt(dq[0]*dq[0] + dq[1]*dq[1] + dq[2]*dq[2] + dq[3]*dq[3]);
   real x = 2*(dq[0]/nq)*(dq[0]/nq) - 1; if (x > 1) x = 1;
   real r_quat = tolerance_linear((real)acos(x), (real)3.14159265358979323846);
-  // ---- termination (flight_imitation.py:203-212)
   int thorax = M.site_bodyid[M.site_thorax];
   real height = w.xpos[3*thorax + 2];
   real cd[3]; sub3(cd, M.ref_qpos + 7*idx, w.qpos);
@@ -519,4 +442,123 @@ __device__ void d_flight_step(const DevModel<real>& M, const WS<real>& w, const 
     w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
   }
   SYNC();
+}
+
+// ------------------------------------------------------------------ the stage machine
+// One launch = one pass of this interpreter.  Every stage is inlined exactly once; the factor and
+// solve stages are shared by their three / two users through a return-stage register.  All stage
+// selectors are wave-uniform.  Order per substep follows dm_control's legacy step: mj_step2
+// (actuation, acceleration, constraint, acceleration-stage sensors), integrate, mj_step1
+// (position + velocity stages for the new state).
+enum { ST_ACT, ST_ACC_PRE, ST_SOLVE, ST_ACC_POST, ST_CONSTR_A, ST_CONSTR_B, ST_SENS, ST_EULER_PRE, ST_FACTOR, ST_EULER_SOLVE,
+       ST_EULER_POST, ST_KIN, ST_COLL, ST_SUBEND, ST_DONE };
+enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
+
+template <typename real>
+__device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, const float* action,
+                      float* obs, float* reward, float* discount, int* step_type, int lane) {
+  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && w.istate[IS_RESET_NEXT] != 0);
+  bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
+  bool actuate = true, damp = false;
+  int nsub = (mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep, sub = 0;
+  int pc, ret = ST_DONE, fret = ST_DONE;
+  if (resetting) {
+    if (M.task == 1) d_flight_init(M, w, env, lane); else d_walk_init(M, w, lane);
+    actuate = false; pc = ST_KIN;
+  } else if (mode == MODE_FORWARD) {
+    pc = ST_KIN;
+  } else {
+    d_lds_load(M, w, lane);
+    if (mode == MODE_STEP) { if (M.task == 1) d_flight_pre(M, w, action, lane); else d_walk_pre(M, w, action, lane); }
+    pc = (nsub > 0) ? ST_ACT : ST_DONE;
+  }
+  bool single_pass = resetting || (mode == MODE_FORWARD);     // KIN..COLL then ACT..SENS once, no integration
+  while (pc != ST_DONE) {
+    switch (pc) {
+      case ST_ACT: {
+        PROF_BEGIN();
+        if (actuate) d_actuation(M, w, lane);
+        else {
+          for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
+          for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
+          SYNC();
+        }
+        PROF(P_ACT);
+        pc = ST_ACC_PRE; break; }
+      case ST_ACC_PRE:
+        for (int i = lane; i < M.nv; i += FB_WAVE) {
+          real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
+          w.qfrc_smooth[i] = f; w.lx[i] = f;
+        }
+        SYNC();
+        ret = ST_ACC_POST; pc = ST_SOLVE; break;
+      case ST_SOLVE: {
+        PROF_BEGIN();
+        d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
+        PROF(P_ACC);
+        pc = ret; break; }
+      case ST_ACC_POST:
+        for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
+        SYNC();
+        pc = ST_CONSTR_A; break;
+      case ST_CONSTR_A: {
+        bool need = d_constraint_a(M, w, lane);
+        ret = ST_CONSTR_B; pc = need ? ST_SOLVE : ST_CONSTR_B; break; }
+      case ST_CONSTR_B:
+        d_constraint_b(M, w, lane);
+        pc = ST_SENS; break;
+      case ST_SENS: {
+        PROF_BEGIN();
+        d_sensor_acc(M, w, lane);
+        PROF(P_SENS);
+        pc = single_pass ? ST_DONE : ST_EULER_PRE; break; }
+      case ST_EULER_PRE:
+        // the factor of M is dead after the constraint solve: its LDS slot is reused for M + h*D
+        for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
+        SYNC();
+        damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break;
+      case ST_FACTOR: {
+        PROF_BEGIN();
+        d_factor(M, w, w.qM, damp ? M.dof_damping : (const real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDg, w.lDinv, lane);
+        PROF(P_FACTOR);
+        pc = fret; break; }
+      case ST_EULER_SOLVE:
+        ret = ST_EULER_POST; pc = ST_SOLVE; break;
+      case ST_EULER_POST: {
+        PROF_BEGIN();
+        d_integrate(M, w, lane);
+        PROF(P_EULER);
+        pc = ST_KIN; break; }
+      case ST_KIN: {
+        PROF_BEGIN();
+        d_kinematics(M, w, lane); PROF(P_KIN);
+        d_com_pos(M, w, lane); PROF(P_COMPOS);
+        d_crb(M, w, lane); PROF(P_CRB);
+        damp = false; fret = ST_COLL; pc = ST_FACTOR; break; }
+      case ST_COLL: {
+        PROF_BEGIN();
+        d_collision(M, w, lane); PROF(P_COLL);
+        d_make_constraint(M, w, lane); PROF(P_MAKEC);
+        d_project_constraint(M, w, lane); PROF(P_PROJ);
+        d_com_vel(M, w, lane);
+        d_passive(M, w, lane);
+        d_rne_bias(M, w, lane);
+        d_sensor_vel(M, w, lane); PROF(P_VEL);
+        pc = single_pass ? ST_ACT : ST_SUBEND; break; }
+      case ST_SUBEND:
+        if (env_logic) { if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane]; SYNC(); }
+        sub++;
+        pc = (sub < nsub) ? ST_ACT : ST_DONE; break;
+      default: pc = ST_DONE;
+    }
+  }
+  if (env_logic) {
+    if (resetting) {
+      d_pack_obs(M, w, w.sens, obs, lane);
+      if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
+      SYNC();
+    } else if (M.task == 1) d_flight_post(M, w, obs, reward, discount, step_type, lane);
+    else d_walk_post(M, w, obs, reward, discount, step_type, lane);
+  }
+  d_lds_store(M, w, lane);
 }
