@@ -161,22 +161,47 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
   SYNC();
 }
 
+// Subtree sums S[b][0..K) = sum of A over the DFS-contiguous subtree of body b ("subtree pull").  The tree root owns
+// every body, so its sum is a 64-lane reduction instead of a 67-iteration serial walk; all other subtrees are short.
+template <int K, typename real>
+__device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real* A, real* S, int lane) {
+  real tot[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) tot[k] = 0;
+  for (int b = 1 + lane; b < M.nbody; b += FB_WAVE) {
+#pragma unroll
+    for (int k = 0; k < K; k++) tot[k] += A[K*b + k];
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) tot[k] = wave_sum(tot[k]);
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real acc[K];
+    if (b == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) acc[k] = 0;
+    } else if (b == 1) {
+#pragma unroll
+      for (int k = 0; k < K; k++) acc[k] = tot[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) acc[k] = 0;
+      int n = M.body_nsub[b];
+#pragma unroll 4
+      for (int d = n - 1; d >= 0; d--) {
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] += A[K*(b + d) + k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) S[K*b + k] = acc[k];
+  }
+  SYNC();
+}
+
 // ------------------------------------------------------------------ composite inertia + mass matrix
 template <typename real>
 __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
-  // subtree pull: crb[b] = sum of cinert over the DFS-contiguous subtree of b
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real acc[10];
-    for (int k = 0; k < 10; k++) acc[k] = 0;
-    int n = (b == 0) ? 0 : M.body_nsub[b];
-#pragma unroll 4
-    for (int d = n - 1; d >= 0; d--) {
-      const real* c = w.cinert + 10*(b + d);
-      for (int k = 0; k < 10; k++) acc[k] += c[k];
-    }
-    for (int k = 0; k < 10; k++) w.crb[10*b + k] = acc[k];
-  }
-  SYNC();
+  subtree_sum<10>(M, w.cinert, w.crb, lane);
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int adr = M.dof_Madr[i];
     real buf[6];
@@ -465,6 +490,7 @@ __device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real
     out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
   }
   SYNC();
+  if (fluid) subtree_sum<6>(M, w.cfrc_ext, w.cacc, lane);       // cacc is free scratch until the sensor stage
   // qfrc_passive[i] = spring + damper + cdof_i . (sum of fluid wrenches over the dof's subtree)
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int j = M.dof_jntid[i];
@@ -473,17 +499,7 @@ __device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real
       int qa = M.jnt_qposadr[j];
       f -= M.jnt_stiffness[j]*(w.qpos[qa] - M.qpos_spring[qa]);
     }
-    if (fluid) {
-      int b = M.dof_bodyid[i];
-      real acc[6] = {0, 0, 0, 0, 0, 0};
-      int n = M.body_nsub[b];
-#pragma unroll 4
-      for (int d = 0; d < n; d++) {
-        const real* c = w.cfrc_ext + 6*(b + d);
-        for (int k = 0; k < 6; k++) acc[k] += c[k];
-      }
-      f += dot6(w.cdof + 6*i, acc);
-    }
+    if (fluid) f += dot6(w.cdof + 6*i, w.cacc + 6*M.dof_bodyid[i]);
     w.qfrc_passive[i] = f;
   }
   SYNC();
@@ -512,16 +528,7 @@ __device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<rea
     for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k];
   }
   SYNC();
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    int b = M.dof_bodyid[i];
-    real acc[6] = {0, 0, 0, 0, 0, 0};
-    int n = M.body_nsub[b];
-#pragma unroll 4
-    for (int d = n - 1; d >= 0; d--) {
-      const real* c = w.cfrc + 6*(b + d);
-      for (int k = 0; k < 6; k++) acc[k] += c[k];
-    }
-    w.qfrc_bias[i] = dot6(w.cdof + 6*i, acc);
-  }
+  subtree_sum<6>(M, w.cfrc, w.cacc, lane);
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_bias[i] = dot6(w.cdof + 6*i, w.cacc + 6*M.dof_bodyid[i]);
   SYNC();
 }
