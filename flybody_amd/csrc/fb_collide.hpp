@@ -278,7 +278,7 @@ FBD void c_plane_cylinder(LaneContacts<real>& lc, const real* ppos, const real* 
 }
 
 template <typename real>
-__device__ __forceinline__ void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
+FB_STAGE_B void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
   int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   real margin = M.pair_margin[p];

@@ -141,7 +141,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
 }
 
 template <typename real, typename ARP>
-__device__ __forceinline__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
+FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
 
 // ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
 template <typename real>
@@ -186,7 +186,7 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
 }
 
 template <typename real, typename ARP>
-__device__ __forceinline__ void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;
@@ -347,7 +347,7 @@ template <typename real, typename RP> FBD real row_dot(RP row, int n, const R3<r
 
 // PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix
 template <typename real, typename ARP>
-__device__ __forceinline__ int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
   PROF_BEGIN();
   R3<real> f, rb, rR, rfr0, rfr1;

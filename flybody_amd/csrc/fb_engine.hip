@@ -32,7 +32,7 @@ struct fb_model {
   std::map<std::string, const BlobEntry*> idx;
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
-  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, dof_cadr, col_dof, lvl_cstart, tri_a, tri_e, adh_act;
+  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, dof_cadr, col_dof, lvl_cstart, adh_act;
   int nlevel;
   std::vector<double> body_box;
   std::vector<int> body_fluid_geom;
@@ -113,8 +113,6 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     while (n_ < la && n_ < lb && m->body_chain[(size_t)a*FB_MAXCH + n_] == m->body_chain[(size_t)b*FB_MAXCH + n_]) n_++;
     m->body_common[(size_t)a*nb + b] = n_;
   }
-  for (int e_ = 0; e_ < FB_MAXCH + 1; e_++) for (int a = 0; a <= e_; a++) { m->tri_a.push_back(a); m->tri_e.push_back(e_); }
-  m->tri_a.resize(FB_NTRI, 0); m->tri_e.resize(FB_NTRI, 0);
   // descendant ranges (dofs are in DFS order) and depth levels
   m->dof_ndesc.assign(nv, 0);
   for (int k = nv - 1; k >= 0; k--) if (dofpar[k] >= 0) m->dof_ndesc[dofpar[k]] += m->dof_ndesc[k] + 1;
@@ -290,7 +288,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(tri_a, tri_a) UV(tri_e, tri_e) UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom) UV(dof_cadr, dof_cadr) UV(col_dof, col_dof) UV(lvl_cstart, lvl_cstart)
+  UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom) UV(dof_cadr, dof_cadr) UV(col_dof, col_dof) UV(lvl_cstart, lvl_cstart)
   M.ncol = (int)m->col_dof.size();
   UI(wing_act_idx, "wing_action_idx")
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);

@@ -8,6 +8,29 @@
 #endif
 
 #define FBD __device__ __forceinline__
+// inlining policy of the heavy stages (tuned by measurement: isolating the solver loops keeps their register
+// allocation independent of the rest of the stage machine)
+#ifdef FB_EMULATE
+#define FB_NOINLINE
+#else
+#define FB_NOINLINE __attribute__((noinline))
+#endif
+#ifndef FB_INL_A
+#define FB_INL_A 1
+#endif
+#ifndef FB_INL_B
+#define FB_INL_B 1
+#endif
+#if FB_INL_A
+#define FB_STAGE_A __device__ FB_NOINLINE
+#else
+#define FB_STAGE_A __device__ __forceinline__
+#endif
+#if FB_INL_B
+#define FB_STAGE_B __device__ FB_NOINLINE
+#else
+#define FB_STAGE_B __device__ __forceinline__
+#endif
 #define FB_MINV ((real)1e-15)
 
 template <typename real> FBD real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }

@@ -232,7 +232,7 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
 #define FB_BIGROW 24
 
 template <typename real>
-__device__ __forceinline__ void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
+FB_STAGE_B void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
                          FB_LDS real* LC, FB_LDS real* Dg, FB_LDS real* Dinv, int lane) {
   PROF_BEGIN();
   for (int d = w.nlevel - 1; d >= 0; d--) {
@@ -298,7 +298,7 @@ __device__ __forceinline__ void d_factor(const DevModel<real>& M, const WS<real>
 
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-__device__ __forceinline__ void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+FB_STAGE_B void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
   PROF_BEGIN();
   // x <- L^-T x, deepest level first: each dof pulls from its (already final) descendants
   for (int d = w.nlevel - 1; d >= 0; d--) {

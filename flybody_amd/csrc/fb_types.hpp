@@ -20,7 +20,6 @@
 #define FB_NPROF 24
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
-#define FB_NTRI 232         // (FB_MAXCH+1)(FB_MAXCH+2)/2 rounded up
 
 enum { JNT_FREE = 0, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -46,7 +45,6 @@ struct DevModel {
   const int *body_common;    // [nbody][nbody] number of shared chain dofs
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
-  const int *tri_a, *tri_e;  // triangular index tables for the LDL update pairs
   const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
   const int *dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
   const int *lvl_dof, *lvl_start; int nlevel;   // dofs grouped by depth

@@ -127,3 +127,60 @@ def test_full_size_properties(gpu_model, reference_traj):
     B.reset(ids); B.synchronize()
     sc = B.get('STEP_COUNT').ravel()
     assert (sc[0::2] == 0).all() and (sc[1::2] == 5).all()
+
+
+def test_rollout_tolerance_fp32(gpu_model, oracle_model, reference_traj):
+    """FP32 kernel vs FP64 oracle over 50 control steps (500 physics steps with contacts): documented
+    tolerance 2e-4 relative on qpos and 5e-3 on qvel (measured: <= 5e-5 / <= 7e-4, tools/parity_report.py)."""
+    import torch
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    B = engine.Batch(gpu_model, 8, precision=32)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    od = _oracle(oracle_model)
+    od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
+    rng = np.random.default_rng(0)
+    for k in range(50):
+        a = rng.uniform(-0.5, 0.5, 59).astype(np.float32)
+        act = torch.from_numpy(np.tile(a, (8, 1))).cuda()
+        B.step_ptr(act.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        od.env_step(a.astype(np.float64))
+    torch.cuda.synchronize()
+    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 2e-4
+    assert _rel(B.get('QVEL')[0], od.field('qvel')) < 5e-3
+
+
+def test_flight_rollout_parity_fp64(oracle_model):
+    """flight_imitation on the GPU against the oracle: 20 control steps with the wing-beat generator,
+    ellipsoid wing fluid forces, flight reward."""
+    import os
+    import torch
+    from conftest import ROOT
+    from flybody_amd import engine
+    from flybody_amd.mjcf_compile import qrot
+    from flybody_amd.model_blob import load_npz, pack_model
+    from flybody_amd.reference import constant_speed_trajectory
+    from flybody_amd.wbpg import build_tables
+    from oracle import fbo
+    arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
+    M = engine.Model(arr); B = engine.Batch(M, 8, precision=64)
+    od = fbo.OracleData(fbo.OracleModel(pack_model(arr)))
+    tabs = build_tables(); od.set_wbpg(tabs, seed=5); B.set_wbpg(tabs, seed=5)
+    cq, cv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+    root = cq.copy()
+    for i in range(len(root)):
+        root[i, :3] = cq[i, :3] + qrot(cq[i, 3:], -arr['com_offset'])
+    od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
+    B.set_reference(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
+    od.env_reset(); B.reset()
+    rng = np.random.default_rng(1)
+    for k in range(20):
+        a = rng.uniform(-1, 1, 12).astype(np.float32)
+        act = torch.from_numpy(np.tile(a, (8, 1))).cuda()
+        B.step_ptr(act.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        od.env_step(a.astype(np.float64))
+        assert abs(float(B.get('REWARD')[0, 0]) - od.scalar('reward')) < 1e-5
+    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-8
+    assert _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-8
+    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-2)
