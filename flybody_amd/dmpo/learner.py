@@ -41,9 +41,11 @@ class DMPOLearner:
         self.policy_params = list(self.online.policy.parameters())
         self.critic_params = list(self.online.critic.parameters())
         self.dual_params = list(self.loss.parameters())
-        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr)
-        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr)
-        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr)
+        cap = self.device.type == 'cuda'          # capturable optimizers: the update can live in a HIP graph
+        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr, capturable=cap)
+        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr, capturable=cap)
+        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr, capturable=cap)
+        self._graph_fb = None; self._graph_opt = None; self._static = None
         self.num_steps = 0
         # one flat gradient buffer; every parameter's .grad is a view into it
         allp = self.policy_params + self.critic_params + self.dual_params
@@ -65,11 +67,51 @@ class DMPOLearner:
         if self.num_steps % self.cfg.target_critic_update_period == 0:
             self.target.critic.load_state_dict(self.online.critic.state_dict())
 
+    # ---- HIP-graph path: the ~200 small kernels of one learner step are replayed as two graphs
+    # (forward+backward | clip+Adam) with the single gradient all-reduce between them.
+    def enable_graphs(self, example_batch):
+        assert self.device.type == 'cuda'
+        self._static = [t.clone() for t in example_batch]
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):                       # warm-up (allocations, optimizer state)
+                self._forward_backward(self._static); self._apply_gradients()
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_fb):
+            self._static_stats = self._forward_backward(self._static)
+        self._graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_opt):
+            self._apply_gradients()
+
+    def _allreduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad)                  # ONE collective per learner step
+            self.flat_grad.div_(dist.get_world_size())
+
+    def _apply_gradients(self):
+        if self.cfg.clipping:
+            torch.nn.utils.clip_grad_norm_(self.policy_params, self.cfg.max_grad_norm)
+            torch.nn.utils.clip_grad_norm_(self.critic_params, self.cfg.max_grad_norm)
+        self.critic_opt.step(); self.policy_opt.step(); self.dual_opt.step()
+
     def step(self, batch) -> Dict[str, torch.Tensor]:
-        cfg = self.cfg
-        o_tm1, a_tm1, r_t, d_t, o_t = batch
         self._sync_targets()
         self.num_steps += 1
+        if self._graph_fb is not None:
+            for dst, src in zip(self._static, batch):
+                dst.copy_(src)
+            self._graph_fb.replay(); self._allreduce(); self._graph_opt.replay()
+            return self._static_stats
+        stats = self._forward_backward(batch)
+        self._allreduce()
+        self._apply_gradients()
+        return stats
+
+    def _forward_backward(self, batch) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        o_tm1, a_tm1, r_t, d_t, o_t = batch
         N, B = cfg.num_samples, o_t.shape[0]
         with torch.no_grad():
             t_mean, t_std = self.target.policy(o_t)
@@ -86,13 +128,6 @@ class DMPOLearner:
         self.flat_grad.zero_()
         # critic loss trains the critic only; policy loss trains policy + duals (independent graphs)
         (critic_loss + policy_loss).backward()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad)                  # ONE collective per learner step
-            self.flat_grad.div_(dist.get_world_size())
-        if cfg.clipping:
-            torch.nn.utils.clip_grad_norm_(self.policy_params, cfg.max_grad_norm)
-            torch.nn.utils.clip_grad_norm_(self.critic_params, cfg.max_grad_norm)
-        self.critic_opt.step(); self.policy_opt.step(); self.dual_opt.step()
         stats = dict(stats); stats['critic_loss'] = critic_loss.detach(); stats['policy_loss'] = policy_loss.detach()
         return stats
 

@@ -50,6 +50,7 @@ class Trainer:
         self.replay = NStepReplay(n_env, nobs, nu, min(replay_capacity, config.max_replay_size), config.n_step, config.discount,
                                   device=self.device, seed=seed + self.rank)
         self.lsteps_per = learner_steps_per_env_step
+        self.use_graphs = os.environ.get('FB_LEARNER_GRAPHS', '1') == '1'
         self.views = self.env.reset_all()
         self.obs = self.views['obs'].clone()
         self.env_steps = 0; self.learner_steps = 0
@@ -67,6 +68,8 @@ class Trainer:
         self.env_steps += self.env.n_env
         stats = None
         if learn and self.replay.size >= min(self.cfg.min_replay_size, self.replay.capacity // 2):
+            if self.use_graphs and self.learner._graph_fb is None:
+                self.learner.enable_graphs(self.replay.sample(self.cfg.batch_size))
             for _ in range(self.lsteps_per):
                 stats = self.learner.step(self.replay.sample(self.cfg.batch_size)); self.learner_steps += 1
         return stats
