@@ -16,7 +16,7 @@
 #define FB_NOINLINE __attribute__((noinline))
 #endif
 #ifndef FB_INL_A
-#define FB_INL_A 1
+#define FB_INL_A 0      // (1,1) trips an AMDGPU back-end assertion in ROCm 7.2 (private-base compare); (0,1) measured equal
 #endif
 #ifndef FB_INL_B
 #define FB_INL_B 1
@@ -128,6 +128,13 @@ template <typename real> FBD void makeframe(real* f) {
   normalize3(y);
   cross3(z, x, y);
 }
+// division on solver hot paths: exact in FP64 (bit-faithful to the oracle), v_rcp_f32 (1 ulp) in FP32
+FBD double fdiv(double a, double b) { return a / b; }
+#ifdef FB_EMULATE
+FBD float fdiv(float a, float b) { return a / b; }
+#else
+FBD float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // ---- wavefront (64-lane) collectives -------------------------------------------------
