@@ -305,7 +305,7 @@ FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real
   for (int it = 0; it < 20; it++) {
     real det = (A11 + la)*(A22 + la) - A12*A12;
     if (det < (real)1e-10) { res[0] = 0; res[1] = 0; return false; }
-    real detinv = fdiv((real)1, det);
+    real detinv = fb_div((real)1, det);
     real P11 = (A22 + la)*detinv, P22 = (A11 + la)*detinv, P12 = -A12*detinv;
     v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
     real val = v1*v1 + v2*v2 - r*r;
@@ -313,7 +313,7 @@ FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real
     const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*r*r + (real)1e-10;
     if (val < tolv) break;
     real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
-    real delta = -fdiv(val, deriv);
+    real delta = -fb_div(val, deriv);
     const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
     if (delta < told) break;
     la += delta;
@@ -388,7 +388,7 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
         real res = r3_get(rb, i) + row_dot(AR + i*nefc, nefc, f, lane);
         real a = AR[i*nefc + i];
         real old = r3_get(f, i);
-        real fn = old - fdiv(res, a);
+        real fn = old - fb_div(res, a);
         if (fn < 0) fn = 0;
         real del = fn - old;
         improvement -= (real)0.5*del*del*a + del*res;
@@ -409,8 +409,8 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
         real Av[3] = {A[0]*v[0] + A[1]*v[1] + A[2]*v[2], A[3]*v[0] + A[4]*v[1] + A[5]*v[2], A[6]*v[0] + A[7]*v[1] + A[8]*v[2]};
         real denom = v[0]*Av[0] + v[1]*Av[1] + v[2]*Av[2];
         if (denom >= FB_MINV) {
-          real x = -fdiv(v[0]*res[0] + v[1]*res[1] + v[2]*res[2], denom);
-          if (fo[0] + x*v[0] < 0) x = -fdiv(fo[0], v[0]);
+          real x = -fb_div(v[0]*res[0] + v[1]*res[1] + v[2]*res[2], denom);
+          if (fo[0] + x*v[0] < 0) x = -fb_div(fo[0], v[0]);
           for (int k = 0; k < 3; k++) fo[k] += x*v[k];
         }
         if (fo[0] < FB_MINV) { fo[0] = 0; fo[1] = 0; fo[2] = 0; }

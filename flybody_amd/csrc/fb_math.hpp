@@ -129,11 +129,11 @@ template <typename real> FBD void makeframe(real* f) {
   cross3(z, x, y);
 }
 // division on solver hot paths: exact in FP64 (bit-faithful to the oracle), v_rcp_f32 (1 ulp) in FP32
-FBD double fdiv(double a, double b) { return a / b; }
+FBD double fb_div(double a, double b) { return a / b; }
 #ifdef FB_EMULATE
-FBD float fdiv(float a, float b) { return a / b; }
+FBD float fb_div(float a, float b) { return a / b; }
 #else
-FBD float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 #endif
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
