@@ -298,26 +298,33 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
 
 // ------------------------------------------------------------------ QCQP for the 2 friction dims
 template <typename real>
-FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real r) {
+FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real r, real* la_ws = nullptr) {
+  // Newton iteration on the multiplier of  min 0.5 x'Ax + x'b  s.t.  sum (x_i/d_i)^2 <= r^2.
+  // FP64 follows the reference solver exactly (start at 0, absolute 1e-10 thresholds).  FP32 scales the
+  // thresholds to single-precision resolution and, when `la_ws` is given, restarts from the multiplier the same
+  // contact had in the previous sweep (the root is unique, only the iteration count changes).
   real A11 = Ain[0]*dd[0]*dd[0], A22 = Ain[3]*dd[1]*dd[1], A12 = Ain[1]*dd[0]*dd[1];
   real b1 = bin[0]*dd[0], b2 = bin[1]*dd[1];
   real la = 0, v1 = 0, v2 = 0;
   for (int it = 0; it < 20; it++) {
     real det = (A11 + la)*(A22 + la) - A12*A12;
-    if (det < (real)1e-10) { res[0] = 0; res[1] = 0; return false; }
+    if (det < (real)1e-10) { res[0] = 0; res[1] = 0; if (la_ws) *la_ws = 0; return false; }
     real detinv = fb_div((real)1, det);
     real P11 = (A22 + la)*detinv, P22 = (A11 + la)*detinv, P12 = -A12*detinv;
     v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
     real val = v1*v1 + v2*v2 - r*r;
-    // FP64: MuJoCo's absolute 1e-10 thresholds; FP32: the same test scaled to single-precision resolution
     const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*r*r + (real)1e-10;
-    if (val < tolv) break;
+    if (it == 0 && sizeof(real) == 4 && la_ws && val >= tolv && *la_ws > 0) { la = *la_ws; continue; }
+    if (val < tolv && (it == 0 || sizeof(real) == 8 || val > -tolv)) break;
     real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
     real delta = -fb_div(val, deriv);
     const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
-    if (delta < told) break;
+    if (sizeof(real) == 8) { if (delta < told) break; }
+    else if (fabs(delta) < told) break;
     la += delta;
+    if (la < 0) la = 0;
   }
+  if (la_ws) *la_ws = la;
   res[0] = v1*dd[0]; res[1] = v2*dd[1];
   return la != 0;
 }
@@ -345,17 +352,32 @@ template <typename real, typename RP> FBD real row_dot(RP row, int n, const R3<r
   return wave_sum(s);
 }
 
-// PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix
+// res += delta * AR[row, :]   (lane k owns columns k, k+64, k+128)
+template <typename real, typename ARP> FBD void res_axpy(R3<real>& res, ARP row, int n, real delta, int lane) {
+  if (lane < n) res.v0 += delta*row[lane];
+  if (lane + 64 < n) res.v1 += delta*row[lane + 64];
+  if (lane + 128 < n) res.v2 += delta*row[lane + 128];
+}
+
+// PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix.
+// Residual-maintaining Gauss-Seidel: the vector res = b + AR f lives in registers (lane k owns rows k, k+64,
+// k+128); a row update reads its residual with v_readlane and, if the force changed by delta, adds
+// delta * AR[row,:] to every lane's residuals -- one LDS row read and one FMA per lane, no reduction on the
+// critical path.  Mathematically identical to recomputing each row's dot product.
 template <typename real, typename ARP>
 FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
   PROF_BEGIN();
-  R3<real> f, rb, rR, rfr0, rfr1;
+  R3<real> f, rb, rR, rfr0, rfr1, rla, res, rdiag;
+  rla.v0 = 0; rla.v1 = 0; rla.v2 = 0;
   R3<int> rtype;
   r3_load(f, w.efc_force, nefc, lane, (real)0);
   r3_load(rb, w.efc_b, nefc, lane, (real)0);
   r3_load(rR, w.efc_R, nefc, lane, (real)0);
   r3_load(rtype, w.efc_type, nefc, lane, 0);
+  rdiag.v0 = (lane < nefc) ? AR[lane*nefc + lane] : (real)1;
+  rdiag.v1 = (lane + 64 < nefc) ? AR[(lane + 64)*nefc + lane + 64] : (real)1;
+  rdiag.v2 = (lane + 128 < nefc) ? AR[(lane + 128)*nefc + lane + 128] : (real)1;
   {
     // friction coefficients of the contact a row belongs to
     real a0[3], a1[3];
@@ -366,15 +388,17 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
     }
     rfr0.v0 = a0[0]; rfr0.v1 = a0[1]; rfr0.v2 = a0[2]; rfr1.v0 = a1[0]; rfr1.v1 = a1[1]; rfr1.v2 = a1[2];
   }
+  // res = b + AR f  (column form over the nonzero warm-start forces)
+  res = rb;
+  for (int k = 0; k < nefc; k++) {
+    real fk = r3_get(f, k);
+    if (fk != 0) res_axpy(res, AR + k*nefc, nefc, fk, lane);
+  }
   {
-    // dual cost of the warm start; fall back to zero if it is worse than zero force
-    real cost = 0;
-    for (int r = 0; r < nefc; r++) {
-      real s = row_dot(AR + r*nefc, nefc, f, lane);
-      real fr = r3_get(f, r);
-      cost += fr*((real)0.5*s + r3_get(rb, r));
-    }
-    if (cost > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; }
+    // dual cost of the warm start 0.5 f'ARf + f'b; fall back to zero force if it is worse than zero
+    real c = (real)0.5*(f.v0*(res.v0 + rb.v0) + f.v1*(res.v1 + rb.v1) + f.v2*(res.v2 + rb.v2));
+    c = wave_sum(c);
+    if (c > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; res = rb; }
   }
   PROF(P_CSETUP);
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
@@ -385,31 +409,31 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
     for (int i = 0; i < nefc;) {
       int type = r3_get(rtype, i);
       if (type != CN_ELLIPTIC) {
-        real res = r3_get(rb, i) + row_dot(AR + i*nefc, nefc, f, lane);
-        real a = AR[i*nefc + i];
+        real r0 = r3_get(res, i);
+        real a = r3_get(rdiag, i);
         real old = r3_get(f, i);
-        real fn = old - fb_div(res, a);
+        real fn = old - fb_div(r0, a);
         if (fn < 0) fn = 0;
         real del = fn - old;
-        improvement -= (real)0.5*del*del*a + del*res;
-        r3_set(f, i, lane, fn);
+        improvement -= (real)0.5*del*del*a + del*r0;
+        if (del != 0) { res_axpy(res, AR + i*nefc, nefc, del, lane); r3_set(f, i, lane, fn); }
         i += 1;
       } else {
-        real res[3], old[3], A[9];
+        real r3v[3], old[3], A[9];
         for (int j = 0; j < 3; j++) {
-          res[j] = r3_get(rb, i+j) + row_dot(AR + (i+j)*nefc, nefc, f, lane);
+          r3v[j] = r3_get(res, i+j);
           old[j] = r3_get(f, i+j);
           for (int k = 0; k < 3; k++) A[3*j+k] = AR[(i+j)*nefc + i + k];
         }
         real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
         real bc[3], fo[3] = {old[0], old[1], old[2]};
-        for (int j = 0; j < 3; j++) bc[j] = res[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
+        for (int j = 0; j < 3; j++) bc[j] = r3v[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
         real v[3];
         if (fo[0] < FB_MINV) { v[0] = 1; v[1] = 0; v[2] = 0; } else { v[0] = old[0]; v[1] = old[1]; v[2] = old[2]; }
         real Av[3] = {A[0]*v[0] + A[1]*v[1] + A[2]*v[2], A[3]*v[0] + A[4]*v[1] + A[5]*v[2], A[6]*v[0] + A[7]*v[1] + A[8]*v[2]};
         real denom = v[0]*Av[0] + v[1]*Av[1] + v[2]*Av[2];
         if (denom >= FB_MINV) {
-          real x = -fb_div(v[0]*res[0] + v[1]*res[1] + v[2]*res[2], denom);
+          real x = -fb_div(v[0]*r3v[0] + v[1]*r3v[1] + v[2]*r3v[2], denom);
           if (fo[0] + x*v[0] < 0) x = -fb_div(fo[0], v[0]);
           for (int k = 0; k < 3; k++) fo[k] += x*v[k];
         }
@@ -418,7 +442,9 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
           real Ac[4] = {A[4], A[5], A[7], A[8]};
           real bf[2] = {bc[1] + A[3]*fo[0], bc[2] + A[6]*fo[0]};
           real fq[2];
-          bool active = qcqp2(fq, Ac, bf, fr, fo[0]);
+          real law = r3_get(rla, i);
+          bool active = qcqp2(fq, Ac, bf, fr, fo[0], &law);
+          r3_set(rla, i, lane, law);
           if (active) {
             real s = sqrt((fq[0]/fr[0])*(fq[0]/fr[0]) + (fq[1]/fr[1])*(fq[1]/fr[1]));
             if (s > FB_MINV) { fq[0] *= fo[0]/s; fq[1] *= fo[0]/s; }
@@ -427,9 +453,10 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
         }
         real del[3] = {fo[0] - old[0], fo[1] - old[1], fo[2] - old[2]};
         real q = 0, l = 0;
-        for (int j = 0; j < 3; j++) { l += del[j]*res[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
+        for (int j = 0; j < 3; j++) { l += del[j]*r3v[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
         improvement -= (real)0.5*q + l;
-        r3_set(f, i, lane, fo[0]); r3_set(f, i+1, lane, fo[1]); r3_set(f, i+2, lane, fo[2]);
+        for (int j = 0; j < 3; j++)
+          if (del[j] != 0) { res_axpy(res, AR + (i+j)*nefc, nefc, del[j], lane); r3_set(f, i+j, lane, fo[j]); }
         i += 3;
       }
     }
@@ -446,16 +473,16 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
       int i = rdlane(my_efc, c);
       if (i < 0) continue;
       real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
-      real res[2], old[2], Rj[2];
+      real rs[2], old[2], Rj[2];
       real fnrm = r3_get(f, i);
       for (int j = 0; j < 2; j++) {
         old[j] = r3_get(f, i+1+j);
         Rj[j] = r3_get(rR, i+1+j);
-        res[j] = r3_get(rb, i+1+j) + row_dot(AR + (i+1+j)*nefc, nefc, f, lane) - Rj[j]*old[j];
+        rs[j] = r3_get(res, i+1+j) - Rj[j]*old[j];
       }
       real Ac[4] = {AR[(i+1)*nefc + i+1] - Rj[0], AR[(i+1)*nefc + i+2],
                     AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - Rj[1]};
-      real bc[2] = {res[0] - (Ac[0]*old[0] + Ac[1]*old[1]), res[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
+      real bc[2] = {rs[0] - (Ac[0]*old[0] + Ac[1]*old[1]), rs[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
       real fq[2] = {0, 0};
       if (fnrm >= FB_MINV) {
         bool active = qcqp2(fq, Ac, bc, fr, fnrm);
@@ -465,8 +492,9 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
         }
       }
       real del[2] = {fq[0] - old[0], fq[1] - old[1]};
-      improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*res[0] + del[1]*res[1];
-      r3_set(f, i+1, lane, fq[0]); r3_set(f, i+2, lane, fq[1]);
+      improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*rs[0] + del[1]*rs[1];
+      for (int j = 0; j < 2; j++)
+        if (del[j] != 0) { res_axpy(res, AR + (i+1+j)*nefc, nefc, del[j], lane); r3_set(f, i+1+j, lane, fq[j]); }
     }
     if (improvement*scale < M.noslip_tolerance) break;
   }
