@@ -332,31 +332,30 @@ FBD bool qcqp2(real* res, const real* Ain, const real* bin, const real* dd, real
 // lane k holds per-row quantities of rows k, k+64, k+128 in registers; a wave-uniform row index is
 // served by v_readlane (no memory traffic inside the Gauss-Seidel sweep)
 template <typename T> struct R3 { T v0, v1, v2; };
-template <typename T> FBD T r3_get(const R3<T>& f, int i) {
+// S (small): the system has at most 64 rows, only v0 is live and the selects fold away
+template <bool S = false, typename T> FBD T r3_get(const R3<T>& f, int i) {
+  if (S) return rdlane(f.v0, i);
   T v = (i < 64) ? f.v0 : (i < 128 ? f.v1 : f.v2);
   return rdlane(v, i & 63);
 }
-template <typename T> FBD void r3_set(R3<T>& f, int i, int lane, T v) {
+template <bool S = false, typename T> FBD void r3_set(R3<T>& f, int i, int lane, T v) {
+  if (S) { if (lane == i) f.v0 = v; return; }
   if (lane == (i & 63)) { if (i < 64) f.v0 = v; else if (i < 128) f.v1 = v; else f.v2 = v; }
 }
-template <typename T> FBD void r3_load(R3<T>& f, const T* p, int n, int lane, T dflt) {
+template <bool S = false, typename T> FBD void r3_load(R3<T>& f, const T* p, int n, int lane, T dflt) {
   f.v0 = (lane < n) ? p[lane] : dflt;
-  f.v1 = (lane + 64 < n) ? p[lane + 64] : dflt;
-  f.v2 = (lane + 128 < n) ? p[lane + 128] : dflt;
-}
-template <typename real, typename RP> FBD real row_dot(RP row, int n, const R3<real>& f, int lane) {
-  real s = 0;
-  if (lane < n) s += row[lane]*f.v0;
-  if (lane + 64 < n) s += row[lane + 64]*f.v1;
-  if (lane + 128 < n) s += row[lane + 128]*f.v2;
-  return wave_sum(s);
+  f.v1 = (!S && lane + 64 < n) ? p[lane + 64] : dflt;
+  f.v2 = (!S && lane + 128 < n) ? p[lane + 128] : dflt;
 }
 
-// res += delta * AR[row, :]   (lane k owns columns k, k+64, k+128)
-template <typename real, typename ARP> FBD void res_axpy(R3<real>& res, ARP row, int n, real delta, int lane) {
-  if (lane < n) res.v0 += delta*row[lane];
-  if (lane + 64 < n) res.v1 += delta*row[lane + 64];
-  if (lane + 128 < n) res.v2 += delta*row[lane + 128];
+// res += delta * AR[row, :]   (lane k owns columns k, k+64, k+128); the residual is accumulated in FP64 in
+// both builds (FP32 products are exact in FP64, so the running residual does not drift over the sweeps)
+template <bool S, typename real, typename ARP> FBD void res_axpy(R3<double>& res, ARP row, int n, real delta, int lane) {
+  if (lane < n) res.v0 += (double)delta*(double)row[lane];
+  if (!S) {
+    if (lane + 64 < n) res.v1 += (double)delta*(double)row[lane + 64];
+    if (lane + 128 < n) res.v2 += (double)delta*(double)row[lane + 128];
+  }
 }
 
 // PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix.
@@ -364,24 +363,25 @@ template <typename real, typename ARP> FBD void res_axpy(R3<real>& res, ARP row,
 // k+128); a row update reads its residual with v_readlane and, if the force changed by delta, adds
 // delta * AR[row,:] to every lane's residuals -- one LDS row read and one FMA per lane, no reduction on the
 // critical path.  Mathematically identical to recomputing each row's dot product.
-template <typename real, typename ARP>
+template <typename real, typename ARP, bool S>
 FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
   PROF_BEGIN();
-  R3<real> f, rb, rR, rfr0, rfr1, rla, res, rdiag;
+  R3<real> f, rb, rR, rfr0, rfr1, rla, rdiag;
+  R3<double> res;
   rla.v0 = 0; rla.v1 = 0; rla.v2 = 0;
   R3<int> rtype;
-  r3_load(f, w.efc_force, nefc, lane, (real)0);
-  r3_load(rb, w.efc_b, nefc, lane, (real)0);
-  r3_load(rR, w.efc_R, nefc, lane, (real)0);
-  r3_load(rtype, w.efc_type, nefc, lane, 0);
+  r3_load<S>(f, w.efc_force, nefc, lane, (real)0);
+  r3_load<S>(rb, w.efc_b, nefc, lane, (real)0);
+  r3_load<S>(rR, w.efc_R, nefc, lane, (real)0);
+  r3_load<S>(rtype, w.efc_type, nefc, lane, 0);
   rdiag.v0 = (lane < nefc) ? AR[lane*nefc + lane] : (real)1;
-  rdiag.v1 = (lane + 64 < nefc) ? AR[(lane + 64)*nefc + lane + 64] : (real)1;
-  rdiag.v2 = (lane + 128 < nefc) ? AR[(lane + 128)*nefc + lane + 128] : (real)1;
+  rdiag.v1 = (!S && lane + 64 < nefc) ? AR[(lane + 64)*nefc + lane + 64] : (real)1;
+  rdiag.v2 = (!S && lane + 128 < nefc) ? AR[(lane + 128)*nefc + lane + 128] : (real)1;
   {
     // friction coefficients of the contact a row belongs to
-    real a0[3], a1[3];
-    for (int q = 0; q < 3; q++) {
+    real a0[3] = {1, 1, 1}, a1[3] = {1, 1, 1};
+    for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
       a0[q] = 1; a1[q] = 1;
       if (r < nefc && w.efc_type[r] == CN_ELLIPTIC) { const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[r]]; a0[q] = fr[0]; a1[q] = fr[1]; }
@@ -389,16 +389,16 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
     rfr0.v0 = a0[0]; rfr0.v1 = a0[1]; rfr0.v2 = a0[2]; rfr1.v0 = a1[0]; rfr1.v1 = a1[1]; rfr1.v2 = a1[2];
   }
   // res = b + AR f  (column form over the nonzero warm-start forces)
-  res = rb;
+  res.v0 = rb.v0; res.v1 = rb.v1; res.v2 = rb.v2;
   for (int k = 0; k < nefc; k++) {
-    real fk = r3_get(f, k);
-    if (fk != 0) res_axpy(res, AR + k*nefc, nefc, fk, lane);
+    real fk = r3_get<S>(f, k);
+    if (fk != 0) res_axpy<S>(res, AR + k*nefc, nefc, fk, lane);
   }
   {
     // dual cost of the warm start 0.5 f'ARf + f'b; fall back to zero force if it is worse than zero
-    real c = (real)0.5*(f.v0*(res.v0 + rb.v0) + f.v1*(res.v1 + rb.v1) + f.v2*(res.v2 + rb.v2));
+    real c = (real)0.5*(f.v0*((real)res.v0 + rb.v0) + f.v1*((real)res.v1 + rb.v1) + f.v2*((real)res.v2 + rb.v2));
     c = wave_sum(c);
-    if (c > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; res = rb; }
+    if (c > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; res.v0 = rb.v0; res.v1 = rb.v1; res.v2 = rb.v2; }
   }
   PROF(P_CSETUP);
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
@@ -407,25 +407,25 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
   for (int it = 0; it < M.iterations; it++) {
     real improvement = 0;
     for (int i = 0; i < nefc;) {
-      int type = r3_get(rtype, i);
+      int type = r3_get<S>(rtype, i);
       if (type != CN_ELLIPTIC) {
-        real r0 = r3_get(res, i);
-        real a = r3_get(rdiag, i);
-        real old = r3_get(f, i);
+        real r0 = (real)r3_get<S>(res, i);
+        real a = r3_get<S>(rdiag, i);
+        real old = r3_get<S>(f, i);
         real fn = old - fb_div(r0, a);
         if (fn < 0) fn = 0;
         real del = fn - old;
         improvement -= (real)0.5*del*del*a + del*r0;
-        if (del != 0) { res_axpy(res, AR + i*nefc, nefc, del, lane); r3_set(f, i, lane, fn); }
+        if (del != 0) { res_axpy<S>(res, AR + i*nefc, nefc, del, lane); r3_set<S>(f, i, lane, fn); }
         i += 1;
       } else {
         real r3v[3], old[3], A[9];
         for (int j = 0; j < 3; j++) {
-          r3v[j] = r3_get(res, i+j);
-          old[j] = r3_get(f, i+j);
+          r3v[j] = (real)r3_get<S>(res, i+j);
+          old[j] = r3_get<S>(f, i+j);
           for (int k = 0; k < 3; k++) A[3*j+k] = AR[(i+j)*nefc + i + k];
         }
-        real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
+        real fr[2] = {r3_get<S>(rfr0, i), r3_get<S>(rfr1, i)};
         real bc[3], fo[3] = {old[0], old[1], old[2]};
         for (int j = 0; j < 3; j++) bc[j] = r3v[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
         real v[3];
@@ -442,9 +442,9 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
           real Ac[4] = {A[4], A[5], A[7], A[8]};
           real bf[2] = {bc[1] + A[3]*fo[0], bc[2] + A[6]*fo[0]};
           real fq[2];
-          real law = r3_get(rla, i);
+          real law = r3_get<S>(rla, i);
           bool active = qcqp2(fq, Ac, bf, fr, fo[0], &law);
-          r3_set(rla, i, lane, law);
+          r3_set<S>(rla, i, lane, law);
           if (active) {
             real s = sqrt((fq[0]/fr[0])*(fq[0]/fr[0]) + (fq[1]/fr[1])*(fq[1]/fr[1]));
             if (s > FB_MINV) { fq[0] *= fo[0]/s; fq[1] *= fo[0]/s; }
@@ -456,7 +456,7 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
         for (int j = 0; j < 3; j++) { l += del[j]*r3v[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
         improvement -= (real)0.5*q + l;
         for (int j = 0; j < 3; j++)
-          if (del[j] != 0) { res_axpy(res, AR + (i+j)*nefc, nefc, del[j], lane); r3_set(f, i+j, lane, fo[j]); }
+          if (del[j] != 0) { res_axpy<S>(res, AR + (i+j)*nefc, nefc, del[j], lane); r3_set<S>(f, i+j, lane, fo[j]); }
         i += 3;
       }
     }
@@ -472,13 +472,13 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
     for (int c = 0; c < ncon; c++) {
       int i = rdlane(my_efc, c);
       if (i < 0) continue;
-      real fr[2] = {r3_get(rfr0, i), r3_get(rfr1, i)};
+      real fr[2] = {r3_get<S>(rfr0, i), r3_get<S>(rfr1, i)};
       real rs[2], old[2], Rj[2];
-      real fnrm = r3_get(f, i);
+      real fnrm = r3_get<S>(f, i);
       for (int j = 0; j < 2; j++) {
-        old[j] = r3_get(f, i+1+j);
-        Rj[j] = r3_get(rR, i+1+j);
-        rs[j] = r3_get(res, i+1+j) - Rj[j]*old[j];
+        old[j] = r3_get<S>(f, i+1+j);
+        Rj[j] = r3_get<S>(rR, i+1+j);
+        rs[j] = (real)r3_get<S>(res, i+1+j) - Rj[j]*old[j];
       }
       real Ac[4] = {AR[(i+1)*nefc + i+1] - Rj[0], AR[(i+1)*nefc + i+2],
                     AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - Rj[1]};
@@ -494,14 +494,16 @@ FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nef
       real del[2] = {fq[0] - old[0], fq[1] - old[1]};
       improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*rs[0] + del[1]*rs[1];
       for (int j = 0; j < 2; j++)
-        if (del[j] != 0) { res_axpy(res, AR + (i+1+j)*nefc, nefc, del[j], lane); r3_set(f, i+1+j, lane, fq[j]); }
+        if (del[j] != 0) { res_axpy<S>(res, AR + (i+1+j)*nefc, nefc, del[j], lane); r3_set<S>(f, i+1+j, lane, fq[j]); }
     }
     if (improvement*scale < M.noslip_tolerance) break;
   }
   PROF(P_NOSLIP);
   if (lane < nefc) w.efc_force[lane] = f.v0;
-  if (lane + 64 < nefc) w.efc_force[lane + 64] = f.v1;
-  if (lane + 128 < nefc) w.efc_force[lane + 128] = f.v2;
+  if (!S) {
+    if (lane + 64 < nefc) w.efc_force[lane + 64] = f.v1;
+    if (lane + 128 < nefc) w.efc_force[lane + 128] = f.v2;
+  }
   return niter;
 }
 
@@ -560,7 +562,10 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     }
   }
   SYNC();
-  int niter = (nefc <= LdsCfg<real>::AR_ROWS) ? d_pgs(M, w, (const FB_LDS real*)w.lAR, nefc, lane) : d_pgs(M, w, (const real*)w.AR, nefc, lane);
+  int niter;
+  if (nefc <= LdsCfg<real>::AR_ROWS) niter = d_pgs<real, const FB_LDS real*, true>(M, w, (const FB_LDS real*)w.lAR, nefc, lane);
+  else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR, nefc, lane);
+  else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR, nefc, lane);
   for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
   if (lane == 0) w.istate[IS_NITER] = niter;
   SYNC();
