@@ -158,16 +158,13 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
         real y[FB_MAXCH];
 #pragma unroll
         for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0;
-        // L[chain[s], chain[t]] lives in column chain[t] at offset chain[s] - chain[t] - 1
-        int cbase[FB_MAXCH];
-#pragma unroll
-        for (int t = 0; t < FB_MAXCH; t++) { int ct = (t < len) ? chain[t] : 0; cbase[t] = (int)w.lcadr[ct] - ct - 1; }
+        // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
 #pragma unroll
         for (int s = FB_MAXCH - 1; s >= 1; s--) {
           if (s < len && y[s] != 0) {
-            int cs = chain[s];
+            const FB_LDS real* row = w.lLD + (int)w.lmadr[chain[s]] + s;
 #pragma unroll
-            for (int t = 0; t < s; t++) y[t] -= w.lLD[cbase[t] + cs] * y[s];
+            for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
           }
         }
 #pragma unroll
@@ -358,13 +355,18 @@ template <bool S, typename real, typename ARP> FBD void res_axpy(R3<double>& res
   }
 }
 
+#ifdef FB_PGS_NOINLINE
+#define FB_PGS_ATTR __device__ FB_NOINLINE
+#else
+#define FB_PGS_ATTR FB_STAGE_A
+#endif
 // PGS + noslip sweeps; ARP is an LDS (address_space(3)) or a global pointer to the Delassus matrix.
 // Residual-maintaining Gauss-Seidel: the vector res = b + AR f lives in registers (lane k owns rows k, k+64,
 // k+128); a row update reads its residual with v_readlane and, if the force changed by delta, adds
 // delta * AR[row,:] to every lane's residuals -- one LDS row read and one FMA per lane, no reduction on the
 // critical path.  Mathematically identical to recomputing each row's dot product.
 template <typename real, typename ARP, bool S>
-FB_STAGE_A int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
   int nv = M.nv;
   PROF_BEGIN();
   R3<real> f, rb, rR, rfr0, rfr1, rla, rdiag;

@@ -7,6 +7,7 @@
 #else
 #include <hip/hip_runtime.h>
 #endif
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +33,8 @@ struct fb_model {
   std::map<std::string, const BlobEntry*> idx;
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
-  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, dof_cadr, col_dof, lvl_cstart, adh_act;
+  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, adh_act;
+  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box;
   std::vector<int> body_fluid_geom;
@@ -130,22 +132,80 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     if ((int)m->lvl_dof.size() - m->lvl_start[d] > FB_WAVE) { delete m; return fail("fb_model_load: more than 64 dofs on one depth level"); }
   }
   m->lvl_start[m->nlevel] = (int)m->lvl_dof.size();
-  // column-major factor layout: columns ordered level by level
-  m->dof_cadr.assign(nv + 1, 0); m->lvl_cstart.assign(m->nlevel + 1, 0);
-  for (int d = 0; d < m->nlevel; d++) {
-    m->lvl_cstart[d] = (int)m->col_dof.size();
-    int npair_max = (m->lvl_start[d + 1] - m->lvl_start[d])*(d + 1);
-    bool wide = false;
-    for (int t = m->lvl_start[d]; t < m->lvl_start[d + 1]; t++) {
-      int k = m->lvl_dof[t];
-      m->dof_cadr[k] = (int)m->col_dof.size();
-      for (int q = 0; q < m->dof_ndesc[k]; q++) m->col_dof.push_back(k);
-      if (m->dof_ndesc[k] > 24) wide = true;
-    }
-    if (npair_max > 4*FB_WAVE || (wide && npair_max > FB_WAVE)) { delete m; return fail("fb_model_load: elimination level too wide for the factor kernel"); }
+  // The factor is stored ROW-major like qM: row k = [1/D[k], L[k,parent], L[k,grandparent], ...] at dof_Madr[k].
+  // Along an unbranched chain consecutive rows grow by one entry, so the row start of the descendant of dof i on
+  // depth level d is  dof_Madr[i] - T(depth[i]) + T(d)  with T(d) = d(d+1)/2 -- no table lookup.
+  const int* madr = m->i("dof_Madr");
+  {
+    int adr = 0;
+    for (int k = 0; k < nv; k++) { if (madr[k] != adr) { delete m; return fail("fb_model_load: dof_Madr does not match the dof tree"); } adr += m->dof_depth[k] + 1; }
+    if (adr != m->nM) { delete m; return fail("fb_model_load: dof_Madr does not match the dof tree"); }
   }
-  m->lvl_cstart[m->nlevel] = (int)m->col_dof.size();
-  if ((int)m->col_dof.size() != m->nM - nv) { delete m; return fail("fb_model_load: inconsistent elimination tree"); }
+  // pure-chain length below each dof (descendants i+1 .. i+cl are one unbranched chain).  The unbranched chain
+  // that starts at dof 0 is the "trunk" (the free joint): its rows are handled wave-parallel.  Other dofs whose
+  // subtree branches further down ("general" dofs: head, ...) get a per-level list of their descendants.
+  {
+    std::vector<int> nchild(nv, 0);
+    for (int k = 0; k < nv; k++) if (dofpar[k] >= 0) nchild[dofpar[k]]++;
+    m->dof_cl.assign(nv, 0);
+    for (int k = nv - 2; k >= 0; k--) m->dof_cl[k] = (nchild[k] == 1) ? m->dof_cl[k + 1] + 1 : 0;
+    m->ntrunk = std::min(m->dof_cl[0] + 1, FB_MAXTRUNK);
+    m->dof_gen.assign(nv, -1);
+    for (int k = m->ntrunk; k < nv; k++) if (m->dof_ndesc[k] > m->dof_cl[k]) m->dof_gen[k] = m->ngen++;
+    if (m->ngen > 15 || m->ngen > FB_MAXGEN) { delete m; return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
+    m->gen_k.assign((size_t)FB_MAXGEN*FB_MAXCH, -1);            // 4 descendant dof ids per (general dof, level), 0xff = none
+    m->gen_m.assign((size_t)FB_MAXGEN*FB_MAXCH*2, -1);          // ... and their row starts, 4 x u16, 0xffff = none
+    for (int k = 0; k < nv; k++) {
+      if (m->dof_gen[k] < 0) continue;
+      for (int d = 0; d < m->nlevel; d++) {
+        unsigned pk = 0xffffffffu; unsigned long long pm = ~0ull; int cnt = 0;
+        for (int t = m->lvl_start[d]; t < m->lvl_start[d + 1]; t++) {
+          int q = m->lvl_dof[t];
+          if (q > k && q <= k + m->dof_ndesc[k]) {
+            if (cnt == 4) { delete m; return fail("fb_model_load: a branching dof has more than 4 descendants on one level"); }
+            pk = (pk & ~(0xffu << (8*cnt))) | ((unsigned)q << (8*cnt));
+            pm = (pm & ~(0xffffull << (16*cnt))) | ((unsigned long long)madr[q] << (16*cnt));
+            cnt++;
+          }
+        }
+        size_t o = (size_t)m->dof_gen[k]*FB_MAXCH + d;
+        m->gen_k[o] = (int)pk; m->gen_m[2*o] = (int)(unsigned)(pm & 0xffffffffu); m->gen_m[2*o + 1] = (int)(unsigned)(pm >> 32);
+      }
+    }
+    // forward-substitution table: ancestor of dof k on level d
+    m->fwd_tab.assign((size_t)FB_MAXCH*FB_MAXNV, 0);
+    for (int k = 0; k < nv; k++)
+      for (int a = dofpar[k]; a >= 0; a = dofpar[a]) m->fwd_tab[(size_t)m->dof_depth[a]*FB_MAXNV + k] = a;
+  }
+  // factorisation work list: every off-diagonal entry (i, j) of the lower triangle with i outside the trunk is
+  // owned by one (lane, slot); the diagonal of dof j belongs to lane j & 63.  Entries are spread so that the number
+  // of triple products (= ndesc[i] per entry) is balanced over the 64 lanes.  Entries of general dofs need the
+  // descendant lists and may only sit in the first FB_FGEN slots.  One packed word per slot (fb_smooth.hpp).
+  {
+    struct Ent { int i, j, work; bool gen; };
+    std::vector<Ent> ents;
+    for (int i = m->ntrunk; i < nv; i++)
+      for (int j = dofpar[i]; j >= 0; j = dofpar[j]) ents.push_back({i, j, m->dof_ndesc[i] + 1, m->dof_gen[i] >= 0});
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { if (a.gen != b.gen) return a.gen; return a.work > b.work; });
+    std::vector<int> load(FB_WAVE, 0), ngs(FB_WAVE, 0), ncs(FB_WAVE, 0);
+    for (int k = m->ntrunk; k < nv; k++) load[k & 63] += m->dof_ndesc[k] + 1;
+    m->fac_w.assign((size_t)FB_FSLOT*FB_WAVE, (31 << 13) | (int)(15u << 28));        // depth 31: empty slot
+    for (const Ent& e : ents) {
+      int best = -1;
+      for (int l = 0; l < FB_WAVE; l++) {
+        bool room = e.gen ? (ngs[l] < FB_FGEN) : (ncs[l] < FB_FSLOT - FB_FGEN || ngs[l] < FB_FGEN);
+        if (room && (best < 0 || load[l] < load[best])) best = l;
+      }
+      if (best < 0) { delete m; return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
+      int slot;
+      if (e.gen || ncs[best] >= FB_FSLOT - FB_FGEN) slot = ngs[best]++; else slot = FB_FGEN + ncs[best]++;
+      load[best] += e.work;
+      int dep = m->dof_depth[e.i], base = madr[e.i] - dep*(dep + 1)/2, ee = dep - m->dof_depth[e.j];
+      if (base < -4096 || base > 4095 || dep > 30) { delete m; return fail("fb_model_load: factor work list field overflow"); }
+      size_t o = (size_t)slot*FB_WAVE + best;
+      m->fac_w[o] = (base & 0x1fff) | (dep << 13) | (m->dof_cl[e.i] << 18) | (ee << 23) | (int)((unsigned)(e.gen ? m->dof_gen[e.i] : 15) << 28);
+    }
+  }
   m->dof_anc.assign((size_t)nv*FB_MAXCH, 0);
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
@@ -194,27 +254,21 @@ template <typename real>
 __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
   __shared__ real s_LD[FB_EPB][FB_MAXNM];
-  __shared__ real s_Dg[FB_EPB][FB_MAXNV];
   __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
   __shared__ real s_x[FB_EPB][FB_MAXNV];
   __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
   // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
-  __shared__ uint8_t s_anc[FB_MAXNV*FB_MAXCH];
   __shared__ uint8_t s_depth[FB_MAXNV];
-  __shared__ uint8_t s_ndesc[FB_MAXNV];
-  __shared__ uint8_t s_lvl_dof[FB_MAXNV];
-  __shared__ uint8_t s_lvl_start[FB_MAXCH + 4];
+  __shared__ uint8_t s_cl[FB_MAXNV];
+  __shared__ uint8_t s_gen[FB_MAXNV];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
-  __shared__ uint16_t s_cadr[FB_MAXNV + 1];
-  __shared__ uint16_t s_lvl_cstart[FB_MAXCH + 4];
-  __shared__ uint8_t s_col_dof[FB_MAXNM];
+  __shared__ uint32_t s_gk[FB_MAXGEN*FB_MAXCH];
+  __shared__ uint32_t s_gm[FB_MAXGEN*FB_MAXCH*2];
   int tid = threadIdx.x;
-  for (int i = tid; i < M.nv*FB_MAXCH; i += FB_WAVE*FB_EPB) s_anc[i] = (uint8_t)M.dof_anc[i];
-  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) { s_depth[i] = (uint8_t)M.dof_depth[i]; s_ndesc[i] = (uint8_t)M.dof_ndesc[i]; s_lvl_dof[i] = (uint8_t)M.lvl_dof[i]; }
-  for (int i = tid; i <= M.nv; i += FB_WAVE*FB_EPB) s_madr[i] = (uint16_t)M.dof_Madr[i];
-  for (int i = tid; i <= M.nlevel; i += FB_WAVE*FB_EPB) { s_lvl_start[i] = (uint8_t)M.lvl_start[i]; s_lvl_cstart[i] = (uint16_t)M.lvl_cstart[i]; }
-  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) s_cadr[i] = (uint16_t)M.dof_cadr[i];
-  for (int i = tid; i < M.ncol; i += FB_WAVE*FB_EPB) s_col_dof[i] = (uint8_t)M.col_dof[i];
+  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) {
+    s_depth[i] = (uint8_t)M.dof_depth[i]; s_cl[i] = (uint8_t)M.dof_cl[i]; s_gen[i] = (uint8_t)M.dof_gen[i]; s_madr[i] = (uint16_t)M.dof_Madr[i];
+  }
+  for (int i = tid; i < FB_MAXGEN*FB_MAXCH; i += FB_WAVE*FB_EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
   int wave = tid / FB_WAVE, lane = tid % FB_WAVE;
   int slot = blockIdx.x*FB_EPB + wave;
@@ -222,12 +276,17 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   int env = env_ids ? env_ids[slot] : slot;
   WS<real> w;
   ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
-  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDg = (FB_LDS real*)s_Dg[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
-  w.lanc = (FB_LDS uint8_t*)s_anc; w.ldepth = (FB_LDS uint8_t*)s_depth; w.lndesc = (FB_LDS uint8_t*)s_ndesc;
-  w.llvl_dof = (FB_LDS uint8_t*)s_lvl_dof; w.llvl_start = (FB_LDS uint8_t*)s_lvl_start; w.lmadr = (FB_LDS uint16_t*)s_madr; w.nlevel = M.nlevel;
-  w.lcadr = (FB_LDS uint16_t*)s_cadr; w.llvl_cstart = (FB_LDS uint16_t*)s_lvl_cstart; w.lcol_dof = (FB_LDS uint8_t*)s_col_dof;
+  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
+  w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
+  w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
   float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long t0_ = clock64(), r0_ = wall_clock64();
+#endif
   d_run(M, w, env, mode, nsub, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
+#endif
 }
 
 // ------------------------------------------------------------------ batch
@@ -288,8 +347,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom) UV(dof_cadr, dof_cadr) UV(col_dof, col_dof) UV(lvl_cstart, lvl_cstart)
-  M.ncol = (int)m->col_dof.size();
+  UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
+  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
   UI(wing_act_idx, "wing_action_idx")
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];

@@ -137,6 +137,33 @@ FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 #endif
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// hide a register value from loop-invariant code motion: values derived from it are recomputed where they are
+// used instead of being hoisted out of a loop into (spilled) registers
+#ifdef FB_EMULATE
+#define FB_OPAQUE(x) do {} while (0)
+#define FB_LDS_AS
+#else
+#define FB_OPAQUE(x) asm volatile("" : "+v"(x))
+#define FB_LDS_AS __attribute__((address_space(3)))
+#endif
+
+// Arguments of a non-inlined device function arrive in VGPRs even when they are wave-uniform.  Moving a uniform
+// pointer to SGPRs (v_readfirstlane) frees two VGPRs per pointer and lets loads through it use scalar addressing.
+#ifdef FB_EMULATE
+template <typename T> FBD T* uniform_ptr(T* p) { return p; }
+FBD int uniform_int(int v) { return v; }
+#else
+template <typename T> FBD T* uniform_ptr(T* p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T> FBD FB_LDS_AS T* uniform_ptr(FB_LDS_AS T* p) {
+  return (FB_LDS_AS T*)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p);
+}
+FBD int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 // ---- wavefront (64-lane) collectives -------------------------------------------------
 #ifdef FB_EMULATE
 template <typename T> FBD T rdlane(T v, int src) { return __shfl(v, src, 64); }

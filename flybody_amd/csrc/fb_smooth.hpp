@@ -18,8 +18,10 @@
 // s_barrier, which would couple unrelated environments.
 #ifdef FB_EMULATE
 #define SYNC() __syncthreads()
-#else
+#elif defined(FB_SYNC_WORKGROUP)
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 // optional per-phase cycle accounting (build with -DFB_PROFILE): lane 0 accumulates s_memtime deltas
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
@@ -219,125 +221,281 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
 
 // Sparse L^T D L factorisation / solves of the joint-space inertia matrix, LDS resident.
 //
-// The elimination order of a kinematic tree is serial along a chain but the dofs of one *depth
-// level* are independent once every deeper level is final.  Storage is COLUMN-major over the
-// elimination tree: column j holds L[k,j] for the descendants k = j+1 .. j+ndesc[j] of dof j -- a
-// DFS-contiguous range -- at LC[cadr[j] + (k-j-1)], D separately.  Every inner loop below is then a
-// unit-stride stream over k (no index-table lookup on the critical path):
-//   factor   U[i,e] = M[i,e] - sum_k L[k,i] L[k,anc_e(i)] D[k]        (pull, deepest level first)
-//   L^-T x   x[j] -= sum_k L[k,j] x[k]                                 (pull, deepest level first)
-//   L^-1 x   x[k] -= L[k,j] x[j]  for k in desc(j)                     (push, shallowest level first;
-//            subtrees of dofs on one level are disjoint, so no two lanes write the same entry)
-// Rows with many descendants (the 6 free-joint dofs) are reduced across the whole wavefront.
-#define FB_BIGROW 24
+// Storage is ROW-major like qM: row k = [1/D[k], L[k,parent], L[k,grandparent], ...] at RM[madr[k] + e], e = depth
+// difference.  Along an unbranched chain consecutive rows grow by one entry, so the row of the descendant of dof i
+// on depth level d starts at  base_i + T(d),  base_i = madr[i] - T(depth[i]),  T(d) = d(d+1)/2 : pure arithmetic.
+//
+// Factorisation (right-looking, level-synchronous, register accumulators): every off-diagonal entry (i,j) is
+// owned by one (lane, slot) -- ONE packed word per slot: base | depth << 13 | chain length << 18 | e << 23 -- the
+// diagonal of dof j by lane j & 63, all kept in registers.  Levels are eliminated deepest first; once the rows k
+// of level d are final they are published to LDS (unnormalised, 1/D[k] in the diagonal slot) and every shallower
+// entry pulls its contribution  M[i,j] -= M~[k,i] M~[k,j] / D[k]  from the descendant k of i on that level: three
+// LDS reads at base + T(d), + delta, + delta + e.  The few branching dofs outside the trunk (head) read a
+// per-level list of <= 4 descendant rows.  The rows of the trunk (the free joint, ancestors of everything) are a
+// dense 6x6 Schur complement: 21 dot products over all other dofs, computed lane-parallel with one wave reduction
+// each, then a tiny dense LDL.
+//
+// Solves keep x[j] of the (<= 2) dofs a lane owns in registers:
+//   L^-T : level d final -> publish -> every shallower dof pulls  x[j] -= L[k,j] x[k]  from its level-d descendants;
+//          the trunk rows are 6 lane-parallel dot products
+//   L^-1 : trunk first (uniform), then level d final -> publish -> every deeper dof pulls x[k] -= L[k,a] x[a]
+//          from its level-d ancestor a
+#define FB_NTT (FB_MAXTRUNK*(FB_MAXTRUNK + 1)/2)
+#define FB_FGROUP 3        // slots whose LDS reads are issued together (FB_FSLOT is a multiple)
+#define FW_BASE(wd) (((int)((unsigned)(wd) << 19)) >> 19)
+#define FW_DEP(wd) (((wd) >> 13) & 31)
+#define FW_CL(wd) (((wd) >> 18) & 31)
+#define FW_E(wd) (((wd) >> 23) & 31)
+
+// sum over the (<= 4) listed descendant rows mk of  RM[mk + oi] * RM[mk + oj] * RM[mk]
+// (the loads are unconditional so that all of them are in flight together; an absent entry reads row `ms`,
+// which always exists, and its product is discarded)
+template <typename real>
+FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, int oj, int ms) {
+  real p[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    int mk = ((c < 2 ? m01 : m23) >> (16*(c & 1))) & 0xffff;
+    bool ok = mk != 0xffff;
+    int mm = ok ? mk : ms;
+    real v = RM[mm + oi]*RM[mm + oj]*RM[mm];
+    p[c] = ok ? v : (real)0;
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
 
 template <typename real>
-FB_STAGE_B void d_factor(const DevModel<real>& M, const WS<real>& w, const real* qM, const real* diag_add, real hscale,
-                         FB_LDS real* LC, FB_LDS real* Dg, FB_LDS real* Dinv, int lane) {
+FB_STAGE_B void d_factor(const DevModel<real>& M_, const WS<real>& w_, const real* qM, const real* diag_add, real hscale,
+                         FB_LDS real* RM, FB_LDS real* Dinv, int lane) {
+  const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
+  qM = uniform_ptr(qM); diag_add = uniform_ptr(diag_add); RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv);
   PROF_BEGIN();
-  for (int d = w.nlevel - 1; d >= 0; d--) {
-    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
-    int width = d + 1, npair = n*width;
-    real val[4]; int cnt = 0;
-    PROF_RESET();
-    for (int p = lane; p < npair; p += FB_WAVE) {
-      int t = p / width, e = p - t*width;
-      int i = w.llvl_dof[s0 + t];
-      int nd = w.lndesc[i];
-      real acc = qM[w.lmadr[i] + e];
-      if (e == 0 && diag_add) acc += hscale*diag_add[i];
-      if (nd <= FB_BIGROW) {
-        int je = e ? w.lanc[i*FB_MAXCH + e - 1] : i;
-        const FB_LDS real* ci = LC + w.lcadr[i];                  // L[k,i],  k = i+1+q
-        const FB_LDS real* cj = LC + w.lcadr[je] + (i - je);      // L[k,je], k = i+1+q
-        const FB_LDS real* dk = Dg + i + 1;
-        for (int q = 0; q < nd; q++) acc -= ci[q]*cj[q]*dk[q];
-      }
-      val[cnt++] = acc;
-    }
-    PROF(17);
-    // wide rows: one (row, entry) at a time, descendants spread over the lanes
-    for (int t = 0; t < n; t++) {
-      int i = w.llvl_dof[s0 + t];
-      int nd = w.lndesc[i];
-      if (nd <= FB_BIGROW) continue;
-      for (int e = 0; e < width; e++) {
-        int je = e ? w.lanc[i*FB_MAXCH + e - 1] : i;
-        const FB_LDS real* ci = LC + w.lcadr[i];
-        const FB_LDS real* cj = LC + w.lcadr[je] + (i - je);
-        real part = 0;
-        for (int q = lane; q < nd; q += FB_WAVE) part += ci[q]*cj[q]*Dg[i + 1 + q];
-        part = wave_sum(part);
-        if (lane == t*width + e) val[0] -= part;                  // the lane that owns this pair (levels with wide rows have <= 64 pairs)
-      }
-    }
-    PROF(18);
-    cnt = 0;
-    for (int p = lane; p < npair; p += FB_WAVE) {
-      int t = p / width, e = p - t*width;
-      if (e == 0) Dg[w.llvl_dof[s0 + t]] = val[cnt];
-      cnt++;
-    }
-    SYNC();
-    cnt = 0;
-    for (int p = lane; p < npair; p += FB_WAVE) {
-      int t = p / width, e = p - t*width;
-      if (e > 0) {
-        int i = w.llvl_dof[s0 + t];
-        int je = w.lanc[i*FB_MAXCH + e - 1];
-        LC[w.lcadr[je] + (i - je - 1)] = val[cnt] / Dg[i];
-      }
-      cnt++;
-    }
-    SYNC();
-    PROF(19);
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
+  const FB_LDS uint32_t* gm = uniform_ptr(w.lgm);          // locals: a fence must not force reloading them from the WS struct
+  const int* madr_g = uniform_ptr(M.dof_Madr);
+  // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
+  int fw[FB_FSLOT];
+  real acc[FB_FSLOT];
+#pragma unroll
+  for (int s = 0; s < FB_FSLOT; s++) {
+    fw[s] = M.fac_w[s*FB_WAVE + lane];
+    int dep = FW_DEP(fw[s]);
+    acc[s] = (dep != 31) ? qM[FW_BASE(fw[s]) + dep*(dep + 1)/2 + FW_E(fw[s])] : (real)0;
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) Dinv[i] = (real)1 / Dg[i];
+  // diagonal entries of the two dofs this lane owns, same packed format (e field = general-dof index, 31 = none)
+  int fd[2]; real accd[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    int j = lane + q*FB_WAVE;
+    bool has = j < nv && j >= nT;
+    int dp = has ? w.ldepth[j] : 31, mj = has ? w.lmadr[j] : 0, g = has ? w.lgen[j] : 255;
+    fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13) | ((has ? w.lcl[j] : 0) << 18) | ((g == 255 ? 31 : g) << 23);
+    real v = 0;
+    if (has) { v = qM[mj]; if (diag_add) v += hscale*diag_add[j]; }
+    accd[q] = v;
+  }
+  PROF(17);
+  for (int d = nlevel - 1; d >= nT; d--) {
+    const int Td = d*(d + 1)/2;
+    // (keep the packed words opaque: otherwise every field of every slot is hoisted into its own register)
+#pragma unroll
+    for (int s = 0; s < FB_FSLOT; s++) FB_OPAQUE(fw[s]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) FB_OPAQUE(fd[q]);
+    // publish the rows of level d (unnormalised) and 1/D
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; Dinv[lane + q*FB_WAVE] = di; }
+#pragma unroll
+    for (int s = 0; s < FB_FSLOT; s++) if (FW_DEP(fw[s]) == d) RM[FW_BASE(fw[s]) + Td + FW_E(fw[s])] = acc[s];
+    SYNC();
+    PROF(16);
+    // pull the contribution of level d into every shallower entry.  The chain loads are unconditional (an LDS read
+    // cannot fault) so that a group's reads are in flight together; inactive slots discard the product.
+#pragma unroll
+    for (int s0 = 0; s0 < FB_FSLOT; s0 += FB_FGROUP) {
+      real la[FB_FGROUP], lb[FB_FGROUP], ld[FB_FGROUP];
+#pragma unroll
+      for (int u = 0; u < FB_FGROUP; u++) {
+        int wd = fw[s0 + u];
+        int aD = FW_BASE(wd) + Td, aI = aD + d - FW_DEP(wd);
+        ld[u] = RM[aD]; la[u] = RM[aI]; lb[u] = RM[aI + FW_E(wd)];
+      }
+#pragma unroll
+      for (int u = 0; u < FB_FGROUP; u++) {
+        int wd = fw[s0 + u];
+        unsigned t = (unsigned)(d - FW_DEP(wd) - 1);
+        real pr = la[u]*lb[u]*ld[u];
+        acc[s0 + u] -= (t < (unsigned)FW_CL(wd)) ? pr : (real)0;
+      }
+    }
+    PROF(22);
+#pragma unroll
+    for (int s = 0; s < FB_FGEN; s++) {
+      int wd = fw[s], dep = FW_DEP(wd), g = (wd >> 28) & 15;
+      if (g != 15 && d - dep - 1 >= FW_CL(wd)) {
+        int oi = d - dep, o = 2*(g*FB_MAXCH + d);
+        acc[s] -= gen_pull3(RM, gm[o], gm[o + 1], oi, oi + FW_E(wd), FW_BASE(wd) + (dep + 1)*(dep + 2)/2);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int wd = fd[q], dep = FW_DEP(wd), t = d - dep - 1;
+      if (t >= 0) {
+        if (t < FW_CL(wd)) { int aD = FW_BASE(wd) + Td; real l = RM[aD + t + 1]; accd[q] -= l*l*RM[aD]; }
+        else if (FW_E(wd) != 31) { int o = 2*(FW_E(wd)*FB_MAXCH + d); accd[q] -= gen_pull3(RM, gm[o], gm[o + 1], t + 1, t + 1, FW_BASE(wd) + (dep + 1)*(dep + 2)/2); }
+      }
+    }
+    PROF(23);
+  }
+  PROF(18);
+  // trunk: S[a,b] = M[a,b] - sum_{k >= nT} M~[k,a] M~[k,b] / D[k], then dense LDL (every lane, uniform values)
+  real S[FB_NTT];
+#pragma unroll
+  for (int e = 0; e < FB_NTT; e++) S[e] = 0;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    int dep = FW_DEP(fd[q]);
+    if (dep != 31) {
+      int row = FW_BASE(fd[q]) + dep*(dep + 1)/2;
+      real dk = RM[row], col[FB_MAXTRUNK];
+#pragma unroll
+      for (int a = 0; a < FB_MAXTRUNK; a++) col[a] = (a < nT) ? RM[row + dep - a] : (real)0;
+#pragma unroll
+      for (int a = 0; a < FB_MAXTRUNK; a++) {
+        real ca = col[a]*dk;
+#pragma unroll
+        for (int b2 = 0; b2 <= a; b2++) S[a*(a + 1)/2 + b2] += ca*col[b2];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++)
+#pragma unroll
+    for (int b2 = 0; b2 <= a; b2++) {
+      int e = a*(a + 1)/2 + b2;
+      real m0 = 0;
+      if (a < nT) { m0 = qM[madr_g[a] + (a - b2)]; if (a == b2 && diag_add) m0 += hscale*diag_add[a]; }
+      S[e] = m0 - wave_sum(S[e]);
+    }
   SYNC();
+  // normalise the published rows: L[i,j] = M~[i,j] / D[i]
+#pragma unroll
+  for (int s = 0; s < FB_FSLOT; s++) {
+    int wd = fw[s], dep = FW_DEP(wd);
+    if (dep != 31) { int ad = FW_BASE(wd) + dep*(dep + 1)/2; RM[ad + FW_E(wd)] = acc[s]*RM[ad]; }
+  }
+  // trunk rows: dof k sits at depth k, row start T(k)
+#pragma unroll
+  for (int k = FB_MAXTRUNK - 1; k >= 0; k--) {
+    if (k < nT) {
+      real Dk = S[k*(k + 1)/2 + k], Di = (real)1/Dk;
+      if (lane == 0) { RM[k*(k + 1)/2] = Di; Dinv[k] = Di; }
+#pragma unroll
+      for (int a = 0; a < k; a++) {
+        real Lka = S[k*(k + 1)/2 + a]*Di;
+        if (lane == 0) RM[k*(k + 1)/2 + (k - a)] = Lka;
+#pragma unroll
+        for (int b2 = 0; b2 <= a; b2++) S[a*(a + 1)/2 + b2] -= Lka*S[k*(k + 1)/2 + b2];
+      }
+    }
+  }
+  SYNC();
+  PROF(19);
 }
 
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-FB_STAGE_B void d_solve(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* LC, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+FB_STAGE_B void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+  const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
+  RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv); x = uniform_ptr(x);
   PROF_BEGIN();
-  // x <- L^-T x, deepest level first: each dof pulls from its (already final) descendants
-  for (int d = w.nlevel - 1; d >= 0; d--) {
-    int s0 = w.llvl_start[d], n = w.llvl_start[d + 1] - s0;
-    if (lane < n) {
-      int j = w.llvl_dof[s0 + lane];
-      int nd = w.lndesc[j];
-      if (nd <= FB_BIGROW) {
-        const FB_LDS real* cj = LC + w.lcadr[j];
-        const FB_LDS real* xk = x + j + 1;
-        real acc = 0;
-        for (int q = 0; q < nd; q++) acc += cj[q]*xk[q];
-        x[j] -= acc;
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
+  const FB_LDS uint32_t* gk = uniform_ptr(w.lgk);
+  const FB_LDS uint16_t* lmadr = uniform_ptr(w.lmadr);
+  const int* fwd = uniform_ptr(M.fwd_tab);
+  int jd[2], dep[2], cl[2], gen[2], base[2], rowt[2]; real a_[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    int j = lane + q*FB_WAVE;
+    bool has = j < nv && j >= nT;
+    int dp = has ? w.ldepth[j] : 31, mj = has ? lmadr[j] : 0;
+    jd[q] = j; dep[q] = dp; cl[q] = has ? w.lcl[j] : 0; gen[q] = has ? w.lgen[j] : 255;
+    base[q] = mj - dp*(dp + 1)/2; rowt[q] = mj + dp;
+    a_[q] = has ? x[j] : (real)0;
+  }
+  // ---- x <- L^-T x, deepest level first
+  for (int d = nlevel - 1; d >= nT; d--) {
+    const int Td = d*(d + 1)/2;
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (dep[q] == d) x[jd[q]] = a_[q];
+    SYNC();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int t = d - dep[q] - 1;
+      if (t >= 0) {
+        if (t < cl[q]) a_[q] -= RM[base[q] + Td + t + 1]*x[jd[q] + t + 1];
+        else if (gen[q] != 255) {
+          unsigned pack = gk[gen[q]*FB_MAXCH + d];
+          real p[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            int k = (pack >> (8*c)) & 255;
+            bool ok = k != 255;
+            int kk = ok ? k : jd[q] + 1;
+            real v = RM[(int)lmadr[kk] + t + 1]*x[kk];
+            p[c] = ok ? v : (real)0;
+          }
+          a_[q] -= (p[0] + p[1]) + (p[2] + p[3]);
+        }
       }
     }
-    for (int t = 0; t < n; t++) {
-      int j = w.llvl_dof[s0 + t];
-      int nd = w.lndesc[j];
-      if (nd <= FB_BIGROW) continue;
-      const FB_LDS real* cj = LC + w.lcadr[j];
-      real part = 0;
-      for (int q = lane; q < nd; q += FB_WAVE) part += cj[q]*x[j + 1 + q];
-      part = wave_sum(part);
-      if (lane == 0) x[j] -= part;
-    }
-    SYNC();
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) x[i] *= Dinv[i];
-  SYNC();
-  PROF(20);
-  // x <- L^-1 x, shallowest level first: each dof pushes to its descendants (disjoint subtrees per level)
-  for (int d = 0; d < w.nlevel - 1; d++) {
-    // columns are laid out level by level, so the (dof, descendant) pairs of a level are one index range of LC
-    int p0 = w.llvl_cstart[d], p1 = w.llvl_cstart[d + 1];
-    for (int p = p0 + lane; p < p1; p += FB_WAVE) {
-      int j = w.lcol_dof[p];
-      x[j + 1 + (p - w.lcadr[j])] -= LC[p]*x[j];
+  // trunk rows: lane-parallel dot products over all other dofs, then the back-substitution inside the trunk
+  real xt[FB_MAXTRUNK], col[2][FB_MAXTRUNK];
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = 0;
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int a = 0; a < FB_MAXTRUNK; a++) {
+      col[q][a] = (dep[q] != 31 && a < nT) ? RM[rowt[q] - a] : (real)0;
+      xt[a] += col[q][a]*a_[q];
     }
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] - wave_sum(xt[a]) : (real)0;
+#pragma unroll
+  for (int a = FB_MAXTRUNK - 1; a >= 0; a--)
+#pragma unroll
+    for (int k = a + 1; k < FB_MAXTRUNK; k++) if (k < nT) xt[a] -= RM[k*(k + 1)/2 + (k - a)]*xt[k];
+  // ---- x <- D^-1 x
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT) xt[a] *= Dinv[a];
+#pragma unroll
+  for (int q = 0; q < 2; q++) if (dep[q] != 31) a_[q] *= Dinv[jd[q]];
+  PROF(20);
+  // ---- x <- L^-1 x: trunk (uniform), trunk -> every other dof, then level by level
+#pragma unroll
+  for (int k = 1; k < FB_MAXTRUNK; k++)
+#pragma unroll
+    for (int a = 0; a < k; a++) if (k < nT) xt[k] -= RM[k*(k + 1)/2 + (k - a)]*xt[a];
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT && lane == 0) x[a] = xt[a];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int a = 0; a < FB_MAXTRUNK; a++) a_[q] -= col[q][a]*xt[a];
+  int nxt[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) nxt[q] = (dep[q] != 31 && dep[q] > nT) ? fwd[nT*FB_MAXNV + jd[q]] : 0;
+  for (int d = nT; d < nlevel; d++) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (dep[q] == d) x[jd[q]] = a_[q];
     SYNC();
+    int cur[2] = {nxt[0], nxt[1]};
+#pragma unroll
+    for (int q = 0; q < 2; q++) nxt[q] = (dep[q] != 31 && dep[q] > d + 1) ? fwd[(d + 1)*FB_MAXNV + jd[q]] : 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (dep[q] != 31 && dep[q] > d) a_[q] -= RM[rowt[q] - d]*x[cur[q]];
   }
   PROF(21);
 }

@@ -182,7 +182,7 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
 // a launch and reloaded at the start of the next one (once per control step, not per substep).
 template <typename real>
 __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.ncol; i += FB_WAVE) w.qLD[i] = w.lLD[i];
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.lLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
   int nefc = w.istate[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.AR[i] = w.lAR[i];
@@ -190,7 +190,7 @@ __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<re
 }
 template <typename real>
 __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.ncol; i += FB_WAVE) w.lLD[i] = w.qLD[i];
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
   int nefc = w.istate[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.lAR[i] = w.AR[i];
@@ -468,8 +468,10 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   } else if (mode == MODE_FORWARD) {
     pc = ST_KIN;
   } else {
+    PROF_BEGIN();
     d_lds_load(M, w, lane);
     if (mode == MODE_STEP) { if (M.task == 1) d_flight_pre(M, w, action, lane); else d_walk_pre(M, w, action, lane); }
+    PROF(27);
     pc = (nsub > 0) ? ST_ACT : ST_DONE;
   }
   bool single_pass = resetting || (mode == MODE_FORWARD);     // KIN..COLL then ACT..SENS once, no integration
@@ -485,41 +487,49 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         }
         PROF(P_ACT);
         pc = ST_ACC_PRE; break; }
-      case ST_ACC_PRE:
+      case ST_ACC_PRE: {
+        PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) {
           real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
           w.qfrc_smooth[i] = f; w.lx[i] = f;
         }
         SYNC();
-        ret = ST_ACC_POST; pc = ST_SOLVE; break;
+        PROF(24);
+        ret = ST_ACC_POST; pc = ST_SOLVE; break; }
       case ST_SOLVE: {
         PROF_BEGIN();
         d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
         PROF(P_ACC);
         pc = ret; break; }
-      case ST_ACC_POST:
+      case ST_ACC_POST: {
+        PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
         SYNC();
-        pc = ST_CONSTR_A; break;
+        PROF(24);
+        pc = ST_CONSTR_A; break; }
       case ST_CONSTR_A: {
         bool need = d_constraint_a(M, w, lane);
         ret = ST_CONSTR_B; pc = need ? ST_SOLVE : ST_CONSTR_B; break; }
-      case ST_CONSTR_B:
+      case ST_CONSTR_B: {
+        PROF_BEGIN();
         d_constraint_b(M, w, lane);
-        pc = ST_SENS; break;
+        PROF(25);
+        pc = ST_SENS; break; }
       case ST_SENS: {
         PROF_BEGIN();
         d_sensor_acc(M, w, lane);
         PROF(P_SENS);
         pc = single_pass ? ST_DONE : ST_EULER_PRE; break; }
-      case ST_EULER_PRE:
+      case ST_EULER_PRE: {
         // the factor of M is dead after the constraint solve: its LDS slot is reused for M + h*D
+        PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
         SYNC();
-        damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break;
+        PROF(24);
+        damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
-        d_factor(M, w, w.qM, damp ? M.dof_damping : (const real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDg, w.lDinv, lane);
+        d_factor(M, w, w.qM, damp ? M.dof_damping : (const real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDinv, lane);
         PROF(P_FACTOR);
         pc = fret; break; }
       case ST_EULER_SOLVE:
@@ -545,13 +555,16 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         d_rne_bias(M, w, lane);
         d_sensor_vel(M, w, lane); PROF(P_VEL);
         pc = single_pass ? ST_ACT : ST_SUBEND; break; }
-      case ST_SUBEND:
+      case ST_SUBEND: {
+        PROF_BEGIN();
         if (env_logic) { if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane]; SYNC(); }
         sub++;
-        pc = (sub < nsub) ? ST_ACT : ST_DONE; break;
+        PROF(26);
+        pc = (sub < nsub) ? ST_ACT : ST_DONE; break; }
       default: pc = ST_DONE;
     }
   }
+  PROF_BEGIN();
   if (env_logic) {
     if (resetting) {
       d_pack_obs(M, w, w.sens, obs, lane);
@@ -561,4 +574,5 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
     else d_walk_post(M, w, obs, reward, discount, step_type, lane);
   }
   d_lds_store(M, w, lane);
+  PROF(28);
 }

@@ -13,11 +13,15 @@
 #define FB_WAVE 64
 #define FB_EPB 4            // environments (wavefronts) per workgroup; they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
+#define FB_MAXGEN 16       // dofs whose subtree branches (free joint, head, ...)
+#define FB_MAXTRUNK 6       // dofs of the unbranched chain at the tree root (free joint) handled wave-parallel
+#define FB_FSLOT 18        // factor work list: off-diagonal entries of M owned by one lane
+#define FB_FGEN 2          // ... of which the first FB_FGEN may belong to branching dofs
 #define FB_MAXDEPTH 10     // deepest body (claw: 9)
 #define FB_MAXCON_ 64
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
-#define FB_NPROF 24
+#define FB_NPROF 32
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
 
@@ -48,7 +52,12 @@ struct DevModel {
   const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
   const int *dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
   const int *lvl_dof, *lvl_start; int nlevel;   // dofs grouped by depth
-  const int *dof_cadr, *col_dof, *lvl_cstart; int ncol;   // column-major factor layout (columns ordered by level)
+  const int *dof_cl;         // [nv] length of the unbranched chain below the dof
+  const int *dof_gen;        // [nv] index of a dof outside the trunk whose subtree branches ("general" dof) or -1
+  const int *gen_k, *gen_m;  // [FB_MAXGEN][FB_MAXCH] descendants of a general dof on a level: 4 dof ids (u8) / 4 row starts (u16)
+  const int *fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
+  const int *fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
+  int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
@@ -120,9 +129,9 @@ template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(
 template <typename real>
 struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
-  FB_LDS real *lLD, *lDg, *lDinv, *lx, *lAR;     // lLD: column-major L (see fb_smooth.hpp)
+  FB_LDS real *lLD, *lDinv, *lx, *lAR;     // lLD: row-major factor, 1/D on the diagonal (see fb_smooth.hpp)
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
-  const FB_LDS uint8_t *lanc, *ldepth, *lndesc, *llvl_dof, *llvl_start, *lcol_dof; const FB_LDS uint16_t *lmadr, *lcadr, *llvl_cstart; int nlevel;
+  const FB_LDS uint8_t *ldepth, *lcl, *lgen; const FB_LDS uint16_t *lmadr; const FB_LDS uint32_t *lgk, *lgm; int nlevel;
 #define X(name, n) real* name;
   FB_WS_REAL(X)
 #undef X

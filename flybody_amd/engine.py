@@ -154,7 +154,7 @@ class Batch:
                     DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
-                    SUBTREE_COM=3, PROF=48)[name]
+                    SUBTREE_COM=3, PROF=64)[name]
 
     def get(self, name: str) -> np.ndarray:
         w = self._width(name)

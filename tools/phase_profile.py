@@ -16,14 +16,14 @@ a = torch.empty(n, 59, device='cuda')
 for _ in range(5):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-B.set('PROF', np.zeros(48, np.int32))
+B.set('PROF', np.zeros(64, np.int32))
 K = 10
 import time; t0 = time.time()
 for _ in range(K):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize(); dt = time.time() - t0
-p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][24]
-names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'pgs_blk_rest', 'fA_small', 'fA_wide', 'fB_write', 'sol_fwd', 'sol_bwd', 'pgs_row1', 'pgs_blk_dots']
+p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
+names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'fA_small', 'fA_wide', 'fB_write', 'sol_fwd', 'sol_bwd', 'f_chain', 'f_gen_diag', 'small_loops', 'constr_b', 'subend', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'x31']
 tot = p.sum(1).mean()
 print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step; mean cycles per env-step {tot/K:.0f}; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
 for i, nm in enumerate(names):
