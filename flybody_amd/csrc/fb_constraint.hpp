@@ -140,6 +140,9 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D[r] = (real)1 / w.efc_R[r];
 }
 
+// the Delassus matrix is symmetric: packed lower triangle, element (r, c), r >= c, at r(r+1)/2 + c
+#define ARIDX(r, c) ((r)*((r) + 1)/2 + (c))
+
 template <typename real, typename ARP>
 FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
 
@@ -213,9 +216,9 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
           }
         }
       }
-      if (valid) {
+      if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
         if (c == r) acc += w.efc_R[r];
-        AR[r*nefc + c] = acc;
+        AR[ARIDX(r, c)] = acc;
       }
     }
   }
@@ -345,13 +348,14 @@ template <bool S = false, typename T> FBD void r3_load(R3<T>& f, const T* p, int
   f.v2 = (!S && lane + 128 < n) ? p[lane + 128] : dflt;
 }
 
-// res += delta * AR[row, :]   (lane k owns columns k, k+64, k+128); the residual is accumulated in FP64 in
+// res += delta * AR[i, :]   (lane k owns columns k, k+64, k+128); the residual is accumulated in FP64 in
 // both builds (FP32 products are exact in FP64, so the running residual does not drift over the sweeps)
-template <bool S, typename real, typename ARP> FBD void res_axpy(R3<double>& res, ARP row, int n, real delta, int lane) {
-  if (lane < n) res.v0 += (double)delta*(double)row[lane];
+template <bool S, typename real, typename ARP> FBD void res_axpy(R3<double>& res, ARP AR, int i, int n, real delta, int lane) {
+  const int Ti = i*(i + 1)/2;
+  { int k = lane; if (k < n) res.v0 += (double)delta*(double)AR[k <= i ? Ti + k : k*(k + 1)/2 + i]; }
   if (!S) {
-    if (lane + 64 < n) res.v1 += (double)delta*(double)row[lane + 64];
-    if (lane + 128 < n) res.v2 += (double)delta*(double)row[lane + 128];
+    { int k = lane + 64; if (k < n) res.v1 += (double)delta*(double)AR[k <= i ? Ti + k : k*(k + 1)/2 + i]; }
+    { int k = lane + 128; if (k < n) res.v2 += (double)delta*(double)AR[k <= i ? Ti + k : k*(k + 1)/2 + i]; }
   }
 }
 
@@ -377,9 +381,9 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   r3_load<S>(rb, w.efc_b, nefc, lane, (real)0);
   r3_load<S>(rR, w.efc_R, nefc, lane, (real)0);
   r3_load<S>(rtype, w.efc_type, nefc, lane, 0);
-  rdiag.v0 = (lane < nefc) ? AR[lane*nefc + lane] : (real)1;
-  rdiag.v1 = (!S && lane + 64 < nefc) ? AR[(lane + 64)*nefc + lane + 64] : (real)1;
-  rdiag.v2 = (!S && lane + 128 < nefc) ? AR[(lane + 128)*nefc + lane + 128] : (real)1;
+  rdiag.v0 = (lane < nefc) ? AR[ARIDX(lane, lane)] : (real)1;
+  rdiag.v1 = (!S && lane + 64 < nefc) ? AR[ARIDX(lane + 64, lane + 64)] : (real)1;
+  rdiag.v2 = (!S && lane + 128 < nefc) ? AR[ARIDX(lane + 128, lane + 128)] : (real)1;
   {
     // friction coefficients of the contact a row belongs to
     real a0[3] = {1, 1, 1}, a1[3] = {1, 1, 1};
@@ -394,7 +398,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   res.v0 = rb.v0; res.v1 = rb.v1; res.v2 = rb.v2;
   for (int k = 0; k < nefc; k++) {
     real fk = r3_get<S>(f, k);
-    if (fk != 0) res_axpy<S>(res, AR + k*nefc, nefc, fk, lane);
+    if (fk != 0) res_axpy<S>(res, AR, k, nefc, fk, lane);
   }
   {
     // dual cost of the warm start 0.5 f'ARf + f'b; fall back to zero force if it is worse than zero
@@ -403,6 +407,33 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     if (c > 0) { f.v0 = 0; f.v1 = 0; f.v2 = 0; res.v0 = rb.v0; res.v1 = rb.v1; res.v2 = rb.v2; }
   }
   PROF(P_CSETUP);
+  // ---- per-contact constants of the 3-row block update, held by the lane of the block's first row
+  // (A block, scaled friction-plane matrix and its inverse at multiplier 0, reciprocals): every sweep fetches them
+  // with v_readlane instead of re-reading and re-deriving them
+  R3<real> cA00, cA01, cA02, cA11, cA12, cA22, cQ11, cQ22, cQ12, cP11, cP22, cP12, cI00;
+  {
+    real t[13][3];
+    for (int q = 0; q < (S ? 1 : 3); q++) {
+      int r = lane + 64*q;
+      for (int u = 0; u < 13; u++) t[u][q] = 0;
+      bool first = r < nefc && w.efc_type[r] == CN_ELLIPTIC && w.con_efc[w.efc_id[r]] == r;
+      if (first) {
+        real a00 = AR[ARIDX(r, r)], a01 = AR[ARIDX(r + 1, r)], a02 = AR[ARIDX(r + 2, r)];
+        real a11 = AR[ARIDX(r + 1, r + 1)], a12 = AR[ARIDX(r + 2, r + 1)], a22 = AR[ARIDX(r + 2, r + 2)];
+        real d0 = q == 0 ? rfr0.v0 : (q == 1 ? rfr0.v1 : rfr0.v2), d1 = q == 0 ? rfr1.v0 : (q == 1 ? rfr1.v1 : rfr1.v2);
+        real q11 = a11*d0*d0, q22 = a22*d1*d1, q12 = a12*d0*d1;
+        real det = q11*q22 - q12*q12;
+        real di = (det < (real)1e-10) ? (real)0 : fb_div((real)1, det);       // 0 marks the singular case
+        t[0][q] = a00; t[1][q] = a01; t[2][q] = a02; t[3][q] = a11; t[4][q] = a12; t[5][q] = a22;
+        t[6][q] = q11; t[7][q] = q22; t[8][q] = q12; t[9][q] = q22*di; t[10][q] = q11*di; t[11][q] = -q12*di;
+        t[12][q] = (a00 >= FB_MINV) ? fb_div((real)1, a00) : (real)0;
+      }
+    }
+#define FB_C3(name, u) name.v0 = t[u][0]; name.v1 = S ? (real)0 : t[u][1]; name.v2 = S ? (real)0 : t[u][2];
+    FB_C3(cA00, 0) FB_C3(cA01, 1) FB_C3(cA02, 2) FB_C3(cA11, 3) FB_C3(cA12, 4) FB_C3(cA22, 5)
+    FB_C3(cQ11, 6) FB_C3(cQ22, 7) FB_C3(cQ12, 8) FB_C3(cP11, 9) FB_C3(cP22, 10) FB_C3(cP12, 11) FB_C3(cI00, 12)
+#undef FB_C3
+  }
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
   real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
   int niter = 0;
@@ -418,47 +449,85 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         if (fn < 0) fn = 0;
         real del = fn - old;
         improvement -= (real)0.5*del*del*a + del*r0;
-        if (del != 0) { res_axpy<S>(res, AR + i*nefc, nefc, del, lane); r3_set<S>(f, i, lane, fn); }
+        if (del != 0) { res_axpy<S>(res, AR, i, nefc, del, lane); r3_set<S>(f, i, lane, fn); }
         i += 1;
       } else {
-        real r3v[3], old[3], A[9];
-        for (int j = 0; j < 3; j++) {
-          r3v[j] = (real)r3_get<S>(res, i+j);
-          old[j] = r3_get<S>(f, i+j);
-          for (int k = 0; k < 3; k++) A[3*j+k] = AR[(i+j)*nefc + i + k];
+        real r0 = (real)r3_get<S>(res, i), o0 = r3_get<S>(f, i), o1 = r3_get<S>(f, i+1), o2 = r3_get<S>(f, i+2);
+        // a contact that carries no force and is separating stays at zero (the ray update below would return 0)
+        if (o0 == 0 && o1 == 0 && o2 == 0 && r0 >= 0) { i += 3; continue; }
+        real r1 = (real)r3_get<S>(res, i+1), r2 = (real)r3_get<S>(res, i+2);
+        real A00 = r3_get<S>(cA00, i), A01 = r3_get<S>(cA01, i), A02 = r3_get<S>(cA02, i);
+        real A11 = r3_get<S>(cA11, i), A12 = r3_get<S>(cA12, i), A22 = r3_get<S>(cA22, i);
+        // A*old and the part of the residual that does not depend on this block
+        real Ao0 = A00*o0 + A01*o1 + A02*o2, Ao1 = A01*o0 + A11*o1 + A12*o2, Ao2 = A02*o0 + A12*o1 + A22*o2;
+        real bc1 = r1 - Ao1, bc2 = r2 - Ao2;
+        // ray update: along e1 when the contact is inactive, along the current force otherwise
+        real f0, f1, f2;
+        if (o0 < FB_MINV) {
+          real x = -r0*r3_get<S>(cI00, i);           // 1/A00 (0 when A00 is degenerate: no move)
+          if (o0 + x < 0) x = -o0;
+          f0 = o0 + x; f1 = o1; f2 = o2;
+        } else {
+          real denom = o0*Ao0 + o1*Ao1 + o2*Ao2;
+          real x = 0;
+          if (denom >= FB_MINV) { x = -fb_div(o0*r0 + o1*r1 + o2*r2, denom); if (o0 + x*o0 < 0) x = -1; }
+          f0 = o0 + x*o0; f1 = o1 + x*o1; f2 = o2 + x*o2;
         }
-        real fr[2] = {r3_get<S>(rfr0, i), r3_get<S>(rfr1, i)};
-        real bc[3], fo[3] = {old[0], old[1], old[2]};
-        for (int j = 0; j < 3; j++) bc[j] = r3v[j] - (A[3*j]*old[0] + A[3*j+1]*old[1] + A[3*j+2]*old[2]);
-        real v[3];
-        if (fo[0] < FB_MINV) { v[0] = 1; v[1] = 0; v[2] = 0; } else { v[0] = old[0]; v[1] = old[1]; v[2] = old[2]; }
-        real Av[3] = {A[0]*v[0] + A[1]*v[1] + A[2]*v[2], A[3]*v[0] + A[4]*v[1] + A[5]*v[2], A[6]*v[0] + A[7]*v[1] + A[8]*v[2]};
-        real denom = v[0]*Av[0] + v[1]*Av[1] + v[2]*Av[2];
-        if (denom >= FB_MINV) {
-          real x = -fb_div(v[0]*r3v[0] + v[1]*r3v[1] + v[2]*r3v[2], denom);
-          if (fo[0] + x*v[0] < 0) x = -fb_div(fo[0], v[0]);
-          for (int k = 0; k < 3; k++) fo[k] += x*v[k];
-        }
-        if (fo[0] < FB_MINV) { fo[0] = 0; fo[1] = 0; fo[2] = 0; }
+        if (f0 < FB_MINV) { f0 = 0; f1 = 0; f2 = 0; }
         else {
-          real Ac[4] = {A[4], A[5], A[7], A[8]};
-          real bf[2] = {bc[1] + A[3]*fo[0], bc[2] + A[6]*fo[0]};
-          real fq[2];
-          real law = r3_get<S>(rla, i);
-          bool active = qcqp2(fq, Ac, bf, fr, fo[0], &law);
-          r3_set<S>(rla, i, lane, law);
-          if (active) {
-            real s = sqrt((fq[0]/fr[0])*(fq[0]/fr[0]) + (fq[1]/fr[1])*(fq[1]/fr[1]));
-            if (s > FB_MINV) { fq[0] *= fo[0]/s; fq[1] *= fo[0]/s; }
+          // friction plane: min 0.5 x'Qx + x'b subject to |x| <= f0 in friction-scaled coordinates
+          real d0 = r3_get<S>(rfr0, i), d1 = r3_get<S>(rfr1, i);
+          real b1 = (bc1 + A01*f0)*d0, b2 = (bc2 + A02*f0)*d1;
+          real P11 = r3_get<S>(cP11, i), P22 = r3_get<S>(cP22, i), P12 = r3_get<S>(cP12, i);
+          real v1 = 0, v2 = 0, la = 0;
+          bool active = false;
+          if (P11 != 0 || P22 != 0) {                 // (both zero: singular friction block, force stays 0)
+            v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
+            real rr = f0*f0;
+            real val = v1*v1 + v2*v2 - rr;
+            const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*rr + (real)1e-10;
+            if (val >= tolv) {
+              // Newton iteration on the multiplier (FP64: from 0 with the reference's absolute thresholds; FP32:
+              // restarted from the multiplier of the previous sweep, thresholds at single-precision resolution)
+              real Q11 = r3_get<S>(cQ11, i), Q22 = r3_get<S>(cQ22, i), Q12 = r3_get<S>(cQ12, i);
+              bool fresh = true;                      // (v, val, P) are the values at the current multiplier
+              if (sizeof(real) == 4) { real law = r3_get<S>(rla, i); if (law > 0) { la = law; fresh = false; } }
+              for (int k = 1; k < 20; k++) {
+                if (!fresh) {
+                  real det = (Q11 + la)*(Q22 + la) - Q12*Q12;
+                  if (det < (real)1e-10) { v1 = 0; v2 = 0; la = 0; break; }
+                  real di = fb_div((real)1, det);
+                  P11 = (Q22 + la)*di; P22 = (Q11 + la)*di; P12 = -Q12*di;
+                  v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
+                  val = v1*v1 + v2*v2 - rr;
+                  if (val < tolv && (sizeof(real) == 8 || val > -tolv)) break;
+                }
+                real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
+                real delta = -fb_div(val, deriv);
+                const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
+                if (sizeof(real) == 8) { if (delta < told) break; }
+                else if (fabs(delta) < told) break;
+                la += delta;
+                if (la < 0) la = 0;
+                fresh = false;
+              }
+              active = la != 0;
+            }
+            if (sizeof(real) == 4) r3_set<S>(rla, i, lane, la);
           }
-          fo[1] = fq[0]; fo[2] = fq[1];
+          if (active) {
+            // put the friction force exactly on the cone boundary
+            real s2 = v1*v1 + v2*v2;
+            if (s2 > FB_MINV*FB_MINV) { real k = f0*fb_rsqrt(s2); v1 *= k; v2 *= k; }
+          }
+          f1 = v1*d0; f2 = v2*d1;
         }
-        real del[3] = {fo[0] - old[0], fo[1] - old[1], fo[2] - old[2]};
-        real q = 0, l = 0;
-        for (int j = 0; j < 3; j++) { l += del[j]*r3v[j]; for (int k = 0; k < 3; k++) q += del[j]*A[3*j+k]*del[k]; }
-        improvement -= (real)0.5*q + l;
-        for (int j = 0; j < 3; j++)
-          if (del[j] != 0) { res_axpy<S>(res, AR + (i+j)*nefc, nefc, del[j], lane); r3_set<S>(f, i+j, lane, fo[j]); }
+        real e0 = f0 - o0, e1 = f1 - o1, e2 = f2 - o2;
+        real Ae0 = A00*e0 + A01*e1 + A02*e2, Ae1 = A01*e0 + A11*e1 + A12*e2, Ae2 = A02*e0 + A12*e1 + A22*e2;
+        improvement -= (real)0.5*(e0*Ae0 + e1*Ae1 + e2*Ae2) + (e0*r0 + e1*r1 + e2*r2);
+        if (e0 != 0) { res_axpy<S>(res, AR, i, nefc, e0, lane); r3_set<S>(f, i, lane, f0); }
+        if (e1 != 0) { res_axpy<S>(res, AR, i+1, nefc, e1, lane); r3_set<S>(f, i+1, lane, f1); }
+        if (e2 != 0) { res_axpy<S>(res, AR, i+2, nefc, e2, lane); r3_set<S>(f, i+2, lane, f2); }
         i += 3;
       }
     }
@@ -482,8 +551,8 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         Rj[j] = r3_get<S>(rR, i+1+j);
         rs[j] = (real)r3_get<S>(res, i+1+j) - Rj[j]*old[j];
       }
-      real Ac[4] = {AR[(i+1)*nefc + i+1] - Rj[0], AR[(i+1)*nefc + i+2],
-                    AR[(i+2)*nefc + i+1], AR[(i+2)*nefc + i+2] - Rj[1]};
+      real Ac[4] = {AR[ARIDX(i+1, i+1)] - Rj[0], AR[ARIDX(i+2, i+1)],
+                    AR[ARIDX(i+2, i+1)], AR[ARIDX(i+2, i+2)] - Rj[1]};
       real bc[2] = {rs[0] - (Ac[0]*old[0] + Ac[1]*old[1]), rs[1] - (Ac[2]*old[0] + Ac[3]*old[1])};
       real fq[2] = {0, 0};
       if (fnrm >= FB_MINV) {
@@ -496,7 +565,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
       real del[2] = {fq[0] - old[0], fq[1] - old[1]};
       improvement -= (real)0.5*(del[0]*(Ac[0]*del[0] + Ac[1]*del[1]) + del[1]*(Ac[2]*del[0] + Ac[3]*del[1])) + del[0]*rs[0] + del[1]*rs[1];
       for (int j = 0; j < 2; j++)
-        if (del[j] != 0) { res_axpy<S>(res, AR + (i+1+j)*nefc, nefc, del[j], lane); r3_set<S>(f, i+1+j, lane, fq[j]); }
+        if (del[j] != 0) { res_axpy<S>(res, AR, i+1+j, nefc, del[j], lane); r3_set<S>(f, i+1+j, lane, fq[j]); }
     }
     if (improvement*scale < M.noslip_tolerance) break;
   }

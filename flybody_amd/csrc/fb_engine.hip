@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   __shared__ real s_LD[FB_EPB][FB_MAXNM];
   __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
   __shared__ real s_x[FB_EPB][FB_MAXNV];
-  __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ROWS*LdsCfg<real>::AR_ROWS];
+  __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ELEMS];
   // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
   __shared__ uint8_t s_depth[FB_MAXNV];
   __shared__ uint8_t s_cl[FB_MAXNV];

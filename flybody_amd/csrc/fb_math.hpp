@@ -135,15 +135,23 @@ FBD float fb_div(float a, float b) { return a / b; }
 #else
 FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 #endif
+FBD double fb_rsqrt(double a) { return 1.0 / sqrt(a); }
+#ifdef FB_EMULATE
+FBD float fb_rsqrt(float a) { return 1.0f / sqrtf(a); }
+#else
+FBD float fb_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
+#endif
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // hide a register value from loop-invariant code motion: values derived from it are recomputed where they are
 // used instead of being hoisted out of a loop into (spilled) registers
 #ifdef FB_EMULATE
 #define FB_OPAQUE(x) do {} while (0)
+#define FB_SETPRIO(p) do {} while (0)
 #define FB_LDS_AS
 #else
 #define FB_OPAQUE(x) asm volatile("" : "+v"(x))
+#define FB_SETPRIO(p) do { if ((p) == 0) __builtin_amdgcn_s_setprio(0); else if ((p) == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); } while (0)
 #define FB_LDS_AS __attribute__((address_space(3)))
 #endif
 

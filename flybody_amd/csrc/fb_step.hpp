@@ -185,7 +185,7 @@ __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<re
   for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.lLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
   int nefc = w.istate[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.AR[i] = w.lAR[i];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.AR[i] = w.lAR[i];
   SYNC();
 }
 template <typename real>
@@ -193,7 +193,7 @@ __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<rea
   for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
   int nefc = w.istate[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*nefc; i += FB_WAVE) w.lAR[i] = w.AR[i];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lAR[i] = w.AR[i];
   SYNC();
 }
 

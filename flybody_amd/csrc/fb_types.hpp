@@ -124,7 +124,8 @@ struct WSOff {
 #define FB_LDS __attribute__((address_space(3)))
 #endif
 
-template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 24 : 16; };
+// LDS copy of the (packed symmetric) Delassus matrix: AR_ROWS*(AR_ROWS+1)/2 <= AR_ELEMS
+template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 33 : 22; static constexpr int AR_ELEMS = (sizeof(real) == 4) ? 576 : 256; };
 
 template <typename real>
 struct WS {
