@@ -26,6 +26,14 @@
 #else
 #define FB_STAGE_A __device__ __forceinline__
 #endif
+#ifndef FB_INL_FS
+#define FB_INL_FS 1
+#endif
+#if FB_INL_FS
+#define FB_STAGE_FS __device__ FB_NOINLINE
+#else
+#define FB_STAGE_FS __device__ __forceinline__
+#endif
 #if FB_INL_B
 #define FB_STAGE_B __device__ FB_NOINLINE
 #else

@@ -265,7 +265,7 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
 }
 
 template <typename real>
-FB_STAGE_B void d_factor(const DevModel<real>& M_, const WS<real>& w_, const real* qM, const real* diag_add, real hscale,
+FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const real* qM, const real* diag_add, real hscale,
                          FB_LDS real* RM, FB_LDS real* Dinv, int lane) {
   const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
   qM = uniform_ptr(qM); diag_add = uniform_ptr(diag_add); RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv);
@@ -405,7 +405,7 @@ FB_STAGE_B void d_factor(const DevModel<real>& M_, const WS<real>& w_, const rea
 
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-FB_STAGE_B void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
   const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
   RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv); x = uniform_ptr(x);
   PROF_BEGIN();
