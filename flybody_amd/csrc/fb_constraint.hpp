@@ -359,6 +359,21 @@ template <bool S, typename real, typename ARP> FBD void res_axpy(R3<double>& res
   }
 }
 
+// res += e0*AR[i,:] + e1*AR[i+1,:] + e2*AR[i+2,:]  (one round of LDS reads)
+template <bool S, typename real, typename ARP> FBD void res_axpy3(R3<double>& res, ARP AR, int i, int n, real e0, real e1, real e2, int lane) {
+  const int T0 = i*(i + 1)/2, T1 = T0 + i + 1, T2 = T1 + i + 2;
+#pragma unroll
+  for (int q = 0; q < (S ? 1 : 3); q++) {
+    int k = lane + 64*q;
+    if (k < n) {
+      int tk = k*(k + 1)/2;
+      real a0 = AR[k <= i ? T0 + k : tk + i], a1 = AR[k <= i + 1 ? T1 + k : tk + i + 1], a2 = AR[k <= i + 2 ? T2 + k : tk + i + 2];
+      double d = (double)e0*(double)a0 + (double)e1*(double)a1 + (double)e2*(double)a2;
+      if (q == 0) res.v0 += d; else if (q == 1) res.v1 += d; else res.v2 += d;
+    }
+  }
+}
+
 #ifdef FB_PGS_NOINLINE
 #define FB_PGS_ATTR __device__ FB_NOINLINE
 #else
@@ -410,7 +425,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // ---- per-contact constants of the 3-row block update, held by the lane of the block's first row
   // (A block, scaled friction-plane matrix and its inverse at multiplier 0, reciprocals): every sweep fetches them
   // with v_readlane instead of re-reading and re-deriving them
-  R3<real> cA00, cA01, cA02, cA11, cA12, cA22, cQ11, cQ22, cQ12, cP11, cP22, cP12, cI00;
+  R3<real> cA00, cA01, cA02, cA11, cA12, cA22, cEc, cEs, cE1, cE2, cR1, cR2, cI00;
   {
     real t[13][3];
     for (int q = 0; q < (S ? 1 : 3); q++) {
@@ -421,19 +436,36 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         real a00 = AR[ARIDX(r, r)], a01 = AR[ARIDX(r + 1, r)], a02 = AR[ARIDX(r + 2, r)];
         real a11 = AR[ARIDX(r + 1, r + 1)], a12 = AR[ARIDX(r + 2, r + 1)], a22 = AR[ARIDX(r + 2, r + 2)];
         real d0 = q == 0 ? rfr0.v0 : (q == 1 ? rfr0.v1 : rfr0.v2), d1 = q == 0 ? rfr1.v0 : (q == 1 ? rfr1.v1 : rfr1.v2);
-        real q11 = a11*d0*d0, q22 = a22*d1*d1, q12 = a12*d0*d1;
-        real det = q11*q22 - q12*q12;
-        real di = (det < (real)1e-10) ? (real)0 : fb_div((real)1, det);       // 0 marks the singular case
+        // friction-plane matrix in friction-scaled coordinates and its eigen-decomposition Q = R diag(e1, e2) R':
+        // in the eigenbasis the multiplier iteration needs two reciprocals and a handful of FMAs
+        // (set up in FP64 in both builds: the determinant / small eigenvalue cancel badly in FP32, and this runs
+        // once per contact and substep, not per sweep)
+        double q11 = (double)a11*d0*d0, q22 = (double)a22*d1*d1, q12 = (double)a12*d0*d1;
+        double det = q11*q22 - q12*q12;
+        double m = 0.5*(q11 + q22), h = 0.5*(q11 - q22), rad = sqrt(h*h + q12*q12);
+        double ev1 = m + rad, ev2 = (ev1 > 0) ? det/ev1 : 0.0;
+        double vx = (h >= 0) ? h + rad : q12, vy = (h >= 0) ? q12 : rad - h;
+        double vn = sqrt(vx*vx + vy*vy);
+        double ec = 1, es = 0;
+        if (vn > 0) { ec = vx/vn; es = vy/vn; }
+        bool sing = det < 1e-10;
         t[0][q] = a00; t[1][q] = a01; t[2][q] = a02; t[3][q] = a11; t[4][q] = a12; t[5][q] = a22;
-        t[6][q] = q11; t[7][q] = q22; t[8][q] = q12; t[9][q] = q22*di; t[10][q] = q11*di; t[11][q] = -q12*di;
+        t[6][q] = (real)ec; t[7][q] = (real)es; t[8][q] = (real)ev1; t[9][q] = (real)ev2;
+        t[10][q] = sing ? (real)0 : (real)(1.0/ev1); t[11][q] = sing ? (real)0 : (real)(1.0/ev2);      // 0: singular block
         t[12][q] = (a00 >= FB_MINV) ? fb_div((real)1, a00) : (real)0;
       }
     }
 #define FB_C3(name, u) name.v0 = t[u][0]; name.v1 = S ? (real)0 : t[u][1]; name.v2 = S ? (real)0 : t[u][2];
     FB_C3(cA00, 0) FB_C3(cA01, 1) FB_C3(cA02, 2) FB_C3(cA11, 3) FB_C3(cA12, 4) FB_C3(cA22, 5)
-    FB_C3(cQ11, 6) FB_C3(cQ22, 7) FB_C3(cQ12, 8) FB_C3(cP11, 9) FB_C3(cP22, 10) FB_C3(cP12, 11) FB_C3(cI00, 12)
+    FB_C3(cEc, 6) FB_C3(cEs, 7) FB_C3(cE1, 8) FB_C3(cE2, 9) FB_C3(cR1, 10) FB_C3(cR2, 11) FB_C3(cI00, 12)
 #undef FB_C3
   }
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long bt_[5] = {0, 0, 0, 0, 0}, bt0_ = 0;
+#define FB_BT(k) do { long long n_ = clock64(); if (k == 0) { bt_[4] += 1; } else bt_[k - 1] += n_ - bt0_; bt0_ = clock64(); } while (0)
+#else
+#define FB_BT(k) do {} while (0)
+#endif
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
   real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
   int niter = 0;
@@ -455,6 +487,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         real r0 = (real)r3_get<S>(res, i), o0 = r3_get<S>(f, i), o1 = r3_get<S>(f, i+1), o2 = r3_get<S>(f, i+2);
         // a contact that carries no force and is separating stays at zero (the ray update below would return 0)
         if (o0 == 0 && o1 == 0 && o2 == 0 && r0 >= 0) { i += 3; continue; }
+        FB_BT(0);
         real r1 = (real)r3_get<S>(res, i+1), r2 = (real)r3_get<S>(res, i+2);
         real A00 = r3_get<S>(cA00, i), A01 = r3_get<S>(cA01, i), A02 = r3_get<S>(cA02, i);
         real A11 = r3_get<S>(cA11, i), A12 = r3_get<S>(cA12, i), A22 = r3_get<S>(cA22, i);
@@ -475,34 +508,35 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         }
         if (f0 < FB_MINV) { f0 = 0; f1 = 0; f2 = 0; }
         else {
+          FB_BT(1);
           // friction plane: min 0.5 x'Qx + x'b subject to |x| <= f0 in friction-scaled coordinates
           real d0 = r3_get<S>(rfr0, i), d1 = r3_get<S>(rfr1, i);
           real b1 = (bc1 + A01*f0)*d0, b2 = (bc2 + A02*f0)*d1;
-          real P11 = r3_get<S>(cP11, i), P22 = r3_get<S>(cP22, i), P12 = r3_get<S>(cP12, i);
+          real ec = r3_get<S>(cEc, i), es = r3_get<S>(cEs, i), R1 = r3_get<S>(cR1, i), R2 = r3_get<S>(cR2, i);
           real v1 = 0, v2 = 0, la = 0;
           bool active = false;
-          if (P11 != 0 || P22 != 0) {                 // (both zero: singular friction block, force stays 0)
-            v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
+          if (R1 != 0 || R2 != 0) {                   // (both zero: singular friction block, force stays 0)
+            real t1 = ec*b1 + es*b2, t2 = ec*b2 - es*b1;             // b in the eigenbasis
+            real u1 = -t1*R1, u2 = -t2*R2;                           // unconstrained minimiser (multiplier 0)
             real rr = f0*f0;
-            real val = v1*v1 + v2*v2 - rr;
+            real val = u1*u1 + u2*u2 - rr;
             const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*rr + (real)1e-10;
             if (val >= tolv) {
               // Newton iteration on the multiplier (FP64: from 0 with the reference's absolute thresholds; FP32:
               // restarted from the multiplier of the previous sweep, thresholds at single-precision resolution)
-              real Q11 = r3_get<S>(cQ11, i), Q22 = r3_get<S>(cQ22, i), Q12 = r3_get<S>(cQ12, i);
-              bool fresh = true;                      // (v, val, P) are the values at the current multiplier
+              real E1 = r3_get<S>(cE1, i), E2 = r3_get<S>(cE2, i);
+              bool fresh = true;                      // (u, val, R) are the values at the current multiplier
               if (sizeof(real) == 4) { real law = r3_get<S>(rla, i); if (law > 0) { la = law; fresh = false; } }
               for (int k = 1; k < 20; k++) {
                 if (!fresh) {
-                  real det = (Q11 + la)*(Q22 + la) - Q12*Q12;
-                  if (det < (real)1e-10) { v1 = 0; v2 = 0; la = 0; break; }
-                  real di = fb_div((real)1, det);
-                  P11 = (Q22 + la)*di; P22 = (Q11 + la)*di; P12 = -Q12*di;
-                  v1 = -P11*b1 - P12*b2; v2 = -P12*b1 - P22*b2;
-                  val = v1*v1 + v2*v2 - rr;
+                  real a1 = E1 + la, a2 = E2 + la;
+                  if (a1*a2 < (real)1e-10) { u1 = 0; u2 = 0; la = 0; break; }
+                  R1 = fb_div((real)1, a1); R2 = fb_div((real)1, a2);
+                  u1 = -t1*R1; u2 = -t2*R2;
+                  val = u1*u1 + u2*u2 - rr;
                   if (val < tolv && (sizeof(real) == 8 || val > -tolv)) break;
                 }
-                real deriv = -(real)2*(P11*v1*v1 + (real)2*P12*v1*v2 + P22*v2*v2);
+                real deriv = -(real)2*(u1*u1*R1 + u2*u2*R2);
                 real delta = -fb_div(val, deriv);
                 const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
                 if (sizeof(real) == 8) { if (delta < told) break; }
@@ -514,26 +548,32 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
               active = la != 0;
             }
             if (sizeof(real) == 4) r3_set<S>(rla, i, lane, la);
-          }
-          if (active) {
-            // put the friction force exactly on the cone boundary
-            real s2 = v1*v1 + v2*v2;
-            if (s2 > FB_MINV*FB_MINV) { real k = f0*fb_rsqrt(s2); v1 *= k; v2 *= k; }
+            if (active) {
+              // put the friction force exactly on the cone boundary
+              real s2 = u1*u1 + u2*u2;
+              if (s2 > FB_MINV*FB_MINV) { real k = f0*fb_rsqrt(s2); u1 *= k; u2 *= k; }
+            }
+            v1 = ec*u1 - es*u2; v2 = es*u1 + ec*u2;
           }
           f1 = v1*d0; f2 = v2*d1;
         }
+        FB_BT(2);
         real e0 = f0 - o0, e1 = f1 - o1, e2 = f2 - o2;
         real Ae0 = A00*e0 + A01*e1 + A02*e2, Ae1 = A01*e0 + A11*e1 + A12*e2, Ae2 = A02*e0 + A12*e1 + A22*e2;
         improvement -= (real)0.5*(e0*Ae0 + e1*Ae1 + e2*Ae2) + (e0*r0 + e1*r1 + e2*r2);
-        if (e0 != 0) { res_axpy<S>(res, AR, i, nefc, e0, lane); r3_set<S>(f, i, lane, f0); }
-        if (e1 != 0) { res_axpy<S>(res, AR, i+1, nefc, e1, lane); r3_set<S>(f, i+1, lane, f1); }
-        if (e2 != 0) { res_axpy<S>(res, AR, i+2, nefc, e2, lane); r3_set<S>(f, i+2, lane, f2); }
+        // the three rows are read together (a zero delta leaves the residual unchanged, so no test is needed)
+        res_axpy3<S>(res, AR, i, nefc, e0, e1, e2, lane);
+        r3_set<S>(f, i, lane, f0); r3_set<S>(f, i+1, lane, f1); r3_set<S>(f, i+2, lane, f2);
+        FB_BT(3);
         i += 3;
       }
     }
     niter = it + 1;
     if (improvement*scale < M.tolerance) break;
   }
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[31] += bt_[4]; pp_[16] += bt_[0]; pp_[22] += bt_[1]; pp_[23] += bt_[2]; }
+#endif
   PROF(P_PGS);
   // ---- noslip: friction dims only, regularisation removed; lane == contact keeps its row address
   int ncon = w.istate[IS_NCON];

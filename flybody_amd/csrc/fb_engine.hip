@@ -36,7 +36,7 @@ struct fb_model {
   std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
   int nlevel;
-  std::vector<double> body_box;
+  std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom;
   double totalmass;
   const double* d(const char* n, size_t* cnt = nullptr) const {
@@ -87,6 +87,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int b = nb - 1; b > 0; b--) m->body_nsub[parent[b]] += m->body_nsub[b];
   for (int b = 1; b < nb; b++) {
     if (m->body_depth[b] > FB_MAXDEPTH) { delete m; return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
+    if (nb > 2*FB_WAVE || 10*nb + 6*m->nv > FB_LDS_SCRATCH || 7*nb + 4*m->njnt > FB_LDS_SCRATCH) { delete m; return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
     // DFS contiguity: every body in (b, b+nsub) must descend from b
     for (int d = b + 1; d < b + m->body_nsub[b]; d++) {
       int a = d; while (a > b) a = parent[a];
@@ -211,6 +212,25 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   const int* trn = m->i("actuator_trntype");
   for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
   const double* mass = m->d("body_mass"); const double* inert = m->d("body_inertia");
+  // per-body kinematics record: every constant the frame composition of one body needs, contiguous, so that a
+  // tree level costs one round of independent loads instead of a chain of table lookups (fb_smooth.hpp: fk_pass)
+  {
+    const double *bp = m->d("body_pos"), *bq = m->d("body_quat"), *bip = m->d("body_ipos"), *biq = m->d("body_iquat");
+    const double *jp = m->d("jnt_pos"), *jx = m->d("jnt_axis");
+    const int *bja = m->i("body_jntadr"), *bjn = m->i("body_jntnum"), *jt = m->i("jnt_type"), *jqa = m->i("jnt_qposadr");
+    m->body_rec.assign((size_t)nb*FB_BODYREC, 0);
+    for (int b = 0; b < nb; b++) {
+      double* R = m->body_rec.data() + (size_t)b*FB_BODYREC;
+      int jn = bjn[b], ja = bja[b];
+      if (jn > 3) { delete m; return fail("fb_model_load: more than 3 joints on one body"); }
+      bool fr = jn > 0 && jt[ja] == JNT_FREE;
+      R[0] = parent[b]; R[1] = ja; R[2] = jn; R[3] = fr ? 1 : 0;
+      for (int k = 0; k < 3; k++) { R[4 + k] = bp[3*b + k]; R[11 + k] = bip[3*b + k]; }
+      for (int k = 0; k < 4; k++) { R[7 + k] = bq[4*b + k]; R[14 + k] = biq[4*b + k]; }
+      for (int q = 0; q < jn; q++) for (int k = 0; k < 3; k++) { R[18 + 6*q + k] = jp[3*(ja + q) + k]; R[21 + 6*q + k] = jx[3*(ja + q) + k]; }
+      R[36] = fr ? jqa[ja] : 0;
+    }
+  }
   m->body_box.assign((size_t)nb*3, 0); m->totalmass = 0;
   for (int b = 1; b < nb; b++) {
     m->totalmass += mass[b];
@@ -253,7 +273,7 @@ struct Batch {
 template <typename real>
 __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
-  __shared__ real s_LD[FB_EPB][FB_MAXNM];
+  __shared__ real s_LD[FB_EPB][FB_LDS_SCRATCH];
   __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
   __shared__ real s_x[FB_EPB][FB_MAXNV];
   __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ELEMS];
@@ -349,6 +369,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
+  { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   UI(wing_act_idx, "wing_action_idx")
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];
@@ -363,6 +384,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UD(body_pos, "body_pos") UD(body_quat, "body_quat") UD(body_ipos, "body_ipos") UD(body_iquat, "body_iquat") UD(body_mass, "body_mass")
   UD(body_inertia, "body_inertia") UD(body_invweight0, "body_invweight0")
   if (upload<real>(b, m->body_box.data(), m->body_box.size(), &M.body_box)) return -1;
+  if (upload<real>(b, m->body_rec.data(), m->body_rec.size(), &M.body_rec)) return -1;
   UD(jnt_pos, "jnt_pos") UD(jnt_axis, "jnt_axis") UD(jnt_stiffness, "jnt_stiffness") UD(jnt_range, "jnt_range") UD(jnt_solref, "jnt_solref")
   UD(jnt_solimp, "jnt_solimp") UD(jnt_margin, "jnt_margin") UD(qpos0, "qpos0") UD(qpos_spring, "qpos_spring")
   UD(dof_armature, "dof_armature") UD(dof_damping, "dof_damping") UD(dof_invweight0, "dof_invweight0")

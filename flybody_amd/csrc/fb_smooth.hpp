@@ -35,60 +35,97 @@
 #endif
 enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_ACT, P_ACC, P_CSETUP, P_PGS, P_NOSLIP, P_CFIN, P_SENS, P_EULER, P_EPI };
 
-// ------------------------------------------------------------------ kinematics (chain walk)
+// ------------------------------------------------------------------ kinematics (level-synchronous)
+// Body frames by depth level: a body composes its parent's frame (staged in LDS scratch, 7 values per body) with
+// its own joints.  One environment is one wavefront, so a level boundary costs a fence, not a barrier.  The joint
+// rotations (the sin/cos of every joint angle) are computed lane-parallel over joints beforehand and staged in
+// LDS, which takes the trigonometry off the serial level chain.  The scratch is the LDS row of the mass-matrix
+// factor, which is dead between the Euler solve and the next factorisation.
 template <typename real>
-__device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
-    int depth = M.body_depth[b];
-    for (int d = 0; d < depth; d++) {
-      int bb = M.body_path[b*FB_MAXDEPTH + d];
-      int ja = M.body_jntadr[bb], jn = M.body_jntnum[bb];
-      if (jn > 0 && M.jnt_type[ja] == JNT_FREE) {
-        const real* q = w.qpos + M.jnt_qposadr[ja];
+FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, int b, int dlo, int dhi, int lane) {
+  bool has = b < M.nbody && b > 0;
+  int dep = has ? M.body_depth[has ? b : 0] : -1;
+  for (int d = dlo; d <= dhi; d++) {
+    if (dep == d) {
+      // one round of independent loads: the body's flattened record (fb_engine.hip) and the free-joint pose
+      real R[37];
+      const real* rec = M.body_rec + b*FB_BODYREC;
+#pragma unroll
+      for (int k = 0; k < 37; k++) R[k] = rec[k];
+      int par = (int)R[0], ja = (int)R[1], jn = (int)R[2];
+      bool free_jnt = R[3] != 0;
+      real pos[3], quat[4];
+      for (int k = 0; k < 3; k++) pos[k] = S[7*par + k];
+      for (int k = 0; k < 4; k++) quat[k] = S[7*par + 3 + k];
+      if (free_jnt) {
+        const real* q = w.qpos + (int)R[36];
         pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
         quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
         normquat(quat);
-        if (bb == b) {
-          copy3(w.xanchor + 3*ja, pos);
-          real ax[3] = {0, 0, 1};
-          rotvecquat(w.xaxis + 3*ja, ax, quat);
-        }
-        ja++; jn--;
+        copy3(w.xanchor + 3*ja, pos);
+        real ax[3] = {0, 0, 1};
+        rotvecquat(w.xaxis + 3*ja, ax, quat);
       } else {
         real t[3], qn[4];
-        rotvecquat(t, M.body_pos + 3*bb, quat);
+        rotvecquat(t, R + 4, quat);
         add3(pos, pos, t);
-        mulquat(qn, quat, M.body_quat + 4*bb);
+        mulquat(qn, quat, R + 7);
         quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
       }
-      for (int j = ja; j < ja + jn; j++) {
-        real anc[3], t[3], qloc[4], qn[4];
-        rotvecquat(t, M.jnt_pos + 3*j, quat);
-        add3(anc, t, pos);
-        if (bb == b) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (k < jn && !(free_jnt && k == 0)) {
+          int j = ja + k;
+          real qloc[4] = {JQ[4*j], JQ[4*j + 1], JQ[4*j + 2], JQ[4*j + 3]};
+          real anc[3], t[3], qn[4];
+          rotvecquat(t, R + 18 + 6*k, quat);
+          add3(anc, t, pos);
           copy3(w.xanchor + 3*j, anc);
-          rotvecquat(w.xaxis + 3*j, M.jnt_axis + 3*j, quat);
+          rotvecquat(w.xaxis + 3*j, R + 21 + 6*k, quat);
+          mulquat(qn, quat, qloc);
+          quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+          rotvecquat(t, R + 18 + 6*k, quat);
+          sub3(pos, anc, t);
         }
-        int qa = M.jnt_qposadr[j];
-        axisangle2quat(qloc, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]);
-        mulquat(qn, quat, qloc);
-        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-        rotvecquat(t, M.jnt_pos + 3*j, quat);
-        sub3(pos, anc, t);
       }
       normquat(quat);
+      for (int k = 0; k < 3; k++) S[7*b + k] = pos[k];
+      for (int k = 0; k < 4; k++) S[7*b + 3 + k] = quat[k];
+      real mat[9], t[3], qi[4];
+      quat2mat(mat, quat);
+      copy3(w.xpos + 3*b, pos);
+      for (int k = 0; k < 4; k++) w.xquat[4*b + k] = quat[k];
+      for (int k = 0; k < 9; k++) w.xmat[9*b + k] = mat[k];
+      mulmat3(t, mat, R + 11);
+      add3(w.xipos + 3*b, pos, t);
+      mulquat(qi, quat, R + 14);
+      quat2mat(w.ximat + 9*b, qi);
     }
-    real mat[9], t[3], qi[4];
-    quat2mat(mat, quat);
-    copy3(w.xpos + 3*b, pos);
-    for (int k = 0; k < 4; k++) w.xquat[4*b + k] = quat[k];
-    for (int k = 0; k < 9; k++) w.xmat[9*b + k] = mat[k];
-    mulmat3(t, mat, M.body_ipos + 3*b);
-    add3(w.xipos + 3*b, pos, t);
-    mulquat(qi, quat, M.body_iquat + 4*b);
-    quat2mat(w.ximat + 9*b, qi);
+    SYNC();
   }
+}
+
+template <typename real>
+__device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
+  PROF_BEGIN();
+  FB_LDS real* S = w.lLD;                       // body frames: 7*nbody
+  FB_LDS real* JQ = w.lLD + 7*M.nbody;          // joint rotations: 4*njnt
+  for (int j = lane; j < M.njnt; j += FB_WAVE) {
+    real q[4] = {1, 0, 0, 0};
+    if (M.jnt_type[j] != JNT_FREE) { int qa = M.jnt_qposadr[j]; axisangle2quat(q, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]); }
+    for (int k = 0; k < 4; k++) JQ[4*j + k] = q[k];
+  }
+  if (lane == 0) {
+    // world body: identity frame
+    for (int k = 0; k < 7; k++) S[k] = (k == 3) ? (real)1 : (real)0;
+    for (int k = 0; k < 3; k++) { w.xpos[k] = 0; w.xipos[k] = 0; }
+    for (int k = 0; k < 4; k++) w.xquat[k] = (k == 0) ? (real)1 : (real)0;
+    for (int k = 0; k < 9; k++) { real v = (k % 4 == 0) ? (real)1 : (real)0; w.xmat[k] = v; w.ximat[k] = v; }
+  }
+  SYNC();
+  fk_pass(M, w, S, JQ, lane, 1, M.fk_dmax, lane);
+  if (M.nbody > FB_WAVE) fk_pass(M, w, S, JQ, lane + FB_WAVE, M.fk2_dlo, M.fk_dmax, lane);
+  PROF(25);
   SYNC();
   // geoms and sites hang off their body frames
   for (int g = lane; g < M.ngeom; g += FB_WAVE) {
@@ -107,6 +144,7 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
     mulquat(q, w.xquat + 4*b, M.site_quat + 4*s);
     quat2mat(w.sxmat + 9*s, q);
   }
+  PROF(26);
   // centre of mass of the (single) kinematic tree
   real c[3] = {0, 0, 0};
   for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos + 3*b, M.body_mass[b]);

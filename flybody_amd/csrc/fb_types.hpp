@@ -14,6 +14,8 @@
 #define FB_EPB 4            // environments (wavefronts) per workgroup; they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
 #define FB_MAXGEN 16       // dofs whose subtree branches (free joint, head, ...)
+#define FB_LDS_SCRATCH 1344  // reals in the per-environment LDS row of the factor (also staging space for the tree passes)
+#define FB_BODYREC 40       // reals per body kinematics record
 #define FB_MAXTRUNK 6       // dofs of the unbranched chain at the tree root (free joint) handled wave-parallel
 #define FB_FSLOT 18        // factor work list: off-diagonal entries of M owned by one lane
 #define FB_FGEN 2          // ... of which the first FB_FGEN may belong to branching dofs
@@ -58,6 +60,7 @@ struct DevModel {
   const int *fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
   const int *fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
+  int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
@@ -67,6 +70,7 @@ struct DevModel {
   const int *obs_jnt, *app_sites, *force_sites, *touch_sites, *wing_jnt;
   // constants
   const real *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_box;
+  const real *body_rec;      // [nbody][FB_BODYREC] flattened kinematics record of a body (fb_engine.hip)
   const real *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_solref, *jnt_solimp, *jnt_margin;
   const real *qpos0, *qpos_spring, *dof_armature, *dof_damping, *dof_invweight0;
   const real *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_fluid;

@@ -23,7 +23,7 @@ for _ in range(K):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize(); dt = time.time() - t0
 p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
-names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'fA_small', 'fA_wide', 'fB_write', 'sol_fwd', 'sol_bwd', 'f_chain', 'f_gen_diag', 'small_loops', 'constr_b', 'subend', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'x31']
+names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'fA_small', 'fA_wide', 'fB_write', 'sol_fwd', 'sol_bwd', 'f_chain', 'f_gen_diag', 'small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated']
 tot = p.sum(1).mean()
 print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step; mean cycles per env-step {tot/K:.0f}; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
 for i, nm in enumerate(names):
