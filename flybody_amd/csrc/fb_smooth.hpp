@@ -310,7 +310,6 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const re
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gm = uniform_ptr(w.lgm);          // locals: a fence must not force reloading them from the WS struct
-  const int* madr_g = uniform_ptr(M.dof_Madr);
   // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
   int fw[FB_FSLOT];
   real acc[FB_FSLOT];
@@ -318,7 +317,8 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const re
   for (int s = 0; s < FB_FSLOT; s++) {
     fw[s] = M.fac_w[s*FB_WAVE + lane];
     int dep = FW_DEP(fw[s]);
-    acc[s] = (dep != 31) ? qM[FW_BASE(fw[s]) + dep*(dep + 1)/2 + FW_E(fw[s])] : (real)0;
+    real v = qM[dep != 31 ? FW_BASE(fw[s]) + dep*(dep + 1)/2 + FW_E(fw[s]) : 0];     // unconditional: all gathers in flight together
+    acc[s] = (dep != 31) ? v : (real)0;
   }
   // diagonal entries of the two dofs this lane owns, same packed format (e field = general-dof index, 31 = none)
   int fd[2]; real accd[2];
@@ -344,7 +344,11 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const re
 #pragma unroll
     for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; Dinv[lane + q*FB_WAVE] = di; }
 #pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) if (FW_DEP(fw[s]) == d) RM[FW_BASE(fw[s]) + Td + FW_E(fw[s])] = acc[s];
+    for (int s = 0; s < FB_FSLOT; s++) {
+      // branch-free: a slot that is not on level d stores to a dummy word behind the factor
+      int adr = (FW_DEP(fw[s]) == d) ? FW_BASE(fw[s]) + Td + FW_E(fw[s]) : FB_LDS_SCRATCH - 1;
+      RM[adr] = acc[s];
+    }
     SYNC();
     PROF(16);
     // pull the contribution of level d into every shallower entry.  The chain loads are unconditional (an LDS read
@@ -411,9 +415,10 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const re
 #pragma unroll
     for (int b2 = 0; b2 <= a; b2++) {
       int e = a*(a + 1)/2 + b2;
-      real m0 = 0;
-      if (a < nT) { m0 = qM[madr_g[a] + (a - b2)]; if (a == b2 && diag_add) m0 += hscale*diag_add[a]; }
-      S[e] = m0 - wave_sum(S[e]);
+      // trunk dof a sits at depth a: its row of M starts at a(a+1)/2 (unconditional load, masked afterwards)
+      real m0 = qM[a < nT ? a*(a + 1)/2 + (a - b2) : 0];
+      if (a == b2 && diag_add) m0 += hscale*diag_add[a < nT ? a : 0];
+      S[e] = (a < nT) ? m0 - wave_sum(S[e]) : (real)0;
     }
   SYNC();
   // normalise the published rows: L[i,j] = M~[i,j] / D[i]
