@@ -143,6 +143,11 @@ void fbo_jac(const fbo_data* d, double* jacp, double* jacr, const double* point,
 void fbo_env_configure(fbo_data* d, const double* ref_qpos, const double* ref_qvel, int T,
                        int future_steps, double terminal_com_dist, double time_limit);
 void fbo_env_reset(fbo_data* d);
+/* test entry points pinned against reference-generated vectors (tests/test_reference_goldens.py) */
+void fbo_wbpg_reset(fbo_data* d, double initial_phase, double* qpos6, double* qvel6);
+void fbo_wbpg_step(fbo_data* d, double ctrl_freq, double* out6);
+void fbo_ellipsoid_local(const double* lvel, const double* size, const double* gf, double density, double viscosity, double* lfrc, double* comps);
+double fbo_ellipsoid_max_moment(const double* size, int dir);
 void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, const int* offset, const double* freqs, int nfreq,
                       double base_freq, double rel_range, double rate, unsigned seed);
 double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode);

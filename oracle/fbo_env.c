@@ -141,6 +141,11 @@ static void wbpg_step(fbo_data* d, double ctrl_freq, double* out6) {
   for (int k = 0; k < 6; k++) out6[k] = d->wb_traj[6*(o + d->wb_step) + k];
 }
 
+/* exported wrappers so that tests can drive the pattern generator against vectors produced by the reference's
+ * own WingBeatPatternGenerator (tests/test_reference_goldens.py) */
+void fbo_wbpg_reset(fbo_data* d, double initial_phase, double* qpos6, double* qvel6) { wbpg_reset(d, initial_phase, qpos6, qvel6); }
+void fbo_wbpg_step(fbo_data* d, double ctrl_freq, double* out6) { wbpg_step(d, ctrl_freq, out6); }
+
 static double tolerance_linear(double x, double margin) {
   /* dm_control rewards.tolerance(bounds=(0,0), sigmoid='linear', value_at_margin=0) */
   double dd = fabs(x)/margin;

@@ -355,55 +355,72 @@ static double ellipsoid_max_moment(const double* size, int dir) {
   return 8.0/15.0 * FBO_PI * d0 * mx*mx*mx*mx;
 }
 
-/* follows flybody/ellipsoid_fluid_model.py:88-310 */
+/* Local-frame wrench of the ellipsoid fluid model for one geom, follows flybody/ellipsoid_fluid_model.py:88-209
+ * (mj_addedMassForces + mj_viscousForces).  lvel = [angular, linear] in the geom frame; gf = [scale, blunt, slender,
+ * angular, kutta, magnus, virtual_mass[3], virtual_inertia[3]].  lfrc = [torque, force] (already scaled by gf[0]);
+ * comps (optional, unscaled) = fA, gA, fM, fK, fD, fV, gD, gV as returned by the reference functions. */
+void fbo_ellipsoid_local(const double* lvel, const double* size, const double* gf, double density, double viscosity,
+                         double* lfrc, double* comps) {
+  double blunt = gf[1], slender = gf[2], angc = gf[3], kutta = gf[4], magnus = gf[5];
+  const double* vmass = gf + 6; const double* vinert = gf + 9;
+  for (int k = 0; k < 6; k++) lfrc[k] = 0;
+  const double* w = lvel; const double* v = lvel + 3;
+  /* added mass */
+  double plin[3], pang[3], t[3], t2[3], fA[3];
+  for (int k = 0; k < 3; k++) { plin[k] = density*vmass[k]*v[k]; pang[k] = density*vinert[k]*w[k]; }
+  cross3(fA, plin, w); add3(lfrc + 3, lfrc + 3, fA);
+  cross3(t, plin, v); add3(lfrc, lfrc, t);
+  cross3(t2, pang, w); add3(lfrc, lfrc, t2);
+  /* viscous / lift */
+  double volume = 4.0/3.0*FBO_PI*size[0]*size[1]*size[2];
+  double dmax = fmax(size[0], fmax(size[1], size[2])), dmin = fmin(size[0], fmin(size[1], size[2]));
+  double dmid = size[0] + size[1] + size[2] - dmax - dmin;
+  double Amax = FBO_PI*dmax*dmid;
+  double mag[3]; cross3(mag, w, v); scl3(mag, mag, magnus*density*volume);
+  double s12 = size[1]*size[2], s20 = size[2]*size[0], s01 = size[0]*size[1];
+  double pden = pow(s12, 4)*v[0]*v[0] + pow(s20, 4)*v[1]*v[1] + pow(s01, 4)*v[2]*v[2];
+  double pnum = (s12*v[0])*(s12*v[0]) + (s20*v[1])*(s20*v[1]) + (s01*v[2])*(s01*v[2]);
+  double Aproj = FBO_PI*sqrt(pden / fmax(FBO_MINVAL, pnum));
+  double nrm[3] = {s12*s12*v[0], s20*s20*v[1], s01*s01*v[2]};
+  double speed = norm3(v);
+  double cosa = pnum / fmax(FBO_MINVAL, speed*pden);
+  double circ[3]; cross3(circ, nrm, v); scl3(circ, circ, kutta*density*cosa*Aproj);
+  double kf[3]; cross3(kf, circ, v);
+  double eqD = 2.0/3.0*(size[0] + size[1] + size[2]);
+  double linc = 3.0*FBO_PI*eqD, angcoef = FBO_PI*eqD*eqD*eqD;
+  double Imax = 8.0/15.0*FBO_PI*dmid*dmax*dmax*dmax*dmax;
+  double mv[3];
+  for (int k = 0; k < 3; k++) {
+    double II = ellipsoid_max_moment(size, k);
+    mv[k] = w[k]*(angc*II + slender*(Imax - II));
+  }
+  double quad = density*speed*(Aproj*blunt + slender*(Amax - Aproj));
+  double dragl = viscosity*linc + quad;
+  double draga = viscosity*angcoef + density*norm3(mv);
+  for (int k = 0; k < 3; k++) {
+    lfrc[k] -= draga*w[k];
+    lfrc[3+k] += mag[k] + kf[k] - dragl*v[k];
+  }
+  if (comps) {
+    for (int k = 0; k < 3; k++) {
+      comps[k] = fA[k]; comps[3+k] = t[k] + t2[k]; comps[6+k] = mag[k]; comps[9+k] = kf[k];
+      comps[12+k] = -quad*v[k]; comps[15+k] = -viscosity*linc*v[k];
+      comps[18+k] = -density*norm3(mv)*w[k]; comps[21+k] = -viscosity*angcoef*w[k];
+    }
+  }
+  for (int k = 0; k < 6; k++) lfrc[k] *= gf[0];
+}
+double fbo_ellipsoid_max_moment(const double* size, int dir) { return ellipsoid_max_moment(size, dir); }
+
 static void ellipsoid_fluid(fbo_data* d, int b) {
   const fbo_model* m = d->m;
   for (int g = 0; g < m->ngeom; g++) {
     if (m->geom_bodyid[g] != b) continue;
     const double* gf = m->geom_fluid + 12*g;
     if (gf[0] == 0.0) continue;
-    const double* size = m->geom_size + 3*g;
-    double blunt = gf[1], slender = gf[2], angc = gf[3], kutta = gf[4], magnus = gf[5];
-    const double* vmass = gf + 6; const double* vinert = gf + 9;
-    double lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+    double lvel[6], lfrc[6];
     object_velocity(d, b, d->geom_xpos + 3*g, d->geom_xmat + 9*g, lvel);
-    const double* w = lvel; const double* v = lvel + 3;
-    /* added mass */
-    double plin[3], pang[3], t[3];
-    for (int k = 0; k < 3; k++) { plin[k] = m->density*vmass[k]*v[k]; pang[k] = m->density*vinert[k]*w[k]; }
-    cross3(t, plin, w); add3(lfrc + 3, lfrc + 3, t);
-    cross3(t, plin, v); add3(lfrc, lfrc, t);
-    cross3(t, pang, w); add3(lfrc, lfrc, t);
-    /* viscous / lift */
-    double volume = 4.0/3.0*FBO_PI*size[0]*size[1]*size[2];
-    double dmax = fmax(size[0], fmax(size[1], size[2])), dmin = fmin(size[0], fmin(size[1], size[2]));
-    double dmid = size[0] + size[1] + size[2] - dmax - dmin;
-    double Amax = FBO_PI*dmax*dmid;
-    double mag[3]; cross3(mag, w, v); scl3(mag, mag, magnus*m->density*volume);
-    double s12 = size[1]*size[2], s20 = size[2]*size[0], s01 = size[0]*size[1];
-    double pden = pow(s12, 4)*v[0]*v[0] + pow(s20, 4)*v[1]*v[1] + pow(s01, 4)*v[2]*v[2];
-    double pnum = (s12*v[0])*(s12*v[0]) + (s20*v[1])*(s20*v[1]) + (s01*v[2])*(s01*v[2]);
-    double Aproj = FBO_PI*sqrt(pden / fmax(FBO_MINVAL, pnum));
-    double nrm[3] = {s12*s12*v[0], s20*s20*v[1], s01*s01*v[2]};
-    double speed = norm3(v);
-    double cosa = pnum / fmax(FBO_MINVAL, speed*pden);
-    double circ[3]; cross3(circ, nrm, v); scl3(circ, circ, kutta*m->density*cosa*Aproj);
-    double kf[3]; cross3(kf, circ, v);
-    double eqD = 2.0/3.0*(size[0] + size[1] + size[2]);
-    double linc = 3.0*FBO_PI*eqD, angcoef = FBO_PI*eqD*eqD*eqD;
-    double Imax = 8.0/15.0*FBO_PI*dmid*dmax*dmax*dmax*dmax;
-    double mv[3];
-    for (int k = 0; k < 3; k++) {
-      double II = ellipsoid_max_moment(size, k);
-      mv[k] = w[k]*(angc*II + slender*(Imax - II));
-    }
-    double dragl = m->viscosity*linc + m->density*speed*(Aproj*blunt + slender*(Amax - Aproj));
-    double draga = m->viscosity*angcoef + m->density*norm3(mv);
-    for (int k = 0; k < 3; k++) {
-      lfrc[k] -= draga*w[k];
-      lfrc[3+k] += mag[k] + kf[k] - dragl*v[k];
-    }
-    for (int k = 0; k < 6; k++) lfrc[k] *= gf[0];
+    fbo_ellipsoid_local(lvel, m->geom_size + 3*g, gf, m->density, m->viscosity, lfrc, NULL);
     double trq[3], frc[3];
     mulmat3(trq, d->geom_xmat + 9*g, lfrc);
     mulmat3(frc, d->geom_xmat + 9*g, lfrc + 3);
