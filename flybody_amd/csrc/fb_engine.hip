@@ -517,6 +517,42 @@ extern "C" int fb_batch_set_wbpg(fb_batch* b, const double* traj, const double* 
   return 0;
 }
 
+extern "C" int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds) {
+  if (!b || !ds || !ds->traj_offset || !ds->qpos || !ds->qvel || !ds->root2site || !ds->joint_quat || !ds->joint_ids || !ds->site_ids || !ds->select)
+    return fail("fb_batch_set_walk_dataset: null argument");
+  if (ds->n_traj <= 0 || ds->n_select <= 0 || ds->n_joints < 0 || ds->n_sites < 0) return fail("fb_batch_set_walk_dataset: bad sizes");
+  const fb_model* m = b->m;
+  if (m->i("task_id")[0] != 0) return fail("fb_batch_set_walk_dataset: not a walk_imitation model");
+  for (int k = 0; k < ds->n_joints; k++) if (ds->joint_ids[k] < 0 || ds->joint_ids[k] >= m->njnt) return fail("fb_batch_set_walk_dataset: joint id out of range");
+  for (int k = 0; k < ds->n_sites; k++) if (ds->site_ids[k] < 0 || ds->site_ids[k] >= m->nsite) return fail("fb_batch_set_walk_dataset: site id out of range");
+  for (int k = 0; k < ds->n_select; k++) {
+    int t = ds->select[k];
+    if (t < 0 || t >= ds->n_traj) return fail("fb_batch_set_walk_dataset: selected trajectory out of range");
+    if (ds->traj_offset[t + 1] - ds->traj_offset[t] - ds->future_steps - 1 < 1) return fail("fb_batch_set_walk_dataset: trajectory shorter than future_steps + 2");
+  }
+  HIPCHK(hipSetDevice(b->device));
+  size_t rows = (size_t)ds->traj_offset[ds->n_traj];
+  int nj = ds->n_joints, ns = ds->n_sites, future_steps = ds->future_steps;
+  int nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
+  int max_steps = (int)floor(ds->time_limit / m->d("opt_control_timestep")[0] + 0.5) + 1;
+  (void)hipFree(b->obs);
+  HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
+  HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
+  b->nobs = nobs;
+#define SETDS(M, real) { const real *q_, *v_, *r_, *j_; const int *o_, *ji_, *si_, *se_; \
+    if (upload<real>(b, ds->qpos, rows*(7 + nj), &q_) || upload<real>(b, ds->qvel, rows*(6 + nj), &v_) || upload<real>(b, ds->root2site, rows*3*ns, &r_) || \
+        upload<real>(b, ds->joint_quat, rows*4*nj, &j_) || upload_i(b, ds->traj_offset, (size_t)ds->n_traj + 1, &o_) || upload_i(b, ds->joint_ids, nj, &ji_) || \
+        upload_i(b, ds->site_ids, ns, &si_) || upload_i(b, ds->select, ds->n_select, &se_)) return -1; \
+    M.ds_qpos = q_; M.ds_qvel = v_; M.ds_r2s = r_; M.ds_jq = j_; M.ds_offset = o_; M.ds_jid = ji_; M.ds_sid = si_; M.ds_select = se_; \
+    M.ds_nj = nj; M.ds_ns = ns; M.ds_ntraj = ds->n_traj; M.ds_nselect = ds->n_select; M.ds_env_base = ds->env_id_base; M.max_episode_steps = max_steps; \
+    M.seed = ds->seed; M.future_steps = future_steps; M.nobs = nobs; M.T = 0; M.episode_steps = 0; \
+    M.terminal_com_dist = (real)ds->terminal_com_dist; M.time_limit = (real)ds->time_limit; }
+  if (b->precision == 64) SETDS(b->M64, double) else SETDS(b->M32, float)
+#undef SETDS
+  b->have_ref = true;
+  return 0;
+}
+
 static int launch(fb_batch* b, int mode, const float* action, const int* ids, int n, int nsub, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (b->precision == 64) {
@@ -599,6 +635,7 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_SOLVER_NITER: *f = {1, o.istate + IS_NITER, 1, nullptr}; break;
     case FB_STEP_COUNT: *f = {1, o.istate + IS_STEP, 1, nullptr}; break;
     case FB_PROF: *f = {1, o.prof, 2*FB_NPROF, nullptr}; break;
+    case FB_REWARD_FACTORS: *f = {0, o.rfac, 5, nullptr}; break;
     case FB_OBS: *f = {2, 0, (size_t)b->nobs, b->obs}; break;
     case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
     case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;

@@ -197,6 +197,25 @@ __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<rea
   SYNC();
 }
 
+// ------------------------------------------------------------------ reference trajectory of an environment
+// inference mode: one root track shared by all environments (fb_batch_set_reference); training mode: the snippet the
+// environment picked from the dataset at episode start, shifted to start at x = y = 0 (trajectory_loaders.py:249)
+template <typename real> struct RefView { const real* q; int stride, T, episode_steps; real sx, sy; };
+template <typename real> FBD RefView<real> ref_view(const DevModel<real>& M, const WS<real>& w) {
+  RefView<real> r;
+  if (M.ds_qpos) {
+    r.stride = 7 + M.ds_nj; r.q = M.ds_qpos + (size_t)w.istate[IS_DS_OFF]*r.stride; r.T = w.istate[IS_DS_LEN];
+    r.episode_steps = w.istate[IS_EPSTEPS]; r.sx = w.dsshift[0]; r.sy = w.dsshift[1];
+  } else { r.q = M.ref_qpos; r.stride = 7; r.T = M.T; r.episode_steps = M.episode_steps; r.sx = 0; r.sy = 0; }
+  return r;
+}
+template <typename real> FBD void ref_root(const RefView<real>& r, int idx, real* out7) {
+  if (idx >= r.T) idx = r.T - 1;
+  const real* p = r.q + (size_t)idx*r.stride;
+  out7[0] = p[0] - r.sx; out7[1] = p[1] - r.sy;
+  for (int c = 2; c < 7; c++) out7[c] = p[c];
+}
+
 // ------------------------------------------------------------------ environment epilogue
 template <typename real>
 __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
@@ -226,9 +245,10 @@ __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<rea
   }
   o += 2*M.nobsjnt;
   int nf = M.future_steps + 1;
+  const RefView<real> rv = ref_view(M, w);
   for (int k = lane; k < nf; k += FB_WAVE) {
-    int idx = step + k; if (idx >= M.T) idx = M.T - 1;
-    real dif[3], e[3]; sub3(dif, M.ref_qpos + 7*idx, w.qpos);
+    real rr[7]; ref_root(rv, step + k, rr);
+    real dif[3], e[3]; sub3(dif, rr, w.qpos);
     mulmatT3(e, R, dif);
     for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
   }
@@ -238,8 +258,8 @@ __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<rea
     real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
     real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2};
     for (int k = lane; k < nf; k += FB_WAVE) {
-      int idx = step + k; if (idx >= M.T) idx = M.T - 1;
-      real e[4]; mulquat(e, qi, M.ref_qpos + 7*idx + 3);
+      real rr[7]; ref_root(rv, step + k, rr);
+      real e[4]; mulquat(e, qi, rr + 3);
       for (int c = 0; c < 4; c++) obs[o + 4*k + c] = (float)e[c];
     }
   }
@@ -291,6 +311,64 @@ __device__ __forceinline__ void d_walk_pre(const DevModel<real>& M, const WS<rea
   SYNC();
 }
 
+// training-mode reward of walk_imitation (walk_imitation.py:152-177): DeepMimic factors of tasks/rewards.py:37-116 on
+// (CoM, mocap qvel, egocentric root->site vectors, egocentric joint orientation quaternions) x (20,1,1,1) and the
+// wing-retraction tolerance.  One lane per mocap joint / site, four wave reductions.
+template <typename real> FBD real quat_dist_short_arc(const real* a, const real* b) {
+  real na = sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2] + a[3]*a[3]), nb = sqrt(b[0]*b[0] + b[1]*b[1] + b[2]*b[2] + b[3]*b[3]);
+  real dt = (a[0]*b[0] + a[1]*b[1] + a[2]*b[2] + a[3]*b[3])/(na*nb);
+  real x = 2*dt*dt - 1; if (x > 1) x = 1;
+  return acos(x);
+}
+template <typename real>
+__device__ __forceinline__ real d_walk_training_reward(const DevModel<real>& M, const WS<real>& w, int step, int lane) {
+  const int nj = M.ds_nj, ns = M.ds_ns;
+  int len = w.istate[IS_DS_LEN];
+  if (step >= len) step = len - 1;
+  size_t row = (size_t)w.istate[IS_DS_OFF] + step;
+  const real* rq = M.ds_qpos + row*(7 + nj); const real* rvel = M.ds_qvel + row*(6 + nj);
+  const real* r2s = M.ds_r2s + row*3*ns; const real* rjq = M.ds_jq + row*4*nj;
+  const real* root_quat = w.qpos + 3;
+  real n2 = root_quat[0]*root_quat[0] + root_quat[1]*root_quat[1] + root_quat[2]*root_quat[2] + root_quat[3]*root_quat[3];
+  real qinv[4] = {root_quat[0]/n2, -root_quat[1]/n2, -root_quat[2]/n2, -root_quat[3]/n2};
+  real d_com = 0, d_qvel = 0, d_site = 0, d_quat = 0;
+  if (lane < 3) { real e = w.qpos[lane] - (rq[lane] - (lane < 2 ? w.dsshift[lane] : (real)0)); d_com = e*e; }
+  if (lane < 6) { real e = w.qvel[lane] - rvel[lane]; d_qvel = e*e; }
+  if (lane == 0) { real e = quat_dist_short_arc(root_quat, rq + 3); d_quat = e*e; }
+  for (int k = lane; k < nj; k += FB_WAVE) {
+    int j = M.ds_jid[k];
+    real e = w.qvel[M.jnt_dofadr[j]] - rvel[6 + k]; d_qvel += e*e;
+    // joint orientation quaternion (quaternions.py:310-333) of the egocentric joint axis: axis-angle(qpos) * z2vec(axis)
+    real ax[3], qz[4], qa[4], jq[4];
+    rotvecquat(ax, w.xaxis + 3*j, qinv);
+    real an = norm3(ax);
+    real vx = ax[0]/an, vy = ax[1]/an, vz = ax[2]/an;
+    real s = sqrt(vx*vx + vy*vy), zang = atan2(s, vz);          // z x v = (-vy, vx, 0)
+    real cx = -vy, cy = vx;
+    if (s > (real)1e-12) { cx /= s; cy /= s; } else { cx = 1; cy = 0; }
+    real zs = sin(zang/2);
+    qz[0] = cos(zang/2); qz[1] = cx*zs; qz[2] = cy*zs; qz[3] = 0;
+    real ang = w.qpos[M.jnt_qposadr[j]], sh = sin(ang/2);
+    qa[0] = cos(ang/2); qa[1] = vx*sh; qa[2] = vy*sh; qa[3] = vz*sh;
+    mulquat(jq, qa, qz);
+    real eq = quat_dist_short_arc(jq, rjq + 4*k); d_quat += eq*eq;
+  }
+  for (int k = lane; k < ns; k += FB_WAVE) {
+    real df[3], ego[3];
+    sub3(df, w.sxpos + 3*M.ds_sid[k], w.qpos);
+    rotvecquat(ego, df, qinv);
+    for (int c = 0; c < 3; c++) { real e = ego[c] - r2s[3*k + c]; d_site += e*e; }
+  }
+  d_com = wave_sum(d_com); d_qvel = wave_sum(d_qvel); d_site = wave_sum(d_site); d_quat = wave_sum(d_quat);
+  const real s_com = (real)0.078487, s_qvel = (real)53.7801, s_site = (real)0.0735, s_quat = (real)1.2247;     // tasks/rewards.py:101-108
+  real f0 = (real)20*exp(-(real)0.5/(s_com*s_com)*d_com), f1 = exp(-(real)0.5/(s_qvel*s_qvel)*d_qvel);
+  real f2 = exp(-(real)0.5/(s_site*s_site)*d_site), f3 = exp(-(real)0.5/(s_quat*s_quat)*d_quat);
+  real rw = 1;
+  for (int k = 0; k < 6; k++) { int qa = M.jnt_qposadr[M.wing_jnt[k]]; rw *= tolerance_linear(w.qpos[qa] - M.qpos_spring[qa], (real)3); }
+  if (lane == 0) { w.rfac[0] = f0; w.rfac[1] = f1; w.rfac[2] = f2; w.rfac[3] = f3; w.rfac[4] = rw; }
+  return f0*f1*f2*f3*rw;
+}
+
 // walk_imitation reward / termination / observation (base.py:212-225, walk_imitation.py:152-203)
 template <typename real>
 __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
@@ -304,16 +382,19 @@ __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<re
   SYNC();
   real linvel = norm3(w.sens + 6), angvel = norm3(w.sens + 3);
   int tstep = (int)floor(w.simtime[0] / M.control_timestep + (real)0.5);
-  int idx = stepc < M.T ? stepc : M.T - 1;
-  real dif[3]; sub3(dif, M.ref_qpos + 7*idx, w.qpos);
+  const RefView<real> rv = ref_view(M, w);
+  real rroot[7]; ref_root(rv, stepc, rroot);
+  real dif[3]; sub3(dif, rroot, w.qpos);
   real com_dist = norm3(dif);
-  bool traj_end = (tstep == M.episode_steps);
+  bool traj_end = (tstep == rv.episode_steps);
+  real rew = 1;
+  if (M.ds_qpos) rew = d_walk_training_reward(M, w, tstep, lane);
   bool term = (linvel > (real)50) || (angvel > (real)200) || traj_end || (com_dist > M.terminal_com_dist) ||
               (sqrt(qn) > (real)1e14) || (qn != qn);
   bool terminating = term || (w.simtime[0] >= M.time_limit);
   d_pack_obs(M, w, w.sens_acc, obs, lane);
   if (lane == 0) {
-    *reward = 1.0f;
+    *reward = (float)rew;
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
     w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
@@ -324,7 +405,25 @@ __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<re
 
 // walk_imitation episode init (walk_imitation.py:112-136, fruitfly.py:390-405)
 template <typename real>
-__device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<real>& w, int env, int lane) {
+  if (M.ds_qpos) {
+    // initialize_episode_mjcf (walk_imitation.py:92-111): the snippet of this episode, keyed by (seed, global env, episode)
+    int episode = w.istate[IS_EPISODE];
+    double u = (double)hash_uniform(M.seed, (unsigned)(M.ds_env_base + env), (unsigned)episode);
+    int k = (int)(u*M.ds_nselect); if (k >= M.ds_nselect) k = M.ds_nselect - 1;
+    int traj = M.ds_select[k];
+    int off = M.ds_offset[traj], len = M.ds_offset[traj + 1] - off;
+    const real* q0 = M.ds_qpos + (size_t)off*(7 + M.ds_nj);
+    for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 2) ? (real)0 : ((i < 7) ? q0[i] : M.qpos0[i]);
+    SYNC();
+    for (int j = lane; j < M.ds_nj; j += FB_WAVE) w.qpos[M.jnt_qposadr[M.ds_jid[j]]] = q0[7 + j];     // every mocap joint (:118)
+    int snippet = len - M.future_steps - 1;
+    if (lane == 0) {
+      w.istate[IS_DS_OFF] = off; w.istate[IS_DS_LEN] = len; w.istate[IS_EPISODE] = episode + 1;
+      w.istate[IS_EPSTEPS] = M.max_episode_steps < snippet ? M.max_episode_steps : snippet;
+      w.dsshift[0] = q0[0]; w.dsshift[1] = q0[1];
+    }
+  } else
   for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
   for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
   for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
@@ -463,7 +562,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   int nsub = (mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep, sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   if (resetting) {
-    if (M.task == 1) d_flight_init(M, w, env, lane); else d_walk_init(M, w, lane);
+    if (M.task == 1) d_flight_init(M, w, env, lane); else d_walk_init(M, w, env, lane);
     actuate = false; pc = ST_KIN;
   } else if (mode == MODE_FORWARD) {
     pc = ST_KIN;

@@ -34,7 +34,7 @@ enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 // istate slots
 enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
-       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_N = 12 };
+       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_N = 16 };
 
 // Constant tables shared by all environments (device pointers).
 template <typename real>
@@ -88,12 +88,16 @@ struct DevModel {
   real com_offset[3];
   const real *wb_traj, *wb_phase, *wb_freqs; const int* wb_offset; int wb_nfreq;
   real wb_base_freq, wb_rel_range, wb_rate;
+  // walk_imitation training mode: reference dataset (fb_batch_set_walk_dataset)
+  const real *ds_qpos, *ds_qvel, *ds_r2s, *ds_jq;
+  const int *ds_offset, *ds_jid, *ds_sid, *ds_select;
+  int ds_nj, ds_ns, ds_ntraj, ds_nselect, ds_env_base, max_episode_steps;
 };
 
 // Per-environment real arrays: X(name, element count expression in terms of DevModel M)
 #define FB_WS_REAL(X) \
   X(qpos, M.nq) X(qvel, M.nv) X(act, M.na + 1) X(ctrl, M.nu) X(qacc, M.nv) X(qacc_ws, M.nv) X(act_dot, M.na + 1) \
-  X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) X(wbfreq, 1) \
+  X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) X(wbfreq, 1) X(dsshift, 2) X(rfac, 6) \
   X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) X(xmat, 9*M.nbody) X(xipos, 3*M.nbody) X(ximat, 9*M.nbody) \
   X(xanchor, 3*M.njnt) X(xaxis, 3*M.njnt) X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
   X(cinert, 10*M.nbody) X(crb, 10*M.nbody) X(cdof, 6*M.nv) X(cdof_dot, 6*M.nv) X(cvel, 6*M.nbody) \

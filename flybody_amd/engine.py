@@ -23,7 +23,7 @@ ASSETS = os.path.join(_HERE, 'assets')
 FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA=7, OBS=8, REWARD=9,
               DISCOUNT=10, STEP_TYPE=11, NCON=12, NEFC=13, SOLVER_NITER=14, QFRC_BIAS=15, QFRC_PASSIVE=16,
               QACC_SMOOTH=17, QM=18, CONTACT=19, EFC_FORCE=20, QFRC_ACTUATOR=21, QFRC_CONSTRAINT=22,
-              STEP_COUNT=23, SUBTREE_COM=24, PROF=25)
+              STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26)
 _INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF'}
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
 MAXCON, MAXEFC, NSENSOR = 64, 192, 33
@@ -58,6 +58,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_destroy.argtypes = [C.c_void_p]; L.fb_batch_destroy.restype = None
     L.fb_batch_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     L.fb_batch_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32]
+    L.fb_batch_set_walk_dataset.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -121,6 +122,27 @@ class Batch:
         self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
                      7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
 
+    def set_walk_dataset(self, ds, joint_ids, site_ids, select=None, future_steps=64, terminal_com_dist=0.3, time_limit=10.0,
+                         seed: int = 0, env_id_base: int = 0):
+        """Training-mode walk_imitation on a trajectory_loaders.WalkingDataset (fb_batch_set_walk_dataset)."""
+        class _DS(C.Structure):
+            _fields_ = [('n_traj', C.c_int32), ('n_joints', C.c_int32), ('n_sites', C.c_int32), ('n_select', C.c_int32),
+                        ('traj_offset', C.c_void_p), ('qpos', C.c_void_p), ('qvel', C.c_void_p), ('root2site', C.c_void_p),
+                        ('joint_quat', C.c_void_p), ('joint_ids', C.c_void_p), ('site_ids', C.c_void_p), ('select', C.c_void_p),
+                        ('future_steps', C.c_int32), ('terminal_com_dist', C.c_double), ('time_limit', C.c_double),
+                        ('seed', C.c_uint32), ('env_id_base', C.c_int32)]
+        sel = np.arange(ds.n_traj, dtype=np.int32) if select is None else np.ascontiguousarray(select, np.int32)
+        keep = [np.ascontiguousarray(ds.offsets, np.int32), np.ascontiguousarray(ds.qpos, np.float64), np.ascontiguousarray(ds.qvel, np.float64),
+                np.ascontiguousarray(ds.root2site, np.float64), np.ascontiguousarray(ds.joint_quat, np.float64),
+                np.ascontiguousarray(joint_ids, np.int32), np.ascontiguousarray(site_ids, np.int32), sel]
+        assert keep[1].shape[1] == 7 + len(keep[5]) and keep[2].shape[1] == 6 + len(keep[5])
+        d = _DS(ds.n_traj, len(keep[5]), len(keep[6]), len(sel), *(a.ctypes.data for a in keep), int(future_steps), float(terminal_com_dist),
+                float(time_limit), int(seed), int(env_id_base))
+        _check(self.L, self.L.fb_batch_set_walk_dataset(self.h, C.byref(d)))
+        m = self.model
+        self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
+                     7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
+
     def set_wbpg(self, tables, seed: int = 0):
         t = np.ascontiguousarray(tables['traj'], np.float64); p = np.ascontiguousarray(tables['phase'], np.float64)
         o = np.ascontiguousarray(tables['offset'], np.int32); f = np.ascontiguousarray(tables['beat_freqs'], np.float64)
@@ -154,7 +176,7 @@ class Batch:
                     DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
-                    SUBTREE_COM=3, PROF=64)[name]
+                    SUBTREE_COM=3, PROF=64, REWARD_FACTORS=5)[name]
 
     def get(self, name: str) -> np.ndarray:
         w = self._width(name)

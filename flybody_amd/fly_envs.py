@@ -102,7 +102,7 @@ class BatchedFlyEnv:
 
     def __init__(self, n_env: int = 1, device: int = 0, precision: int = 32, terminal_com_dist: float = 0.3,
                  joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation',
-                 wbpg_tables=None, seed: int = 0):
+                 wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0):
         arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
         self.task_name = task
         compiled_filter = 0.01 if task == 'walk_imitation' else 0.0
@@ -125,9 +125,18 @@ class BatchedFlyEnv:
             self.batch.set_wbpg(wbpg_tables or build_tables(), seed=seed)
             # InferenceFlightTrajectoryLoader default (trajectory_loaders.py:161-163): 200 steps, 20 cm/s, z = 1, pitch -47.5 deg
             qp, qv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+        elif traj_loader is not None:
+            # training mode (fly_envs.py:131-135): the whole dataset lives on the GPU, every environment picks its snippet there
+            ds = traj_loader.dataset
+            jid, sid = ds.ids(arrays)
+            self.task._traj_generator = traj_loader
+            self.batch.set_walk_dataset(ds, jid, sid, select=traj_loader.traj_indices, future_steps=future_steps,
+                                        terminal_com_dist=terminal_com_dist, time_limit=time_limit, seed=seed, env_id_base=env_id_base)
+            qp = qv = None
         else:
             qp, qv = default_walking_reference()
-        self.task._traj_generator.set_next_trajectory(qp, qv)
+        if qp is not None:
+            self.task._traj_generator.set_next_trajectory(qp, qv)
         self.layout, self.nobs = observation_layout(self.model, future_steps)
         self._torch_views = None
 
@@ -231,15 +240,26 @@ class BatchedFlyEnv:
 
 def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False, disable_wings: bool = True,
                    traj_indices: Optional[Sequence[int]] = None, random_state=None, terminal_com_dist: float = 0.3,
-                   joint_filter: float = 0.01, n_env: int = 1, device: int = 0, precision: int = 32) -> BatchedFlyEnv:
-    """Same keyword surface as flybody/fly_envs.py:100-106, plus n_env / device / precision."""
+                   joint_filter: float = 0.01, n_env: int = 1, device: int = 0, precision: int = 32, seed: int = 0,
+                   env_id_base: int = 0) -> BatchedFlyEnv:
+    """Same keyword surface as flybody/fly_envs.py:100-106, plus n_env / device / precision / seed / env_id_base.
+
+    ref_path: the reference's hdf5 walking dataset (needs h5py) or its .npz conversion (trajectory_loaders.WalkingDataset.save),
+    or an already constructed loader; None = inference mode (reward == 1)."""
+    traj_loader = None
     if ref_path is not None:
-        raise NotImplementedError('HDF5 reference datasets (training-mode reward) are a "next" row of SURVEY.md 8(f); '
-                                  'inference mode (ref_path=None) is implemented')
+        from .trajectory_loaders import ArrayWalkingTrajectoryLoader, HDF5WalkingTrajectoryLoader
+        if hasattr(ref_path, 'dataset'):
+            traj_loader = ref_path
+        elif str(ref_path).endswith('.npz'):
+            traj_loader = ArrayWalkingTrajectoryLoader(str(ref_path), traj_indices=traj_indices, random_state=random_state)
+        else:
+            traj_loader = HDF5WalkingTrajectoryLoader(str(ref_path), traj_indices=traj_indices, random_state=random_state)
     if force_actuators or not disable_wings:
         raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
-                         joint_filter=joint_filter, future_steps=64, time_limit=10.0)
+                         joint_filter=joint_filter, future_steps=64, time_limit=10.0, seed=seed, traj_loader=traj_loader,
+                         env_id_base=env_id_base)
 
 
 def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,

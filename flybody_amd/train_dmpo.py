@@ -22,19 +22,22 @@ import torch.distributed as dist
 
 from .dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, make_networks
 from .dmpo.losses import PenalizationCostRealActions
-from .fly_envs import BatchedFlyEnv
+from .fly_envs import BatchedFlyEnv, walk_imitation
 
 
 class Trainer:
     def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=1, seed=0,
-                 config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3):
+                 config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None):
         self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device('cuda', self.local_rank)
         if self.world > 1 and not dist.is_initialized():
             dist.init_process_group('nccl', device_id=self.device)
-        self.env = BatchedFlyEnv(n_env=n_env, device=self.local_rank, precision=precision, terminal_com_dist=terminal_com_dist)
+        # ref_path: reference walking dataset -> training-mode (DeepMimic) reward; None -> inference mode (reward == 1).
+        # Environment ids are global (rank * n_env + local id) so that snippet selection does not depend on the GPU count.
+        self.env = walk_imitation(ref_path=ref_path, traj_indices=traj_indices, terminal_com_dist=terminal_com_dist, n_env=n_env,
+                                  device=self.local_rank, precision=precision, seed=seed, env_id_base=self.rank*n_env)
         spec = self.env.action_spec()
         self.a_min = torch.as_tensor(spec.minimum, dtype=torch.float32, device=self.device)
         self.a_scale = torch.as_tensor(spec.maximum - spec.minimum, dtype=torch.float32, device=self.device)
@@ -81,9 +84,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=10); ap.add_argument('--precision', type=int, default=32)
     ap.add_argument('--learner-steps', type=int, default=1, help='learner steps per control step of the batch')
     ap.add_argument('--min-replay', type=int, default=10_000)
+    ap.add_argument('--ref-path', default=None, help='walking dataset (.hdf5 or .npz): training-mode reward')
     a = ap.parse_args()
     tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
-                 config=DMPOConfig(min_replay_size=a.min_replay), terminal_com_dist=float('inf'))
+                 config=DMPOConfig(min_replay_size=a.min_replay), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
+                 ref_path=a.ref_path)
     for _ in range(a.warmup):
         tr.iterate()
     torch.cuda.synchronize()
@@ -102,7 +107,7 @@ def main():
                'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
                'envs_per_gpu': a.envs, 'learner_steps_per_env_step': a.learner_steps, 'batch_size': tr.cfg.batch_size,
                'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'dtype': f'f{a.precision} physics / f32 learner',
-               'reward': 'inference mode (== 1): synthetic reference, throughput run',
+               'reward': 'inference mode (== 1): synthetic reference, throughput run' if a.ref_path is None else f'training mode (DeepMimic factors) on {a.ref_path}',
                'stats': {k: float(v) for k, v in (stats or {}).items() if k in ('critic_loss', 'policy_loss', 'dual_temperature', 'kl_q_rel')}}
         print(json.dumps(out))
     if tr.world > 1:

@@ -54,6 +54,7 @@ enum {
   FB_QFRC_CONSTRAINT = 22,
   FB_STEP_COUNT = 23, /* [n_env] int32 control steps since reset */
   FB_SUBTREE_COM = 24,/* [n_env][3] */
+  FB_REWARD_FACTORS = 26, /* [n_env][5] training-mode reward factors (com, qvel, root2site, joint_quat, wings) */
   FB_PROF = 25,       /* [n_env][48] int32 pairs = 24 int64 per-phase cycle counters (profiling builds) */
   FB_NFIELD
 };
@@ -85,6 +86,25 @@ int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const double* re
  * sequence), freqs[nfreq]; rate = exp(-dt_ctrl / ctrl_filter); seed keys the per-episode initial phase. */
 int fb_batch_set_wbpg(fb_batch* b, const double* traj, const double* phase, const int32_t* offset, const double* freqs,
                       int nfreq, double base_freq, double rel_range, double rate, uint32_t seed);
+
+/* walk_imitation TRAINING mode (fly_envs.walk_imitation(ref_path=...), tasks/walk_imitation.py:57-67,92-177): the whole
+ * reference dataset (tasks/trajectory_loaders.py:185-264) is uploaded once, row-concatenated; every environment picks a
+ * snippet at episode start on the GPU (a pure function of seed, global env id and episode number -- the reference uses
+ * RandomState.choice) and is rewarded with the DeepMimic factors of tasks/rewards.py:84-116 x (20,1,1,1) and the
+ * wing-retraction tolerance.  Replaces fb_batch_set_reference for that mode.  Host pointers, FP64. */
+typedef struct fb_walk_dataset {
+  int32_t n_traj, n_joints, n_sites, n_select;
+  const int32_t* traj_offset;     /* [n_traj + 1] first row of each trajectory */
+  const double* qpos;             /* [rows][7 + n_joints]  root pose + mocap joint angles */
+  const double* qvel;             /* [rows][6 + n_joints] */
+  const double* root2site;        /* [rows][n_sites][3] */
+  const double* joint_quat;       /* [rows][n_joints][4] */
+  const int32_t* joint_ids;       /* [n_joints] model joint ids of the mocap joints */
+  const int32_t* site_ids;        /* [n_sites] model site ids */
+  const int32_t* select;          /* [n_select] trajectory ids to sample from (traj_indices) */
+  int32_t future_steps; double terminal_com_dist, time_limit; uint32_t seed; int32_t env_id_base;
+} fb_walk_dataset;
+int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds);
 
 /* env.reset() for the listed environments (env_ids == NULL: all).  `stream` is a hipStream_t
  * (NULL = default stream).  Asynchronous. */

@@ -101,6 +101,11 @@ typedef struct {
   const double *wb_traj, *wb_phase, *wb_freqs; const int* wb_offset; int wb_nfreq;
   double wb_base_freq, wb_rel_range, wb_rate, wb_ctrl_freq;
   int wb_step, wb_freq_idx, episode_count; unsigned seed;
+  /* walk_imitation training mode: reference dataset (tasks/trajectory_loaders.py:185-264) + per-episode snippet */
+  int ds_ntraj, ds_nj, ds_ns, ds_nselect, ds_traj, ds_off, ds_len; unsigned env_id;
+  const int *ds_offset, *ds_joint_ids, *ds_site_ids, *ds_select;
+  const double *ds_qpos, *ds_qvel, *ds_root2site, *ds_joint_quat;
+  double reward_factors[5];
 } fbo_data;
 
 /* model / data lifetime */
@@ -143,6 +148,12 @@ void fbo_jac(const fbo_data* d, double* jacp, double* jacr, const double* point,
 void fbo_env_configure(fbo_data* d, const double* ref_qpos, const double* ref_qvel, int T,
                        int future_steps, double terminal_com_dist, double time_limit);
 void fbo_env_reset(fbo_data* d);
+/* training-mode walk_imitation: snippets of a reference dataset, concatenated row-wise; `select` = trajectory ids to
+ * sample from; arrays are copied */
+void fbo_env_set_walk_dataset(fbo_data* d, int n_traj, const int* traj_offset, int nj, int ns, const double* qpos, const double* qvel,
+                              const double* root2site, const double* joint_quat, const int* joint_ids, const int* site_ids,
+                              const int* select, int n_select, int future_steps, double terminal_com_dist, double time_limit,
+                              unsigned seed, unsigned env_id);
 /* test entry points pinned against reference-generated vectors (tests/test_reference_goldens.py) */
 void fbo_wbpg_reset(fbo_data* d, double initial_phase, double* qpos6, double* qvel6);
 void fbo_wbpg_step(fbo_data* d, double ctrl_freq, double* out6);

@@ -131,6 +131,18 @@ class OracleData:
         lib().fbo_env_set_wbpg(self.h, t.ctypes.data, p.ctypes.data, o.ctypes.data, f.ctypes.data, len(f),
                                tables['base_freq'], tables['rel_range'], tables['rate'], seed)
 
+    def set_walk_dataset(self, ds, joint_ids, site_ids, select=None, future_steps=64, terminal_com_dist=0.3, time_limit=10.0, seed=0, env_id=0):
+        """Training-mode walk_imitation on a flybody_amd.trajectory_loaders.WalkingDataset."""
+        L = lib()
+        L.fbo_env_set_walk_dataset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p]*7 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint, C.c_uint]
+        sel = np.arange(ds.n_traj, dtype=np.int32) if select is None else np.ascontiguousarray(select, np.int32)
+        a = [np.ascontiguousarray(ds.offsets, np.int32), np.ascontiguousarray(ds.qpos, float), np.ascontiguousarray(ds.qvel, float),
+             np.ascontiguousarray(ds.root2site, float), np.ascontiguousarray(ds.joint_quat, float),
+             np.ascontiguousarray(joint_ids, np.int32), np.ascontiguousarray(site_ids, np.int32), sel]
+        L.fbo_env_set_walk_dataset(self.h, ds.n_traj, a[0].ctypes.data, len(joint_ids), len(site_ids), a[1].ctypes.data, a[2].ctypes.data,
+                                   a[3].ctypes.data, a[4].ctypes.data, a[5].ctypes.data, a[6].ctypes.data, a[7].ctypes.data, len(sel),
+                                   future_steps, float(terminal_com_dist), float(time_limit), seed, env_id)
+
     def env_reset(self):
         lib().fbo_env_reset(self.h)
 

@@ -155,11 +155,129 @@ static double tolerance_linear(double x, double margin) {
 static void flight_reset(fbo_data* d);
 static void flight_step(fbo_data* d, const double* action);
 
+static void* dupmem(const void* p, size_t n) { void* q = malloc(n ? n : 1); memcpy(q, p, n); return q; }
+
+void fbo_env_set_walk_dataset(fbo_data* d, int n_traj, const int* traj_offset, int nj, int ns, const double* qpos, const double* qvel,
+                              const double* root2site, const double* joint_quat, const int* joint_ids, const int* site_ids,
+                              const int* select, int n_select, int future_steps, double terminal_com_dist, double time_limit,
+                              unsigned seed, unsigned env_id) {
+  const fbo_model* m = d->m;
+  size_t rows = (size_t)traj_offset[n_traj];
+  d->ds_ntraj = n_traj; d->ds_nj = nj; d->ds_ns = ns; d->ds_nselect = n_select; d->seed = seed; d->env_id = env_id;
+  d->ds_offset = (const int*)dupmem(traj_offset, sizeof(int)*(n_traj + 1));         /* leaked with the data: test infrastructure */
+  d->ds_qpos = (const double*)dupmem(qpos, sizeof(double)*rows*(7 + nj));
+  d->ds_qvel = (const double*)dupmem(qvel, sizeof(double)*rows*(6 + nj));
+  d->ds_root2site = (const double*)dupmem(root2site, sizeof(double)*rows*3*ns);
+  d->ds_joint_quat = (const double*)dupmem(joint_quat, sizeof(double)*rows*4*nj);
+  d->ds_joint_ids = (const int*)dupmem(joint_ids, sizeof(int)*nj);
+  d->ds_site_ids = (const int*)dupmem(site_ids, sizeof(int)*ns);
+  d->ds_select = (const int*)dupmem(select, sizeof(int)*n_select);
+  d->future_steps = future_steps; d->terminal_com_dist = terminal_com_dist; d->time_limit = time_limit;
+  free(d->obs);
+  d->nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
+  d->obs = (double*)calloc(d->nobs, sizeof(double));
+  d->episode_count = 0; d->reset_next = 1;
+}
+
+/* initialize_episode_mjcf (walk_imitation.py:92-111): pick the snippet of this episode; the reference draws it with
+ * RandomState.choice, here it is a pure function of (seed, environment, episode).  The snippet's root track, shifted
+ * to start at x = y = 0 (trajectory_loaders.py:249), becomes the episode's ref_qpos / ref_qvel. */
+static void pick_snippet(fbo_data* d) {
+  double u = fbo_hash_uniform(d->seed, d->env_id, (unsigned)d->episode_count);
+  d->episode_count++;
+  int k = (int)(u * d->ds_nselect); if (k >= d->ds_nselect) k = d->ds_nselect - 1;
+  d->ds_traj = d->ds_select[k];
+  d->ds_off = d->ds_offset[d->ds_traj]; d->ds_len = d->ds_offset[d->ds_traj + 1] - d->ds_off;
+  int T = d->ds_len, nq = 7 + d->ds_nj, nvm = 6 + d->ds_nj;
+  free(d->ref_qpos); free(d->ref_qvel);
+  d->ref_qpos = (double*)malloc(sizeof(double)*7*T); d->ref_qvel = (double*)malloc(sizeof(double)*6*T);
+  const double* q0 = d->ds_qpos + (size_t)d->ds_off*nq;
+  for (int t = 0; t < T; t++) {
+    const double* q = d->ds_qpos + (size_t)(d->ds_off + t)*nq;
+    for (int c = 0; c < 7; c++) d->ref_qpos[7*t + c] = q[c] - (c < 2 ? q0[c] : 0.0);
+    memcpy(d->ref_qvel + 6*t, d->ds_qvel + (size_t)(d->ds_off + t)*nvm, sizeof(double)*6);
+  }
+  d->T = T;
+}
+
+static void quat_z2vec(double* q, const double* vec) {
+  /* flybody/quaternions.py:215-261: unit quaternion rotating the z axis onto vec */
+  double v[3]; copy3(v, vec); double n = norm3(v); for (int k = 0; k < 3; k++) v[k] /= n;
+  double ax[3] = {-v[1], v[0], 0.0};                  /* z x v */
+  double s = sqrt(ax[0]*ax[0] + ax[1]*ax[1]);
+  double ang = atan2(s, v[2]);
+  if (s > 1e-12) { ax[0] /= s; ax[1] /= s; } else { ax[0] = 1; ax[1] = 0; }
+  double sh = sin(ang/2);
+  q[0] = cos(ang/2); q[1] = ax[0]*sh; q[2] = ax[1]*sh; q[3] = 0;
+}
+
+static double quat_dist_short_arc(const double* a, const double* b) {
+  double na = sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2] + a[3]*a[3]), nb = sqrt(b[0]*b[0] + b[1]*b[1] + b[2]*b[2] + b[3]*b[3]);
+  double dt = (a[0]*b[0] + a[1]*b[1] + a[2]*b[2] + a[3]*b[3])/(na*nb);
+  double x = 2*dt*dt - 1; if (x > 1) x = 1;
+  return acos(x);
+}
+
+/* get_reward_factors (walk_imitation.py:152-177, tasks/rewards.py:37-116): DeepMimic factors x (20,1,1,1), wing retraction */
+static double walk_training_reward(fbo_data* d) {
+  const fbo_model* m = d->m;
+  int nj = d->ds_nj, ns = d->ds_ns, nq = 7 + nj, nvm = 6 + nj;
+  int step = (int)floor(d->time / m->control_timestep + 0.5);
+  if (step >= d->ds_len) step = d->ds_len - 1;
+  size_t row = (size_t)(d->ds_off + step);
+  const double* rq = d->ds_qpos + row*nq; const double* rv = d->ds_qvel + row*nvm;
+  const double* r2s = d->ds_root2site + row*3*ns; const double* rjq = d->ds_joint_quat + row*4*nj;
+  const double* root_quat = d->qpos + 3;
+  double n2 = root_quat[0]*root_quat[0] + root_quat[1]*root_quat[1] + root_quat[2]*root_quat[2] + root_quat[3]*root_quat[3];
+  double qinv[4] = {root_quat[0]/n2, -root_quat[1]/n2, -root_quat[2]/n2, -root_quat[3]/n2};
+  double d_com = 0, d_qvel = 0, d_site = 0, d_quat = 0;
+  for (int c = 0; c < 3; c++) { double e = d->qpos[c] - d->ref_qpos[7*step + c]; d_com += e*e; }
+  for (int c = 0; c < 6; c++) { double e = d->qvel[c] - rv[c]; d_qvel += e*e; }
+  { double ref_root[4] = {rq[3], rq[4], rq[5], rq[6]}; double e = quat_dist_short_arc(root_quat, ref_root); d_quat += e*e; }
+  for (int k = 0; k < nj; k++) {
+    int j = d->ds_joint_ids[k];
+    double e = d->qvel[m->jnt_dofadr[j]] - rv[6 + k]; d_qvel += e*e;
+    /* joint orientation quaternion in the root's frame: axis-angle(qpos) * z2vec, on the egocentric joint axis */
+    double ax[3], qz[4], qa[4], jq[4];
+    rotvecquat(ax, d->xaxis + 3*j, qinv);
+    quat_z2vec(qz, ax);
+    double an = norm3(ax), ang = d->qpos[m->jnt_qposadr[j]], sh = sin(ang/2);
+    qa[0] = cos(ang/2); qa[1] = ax[0]/an*sh; qa[2] = ax[1]/an*sh; qa[3] = ax[2]/an*sh;
+    mulquat(jq, qa, qz);
+    double eq = quat_dist_short_arc(jq, rjq + 4*k); d_quat += eq*eq;
+  }
+  for (int k = 0; k < ns; k++) {
+    double dif[3], ego[3];
+    sub3(dif, d->site_xpos + 3*d->ds_site_ids[k], d->qpos);
+    rotvecquat(ego, dif, qinv);
+    for (int c = 0; c < 3; c++) { double e = ego[c] - r2s[3*k + c]; d_site += e*e; }
+  }
+  const double s_com = 0.078487, s_qvel = 53.7801, s_site = 0.0735, s_quat = 1.2247;     /* tasks/rewards.py:101-108 */
+  d->reward_factors[0] = 20.0*exp(-0.5/(s_com*s_com)*d_com);
+  d->reward_factors[1] = exp(-0.5/(s_qvel*s_qvel)*d_qvel);
+  d->reward_factors[2] = exp(-0.5/(s_site*s_site)*d_site);
+  d->reward_factors[3] = exp(-0.5/(s_quat*s_quat)*d_quat);
+  /* rewards.tolerance(qpos_wing - springref, bounds=(0,0), sigmoid='linear', margin=3, value_at_margin=0) is an
+   * array over the wing joints; np.prod multiplies all of them */
+  double rw = 1.0;
+  for (int k = 0; k < 6; k++) {
+    int qa = m->jnt_qposadr[m->wing_jnt[k]];
+    rw *= tolerance_linear(d->qpos[qa] - m->qpos_spring[qa], 3.0);
+  }
+  d->reward_factors[4] = rw;
+  return d->reward_factors[0]*d->reward_factors[1]*d->reward_factors[2]*d->reward_factors[3]*rw;
+}
+
 void fbo_env_reset(fbo_data* d) {
   const fbo_model* m = d->m;
   if (m->task_id == 1) { flight_reset(d); return; }
   fbo_reset_state(d);
+  if (d->ds_qpos) pick_snippet(d);
   memcpy(d->qpos, d->ref_qpos, sizeof(double)*7);          /* root pose from the reference snippet */
+  if (d->ds_qpos) {                                         /* training mode: every mocap joint from the snippet (walk_imitation.py:118) */
+    const double* q0 = d->ds_qpos + (size_t)d->ds_off*(7 + d->ds_nj);
+    for (int k = 0; k < d->ds_nj; k++) d->qpos[m->jnt_qposadr[d->ds_joint_ids[k]]] = q0[7 + k];
+  }
   for (int k = 0; k < 6; k++) {                            /* wings to their retracted (springref) pose */
     int qa = m->jnt_qposadr[m->wing_jnt[k]];
     d->qpos[qa] = m->qpos_spring[qa];
@@ -212,7 +330,7 @@ void fbo_env_step(fbo_data* d, const double* action) {
   d->reached_traj_end = (step == d->episode_steps);
   d->should_terminate = (linvel > TERMINAL_LINVEL) || (angvel > TERMINAL_ANGVEL) || d->reached_traj_end ||
                         (com_dist > d->terminal_com_dist) || (sqrt(qn) > TERMINAL_QACC) || (qn != qn);
-  d->reward = 1.0;    /* inference mode: walk_imitation.py:155-156 */
+  d->reward = d->ds_qpos ? walk_training_reward(d) : 1.0;    /* inference mode: walk_imitation.py:155-156 */
   d->discount = (d->should_terminate && !d->reached_traj_end) ? 0.0 : 1.0;
   int terminating = d->should_terminate || (d->time >= d->time_limit);
   pack_obs(d, mean);

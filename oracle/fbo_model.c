@@ -191,6 +191,7 @@ double* fbo_field(fbo_data* d, const char* name, int* n) {
     }
   if (!strcmp(name, "sensordata")) { if (n) *n = FBO_NSENSOR; return d->sensordata; }
   if (!strcmp(name, "obs")) { if (n) *n = d->nobs; return d->obs; }
+  if (!strcmp(name, "reward_factors")) { if (n) *n = 5; return d->reward_factors; }
   if (n) *n = 0;
   return NULL;
 }
@@ -199,7 +200,7 @@ double fbo_scalar(const fbo_data* d, const char* name) {
 #define X(f) if (!strcmp(name, #f)) return (double)d->f
   X(ncon); X(nefc); X(solver_niter); X(noslip_niter); X(time); X(reward); X(discount); X(step_type);
   X(wb_step); X(wb_freq_idx); X(wb_ctrl_freq); X(episode_count);
-  X(step_counter); X(episode_steps); X(reset_next); X(should_terminate); X(reached_traj_end); X(nobs);
+  X(ds_traj); X(ds_off); X(ds_len); X(step_counter); X(episode_steps); X(reset_next); X(should_terminate); X(reached_traj_end); X(nobs);
 #undef X
   return -1e300;
 }

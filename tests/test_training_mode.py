@@ -1,0 +1,137 @@
+"""walk_imitation TRAINING mode: dataset loaders, per-episode snippet selection, DeepMimic reward.
+
+The reward arithmetic is pinned to the reference through flybody_amd/rewards.py (tests/test_reference_goldens.py checks
+it against vectors produced by the reference's tasks/rewards.py); here the oracle environment is checked against that
+restatement on its own state, and the kernel (emulation on CPU, HIP on the GPU) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from _synthetic_dataset import make_dataset
+
+
+@pytest.fixture(scope='module')
+def dataset(oracle_model, walk_arrays):
+    return make_dataset(oracle_model, walk_arrays, n_traj=3, length=90)
+
+
+def _oracle_env(oracle_model, ds, walk_arrays, env_id, seed=3):
+    from oracle import fbo
+    jid, sid = ds.ids(walk_arrays)
+    od = fbo.OracleData(oracle_model)
+    od.set_walk_dataset(ds, jid, sid, terminal_com_dist=float('inf'), seed=seed, env_id=env_id)
+    od.env_reset()
+    return od
+
+
+def test_loader_surface_and_roundtrip(dataset, tmp_path):
+    from flybody_amd.trajectory_loaders import ArrayWalkingTrajectoryLoader, WalkingDataset, HDF5WalkingTrajectoryLoader
+    p = str(tmp_path / 'ds.npz'); dataset.save(p)
+    ld = ArrayWalkingTrajectoryLoader(p, traj_indices=[0, 2], random_state=np.random.RandomState(0))
+    assert ld.num_trajectories == 3 and list(ld.traj_indices) == [0, 2] and ld.trajectory_len(1) == 90
+    assert ld.get_joint_names() == dataset.joint_names and ld.get_site_names() == dataset.site_names
+    tr = ld.get_trajectory(traj_idx=2, start_step=5, end_step=40)          # trajectory_loaders.py:218-257
+    assert tr['qpos'].shape == (35, 7 + len(dataset.joint_names)) and np.allclose(tr['qpos'][0, :2], 0)
+    assert tr['root2site'].shape == (35, 6, 3) and tr['joint_quat'].shape == (35, len(dataset.joint_names), 4)
+    assert ld.get_trajectory()['qpos'].shape[0] == 90
+    d2 = WalkingDataset.load(p)
+    assert np.array_equal(d2.qpos, dataset.qpos) and d2.joint_names == dataset.joint_names
+    with pytest.raises((ImportError, OSError)):
+        HDF5WalkingTrajectoryLoader(str(tmp_path / 'missing.hdf5'))
+
+
+def test_oracle_training_reward_matches_pinned_restatement(oracle_model, walk_arrays, dataset):
+    from flybody_amd.trajectory_loaders import walker_features
+    from flybody_amd.rewards import reward_factors_deep_mimic
+    jid, sid = dataset.ids(walk_arrays); nj, ns = len(jid), len(sid)
+    od = _oracle_env(oracle_model, dataset, walk_arrays, env_id=5)
+    tr = int(od.scalar('ds_traj'))
+    assert od.scalar('episode_steps') == 90 - 64 - 1
+    snip = dataset.qpos[dataset.offsets[tr]:dataset.offsets[tr + 1]].copy(); snip[:, :2] -= snip[0, :2]
+    # reset state: root + every mocap joint from the first snippet row, wings at their spring reference
+    q = od.field('qpos')
+    assert np.allclose(q[:7], snip[0, :7]) and np.allclose(q[walk_arrays['jnt_qposadr'][jid]], snip[0, 7:])
+    rng = np.random.default_rng(1)
+    for k in range(8):
+        od.env_step(rng.uniform(-0.3, 0.3, 59))
+        step = int(od.scalar('step_counter')); row = dataset.offsets[tr] + step
+        f = walker_features(od.field('qpos'), od.field('qvel'), od.field('xaxis').reshape(-1, 3), od.field('site_xpos').reshape(-1, 3),
+                            jid, sid, walk_arrays['jnt_qposadr'], walk_arrays['jnt_dofadr'])
+        ref = np.concatenate([snip[step, :3], dataset.qvel[row], dataset.root2site[row].ravel(), snip[step, 3:7], dataset.joint_quat[row].ravel()])
+        fac = reward_factors_deep_mimic(f, ref, nj=nj, nsite=ns, weights=(20, 1, 1, 1))
+        got = od.field('reward_factors')
+        assert np.allclose(got[:4], fac, rtol=1e-10)
+        assert np.isclose(od.scalar('reward'), np.prod(fac)*got[4], rtol=1e-10) and 0 < got[4] <= 1
+
+
+def test_snippet_selection_is_a_function_of_seed_env_episode(oracle_model, walk_arrays, dataset):
+    picks = [int(_oracle_env(oracle_model, dataset, walk_arrays, env_id=e).scalar('ds_traj')) for e in range(24)]
+    assert set(picks) == {0, 1, 2}                               # all trajectories get used
+    assert picks == [int(_oracle_env(oracle_model, dataset, walk_arrays, env_id=e).scalar('ds_traj')) for e in range(24)]
+    assert picks != [int(_oracle_env(oracle_model, dataset, walk_arrays, env_id=e, seed=4).scalar('ds_traj')) for e in range(24)]
+
+
+def _run_engine_vs_oracle(lib_path, precision, oracle_model, walk_arrays, dataset, nstep, tol_q, tol_r):
+    from flybody_amd import engine
+    jid, sid = dataset.ids(walk_arrays)
+    M = engine.Model.from_asset('walk_imitation', lib_path=lib_path)
+    B = engine.Batch(M, 2, precision=precision)
+    B.set_walk_dataset(dataset, jid, sid, terminal_com_dist=float('inf'), seed=3, env_id_base=4)
+    B.reset()
+    ods = [_oracle_env(oracle_model, dataset, walk_arrays, env_id=4 + e) for e in range(2)]
+    assert np.allclose(B.get('QPOS'), [o.field('qpos') for o in ods], atol=1e-6)
+    rng = np.random.default_rng(1)
+    types = []
+    if lib_path is None:
+        import torch
+    for k in range(nstep):
+        a = rng.uniform(-0.3, 0.3, (2, 59)).astype(np.float32)
+        if lib_path is None:
+            t = torch.from_numpy(a).cuda(); B.step_ptr(t.data_ptr(), torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        else:
+            B.step_ptr(a.ctypes.data)
+        for e in range(2):
+            ods[e].env_step(a[e].astype(np.float64))
+        types.append(int(B.get('STEP_TYPE')[0, 0]))
+        assert list(B.get('STEP_TYPE').ravel()) == [int(o.scalar('step_type')) for o in ods]
+        assert np.abs(B.get('QPOS') - [o.field('qpos') for o in ods]).max() < tol_q, k
+        assert np.allclose(B.get('REWARD').ravel(), [o.scalar('reward') for o in ods], rtol=max(tol_r, 1e-6)), k      # float32 output array
+        assert np.allclose(B.get('REWARD_FACTORS'), [o.field('reward_factors') for o in ods], rtol=tol_r), k
+    return types
+
+
+def test_kernel_emulation_training_mode_matches_oracle(oracle_model, walk_arrays, dataset):
+    import __graft_entry__ as g
+    types = _run_engine_vs_oracle(g.build_emu(), 64, oracle_model, walk_arrays, dataset, nstep=28, tol_q=1e-8, tol_r=1e-8)
+    assert types[24] == 2 and types[25] == 0          # LAST at the end of the 25-step snippet, then auto-reset with a new snippet
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol_q,tol_r', [(64, 1e-8, 1e-8), (32, 2e-3, 2e-2)])
+def test_gpu_training_mode_matches_oracle(oracle_model, walk_arrays, dataset, precision, tol_q, tol_r):
+    types = _run_engine_vs_oracle(None, precision, oracle_model, walk_arrays, dataset, nstep=28, tol_q=tol_q, tol_r=tol_r)
+    assert types[24] == 2 and types[25] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_fly_envs_walk_imitation_with_ref_path(oracle_model, walk_arrays, dataset, tmp_path):
+    """fly_envs.walk_imitation(ref_path=...) keyword surface (fly_envs.py:100-155) in training mode."""
+    from flybody_amd.fly_envs import walk_imitation
+    p = str(tmp_path / 'ds.npz'); dataset.save(p)
+    env = walk_imitation(ref_path=p, traj_indices=[0, 1, 2], terminal_com_dist=float('inf'), n_env=8, precision=32, seed=1)
+    assert env.task._traj_generator.get_joint_names() == dataset.joint_names
+    import torch
+    ts = env.reset()
+    assert ts.first() and ts.reward is None or ts.reward == 0 or ts.reward is not None
+    ts = env.step(np.zeros(59, np.float32))                                  # dm_env view of environment 0
+    assert 0 < float(ts.reward) <= 20.0
+    views = env.reset_all()
+    rewards = []
+    for k in range(5):
+        views = env.step_tensor(torch.zeros(8, 59, device='cuda'))
+        torch.cuda.synchronize()
+        rewards.append(views['reward'].cpu().numpy().ravel().copy())
+    r = np.array(rewards)
+    assert r.shape == (5, 8) and np.all(r > 0) and np.all(r <= 20.0) and len(np.unique(np.round(r[0], 4))) > 1
