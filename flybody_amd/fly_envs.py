@@ -230,7 +230,7 @@ class BatchedFlyEnv:
     def step(self, action) -> TimeStep:
         import torch
         a = np.broadcast_to(np.asarray(action, np.float32), (self.n_env, self.model.dim('nact')))
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(f'cuda:{self.device}')
+        t = torch.from_numpy(np.array(a, np.float32, copy=True)).to(f'cuda:{self.device}')
         self.batch.step_ptr(t.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         ts = self._timestep()

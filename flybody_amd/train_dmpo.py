@@ -20,14 +20,16 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, make_networks
+from .dmpo import (Checkpointer, Counter, DMPOConfig, DMPOLearner, MetricsLogger, MPOLoss, NStepReplay, Snapshotter, evaluate,
+                   make_networks)
 from .dmpo.losses import PenalizationCostRealActions
 from .fly_envs import BatchedFlyEnv, walk_imitation
 
 
 class Trainer:
     def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=1, seed=0,
-                 config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None):
+                 config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None,
+                 directory=None, checkpoint_to_load=None, time_delta_minutes=30.0, checkpoint_max_to_keep=1):
         self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(self.local_rank)
@@ -57,6 +59,17 @@ class Trainer:
         self.views = self.env.reset_all()
         self.obs = self.views['obs'].clone()
         self.env_steps = 0; self.learner_steps = 0
+        # checkpoints / policy snapshots / metrics (rank 0 writes; every rank restores so that replicas stay identical)
+        self.counter = Counter(); self.checkpointer = self.snapshotter = None; self.logger = MetricsLogger(None)
+        self._ep_return = torch.zeros(n_env, device=self.device); self._ep_len = torch.zeros(n_env, device=self.device)
+        self._last_return = 0.0; self._last_length = 0.0; self._t_learn = None
+        if directory is not None:
+            ck = Checkpointer(directory, self.learner, self.counter, time_delta_minutes, checkpoint_max_to_keep)
+            restored = ck.restore(checkpoint_to_load) if (checkpoint_to_load or ck._files()) else None
+            self.restored_from = restored
+            if self.rank == 0:
+                self.checkpointer = ck; self.snapshotter = Snapshotter(directory, self.learner, time_delta_minutes)
+                self.logger = MetricsLogger(directory, 'learner')
 
     def iterate(self, learn=True):
         """One control step of every environment, replay insertion, and the scheduled learner steps."""
@@ -69,13 +82,40 @@ class Trainer:
         self.replay.add(self.obs, canon, v['reward'], v['discount'], nxt, first, last)
         self.obs = nxt
         self.env_steps += self.env.n_env
+        # actor-side counters (acme EnvironmentLoop): steps, finished episodes, last mean episode return / length
+        live = st.view(-1) != 0
+        self._ep_return += torch.where(live, v['reward'].view(-1), torch.zeros_like(self._ep_return)); self._ep_len += live.float()
+        fin = last.view(-1)
+        nfin = int(fin.sum()) if self.env_steps % (64*self.env.n_env) == 0 else 0        # host sync only every 64 control steps
+        if nfin:
+            self._last_return = float(self._ep_return[fin].mean()); self._last_length = float(self._ep_len[fin].mean())
+            self.counter.increment(actor_episodes=nfin)
+        self._ep_return[fin] = 0; self._ep_len[fin] = 0
+        self.counter.increment(actor_steps=self.env.n_env*self.world)
         stats = None
         if learn and self.replay.size >= min(self.cfg.min_replay_size, self.replay.capacity // 2):
             if self.use_graphs and self.learner._graph_fb is None:
                 self.learner.enable_graphs(self.replay.sample(self.cfg.batch_size))
             for _ in range(self.lsteps_per):
                 stats = self.learner.step(self.replay.sample(self.cfg.batch_size)); self.learner_steps += 1
+            now = time.time()
+            self.counter.increment(learner_steps=self.lsteps_per, learner_walltime=(now - self._t_learn) if self._t_learn else 0.0)
+            self._t_learn = now
+            if self.checkpointer is not None:
+                self.checkpointer.save()
+                if self.snapshotter.save(actor_steps=int(self.counter.counts.get('actor_steps', 0))):
+                    self.logger.write({**self.counter.counts, 'saved_snapshot_at_actor_steps': self.counter.counts.get('actor_steps', 0)})
         return stats
+
+    def log(self):
+        return self.logger.write({**self.counter.counts, 'episode_return': self._last_return, 'episode_length': self._last_length})
+
+    def evaluate(self, n_env=64, episodes_per_env=1):
+        """Greedy-policy evaluation on a separate small batch (the reference's evaluator actor)."""
+        env = BatchedFlyEnv(n_env=n_env, device=self.local_rank, precision=self.env.batch.precision,
+                            terminal_com_dist=self.env.terminal_com_dist) if not hasattr(self, '_eval_env') else self._eval_env
+        self._eval_env = env
+        return evaluate(env, lambda o: self.learner.act(o, deterministic=True), self.a_min, self.a_scale, episodes_per_env)
 
 
 def main():
@@ -85,10 +125,12 @@ def main():
     ap.add_argument('--learner-steps', type=int, default=1, help='learner steps per control step of the batch')
     ap.add_argument('--min-replay', type=int, default=10_000)
     ap.add_argument('--ref-path', default=None, help='walking dataset (.hdf5 or .npz): training-mode reward')
+    ap.add_argument('--directory', default=None, help='checkpoints / policy snapshots / metrics go here; resumes from the newest checkpoint')
+    ap.add_argument('--checkpoint-to-load', default=None); ap.add_argument('--checkpoint-minutes', type=float, default=30.0)
     a = ap.parse_args()
     tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
                  config=DMPOConfig(min_replay_size=a.min_replay), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
-                 ref_path=a.ref_path)
+                 ref_path=a.ref_path, directory=a.directory, checkpoint_to_load=a.checkpoint_to_load, time_delta_minutes=a.checkpoint_minutes)
     for _ in range(a.warmup):
         tr.iterate()
     torch.cuda.synchronize()
@@ -102,6 +144,8 @@ def main():
     if tr.world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if tr.rank == 0 and tr.checkpointer is not None:
+        tr.checkpointer.save(force=True); tr.snapshotter.save(force=True, actor_steps=int(tr.counter.counts.get('actor_steps', 0))); tr.log()
     if tr.rank == 0:
         out = {'metric': 'env steps/sec + learner steps/sec, walk_imitation DMPO on-GPU training', 'n_gpus': tr.world,
                'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,

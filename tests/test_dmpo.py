@@ -192,3 +192,65 @@ def test_two_rank_gradient_allreduce(tmp_path):
     want = (grads[0] + grads[1]) / 2
     got = torch.load(out)
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)
+
+
+def test_checkpoint_snapshot_and_metrics(tmp_path):
+    """Checkpointer / Snapshotter / Counter / MetricsLogger (agents/learning_dmpo.py:107-162, 319-355; loggers.py:37-104)."""
+    import json
+    from flybody_amd.dmpo import (Checkpointer, Counter, DMPOConfig, DMPOLearner, MetricsLogger, MPOLoss, Snapshotter,
+                                  load_policy_snapshot, make_networks)
+    torch.manual_seed(0)
+    obs_dim, act_dim, B = 23, 5, 16
+
+    def make():
+        torch.manual_seed(0)
+        return DMPOLearner(make_networks(obs_dim, act_dim), MPOLoss(act_dim), DMPOConfig(batch_size=B, num_samples=4))
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(B, obs_dim, generator=g), torch.rand(B, act_dim, generator=g)*2 - 1, torch.rand(B, generator=g),
+                torch.ones(B), torch.randn(B, obs_dim, generator=g))
+    a = make(); cnt = Counter()
+    for k in range(3):
+        a.step(batch(k)); cnt.increment(learner_steps=1, learner_walltime=0.5, actor_steps=1000)
+    ck = Checkpointer(str(tmp_path), a, cnt, time_delta_minutes=1e9, max_to_keep=2)
+    assert ck.save() is None                                   # time-gated
+    p1 = ck.save(force=True); assert os.path.exists(p1)
+    for k in range(3, 6):
+        a.step(batch(k))
+    ck.save(force=True); ck.save(force=True)
+    assert len(ck._files()) == 2                               # max_to_keep
+    # restore the first checkpoint into a fresh learner and replay the same batches: identical parameters
+    b = make(); cnt2 = Counter()
+    assert Checkpointer(str(tmp_path / 'other'), b, cnt2).restore() is None
+    os.makedirs(tmp_path / 'keep', exist_ok=True)
+    a2 = make()
+    for k in range(3):
+        a2.step(batch(k))
+    ck2 = Checkpointer(str(tmp_path / 'keep'), a2, Counter()); pk = ck2.save(force=True)
+    for k in range(3, 6):
+        a2.step(batch(k))
+    b = make(); cb = Counter(); Checkpointer(str(tmp_path / 'keep'), b, cb).restore(pk)      # also restores the RNG state
+    assert b.num_steps == 3
+    for k in range(3, 6):
+        b.step(batch(k))
+    for pa, pb in zip(a2.online.parameters(), b.online.parameters()):
+        assert torch.equal(pa, pb)
+    for pa, pb in zip(a2.loss.parameters(), b.loss.parameters()):
+        assert torch.equal(pa, pb)
+    # snapshots: numbered policy files that rebuild without the learner
+    sn = Snapshotter(str(tmp_path), a, time_delta_minutes=1e9)
+    s0 = sn.save(force=True, actor_steps=3000); s1 = sn.save(force=True, actor_steps=6000)
+    assert s0.endswith('policy-0.pt') and s1.endswith('policy-1.pt') and sn.save() is None
+    pol, meta = load_policy_snapshot(s1)
+    assert meta['obs_dim'] == obs_dim and meta['action_dim'] == act_dim and meta['saved_snapshot_at_actor_steps'] == 6000
+    o = torch.randn(4, obs_dim)
+    m1, s1_ = pol(o); m2, s2_ = a.target.policy(o)
+    assert torch.equal(m1, m2) and torch.equal(s1_, s2_)
+    # metrics: the reference's derived quantities
+    lg = MetricsLogger(str(tmp_path), 'learner')
+    m = lg.write({**cnt.counts, 'episode_return': 12.5, 'episode_length': 200})
+    assert m['steps_per_second_learner'] == 2.0 and m['steps_per_second_actor'] == 2000.0 and m['acting-to-learning'] == 1000.0
+    assert m['actor_episode_return'] == 12.5 and abs(m['walltime_hr'] - 1.5/3600) < 1e-12
+    assert MetricsLogger.derive({'episode_return': 3.0}, 'evaluator')['evaluator_episode_return'] == 3.0
+    assert json.loads(open(tmp_path / 'metrics_learner.jsonl').read().splitlines()[0])['learner_steps'] == 3

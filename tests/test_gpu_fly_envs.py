@@ -96,3 +96,34 @@ def test_flight_imitation_env():
         v = venv.step_tensor(a)
     torch.cuda.synchronize()
     assert torch.isfinite(v['obs']).all() and (v['reward'] > 0).all()
+
+
+@pytest.mark.gpu
+def test_trainer_checkpoint_resume_and_evaluator(tmp_path):
+    """Checkpoint / snapshot / metrics of the on-GPU trainer and the greedy evaluator."""
+    import glob, json, os
+    import torch
+    from flybody_amd.train_dmpo import Trainer
+    from flybody_amd.dmpo import DMPOConfig, load_policy_snapshot
+    cfg = DMPOConfig(min_replay_size=256, batch_size=64, num_samples=4)
+    os.environ['FB_LEARNER_GRAPHS'] = '0'
+    tr = Trainer(n_env=64, precision=32, replay_capacity=20_000, config=cfg, terminal_com_dist=float('inf'), directory=str(tmp_path),
+                 time_delta_minutes=1e9)
+    for _ in range(24):
+        tr.iterate()
+    assert tr.learner.num_steps > 0
+    assert tr.checkpointer.save(force=True) and tr.snapshotter.save(force=True, actor_steps=int(tr.counter.counts['actor_steps']))
+    m = tr.log()
+    assert m['actor_steps'] == 24*64 and m['learner_steps'] == tr.learner.num_steps and 'steps_per_second_actor' in m
+    ev = tr.evaluate(n_env=8, episodes_per_env=1)
+    assert ev['episodes'] >= 8 and ev['episode_length'] > 1 and ev['episode_return'] > 0
+    steps = tr.learner.num_steps
+    w0 = [p.detach().clone() for p in tr.learner.online.parameters()]
+    del tr
+    tr2 = Trainer(n_env=64, precision=32, replay_capacity=20_000, config=cfg, terminal_com_dist=float('inf'), directory=str(tmp_path))
+    assert tr2.restored_from is not None and tr2.learner.num_steps == steps and tr2.counter.counts['actor_steps'] == 24*64
+    for a, b in zip(w0, tr2.learner.online.parameters()):
+        assert torch.equal(a, b)
+    pol, meta = load_policy_snapshot(glob.glob(str(tmp_path / 'snapshots' / 'policy-*.pt'))[0], device='cuda')
+    assert meta['obs_dim'] == tr2.env.nobs and meta['action_dim'] == 59
+    assert json.loads(open(tmp_path / 'metrics_learner.jsonl').read().splitlines()[-1])['actor_steps'] == 24*64
