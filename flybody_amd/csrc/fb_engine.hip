@@ -636,6 +636,9 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_STEP_COUNT: *f = {1, o.istate + IS_STEP, 1, nullptr}; break;
     case FB_PROF: *f = {1, o.prof, 2*FB_NPROF, nullptr}; break;
     case FB_REWARD_FACTORS: *f = {0, o.rfac, 5, nullptr}; break;
+    case FB_GEOM_XPOS: *f = {0, o.gxpos, (size_t)3*m->ngeom, nullptr}; break;
+    case FB_GEOM_XMAT: *f = {0, o.gxmat, (size_t)9*m->ngeom, nullptr}; break;
+    case FB_CVEL: *f = {0, o.cvel, (size_t)6*m->nbody, nullptr}; break;
     case FB_OBS: *f = {2, 0, (size_t)b->nobs, b->obs}; break;
     case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
     case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;

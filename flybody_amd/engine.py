@@ -23,7 +23,7 @@ ASSETS = os.path.join(_HERE, 'assets')
 FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA=7, OBS=8, REWARD=9,
               DISCOUNT=10, STEP_TYPE=11, NCON=12, NEFC=13, SOLVER_NITER=14, QFRC_BIAS=15, QFRC_PASSIVE=16,
               QACC_SMOOTH=17, QM=18, CONTACT=19, EFC_FORCE=20, QFRC_ACTUATOR=21, QFRC_CONSTRAINT=22,
-              STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26)
+              STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26, GEOM_XPOS=27, GEOM_XMAT=28, CVEL=29)
 _INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF'}
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
 MAXCON, MAXEFC, NSENSOR = 64, 192, 33
@@ -176,7 +176,8 @@ class Batch:
                     DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
-                    SUBTREE_COM=3, PROF=64, REWARD_FACTORS=5)[name]
+                    SUBTREE_COM=3, PROF=64, REWARD_FACTORS=5, GEOM_XPOS=3*m.dim('ngeom'),
+                    GEOM_XMAT=9*m.dim('ngeom'), CVEL=6*m.dim('nbody'))[name]
 
     def get(self, name: str) -> np.ndarray:
         w = self._width(name)

@@ -54,6 +54,9 @@ enum {
   FB_QFRC_CONSTRAINT = 22,
   FB_STEP_COUNT = 23, /* [n_env] int32 control steps since reset */
   FB_SUBTREE_COM = 24,/* [n_env][3] */
+  FB_GEOM_XPOS = 27,  /* [n_env][ngeom][3] */
+  FB_GEOM_XMAT = 28,  /* [n_env][ngeom][9] */
+  FB_CVEL = 29,       /* [n_env][nbody][6] spatial velocity [angular, linear] about the tree CoM */
   FB_REWARD_FACTORS = 26, /* [n_env][5] training-mode reward factors (com, qvel, root2site, joint_quat, wings) */
   FB_PROF = 25,       /* [n_env][48] int32 pairs = 24 int64 per-phase cycle counters (profiling builds) */
   FB_NFIELD

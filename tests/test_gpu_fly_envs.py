@@ -127,3 +127,45 @@ def test_trainer_checkpoint_resume_and_evaluator(tmp_path):
     pol, meta = load_policy_snapshot(glob.glob(str(tmp_path / 'snapshots' / 'policy-*.pt'))[0], device='cuda')
     assert meta['obs_dim'] == tr2.env.nobs and meta['action_dim'] == 59
     assert json.loads(open(tmp_path / 'metrics_learner.jsonl').read().splitlines()[-1])['actor_steps'] == 24*64
+
+
+@pytest.mark.gpu
+def test_ellipsoid_fluid_force_analysis_api():
+    """flybody_amd.fluid.ellipsoid_fluid_forces (counterpart of flybody/ellipsoid_fluid_model.py:16-78) on a flapping fly:
+    components in global coordinates and qfrc_fluid against the CPU oracle evaluated at the same state."""
+    import ctypes as C, os
+    from conftest import ROOT
+    from flybody_amd.fly_envs import flight_imitation
+    from flybody_amd.fluid import ellipsoid_fluid_forces, COMPONENTS
+    from flybody_amd.model_blob import load_npz, pack_model
+    from oracle import fbo
+    env = flight_imitation(precision=64)
+    env.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        env.step(rng.uniform(-0.5, 0.5, 12))
+    forces, qfrc_fluid = ellipsoid_fluid_forces(env)
+    assert set(forces) == {'wing_left', 'wing_right'}
+    arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
+    od = fbo.OracleData(fbo.OracleModel(pack_model(arr)))
+    od.field('qpos')[:] = env.batch.get('QPOS')[0]; od.field('qvel')[:] = env.batch.get('QVEL')[0]
+    od.call('fwd_position'); od.call('fwd_velocity')
+    assert np.allclose(qfrc_fluid, od.field('qfrc_fluid'), rtol=1e-7, atol=1e-12)
+    L = fbo.lib()
+    L.fbo_ellipsoid_local.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    gxp = od.field('geom_xpos').reshape(-1, 3); gxm = od.field('geom_xmat').reshape(-1, 3, 3)
+    cvel = od.field('cvel').reshape(-1, 6); com = od.field('subtree_com')[3:6]
+    for body, geoms in forces.items():
+        for g, comp in geoms.items():
+            b = int(arr['geom_bodyid'][g])
+            ang, lin = cvel[b, :3], cvel[b, 3:] - np.cross(gxp[g] - com, cvel[b, :3])
+            lvel = np.ascontiguousarray(np.concatenate([gxm[g].T @ ang, gxm[g].T @ lin]))
+            lfrc = np.zeros(6); cc = np.zeros(24)
+            size = np.ascontiguousarray(arr['geom_size'][g]); gf = np.ascontiguousarray(arr['geom_fluid'][g])
+            L.fbo_ellipsoid_local(lvel.ctypes.data, size.ctypes.data, gf.ctypes.data, float(arr['opt_density']), float(arr['opt_viscosity']),
+                                  lfrc.ctypes.data, cc.ctypes.data)
+            for k, name in enumerate(COMPONENTS):
+                assert np.allclose(comp[name], gxm[g] @ (cc[3*k:3*k + 3]*gf[0]), rtol=1e-6, atol=1e-14), (body, g, name)
+            total_f = sum(comp[n] for n in COMPONENTS if n.startswith('f')); total_g = sum(comp[n] for n in COMPONENTS if n.startswith('g'))
+            assert np.allclose(total_f, gxm[g] @ lfrc[3:], rtol=1e-6, atol=1e-14) and np.allclose(total_g, gxm[g] @ lfrc[:3], rtol=1e-6, atol=1e-14)
+            assert np.linalg.norm(total_f) > 0

@@ -129,3 +129,15 @@ def test_task_observables_use_reference_frame_conventions(G, oracle_model):
     assert np.allclose(obs[274:274 + 195].reshape(65, 3), disp, atol=1e-6)
     assert np.allclose(obs[469:469 + 260].reshape(65, 4), dq, atol=1e-6)
     assert np.allclose(G['const_terminal'], [50, 200, 1e14])
+
+
+def test_fluid_analysis_api_components_match_reference(G):
+    """flybody_amd/fluid.py (the ellipsoid_fluid_forces API) against the reference's force-component functions."""
+    from flybody_amd.fluid import ellipsoid_local, max_moment
+    size, coefs = G['fl_size'], G['fl_coefs']; dens, visc = G['fl_dens_visc']
+    assert np.allclose([max_moment(size, k) for k in range(3)], G['fl_max_moment'], rtol=1e-14)
+    for c in range(len(G['fl_lvel'])):
+        gf = np.concatenate([[1.0], coefs, G['fl_virtual'][c]])
+        comps, lfrc = ellipsoid_local(G['fl_lvel'][c], size, gf, dens, visc)
+        got = np.concatenate([comps[k] for k in ('fA', 'gA', 'fM', 'fK', 'fD', 'fV', 'gD', 'gV')])
+        assert np.allclose(got, G['fl_components'][c], rtol=1e-11, atol=1e-18) and np.allclose(lfrc, G['fl_local_force'][c], rtol=1e-11, atol=1e-18)
