@@ -93,7 +93,6 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
       int a = d; while (a > b) a = parent[a];
       if (a != b) { delete m; return fail("fb_model_load: bodies are not in DFS order"); }
     }
-    if (parent[b] == 0 && b != 1) { delete m; return fail("fb_model_load: more than one kinematic tree"); }
   }
   m->body_path.assign((size_t)nb*FB_MAXDEPTH, 0);
   for (int b = 1; b < nb; b++) { int a = b; for (int d = m->body_depth[b] - 1; d >= 0; d--) { m->body_path[(size_t)b*FB_MAXDEPTH + d] = a; a = parent[a]; } }
@@ -150,7 +149,10 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     for (int k = 0; k < nv; k++) if (dofpar[k] >= 0) nchild[dofpar[k]]++;
     m->dof_cl.assign(nv, 0);
     for (int k = nv - 2; k >= 0; k--) m->dof_cl[k] = (nchild[k] == 1) ? m->dof_cl[k + 1] + 1 : 0;
-    m->ntrunk = std::min(m->dof_cl[0] + 1, FB_MAXTRUNK);
+    // the trunk optimisation needs ONE dof tree whose root chain is an ancestor of every other dof (free-joint models);
+    // a forest (tethered fly: every limb is its own tree) has no trunk
+    int nroots = 0; for (int k = 0; k < nv; k++) if (dofpar[k] < 0) nroots++;
+    m->ntrunk = (nroots == 1) ? std::min(m->dof_cl[0] + 1, FB_MAXTRUNK) : 0;
     m->dof_gen.assign(nv, -1);
     for (int k = m->ntrunk; k < nv; k++) if (m->dof_ndesc[k] > m->dof_cl[k]) m->dof_gen[k] = m->ngen++;
     if (m->ngen > 15 || m->ngen > FB_MAXGEN) { delete m; return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
@@ -497,6 +499,24 @@ extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const
   M.terminal_com_dist = (decltype(M.terminal_com_dist))terminal_com_dist; M.time_limit = (decltype(M.time_limit))time_limit;
   SETREF(b->M64) SETREF(b->M32)
 #undef SETREF
+  b->have_ref = true;
+  return 0;
+}
+
+extern "C" int fb_batch_set_time_limit(fb_batch* b, double time_limit) {
+  if (!b || !(time_limit > 0)) return fail("fb_batch_set_time_limit: bad arguments");
+  const fb_model* m = b->m;
+  if (m->i("task_id")[0] != 2) return fail("fb_batch_set_time_limit: only the walk_on_ball task has no reference trajectory");
+  HIPCHK(hipSetDevice(b->device));
+  int nobs = 3 + m->na + 3*m->napp + 3 + 3*m->nforce + 3 + 2*m->nobsjnt + m->ntouch + 3 + 3;
+  (void)hipFree(b->obs);
+  HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
+  HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
+  b->nobs = nobs;
+#define SETTL(M) M.nobs = nobs; M.T = 0; M.future_steps = 0; M.episode_steps = 0; M.time_limit = (decltype(M.time_limit))time_limit; \
+  M.terminal_com_dist = (decltype(M.terminal_com_dist))1e30;
+  SETTL(b->M64) SETTL(b->M32)
+#undef SETTL
   b->have_ref = true;
   return 0;
 }

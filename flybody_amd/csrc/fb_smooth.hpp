@@ -112,7 +112,9 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   FB_LDS real* JQ = w.lLD + 7*M.nbody;          // joint rotations: 4*njnt
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
     real q[4] = {1, 0, 0, 0};
-    if (M.jnt_type[j] != JNT_FREE) { int qa = M.jnt_qposadr[j]; axisangle2quat(q, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]); }
+    int jt = M.jnt_type[j], qa = M.jnt_qposadr[j];
+    if (jt == JNT_HINGE) axisangle2quat(q, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]);
+    else if (jt == JNT_BALL) { for (int k = 0; k < 4; k++) q[k] = w.qpos[qa + k]; normquat(q); }
     for (int k = 0; k < 4; k++) JQ[4*j + k] = q[k];
   }
   if (lane == 0) {
@@ -188,6 +190,12 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
         real ax[3] = {R[k-3], R[3+k-3], R[6+k-3]};
         copy3(c, ax); cross3(c + 3, ax, off);
       }
+    } else if (M.jnt_type[j] == JNT_BALL) {
+      // three rotations about the body axes through the anchor
+      int k = i - M.jnt_dofadr[j];
+      const real* R = w.xmat + 9*b;
+      real ax[3] = {R[k], R[3+k], R[6+k]};
+      copy3(c, ax); cross3(c + 3, ax, off);
     } else {
       copy3(c, w.xaxis + 3*j); cross3(c + 3, w.xaxis + 3*j, off);
     }
@@ -208,7 +216,8 @@ __device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real*
   real tot[K];
 #pragma unroll
   for (int k = 0; k < K; k++) tot[k] = 0;
-  for (int b = 1 + lane; b < M.nbody; b += FB_WAVE) {
+  const int nsub1 = (M.nbody > 1) ? M.body_nsub[1] : 0;        // body 1 and its subtree (the fly); further trees take the generic path
+  for (int b = 1 + lane; b < 1 + nsub1; b += FB_WAVE) {
 #pragma unroll
     for (int k = 0; k < K; k++) tot[k] += A[K*b + k];
   }
@@ -568,7 +577,8 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
       int k = i - M.jnt_dofadr[j];
       if (k < 3) { for (int q = 0; q < 6; q++) cd[q] = 0; continue; }
       nprev = 3;             // all three rotational axes see parent + translational velocity only
-    } else nprev = M.dof_depth[i];
+    } else if (M.jnt_type[j] == JNT_BALL) nprev = M.dof_depth[M.jnt_dofadr[j]];     // all three axes see the velocity before the joint
+    else nprev = M.dof_depth[i];
     const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
     real v[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 4

@@ -171,6 +171,15 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
       mulquat(res, q, qr);
       normquat(res);
       for (int k = 0; k < 4; k++) w.qpos[qa+3+k] = res[k];
+    } else if (M.jnt_type[j] == JNT_BALL) {
+      real ax[3] = {w.qvel[da], w.qvel[da+1], w.qvel[da+2]};
+      real n = normalize3(ax);
+      real q[4] = {w.qpos[qa], w.qpos[qa+1], w.qpos[qa+2], w.qpos[qa+3]}, qr[4], res[4];
+      axisangle2quat(qr, ax, n*h);
+      normquat(q);
+      mulquat(res, q, qr);
+      normquat(res);
+      for (int k = 0; k < 4; k++) w.qpos[qa+k] = res[k];
     } else w.qpos[qa] += h*w.qvel[da];
   }
   if (lane == 0) w.simtime[0] += h;
@@ -234,6 +243,7 @@ __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<rea
     for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
   }
   o += 3*M.napp;
+  if (M.task == 2) { if (lane < 3) obs[o + lane] = (float)w.qvel[M.nv - 3 + lane]; o += 3; }      // ball_qvel (walk_on_ball.py:84-90)
   for (int k = lane; k < 3*M.nforce; k += FB_WAVE) obs[o + k] = (float)sm[9 + k];
   o += 3*M.nforce;
   if (lane < 3) obs[o + lane] = (float)sm[3 + lane];
@@ -244,7 +254,7 @@ __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<rea
     obs[o + M.nobsjnt + k] = (float)w.qvel[M.jnt_dofadr[j]];
   }
   o += 2*M.nobsjnt;
-  int nf = M.future_steps + 1;
+  int nf = (M.task == 2) ? 0 : M.future_steps + 1;        // walk_on_ball has no reference observables
   const RefView<real> rv = ref_view(M, w);
   for (int k = lane; k < nf; k += FB_WAVE) {
     real rr[7]; ref_root(rv, step + k, rr);
@@ -253,7 +263,7 @@ __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<rea
     for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
   }
   o += 3*nf;
-  {
+  if (nf > 0) {
     const real* q = w.qpos + 3;
     real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
     real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2};
@@ -396,6 +406,48 @@ __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<re
   if (lane == 0) {
     *reward = (float)rew;
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
+    *step_type = terminating ? 2 : 1;
+    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------ walk_on_ball (fly_envs.py:158-191, tasks/walk_on_ball.py)
+// episode init: default pose with retracted wings (fruitfly.py:390-405); no reference trajectory
+template <typename real>
+__device__ __forceinline__ void d_ball_init(const DevModel<real>& M, const WS<real>& w, int lane) {
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  SYNC();
+  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
+  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
+  SYNC();
+}
+
+// reward: ball spinning at (0, -5, 0) rad/s, linear tolerance with margin 6 per component (walk_on_ball.py:62-73);
+// termination on sensor velocities / qacc (:75-80); discount 0 on termination (base.py:206-210)
+template <typename real>
+__device__ __forceinline__ void d_ball_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
+  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
+  int stepc = w.istate[IS_STEP] + 1;
+  SYNC();
+  if (lane == 0) w.istate[IS_STEP] = stepc;
+  real qn = 0;
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  qn = wave_sum(qn);
+  SYNC();
+  real linvel = norm3(w.sens + 6), angvel = norm3(w.sens + 3);
+  const real* bv = w.qvel + M.nv - 3;
+  real r = tolerance_linear(bv[0], (real)6)*tolerance_linear(bv[1] + (real)5, (real)6)*tolerance_linear(bv[2], (real)6);
+  bool term = (linvel > (real)50) || (angvel > (real)200) || (sqrt(qn) > (real)1e14) || (qn != qn);
+  bool terminating = term || (w.simtime[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  if (lane == 0) {
+    *reward = (float)r;
+    *discount = term ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
     w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
     w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
@@ -562,7 +614,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   int nsub = (mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep, sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   if (resetting) {
-    if (M.task == 1) d_flight_init(M, w, env, lane); else d_walk_init(M, w, env, lane);
+    if (M.task == 1) d_flight_init(M, w, env, lane); else if (M.task == 2) d_ball_init(M, w, lane); else d_walk_init(M, w, env, lane);
     actuate = false; pc = ST_KIN;
   } else if (mode == MODE_FORWARD) {
     pc = ST_KIN;
@@ -670,6 +722,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
       if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
       SYNC();
     } else if (M.task == 1) d_flight_post(M, w, obs, reward, discount, step_type, lane);
+    else if (M.task == 2) d_ball_post(M, w, obs, reward, discount, step_type, lane);
     else d_walk_post(M, w, obs, reward, discount, step_type, lane);
   }
   d_lds_store(M, w, lane);

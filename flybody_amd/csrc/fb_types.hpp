@@ -27,7 +27,7 @@
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
 
-enum { JNT_FREE = 0, JNT_HINGE = 3 };
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
 enum { TRN_JOINT = 0, TRN_TENDON = 3, TRN_BODY = 5 };
 enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };

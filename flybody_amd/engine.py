@@ -59,6 +59,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     L.fb_batch_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32]
     L.fb_batch_set_walk_dataset.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_set_time_limit.argtypes = [C.c_void_p, C.c_double]
     L.fb_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -142,6 +143,12 @@ class Batch:
         m = self.model
         self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
                      7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
+
+    def set_time_limit(self, time_limit: float = 2.0):
+        """walk_on_ball: no reference trajectory, only the episode time limit."""
+        _check(self.L, self.L.fb_batch_set_time_limit(self.h, float(time_limit)))
+        m = self.model
+        self.nobs = 3 + m.dim('na') + 3*m.dim('napp') + 3 + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') + m.dim('ntouch') + 3 + 3
 
     def set_wbpg(self, tables, seed: int = 0):
         t = np.ascontiguousarray(tables['traj'], np.float64); p = np.ascontiguousarray(tables['phase'], np.float64)

@@ -52,14 +52,15 @@ class BoundedArray(Array):
 # reference returns lists the walker observables first and the two task observables last
 # (tests/test_walking_env.py:11-23)
 _DICT_ORDER = ['accelerometer', 'actuator_activation', 'appendages_pos', 'force', 'gyro', 'joints_pos', 'joints_vel',
-               'touch', 'velocimeter', 'world_zaxis', 'ref_displacement', 'ref_root_quat']
+               'touch', 'velocimeter', 'world_zaxis', 'ref_displacement', 'ref_root_quat', 'ball_qvel']
 
 
-def observation_layout(model: engine.Model, future_steps: int):
+def observation_layout(model: engine.Model, future_steps: int, ball: bool = False):
     na, napp, nforce, nobsj, ntouch = (model.dim(k) for k in ('na', 'napp', 'nforce', 'nobsjnt', 'ntouch'))
-    nf = future_steps + 1
+    nf = 0 if ball else future_steps + 1                      # walk_on_ball: no reference observables, ball_qvel instead
     sizes = collections.OrderedDict([
-        ('accelerometer', (3,)), ('actuator_activation', (na,)), ('appendages_pos', (3*napp,)), ('force', (3*nforce,)),
+        ('accelerometer', (3,)), ('actuator_activation', (na,)), ('appendages_pos', (3*napp,)), ('ball_qvel', (3 if ball else 0,)),
+        ('force', (3*nforce,)),
         ('gyro', (3,)), ('joints_pos', (nobsj,)), ('joints_vel', (nobsj,)), ('ref_displacement', (nf, 3)),
         ('ref_root_quat', (nf, 4)), ('touch', (ntouch,)), ('velocimeter', (3,)), ('world_zaxis', (3,))])
     layout = collections.OrderedDict(); off = 0
@@ -105,7 +106,7 @@ class BatchedFlyEnv:
                  wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0):
         arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
         self.task_name = task
-        compiled_filter = 0.01 if task == 'walk_imitation' else 0.0
+        compiled_filter = 0.0 if task == 'flight_imitation' else 0.01
         if (joint_filter > 0) != (compiled_filter > 0):
             raise NotImplementedError('switching the joint filter on/off changes the activation layout: recompile the model '
                                       'with tools/compile_models.py (needs the reference fruitfly.xml)')
@@ -125,6 +126,9 @@ class BatchedFlyEnv:
             self.batch.set_wbpg(wbpg_tables or build_tables(), seed=seed)
             # InferenceFlightTrajectoryLoader default (trajectory_loaders.py:161-163): 200 steps, 20 cm/s, z = 1, pitch -47.5 deg
             qp, qv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+        elif task == 'walk_on_ball':
+            self.batch.set_time_limit(time_limit)             # fly_envs.py:177: 2 s; no reference trajectory
+            qp = qv = None
         elif traj_loader is not None:
             # training mode (fly_envs.py:131-135): the whole dataset lives on the GPU, every environment picks its snippet there
             ds = traj_loader.dataset
@@ -137,7 +141,7 @@ class BatchedFlyEnv:
             qp, qv = default_walking_reference()
         if qp is not None:
             self.task._traj_generator.set_next_trajectory(qp, qv)
-        self.layout, self.nobs = observation_layout(self.model, future_steps)
+        self.layout, self.nobs = observation_layout(self.model, future_steps, ball=(task == 'walk_on_ball'))
         self._torch_views = None
 
     def _apply_reference(self):
@@ -260,6 +264,17 @@ def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
                          joint_filter=joint_filter, future_steps=64, time_limit=10.0, seed=seed, traj_loader=traj_loader,
                          env_id_base=env_id_base)
+
+
+def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, random_state=None, n_env: int = 1, device: int = 0,
+                 precision: int = 32) -> BatchedFlyEnv:
+    """Tethered fly walking on a floating ball: same keyword surface as flybody/fly_envs.py:158-191, plus n_env / device /
+    precision.  Observation = the walker observables + `ball_qvel`; reward = product of linear tolerances on the ball's
+    angular velocity around the target (0, -5, 0) rad/s (tasks/walk_on_ball.py:62-73); 2 s episodes."""
+    if force_actuators or not disable_wings:
+        raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
+    return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=float('inf'), joint_filter=0.01,
+                         future_steps=0, time_limit=2.0, task='walk_on_ball')
 
 
 def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,

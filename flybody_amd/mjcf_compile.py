@@ -37,7 +37,7 @@ import numpy as np
 
 # ----------------------------------------------------------------------------
 # enums shared with include/flybody_engine.h
-JNT_FREE, JNT_HINGE = 0, 3
+JNT_FREE, JNT_BALL, JNT_HINGE = 0, 1, 3
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 4, 5, 6
 TRN_JOINT, TRN_TENDON, TRN_BODY = 0, 3, 5
 DYN_NONE, DYN_FILTER, DYN_FILTEREXACT = 0, 2, 3
@@ -267,10 +267,19 @@ class TaskConfig:
     fluidcoef: Optional[Tuple[float, ...]] = None  # Flying: ellipsoid fluid on *fluid* geoms
     num_user_actions: int = 0
     spawn_pos: Tuple[float, float, float] = (0.0, 0.0, 0.1278)   # fruitfly.py:23
+    tethered: bool = False             # walk_on_ball.py:28-30: the attachment frame's free joint is removed
+    ball: Optional[Tuple[Tuple[float, float, float], float, float]] = None   # arenas/ball.py: (pos, radius, density)
+    thorax_child_excludes: bool = False   # walk_on_ball.py:32-40
 
 
 def walk_imitation_config(joint_filter: float = 0.01) -> TaskConfig:
     return TaskConfig(name='walk_imitation', joint_filter=joint_filter)
+
+
+def walk_on_ball_config() -> TaskConfig:
+    # fly_envs.py:158-191, tasks/walk_on_ball.py:15-48, tasks/arenas/ball.py
+    return TaskConfig(name='walk_on_ball', floor=False, tethered=True, ball=((-0.05, 0.0, -0.419), 0.454, 0.0025),
+                      thorax_child_excludes=True)
 
 
 def flight_imitation_config(joint_filter: float = 0.0) -> TaskConfig:
@@ -358,8 +367,20 @@ class FlyCompiler:
         # free joint with qpos0 = spawn pose.
         thorax = B[self.bname['thorax']]
         thorax.joints = [j for j in thorax.joints if j.get('type') != 'free']
-        thorax.joints.insert(0, {'name': 'root', 'type': 'free', '_class': 'main'})
+        if not cfg.tethered:
+            thorax.joints.insert(0, {'name': 'root', 'type': 'free', '_class': 'main'})
         thorax.pos = np.array(cfg.spawn_pos, float)
+        if cfg.ball is not None:
+            # BallFloor (tasks/arenas/ball.py:62-69): a sphere on a ball joint.  dm_control puts the arena's bodies before
+            # the attached walker; here the ball is the LAST body (its quaternion / dofs are the last entries of qpos / qvel)
+            # so that the fly keeps the body and dof numbering of the other tasks.
+            pos, radius, density = cfg.ball
+            ball = Body('ball', 0, np.array(pos, float), np.array([1., 0, 0, 0]), None)
+            ball.joints.append({'name': 'ball', 'type': 'ball', '_class': 'main'})
+            ball.geoms.append({'name': 'ball', 'type': 'sphere', 'size': repr(float(radius)), 'density': repr(float(density)), '_class': 'main',
+                               'friction': repr(cfg.floor_friction), 'solref': ' '.join(map(repr, cfg.floor_solref)),
+                               'solimp': ' '.join(map(repr, cfg.floor_solimp)), 'condim': '3', 'contype': '1', 'conaffinity': '1'})
+            B.append(ball); self.bname['ball'] = len(B) - 1
 
         self.actuators = []
         for el in self.root.find('actuator'):
@@ -372,7 +393,7 @@ class FlyCompiler:
                                  'joints': [(j.attrib['joint'], float(j.attrib['coef'])) for j in el.findall('joint')]})
         self.excludes = [(e.attrib['body1'], e.attrib['body2']) for e in self.root.find('contact').findall('exclude')]
         self.sensors = [(s.tag, s.attrib['name'], s.attrib['site']) for s in self.root.find('sensor')]
-        self.observable_joints = [j['name'] for b in B for j in b.joints if j.get('type') != 'free']
+        self.observable_joints = [j['name'] for b in B for j in b.joints if j.get('type') not in ('free', 'ball')]
 
         def rm_act(name):
             self.actuators = [a for a in self.actuators if a['name'] != name]
@@ -456,6 +477,11 @@ class FlyCompiler:
                 for g in b.geoms:
                     if g['_class'] == 'adhesion-collision':
                         g['friction'] = str(cfg.claw_friction)
+        if cfg.thorax_child_excludes:
+            ti = self.bname['thorax']
+            for b in B:
+                if b.parent == ti:
+                    self.excludes.append(('thorax', b.name))
         if cfg.wing_leg_excludes:
             for b in B:
                 if _any_in(['coxa', 'femur', 'tibia', 'tarsus', 'claw'], b.name):
@@ -579,16 +605,16 @@ class FlyCompiler:
         for bi, b in enumerate(B):
             body_jntadr[bi] = len(jnt['type']); body_dofadr[bi] = nv
             for j in b.joints:
-                free = j.get('type') == 'free'
-                jnt['type'].append(JNT_FREE if free else JNT_HINGE)
+                free = j.get('type') == 'free'; ballj = j.get('type') == 'ball'
+                jnt['type'].append(JNT_FREE if free else (JNT_BALL if ballj else JNT_HINGE))
                 jnt['qposadr'].append(nq); jnt['dofadr'].append(nv); jnt['bodyid'].append(bi)
                 jnt['name'].append(j['name'])
                 jnt['pos'].append(_floats(j.get('pos', '0 0 0')))
                 ax = _floats(j.get('axis', '0 0 1'))
                 jnt['axis'].append(ax / np.linalg.norm(ax))
                 jnt['stiffness'].append(float(j.get('stiffness', 0)))
-                jnt['damping'].append(0.0 if free else float(j.get('damping', 0)))
-                jnt['armature'].append(0.0 if free else float(j.get('armature', 0)))
+                jnt['damping'].append(0.0 if (free or ballj) else float(j.get('damping', 0)))
+                jnt['armature'].append(0.0 if (free or ballj) else float(j.get('armature', 0)))
                 sd = _floats(j.get('springdamper', '0 0'))
                 jnt['springdamper'].append(sd)
                 rng = _floats(j.get('range', '0 0'))
@@ -597,7 +623,7 @@ class FlyCompiler:
                 limited = (lim == 'true') or (lim == 'auto' and 'range' in j)
                 if lim == 'true' and 'range' not in j:
                     limited = False if free else True
-                jnt['limited'].append(0 if free else int(limited and 'range' in j))
+                jnt['limited'].append(0 if (free or ballj) else int(limited and 'range' in j))
                 jnt['solref'].append(_floats(j.get('solreflimit', '0.02 1')))
                 si = _floats(j.get('solimplimit', '0.9 0.95 0.001 0.5 2'))
                 jnt['solimp'].append(np.concatenate([si, [0.9, 0.95, 0.001, 0.5, 2][len(si):]]))
@@ -608,6 +634,11 @@ class FlyCompiler:
                     for _ in range(6):
                         dof_body.append(bi); dof_jnt.append(len(jnt['type']) - 1)
                     nq += 7; nv += 6
+                elif ballj:
+                    jnt['qpos0'].append(np.array([1., 0, 0, 0])); jnt['qpos_spring'].append(np.array([1., 0, 0, 0]))
+                    for _ in range(3):
+                        dof_body.append(bi); dof_jnt.append(len(jnt['type']) - 1)
+                    nq += 4; nv += 3
                 else:
                     jnt['qpos0'].append(np.array([float(j.get('ref', 0))]))
                     jnt['qpos_spring'].append(np.array([float(j.get('springref', 0))]))
@@ -869,7 +900,7 @@ class FlyCompiler:
         act_order = [names_act[i] for i in self.action_to_ctrl]
         m['wing_action_idx'] = np.array([k for k, n in enumerate(act_order) if 'wing' in n], int)
         m['user_action_idx'] = np.array(len(act_order) if cfg.num_user_actions else -1)
-        m['task_id'] = np.array(1 if cfg.name == 'flight_imitation' else 0)
+        m['task_id'] = np.array({'walk_imitation': 0, 'flight_imitation': 1, 'walk_on_ball': 2}[cfg.name])
         m['com_offset'] = np.array([-0.03697732, 0.00029205, -0.0142447])     # tasks/task_utils.py:237
         m['notes'] = np.array(self.notes)
         m['config_name'] = np.array(cfg.name)
@@ -911,6 +942,10 @@ class FlyCompiler:
                 for k in range(3):
                     dof_axis[d + k] = np.eye(3)[k]; dof_istrans[d + k] = True
                     dof_axis[d + 3 + k] = R[:, k]; dof_isrot[d + 3 + k] = True; dof_anchor[d + 3 + k] = xpos[b]
+            elif m['jnt_type'][j] == JNT_BALL:
+                R = q2mat(xquat[b])
+                for k in range(3):
+                    dof_axis[d + k] = R[:, k]; dof_isrot[d + k] = True; dof_anchor[d + k] = xpos[b] + qrot(xquat[b], m['jnt_pos'][j])
             else:
                 dof_axis[d] = qrot(xquat[b], m['jnt_axis'][j]); dof_isrot[d] = True
                 dof_anchor[d] = xpos[b] + qrot(xquat[b], m['jnt_pos'][j])
@@ -956,6 +991,8 @@ class FlyCompiler:
             d = m['jnt_dofadr'][j]
             if m['jnt_type'][j] == JNT_FREE:
                 diw[d:d + 3] = np.mean(np.diag(Minv)[d:d + 3]); diw[d + 3:d + 6] = np.mean(np.diag(Minv)[d + 3:d + 6])
+            elif m['jnt_type'][j] == JNT_BALL:
+                diw[d:d + 3] = np.mean(np.diag(Minv)[d:d + 3])
             else:
                 diw[d] = Minv[d, d]
         m['dof_invweight0'] = diw

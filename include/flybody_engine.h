@@ -84,6 +84,10 @@ void fb_batch_destroy(fb_batch* b);
 int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const double* ref_qvel, int T,
                            int future_steps, double terminal_com_dist, double time_limit);
 
+/* walk_on_ball (fly_envs.py:158-191): no reference trajectory; only the episode time limit is configurable
+ * (2 s in the reference).  Replaces fb_batch_set_reference for that task. */
+int fb_batch_set_time_limit(fb_batch* b, double time_limit);
+
 /* flight_imitation only: wing-beat pattern generator tables (flybody/tasks/pattern_generators.py:17-129 builds them;
  * flybody_amd/wbpg.py restates it).  traj[rows][6], phase[rows], offset[nfreq+1] (row range of each frequency's
  * sequence), freqs[nfreq]; rate = exp(-dt_ctrl / ctrl_filter); seed keys the per-episode initial phase. */

@@ -23,7 +23,7 @@ extern "C" {
 #define FBO_MAXEFC 192
 #define FBO_NSENSOR 33   /* accel3 gyro3 velo3 force18 touch6 */
 
-enum { FBO_JNT_FREE = 0, FBO_JNT_HINGE = 3 };
+enum { FBO_JNT_FREE = 0, FBO_JNT_BALL = 1, FBO_JNT_HINGE = 3 };
 enum { FBO_GEOM_PLANE = 0, FBO_GEOM_SPHERE = 2, FBO_GEOM_CAPSULE = 3, FBO_GEOM_ELLIPSOID = 4, FBO_GEOM_CYLINDER = 5, FBO_GEOM_BOX = 6 };
 enum { FBO_TRN_JOINT = 0, FBO_TRN_TENDON = 3, FBO_TRN_BODY = 5 };
 enum { FBO_DYN_NONE = 0, FBO_DYN_FILTER = 2, FBO_DYN_FILTEREXACT = 3 };
@@ -147,6 +147,7 @@ void fbo_jac(const fbo_data* d, double* jacp, double* jacr, const double* point,
 /* env level */
 void fbo_env_configure(fbo_data* d, const double* ref_qpos, const double* ref_qvel, int T,
                        int future_steps, double terminal_com_dist, double time_limit);
+void fbo_env_configure_ball(fbo_data* d, double time_limit);      /* walk_on_ball: no reference trajectory */
 void fbo_env_reset(fbo_data* d);
 /* training-mode walk_imitation: snippets of a reference dataset, concatenated row-wise; `select` = trajectory ids to
  * sample from; arrays are copied */

@@ -125,6 +125,10 @@ class OracleData:
         lib().fbo_env_configure(self.h, rq.ctypes.data, rv.ctypes.data, rq.shape[0], future_steps,
                                 float(terminal_com_dist), float(time_limit))
 
+    def configure_ball(self, time_limit=2.0):
+        lib().fbo_env_configure_ball.argtypes = [C.c_void_p, C.c_double]
+        lib().fbo_env_configure_ball(self.h, float(time_limit))
+
     def set_wbpg(self, tables, seed=0):
         t = np.ascontiguousarray(tables['traj'], float); p = np.ascontiguousarray(tables['phase'], float)
         o = np.ascontiguousarray(tables['offset'], np.int32); f = np.ascontiguousarray(tables['beat_freqs'], float)

@@ -52,6 +52,8 @@ static void pack_obs(fbo_data* d, const double* sens_mean) {
     double dif[3]; sub3(dif, d->site_xpos + 3*m->appendage_sites[k], tp);
     mulmatT3(o, R, dif); o += 3;
   }
+  /* ball_qvel (walk_on_ball.py:84-90): the ball joint's dofs are the last three */
+  if (m->task_id == 2) { for (int k = 0; k < 3; k++) *o++ = d->qvel[m->nv - 3 + k]; }
   /* force */
   for (int k = 0; k < 3*m->nforce; k++) *o++ = sens_mean[9 + k];
   /* gyro */
@@ -59,6 +61,7 @@ static void pack_obs(fbo_data* d, const double* sens_mean) {
   /* joints_pos, joints_vel */
   for (int k = 0; k < m->nobsjnt; k++) *o++ = d->qpos[m->jnt_qposadr[m->observable_joints[k]]];
   for (int k = 0; k < m->nobsjnt; k++) *o++ = d->qvel[m->jnt_dofadr[m->observable_joints[k]]];
+  if (m->task_id != 2) {
   /* ref_displacement */
   for (int k = 0; k <= d->future_steps; k++) {
     int idx = d->step_counter + k; if (idx >= d->T) idx = d->T - 1;
@@ -74,6 +77,7 @@ static void pack_obs(fbo_data* d, const double* sens_mean) {
       int idx = d->step_counter + k; if (idx >= d->T) idx = d->T - 1;
       mulquat(o, qi, d->ref_qpos + 7*idx + 3); o += 4;
     }
+  }
   }
   /* touch */
   for (int k = 0; k < m->ntouch; k++) *o++ = sens_mean[9 + 3*m->nforce + k];
@@ -154,6 +158,61 @@ static double tolerance_linear(double x, double margin) {
 
 static void flight_reset(fbo_data* d);
 static void flight_step(fbo_data* d, const double* action);
+
+/* ---- walk_on_ball: fly_envs.py:158-191, tasks/walk_on_ball.py (tethered fly on a floating ball, no reference) ---- */
+void fbo_env_configure_ball(fbo_data* d, double time_limit) {
+  const fbo_model* m = d->m;
+  free(d->obs);
+  d->time_limit = time_limit; d->future_steps = 0; d->T = 0;
+  d->nobs = 3 + m->na + 3*m->napp + 3 + 3*m->nforce + 3 + 2*m->nobsjnt + m->ntouch + 3 + 3;
+  d->obs = (double*)calloc(d->nobs, sizeof(double));
+  d->reset_next = 1;
+}
+
+static void ball_reset(fbo_data* d) {
+  const fbo_model* m = d->m;
+  fbo_reset_state(d);
+  for (int k = 0; k < 6; k++) {                            /* FruitFly.initialize_episode (fruitfly.py:397-403): retract the wings */
+    int qa = m->jnt_qposadr[m->wing_jnt[k]];
+    d->qpos[qa] = m->qpos_spring[qa];
+  }
+  d->step_counter = 0; d->should_terminate = 0; d->reached_traj_end = 0; d->reset_next = 0;
+  fbo_fwd_position(d); fbo_fwd_velocity(d); fbo_sensor_vel(d);
+  memset(d->qfrc_actuator, 0, sizeof(double)*m->nv);
+  memset(d->act_dot, 0, sizeof(double)*(m->na > 0 ? m->na : 1));
+  fbo_fwd_acceleration(d); fbo_fwd_constraint(d); fbo_sensor_acc(d);
+  pack_obs(d, d->sensordata);
+  d->reward = 0; d->discount = 1; d->step_type = 0;
+}
+
+static void ball_step(fbo_data* d, const double* action) {
+  const fbo_model* m = d->m;
+  memset(d->ctrl, 0, sizeof(double)*m->nu);
+  for (int k = 0; k < m->nu; k++) { double a = action[k]; if (a != a) a = 0; d->ctrl[m->action_to_ctrl[k]] = a; }
+  d->step_counter++;
+  memset(d->sensor_acc, 0, sizeof(d->sensor_acc));
+  for (int s = 0; s < m->nsubstep; s++) {
+    fbo_step(d);
+    for (int k = 0; k < FBO_NSENSOR; k++) d->sensor_acc[k] += d->sensordata[k];
+  }
+  double mean[FBO_NSENSOR];
+  for (int k = 0; k < FBO_NSENSOR; k++) mean[k] = d->sensor_acc[k] / m->nsubstep;
+  /* reward (walk_on_ball.py:62-73): ball spinning at (0, -5, 0) rad/s, linear tolerance with margin 6 per component */
+  const double target[3] = {0.0, -5.0, 0.0};
+  double r = 1.0;
+  for (int k = 0; k < 3; k++) r *= tolerance_linear(d->qvel[m->nv - 3 + k] - target[k], 6.0);
+  double linvel = norm3(d->sensordata + 6), angvel = norm3(d->sensordata + 3);
+  double qn = 0;
+  for (int i = 0; i < m->nv; i++) qn += d->qacc[i]*d->qacc[i];
+  d->should_terminate = (linvel > TERMINAL_LINVEL) || (angvel > TERMINAL_ANGVEL) || (sqrt(qn) > TERMINAL_QACC) || (qn != qn);
+  d->reached_traj_end = 0;
+  d->reward = r;
+  d->discount = d->should_terminate ? 0.0 : 1.0;             /* base.py:206-210 */
+  int terminating = d->should_terminate || (d->time >= d->time_limit);
+  pack_obs(d, mean);
+  d->step_type = terminating ? 2 : 1;
+  d->reset_next = terminating;
+}
 
 static void* dupmem(const void* p, size_t n) { void* q = malloc(n ? n : 1); memcpy(q, p, n); return q; }
 
@@ -271,6 +330,7 @@ static double walk_training_reward(fbo_data* d) {
 void fbo_env_reset(fbo_data* d) {
   const fbo_model* m = d->m;
   if (m->task_id == 1) { flight_reset(d); return; }
+  if (m->task_id == 2) { ball_reset(d); return; }
   fbo_reset_state(d);
   if (d->ds_qpos) pick_snippet(d);
   memcpy(d->qpos, d->ref_qpos, sizeof(double)*7);          /* root pose from the reference snippet */
@@ -304,6 +364,7 @@ void fbo_env_step(fbo_data* d, const double* action) {
   const fbo_model* m = d->m;
   if (d->reset_next) { fbo_env_reset(d); return; }
   if (m->task_id == 1) { flight_step(d, action); return; }
+  if (m->task_id == 2) { ball_step(d, action); return; }
   /* before_step */
   memset(d->ctrl, 0, sizeof(double)*m->nu);
   for (int k = 0; k < m->nu; k++) {

@@ -36,15 +36,21 @@ void fbo_kinematics(fbo_data* d) {
       mulquat(xq, d->xquat + 4*p, m->body_quat + 4*b);
     }
     for (int j = ja; j < ja + jn; j++) {
-      /* hinge: anchor & axis in world, then rotate about the axis through the anchor */
+      /* hinge / ball: anchor & axis in world, then rotate about the anchor */
       double* anc = d->xanchor + 3*j; double* axis = d->xaxis + 3*j;
       double t[3];
       rotvecquat(t, m->jnt_pos + 3*j, xq);
       add3(anc, t, xp);
       rotvecquat(axis, m->jnt_axis + 3*j, xq);
-      double ang = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
       double qloc[4], qn[4];
-      axisangle2quat(qloc, m->jnt_axis + 3*j, ang);
+      if (m->jnt_type[j] == FBO_JNT_BALL) {
+        const double* q = d->qpos + m->jnt_qposadr[j];
+        qloc[0] = q[0]; qloc[1] = q[1]; qloc[2] = q[2]; qloc[3] = q[3];
+        normquat(qloc);
+      } else {
+        double ang = d->qpos[m->jnt_qposadr[j]] - m->qpos0[m->jnt_qposadr[j]];
+        axisangle2quat(qloc, m->jnt_axis + 3*j, ang);
+      }
       mulquat(qn, xq, qloc);
       xq[0] = qn[0]; xq[1] = qn[1]; xq[2] = qn[2]; xq[3] = qn[3];
       /* correct for off-centre rotation */
@@ -122,6 +128,14 @@ void fbo_com_pos(fbo_data* d) {
       for (int k = 0; k < 3; k++) {
         double ax[3] = {R[k], R[3+k], R[6+k]};
         double* c = d->cdof + 6*(da+3+k);
+        copy3(c, ax); cross3(c + 3, ax, off);
+      }
+    } else if (m->jnt_type[j] == FBO_JNT_BALL) {
+      /* three rotations about the body axes through the anchor */
+      const double* R = d->xmat + 9*b;
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {R[k], R[3+k], R[6+k]};
+        double* c = d->cdof + 6*(da+k);
         copy3(c, ax); cross3(c + 3, ax, off);
       }
     } else {
@@ -267,6 +281,10 @@ void fbo_com_vel(fbo_data* d) {
         for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6*(da+k) + c] * d->qvel[da+k];
         for (int k = 3; k < 6; k++) crossmotion(d->cdof_dot + 6*(da+k), cvel, d->cdof + 6*(da+k));
         for (int k = 3; k < 6; k++) for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6*(da+k) + c] * d->qvel[da+k];
+      } else if (m->jnt_type[j] == FBO_JNT_BALL) {
+        /* all three axes see the velocity before the joint */
+        for (int k = 0; k < 3; k++) crossmotion(d->cdof_dot + 6*(da+k), cvel, d->cdof + 6*(da+k));
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6*(da+k) + c] * d->qvel[da+k];
       } else {
         crossmotion(d->cdof_dot + 6*da, cvel, d->cdof + 6*da);
         for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6*da + c] * d->qvel[da];

@@ -225,7 +225,8 @@ void fbo_euler(fbo_data* d) {
     if (m->jnt_type[j] == FBO_JNT_FREE) {
       for (int k = 0; k < 3; k++) d->qpos[qa+k] += h*d->qvel[da+k];
       quatintegrate(d->qpos + qa + 3, d->qvel + da + 3, h);
-    } else d->qpos[qa] += h*d->qvel[da];
+    } else if (m->jnt_type[j] == FBO_JNT_BALL) quatintegrate(d->qpos + qa, d->qvel + da, h);
+    else d->qpos[qa] += h*d->qvel[da];
   }
   d->time += h;
 }

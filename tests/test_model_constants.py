@@ -78,7 +78,7 @@ def test_flight_model_dimensions():
 
 def test_observation_layout_matches_reference(walk_arrays):
     from flybody_amd.fly_envs import _DICT_ORDER
-    assert _DICT_ORDER == PINS['walk_env']['obs_names']
+    assert [k for k in _DICT_ORDER if k != 'ball_qvel'] == PINS['walk_env']['obs_names']     # ball_qvel: walk_on_ball only
     a = walk_arrays
     nobs = 3 + 59 + 3*len(a['appendage_sites']) + 3*len(a['sensor_force_sites']) + 3 + 2*len(a['observable_joints']) + 65*7 + len(a['sensor_touch_sites']) + 3 + 3
     assert nobs == PINS['hot_path_dims']['walk']['nobs']

@@ -8,7 +8,7 @@ The .npz files are committed: the GPU box has no /root/reference.
 import argparse, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 from flybody_amd.mjcf_compile import (compile_model, save_model, walk_imitation_config,
-                                      flight_imitation_config)
+                                      flight_imitation_config, walk_on_ball_config)
 
 def main():
     ap = argparse.ArgumentParser()
@@ -16,7 +16,7 @@ def main():
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'flybody_amd', 'assets'))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    for cfg in (walk_imitation_config(), flight_imitation_config()):
+    for cfg in (walk_imitation_config(), flight_imitation_config(), walk_on_ball_config()):
         m = compile_model(a.xml, cfg)
         path = os.path.join(a.out, cfg.name + '.npz')
         save_model(m, path)
