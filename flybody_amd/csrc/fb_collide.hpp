@@ -324,6 +324,7 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, 
 template <typename real>
 __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  PROF_BEGIN();
   // ---- mid phase: bounding spheres
   int ncand = 0;
   const int maxcand = 2*FB_MAXCON_ + 64;
@@ -350,6 +351,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   }
   if (ncand > maxcand) ncand = maxcand;
   SYNC();
+  PROF(25);
   // ---- narrow phase
   int ncon = 0;
   for (int base = 0; base < ncand; base += FB_WAVE) {
@@ -373,4 +375,5 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   if (ncon > FB_MAXCON_) ncon = FB_MAXCON_;
   if (lane == 0) { w.istate[IS_NCON] = ncon; w.istate[IS_NCAND] = ncand; }
   SYNC();
+  PROF(26);
 }

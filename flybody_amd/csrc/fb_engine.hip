@@ -292,7 +292,8 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   }
   for (int i = tid; i < FB_MAXGEN*FB_MAXCH; i += FB_WAVE*FB_EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
-  int wave = tid / FB_WAVE, lane = tid % FB_WAVE;
+  // the wave index is wave-uniform: say so (v_readfirstlane), otherwise every per-environment base address is 64-bit VALU math
+  int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
   int slot = blockIdx.x*FB_EPB + wave;
   if (slot >= nslot) return;
   int env = env_ids ? env_ids[slot] : slot;
