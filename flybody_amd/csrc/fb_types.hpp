@@ -133,7 +133,7 @@ struct WSOff {
 #endif
 
 // LDS copy of the (packed symmetric) Delassus matrix: AR_ROWS*(AR_ROWS+1)/2 <= AR_ELEMS
-template <typename real> struct LdsCfg { static constexpr int AR_ROWS = (sizeof(real) == 4) ? 33 : 22; static constexpr int AR_ELEMS = (sizeof(real) == 4) ? 576 : 256; };
+template <typename real> struct LdsCfg { static constexpr int AR_ROWS = 36; static constexpr int AR_ELEMS = 666; };
 
 template <typename real>
 struct WS {
