@@ -46,6 +46,14 @@ FBD void kbi(const DevModel<real>& M, const real* solref, const real* solimp, re
   if (friction_row) K = 0;
 }
 
+// the dof chain of a body (root first) into registers: FB_MAXCH unconditional loads issued together; slots >= len hold dof 0
+template <typename real>
+FBD void load_chain(const DevModel<real>& M, int body, int* ch) {
+  const int* p = M.body_chain + body*FB_MAXCH;
+#pragma unroll
+  for (int s = 0; s < FB_MAXCH; s++) ch[s] = p[s];
+}
+
 // ------------------------------------------------------------------ rows
 template <typename real>
 __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
@@ -123,15 +131,28 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       int body = side ? b2 : b1;
       real sgn = side ? (real)1 : (real)-1;
       int len = M.body_chlen[body];
-      const int* chain = M.body_chain + body*FB_MAXCH;
-      for (int s = 0; s < FB_MAXCH; s++) {
-        real jp[3] = {0, 0, 0};
-        if (s < len) {
-          const real* c = w.cdof + 6*chain[s];
-          real t[3]; cross3(t, c, off);
-          jp[0] = c[3] + t[0]; jp[1] = c[4] + t[1]; jp[2] = c[5] + t[2];
+      int ch[FB_MAXCH];
+      load_chain(M, body, ch);
+      // motion axes of the chain in chunks of 5 slots: 30 independent gathers per chunk instead of 20 dependent round trips
+#pragma unroll
+      for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
+        real c[5][6];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          const real* cp = w.cdof + 6*((s0 + u < len) ? ch[s0 + u] : 0);
+#pragma unroll
+          for (int k = 0; k < 6; k++) c[u][k] = cp[k];
         }
-        for (int k = 0; k < dim; k++) w.efc_J[JIDX(side, s, adr + k)] = sgn*dot3(frame + 3*k, jp);
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          int sl = s0 + u;
+          real jp[3] = {0, 0, 0};
+          if (sl < len) {
+            real t[3]; cross3(t, c[u], off);
+            jp[0] = c[u][3] + t[0]; jp[1] = c[u][4] + t[1]; jp[2] = c[u][5] + t[2];
+          }
+          for (int k = 0; k < dim; k++) w.efc_J[JIDX(side, sl, adr + k)] = sgn*dot3(frame + 3*k, jp);
+        }
       }
     }
   }
@@ -157,15 +178,16 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
       for (int side = 0; side < 2; side++) {
         int body = side ? w.efc_bB[r] : w.efc_bA[r];
         int len = side ? w.efc_lB[r] : w.efc_lA[r];
-        const int* chain = M.body_chain + body*FB_MAXCH;
+        int chain[FB_MAXCH], rowadr[FB_MAXCH];
+        load_chain(M, body, chain);
         real y[FB_MAXCH];
 #pragma unroll
-        for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0;
+        for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
         // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
 #pragma unroll
         for (int s = FB_MAXCH - 1; s >= 1; s--) {
           if (s < len && y[s] != 0) {
-            const FB_LDS real* row = w.lLD + (int)w.lmadr[chain[s]] + s;
+            const FB_LDS real* row = w.lLD + rowadr[s];
 #pragma unroll
             for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
           }
@@ -199,6 +221,35 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
       yA[s] = valid ? w.efc_Y[JIDX(0, s, c)] : (real)0;
       yB[s] = valid ? w.efc_Y[JIDX(1, s, c)] : (real)0;
     }
+    if (nefc <= FB_WAVE) {
+      // every row's Y, bodies and chain lengths are in the registers of lane == row: the row loop broadcasts them with
+      // v_readlane instead of re-reading them from memory; the shared-prefix lengths of the NEXT row are fetched while
+      // the current row is accumulated
+      const int* common = M.body_common; const int nb = M.nbody;
+      int rbA = rdlane(bA, 0), rbB = rdlane(bB, 0);
+      int cAA = common[rbA*nb + bA], cAB = common[rbA*nb + bB], cBA = common[rbB*nb + bA], cBB = common[rbB*nb + bB];
+      for (int r = 0; r < nefc; r++) {
+        int rlA = rdlane(lA, r), rlB = rdlane(lB, r);
+        int cmAA = min(min(cAA, lA), rlA), cmAB = min(min(cAB, lB), rlA), cmBA = min(min(cBA, lA), rlB), cmBB = min(min(cBB, lB), rlB);
+        if (r + 1 < nefc) {
+          rbA = rdlane(bA, r + 1); rbB = rdlane(bB, r + 1);
+          cAA = common[rbA*nb + bA]; cAB = common[rbA*nb + bB]; cBA = common[rbB*nb + bA]; cBB = common[rbB*nb + bB];
+        }
+        real acc = 0;
+#pragma unroll
+        for (int s = 0; s < FB_MAXCH; s++) {
+          if (s < rlA) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
+        }
+#pragma unroll
+        for (int s = 0; s < FB_MAXCH; s++) {
+          if (s < rlB) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
+        }
+        if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
+          if (c == r) acc += w.efc_R[r];
+          AR[ARIDX(r, c)] = acc;
+        }
+      }
+    } else
     for (int r = 0; r < nefc; r++) {
       real acc = 0;
       for (int side = 0; side < 2; side++) {
@@ -631,16 +682,24 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   }
   PROF_BEGIN();
   // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
+  // (the chain and its four gathers per slot are issued in chunks of 5 slots; slots past the chain read dof 0 and are masked)
   for (int r = lane; r < nefc; r += FB_WAVE) {
     real vel = 0, ja = 0, jw = 0;
     for (int side = 0; side < 2; side++) {
       int body = side ? w.efc_bB[r] : w.efc_bA[r];
       int len = side ? w.efc_lB[r] : w.efc_lA[r];
-      const int* chain = M.body_chain + body*FB_MAXCH;
-      for (int s = 0; s < len; s++) {
-        real j = w.efc_J[JIDX(side, s, r)];
-        int dof = chain[s];
-        vel += j*w.qvel[dof]; ja += j*w.qacc_smooth[dof]; jw += j*w.qacc_ws[dof];
+      int ch[FB_MAXCH];
+      load_chain(M, body, ch);
+#pragma unroll
+      for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
+        real jv[5], qv[5], qs[5], qw[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+          int sl = s0 + u; int dof = (sl < len) ? ch[sl] : 0;
+          jv[u] = w.efc_J[JIDX(side, sl, r)]; qv[u] = w.qvel[dof]; qs[u] = w.qacc_smooth[dof]; qw[u] = w.qacc_ws[dof];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) if (s0 + u < len) { vel += jv[u]*qv[u]; ja += jv[u]*qs[u]; jw += jv[u]*qw[u]; }
       }
     }
     real aref = -w.efc_B[r]*vel - w.efc_K[r]*w.efc_imp[r]*(w.efc_pos[r] - w.efc_margin[r]);
@@ -677,8 +736,40 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   if (nefc <= LdsCfg<real>::AR_ROWS) niter = d_pgs<real, const FB_LDS real*, true>(M, w, (const FB_LDS real*)w.lAR, nefc, lane);
   else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR, nefc, lane);
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR, nefc, lane);
-  for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
   if (lane == 0) w.istate[IS_NITER] = niter;
+  SYNC();
+  if (nefc <= FB_WAVE) {
+    // ---- qfrc_constraint = J^T f, one lane per dof: lane == row keeps (force, last dof of each chain) in registers and
+    // broadcasts them with v_readlane; dof i collects J[side][depth(i)][r] f_r from every row whose chain runs through it
+    // (the chain's last dof lies in i's DFS subtree).  Same summation order as the row-major loop, no global read-modify-write.
+    real fr = (lane < nefc) ? w.efc_force[lane] : (real)0;
+    int eA = -1, eB = -1;
+    if (lane < nefc) {
+      int lA = w.efc_lA[lane], lB = w.efc_lB[lane];
+      if (lA > 0) eA = M.body_chain[w.efc_bA[lane]*FB_MAXCH + lA - 1];
+      if (lB > 0) eB = M.body_chain[w.efc_bB[lane]*FB_MAXCH + lB - 1];
+    }
+    int dep[2], nd[2]; real acc[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; bool has = i < nv; dep[q] = has ? M.dof_depth[i] : 0; nd[q] = has ? M.dof_ndesc[i] : -1; }
+    for (int r = 0; r < nefc; r++) {
+      real f = rdlane(fr, r);
+      if (f == 0) continue;
+      int ea = rdlane(eA, r), eb = rdlane(eB, r);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        int i = lane + q*FB_WAVE;
+        bool onA = nd[q] >= 0 && ea >= i && ea <= i + nd[q], onB = nd[q] >= 0 && eb >= i && eb <= i + nd[q];
+        real ja = w.efc_J[JIDX(0, dep[q], r)], jb = w.efc_J[JIDX(1, dep[q], r)];
+        if (onA) acc[q] += ja*f;
+        if (onB) acc[q] += jb*f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; if (i < nv) { w.qfrc_constraint[i] = acc[q]; w.lx[i] = acc[q]; } }
+    SYNC();
+  } else {
+  for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
   SYNC();
   // ---- qfrc_constraint = J^T f : lane == chain slot, a dof is owned by the lane of its depth
   if (lane < FB_MAXCH) {
@@ -698,6 +789,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   SYNC();
   for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint[i];
   SYNC();
+  }
   PROF(P_CFIN);
   return true;
 }
