@@ -46,14 +46,6 @@ FBD void kbi(const DevModel<real>& M, const real* solref, const real* solimp, re
   if (friction_row) K = 0;
 }
 
-// the dof chain of a body (root first) into registers: FB_MAXCH unconditional loads issued together; slots >= len hold dof 0
-template <typename real>
-FBD void load_chain(const DevModel<real>& M, int body, int* ch) {
-  const int* p = M.body_chain + body*FB_MAXCH;
-#pragma unroll
-  for (int s = 0; s < FB_MAXCH; s++) ch[s] = p[s];
-}
-
 // ------------------------------------------------------------------ rows
 template <typename real>
 __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {

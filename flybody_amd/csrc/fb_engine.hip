@@ -373,6 +373,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
+  { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   UI(wing_act_idx, "wing_action_idx")
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];

@@ -35,6 +35,61 @@
 #endif
 enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_ACT, P_ACC, P_CSETUP, P_PGS, P_NOSLIP, P_CFIN, P_SENS, P_EULER, P_EPI };
 
+// ------------------------------------------------------------------ chain gathers
+// Walking a root->leaf dof chain with `load index, then load data` per slot is a string of dependent memory round trips.
+// These helpers fetch the whole chain first and then gather CH slots at a time with unconditional loads (slots past the
+// chain read dof 0 and are masked), so a chain costs a handful of round trips instead of one or two per slot.
+template <typename real>
+FBD void load_chain(const DevModel<real>& M, int body, int* ch) {
+  const int* p = M.body_chain + body*FB_MAXCH;
+#pragma unroll
+  for (int s = 0; s < FB_MAXCH; s++) ch[s] = p[s];
+}
+// a[0..6) += sum_{s < n} X[6*ch[s] + k] * q[ch[s]]   (summed in slot order; nmax = wave-uniform bound on n)
+template <int CH, typename real>
+FBD void chain_axpy6(const int* ch, int n, int nmax, const real* X, const real* q, real* a) {
+#pragma unroll
+  for (int s0 = 0; s0 < FB_MAXCH; s0 += CH) {
+    if (s0 >= nmax) break;
+    real x[CH][6], qq[CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      int i = (s0 + u < n) ? ch[s0 + u < FB_MAXCH ? s0 + u : 0] : 0;
+      qq[u] = q[i];
+#pragma unroll
+      for (int k = 0; k < 6; k++) x[u][k] = X[6*i + k];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+      if (s0 + u < n) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] += x[u][k]*qq[u];
+      }
+  }
+}
+// a[0..6) += sum_{s < n} (X1[6*ch[s] + k] * q1[ch[s]] + X2[6*ch[s] + k] * q2[ch[s]])
+template <int CH, typename real>
+FBD void chain_axpy6x2(const int* ch, int n, int nmax, const real* X1, const real* q1, const real* X2, const real* q2, real* a) {
+#pragma unroll
+  for (int s0 = 0; s0 < FB_MAXCH; s0 += CH) {
+    if (s0 >= nmax) break;
+    real x1[CH][6], x2[CH][6], qa[CH], qb[CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      int i = (s0 + u < n) ? ch[s0 + u < FB_MAXCH ? s0 + u : 0] : 0;
+      qa[u] = q1[i]; qb[u] = q2[i];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { x1[u][k] = X1[6*i + k]; x2[u][k] = X2[6*i + k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+      if (s0 + u < n) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] += x1[u][k]*qa[u] + x2[u][k]*qb[u];
+      }
+  }
+}
+
 // ------------------------------------------------------------------ kinematics (level-synchronous)
 // Body frames by depth level: a body composes its parent's frame (staged in LDS scratch, 7 values per body) with
 // its own joints.  One environment is one wavefront, so a level boundary costs a fence, not a barrier.  The joint
@@ -256,11 +311,28 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
     real buf[6];
     mulinertvec(buf, w.crb + 10*M.dof_bodyid[i], w.cdof + 6*i);
     real arm = M.dof_armature[i];
-#pragma unroll 4
-    for (int j = i; j >= 0; j = M.dof_parentid[j]) {
-      real v = dot6(w.cdof + 6*j, buf);
-      if (j == i) v += arm;
-      w.qM[adr++] = v;
+    // row i of M: entries for the ancestors of dof i = the first depth(i)+1 slots of its body's chain (slot depth(i) is i itself)
+    int ch[FB_MAXCH]; load_chain(M, M.dof_bodyid[i], ch);
+    int di = M.dof_depth[i];
+#pragma unroll
+    for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
+      if (s0 >= M.chmax) break;
+      real c[5][6];
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const real* cp = w.cdof + 6*((s0 + u <= di) ? ch[s0 + u] : 0);
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[u][k] = cp[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        int sl = s0 + u;
+        if (sl <= di) {
+          real v = dot6(c[u], buf);
+          if (sl == di) v += arm;
+          w.qM[adr + (di - sl)] = v;
+        }
+      }
     }
   }
   SYNC();
@@ -559,33 +631,29 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real v[6] = {0, 0, 0, 0, 0, 0};
     int n = M.body_chlen[b];
-    const int* chain = M.body_chain + b*FB_MAXCH;
-#pragma unroll 4
-    for (int s = 0; s < n; s++) {
-      int i = chain[s];
-      real qv = w.qvel[i];
-      const real* c = w.cdof + 6*i;
-      for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
-    }
+    int ch[FB_MAXCH]; load_chain(M, b, ch);
+    chain_axpy6<4>(ch, n, M.chmax, w.cdof, w.qvel, v);
     for (int k = 0; k < 6; k++) w.cvel[6*b + k] = v[k];
   }
+  SYNC();
+  // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i: the parent body's velocity plus the earlier dofs of the
+  // same body (free joint: its rotational axes see the three translational dofs; ball joint: none of its own dofs)
   for (int i = lane; i < M.nv; i += FB_WAVE) {
-    int j = M.dof_jntid[i];
+    int j = M.dof_jntid[i], b = M.dof_bodyid[i];
     real* cd = w.cdof_dot + 6*i;
-    int nprev;   // number of leading chain dofs whose velocity precedes this dof's axis
+    int first = M.body_dofadr[b], nsame;
     if (M.jnt_type[j] == JNT_FREE) {
       int k = i - M.jnt_dofadr[j];
       if (k < 3) { for (int q = 0; q < 6; q++) cd[q] = 0; continue; }
-      nprev = 3;             // all three rotational axes see parent + translational velocity only
-    } else if (M.jnt_type[j] == JNT_BALL) nprev = M.dof_depth[M.jnt_dofadr[j]];     // all three axes see the velocity before the joint
-    else nprev = M.dof_depth[i];
-    const int* chain = M.body_chain + M.dof_bodyid[i]*FB_MAXCH;
-    real v[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int s = 0; s < nprev; s++) {
-      int a = chain[s];
-      real qv = w.qvel[a];
-      const real* c = w.cdof + 6*a;
+      nsame = M.jnt_dofadr[j] + 3 - first;
+    } else if (M.jnt_type[j] == JNT_BALL) nsame = M.jnt_dofadr[j] - first;
+    else nsame = i - first;
+    real v[6];
+    const real* pv = w.cvel + 6*M.body_parent[b];
+    for (int k = 0; k < 6; k++) v[k] = pv[k];
+    for (int s = 0; s < nsame; s++) {                 // at most 5 (free joint), usually 0..2
+      real qv = w.qvel[first + s];
+      const real* c = w.cdof + 6*(first + s);
       for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
     }
     crossmotion(cd, v, w.cdof + 6*i);
@@ -724,14 +792,8 @@ __device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<rea
     real* out = w.cfrc + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
     int n = M.body_chlen[b];
-    const int* chain = M.body_chain + b*FB_MAXCH;
-#pragma unroll 4
-    for (int s = 0; s < n; s++) {
-      int i = chain[s];
-      real qv = w.qvel[i];
-      const real* c = w.cdof_dot + 6*i;
-      for (int k = 0; k < 6; k++) a[k] += c[k]*qv;
-    }
+    int ch[FB_MAXCH]; load_chain(M, b, ch);
+    chain_axpy6<4>(ch, n, M.chmax, w.cdof_dot, w.qvel, a);
     real t[6], t1[6], t2[6];
     mulinertvec(t, w.cinert + 10*b, a);
     mulinertvec(t1, w.cinert + 10*b, w.cvel + 6*b);

@@ -58,28 +58,38 @@ FBD real ray_site(const real* pos, const real* mat, const real* size, int type, 
 template <typename real>
 __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
   int ncon = w.istate[IS_NCON];
-  // external (contact) wrench per body about the tree CoM: lane == body pulls from the contact list
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+  // wrench of each active contact about the tree CoM, in the lane that owns the contact (at most 64 contacts)
+  int cb1 = -1, cb2 = -1;
+  real cw[6] = {0, 0, 0, 0, 0, 0}, cfn = 0;
+  if (lane < ncon) {
+    int adr = w.con_efc[lane];
+    if (adr >= 0) {
+      int p = w.con_pair[lane];
+      cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
+      cfn = w.efc_force[adr];
+      real lf[3] = {cfn, 0, 0};
+      if (w.con_dim[lane] > 1) { lf[1] = w.efc_force[adr+1]; lf[2] = w.efc_force[adr+2]; }
+      real r[3];
+      mulmatT3(cw + 3, w.con_frame + 9*lane, lf);
+      sub3(r, w.con_pos + 3*lane, w.com);
+      cross3(cw, r, cw + 3);
+    }
+  }
+  // external wrench per body: lane == body, the contacts are broadcast one at a time (in contact order)
+  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
+    int b = b0 + lane;
     real acc[6] = {0, 0, 0, 0, 0, 0};
-    if (b > 0) {
-      for (int c = 0; c < ncon; c++) {
-        int adr = w.con_efc[c];
-        if (adr < 0) continue;
-        int p = w.con_pair[c];
-        int b1 = M.geom_bodyid[M.pair_geom1[p]], b2 = M.geom_bodyid[M.pair_geom2[p]];
-        if (b != b1 && b != b2) continue;
-        real lf[3] = {w.efc_force[adr], 0, 0};
-        if (w.con_dim[c] > 1) { lf[1] = w.efc_force[adr+1]; lf[2] = w.efc_force[adr+2]; }
-        real f[3], r[3], tq[3];
-        mulmatT3(f, w.con_frame + 9*c, lf);
-        sub3(r, w.con_pos + 3*c, w.com);
-        cross3(tq, r, f);
-        real sgn = (b == b2) ? (real)1 : (real)-1;
-        if (b1 == b2) sgn = 0;
-        for (int k = 0; k < 3; k++) { acc[k] += sgn*tq[k]; acc[3+k] += sgn*f[k]; }
+    for (int c = 0; c < ncon; c++) {
+      int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
+      if (rb1 < 0 || rb1 == rb2) continue;
+      real wr[6];
+      for (int k = 0; k < 6; k++) wr[k] = rdlane(cw[k], c);
+      if (b > 0 && (b == rb1 || b == rb2)) {
+        real sgn = (b == rb2) ? (real)1 : (real)-1;
+        for (int k = 0; k < 6; k++) acc[k] += sgn*wr[k];
       }
     }
-    for (int k = 0; k < 6; k++) w.cfrc_ext[6*b + k] = acc[k];
+    if (b < M.nbody) for (int k = 0; k < 6; k++) w.cfrc_ext[6*b + k] = acc[k];
   }
   SYNC();
   // body accelerations (chain walk, now including qacc) and body forces
@@ -88,13 +98,8 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     real* out = w.cfrc + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc[k] = a[k]; } continue; }
     int n = M.body_chlen[b];
-    const int* chain = M.body_chain + b*FB_MAXCH;
-    for (int s = 0; s < n; s++) {
-      int i = chain[s];
-      real qv = w.qvel[i], qa = w.qacc[i];
-      const real* cd = w.cdof_dot + 6*i; const real* c = w.cdof + 6*i;
-      for (int k = 0; k < 6; k++) a[k] += cd[k]*qv + c[k]*qa;
-    }
+    int ch[FB_MAXCH]; load_chain(M, b, ch);
+    chain_axpy6x2<2>(ch, n, M.chmax, w.cdof_dot, w.qvel, w.cdof, w.qacc, a);
     for (int k = 0; k < 6; k++) w.cacc[6*b + k] = a[k];
     real t[6], t1[6], t2[6];
     mulinertvec(t, w.cinert + 10*b, a);
@@ -124,23 +129,21 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
     mulmatT3(w.sens + 9 + 3*k, w.sxmat + 9*s, acc);
   }
-  if (lane >= 16 && lane < 16 + M.ntouch) {
+  {
+    bool on = lane >= 16 && lane < 16 + M.ntouch;
     int k = lane - 16;
-    int s = M.touch_sites[k], b = M.site_bodyid[s];
+    int s = on ? M.touch_sites[k] : 0, b = on ? M.site_bodyid[s] : -2;
     real sum = 0;
     for (int c = 0; c < ncon; c++) {
-      int adr = w.con_efc[c];
-      if (adr < 0) continue;
-      int p = w.con_pair[c];
-      int b1 = M.geom_bodyid[M.pair_geom1[p]], b2 = M.geom_bodyid[M.pair_geom2[p]];
-      if (b != b1 && b != b2) continue;
-      real fn = w.efc_force[adr];
-      if (fn <= 0) continue;
+      int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
+      real fn = rdlane(cfn, c);
+      if (rb1 < 0 || fn <= 0) continue;
+      if (b != rb1 && b != rb2) continue;
       real ray[3]; copy3(ray, w.con_frame + 9*c);
-      if (b == b2) scl3(ray, ray, (real)-1);
+      if (b == rb2) scl3(ray, ray, (real)-1);
       if (ray_site(w.sxpos + 3*s, w.sxmat + 9*s, M.site_size + 3*s, M.site_type[s], w.con_pos + 3*c, ray) >= 0) sum += fn;
     }
-    w.sens[9 + 3*M.nforce + k] = sum;
+    if (on) w.sens[9 + 3*M.nforce + k] = sum;
   }
   SYNC();
 }

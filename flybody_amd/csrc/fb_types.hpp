@@ -60,6 +60,7 @@ struct DevModel {
   const int *fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
   const int *fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
+  int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
   const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
   const int *tendon_adr, *tendon_num, *wrap_dofid;
