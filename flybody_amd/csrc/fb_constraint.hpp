@@ -282,36 +282,42 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
       w.act_dot[aa] = (ctrl - w.act[aa]) / fmax(FB_MINV, M.act_dynprm[i]);
       input = w.act[aa];
     }
+    // flattened transmission record (fb_engine.hip): every dof / moment arm with one round of independent loads
+    int tt = M.act_trntype[i], wn = M.act_wn[i], la = M.act_lenadr[i];
+    int wd[FB_MAXWRAP]; real wc[FB_MAXWRAP], qv[FB_MAXWRAP];
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) { wd[k] = M.act_wdof[FB_MAXWRAP*i + k]; wc[k] = M.act_wcoef[FB_MAXWRAP*i + k]; }
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qvel[wd[k]];
+    real lq = w.qpos[tt == TRN_JOINT ? la : 0];
     real length = 0, vel = 0;
-    int tt = M.act_trntype[i], id = M.act_trnid[i];
-    if (tt == TRN_JOINT) { length = w.qpos[M.jnt_qposadr[id]]; vel = w.qvel[M.jnt_dofadr[id]]; }
-    else if (tt == TRN_TENDON) {
-      length = w.ten_length[id];
-      for (int k = M.tendon_adr[id]; k < M.tendon_adr[id] + M.tendon_num[id]; k++) vel += M.wrap_coef[k]*w.qvel[M.wrap_dofid[k]];
-    }
+    if (tt == TRN_JOINT) length = lq;
+    else if (tt == TRN_TENDON) length = w.ten_length[la];
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) vel += wc[k]*qv[k];
     real force = M.act_gainprm[3*i]*input;
     if (M.act_biastype[i] == 1) force += M.act_biasprm[3*i] + M.act_biasprm[3*i+1]*length + M.act_biasprm[3*i+2]*vel;
     if (M.act_forcelimited[i]) force = clampr(force, M.act_forcerange[2*i], M.act_forcerange[2*i+1]);
     w.act_force[i] = force;
-    // joint / tendon transmissions touch disjoint dofs: plain stores
-    if (tt == TRN_JOINT) w.qfrc_actuator[M.jnt_dofadr[id]] += force;
-    else if (tt == TRN_TENDON)
-      for (int k = M.tendon_adr[id]; k < M.tendon_adr[id] + M.tendon_num[id]; k++) w.qfrc_actuator[M.wrap_dofid[k]] += M.wrap_coef[k]*force;
+    // joint / tendon transmissions own their dofs (checked at model load): plain stores over the zeroed array
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) w.qfrc_actuator[wd[k]] = wc[k]*force;
   }
   SYNC();
   // adhesion (body transmission): pull along the mean contact normal of the body's contacts.
-  // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
+  // lane == contact holds the two bodies, lane == adhesion actuator holds (body, force); both are broadcast by readlane.
   int ncon = w.istate[IS_NCON];
+  int cb1 = 0, cb2 = 0;
+  if (lane < ncon) {
+    int p = w.con_pair[lane];
+    cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
+  }
+  int aid = -1; real aforce = 0;
+  if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force[ai]; }
   for (int a = 0; a < M.nadh; a++) {
-    int ai = M.adh_act[a];
-    int id = M.act_trnid[ai];
-    real force = w.act_force[ai];
-    bool mine = false; int b1 = 0, b2 = 0;
-    if (lane < ncon) {
-      int p = w.con_pair[lane];
-      b1 = M.geom_bodyid[M.pair_geom1[p]]; b2 = M.geom_bodyid[M.pair_geom2[p]];
-      mine = (b1 == id || b2 == id);
-    }
+    int id = rdlane(aid, a);
+    real force = rdlane(aforce, a);
+    bool mine = lane < ncon && (cb1 == id || cb2 == id);
     unsigned long long bal = __ballot(mine);
     int cnt = __popcll(bal);
     if (cnt == 0 || force == 0) continue;
@@ -319,12 +325,12 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
     while (bal) {
       int c = __ffsll((long long)bal) - 1;
       bal &= bal - 1;
-      int p = w.con_pair[c];
-      int cb1 = M.geom_bodyid[M.pair_geom1[p]], cb2 = M.geom_bodyid[M.pair_geom2[p]];
+      int b1c = rdlane(cb1, c), b2c = rdlane(cb2, c);
       real off[3]; sub3(off, w.con_pos + 3*c, w.com);
       const real* nrm = w.con_frame + 9*c;
+      // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
       for (int side = 0; side < 2; side++) {
-        int body = side ? cb2 : cb1;
+        int body = side ? b2c : b1c;
         if (body <= 0) continue;
         if (lane < M.body_chlen[body]) {
           int dof = M.body_chain[body*FB_MAXCH + lane];

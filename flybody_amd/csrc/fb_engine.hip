@@ -34,6 +34,7 @@ struct fb_model {
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
   std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, adh_act;
+  std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
@@ -213,6 +214,35 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
   for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
+  // flattened actuator transmissions and tendon wraps: one padded record per actuator / wrap, so that the kernel fetches
+  // them with a fixed number of independent loads instead of walking tendon_adr -> wrap_dofid -> dof_jntid -> jnt_qposadr
+  {
+    size_t nw_ = 0, c_ = 0;
+    const int *wd = m->i("wrap_dofid", &nw_), *tadr = m->i("tendon_adr"), *tnum = m->i("tendon_num"), *tid = m->i("actuator_trnid");
+    const int *djnt = m->i("dof_jntid"), *jqa = m->i("jnt_qposadr"), *jda = m->i("jnt_dofadr");
+    const double* wc = m->d("wrap_coef", &c_);
+    m->wrap_qadr.assign(std::max<size_t>(nw_, 1), 0);
+    for (size_t k = 0; k < nw_; k++) m->wrap_qadr[k] = jqa[djnt[wd[k]]];
+    for (int t = 0; t < m->ntendon; t++) if (tnum[t] > FB_MAXWRAP) { delete m; return fail("fb_model_load: tendon with more than FB_MAXWRAP joints"); }
+    m->act_wn.assign(m->nu, 0); m->act_lenadr.assign(m->nu, 0);
+    m->act_wdof.assign((size_t)m->nu*FB_MAXWRAP, 0); m->act_wcoef.assign((size_t)m->nu*FB_MAXWRAP, 0.0);
+    std::vector<int> owner(m->nv, -1);
+    for (int k = 0; k < m->nu; k++) {
+      int n_ = 0;
+      if (trn[k] == TRN_JOINT) { m->act_wdof[(size_t)k*FB_MAXWRAP] = jda[tid[k]]; m->act_wcoef[(size_t)k*FB_MAXWRAP] = 1.0; m->act_lenadr[k] = jqa[tid[k]]; n_ = 1; }
+      else if (trn[k] == TRN_TENDON) {
+        for (int q = 0; q < tnum[tid[k]]; q++) { m->act_wdof[(size_t)k*FB_MAXWRAP + q] = wd[tadr[tid[k]] + q]; m->act_wcoef[(size_t)k*FB_MAXWRAP + q] = wc[tadr[tid[k]] + q]; }
+        m->act_lenadr[k] = tid[k]; n_ = tnum[tid[k]];
+      }
+      m->act_wn[k] = n_;
+      // the kernel scatters joint / tendon actuator forces with plain stores (one lane per actuator): dofs must not be shared
+      for (int q = 0; q < n_; q++) {
+        int dq = m->act_wdof[(size_t)k*FB_MAXWRAP + q];
+        if (owner[dq] >= 0) { delete m; return fail("fb_model_load: two joint/tendon actuators drive the same dof"); }
+        owner[dq] = k;
+      }
+    }
+  }
   const double* mass = m->d("body_mass"); const double* inert = m->d("body_inertia");
   // per-body kinematics record: every constant the frame composition of one body needs, contiguous, so that a
   // tree level costs one round of independent loads instead of a chain of table lookups (fb_smooth.hpp: fk_pass)
@@ -383,6 +413,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(act_trntype, "actuator_trntype") UI(act_trnid, "actuator_trnid") UI(act_dyntype, "actuator_dyntype") UI(act_biastype, "actuator_biastype")
   UI(act_ctrllimited, "actuator_ctrllimited") UI(act_forcelimited, "actuator_forcelimited") UI(act_actadr, "actuator_actadr")
   UV(adh_act, adh_act) UI(action_to_ctrl, "action_to_ctrl")
+  UV(wrap_qadr, wrap_qadr) UV(act_wn, act_wn) UV(act_wdof, act_wdof) UV(act_lenadr, act_lenadr)
+  if (upload<real>(b, m->act_wcoef.data(), m->act_wcoef.size(), &M.act_wcoef)) return -1;
   UI(pair_geom1, "pair_geom1") UI(pair_geom2, "pair_geom2") UI(pair_condim, "pair_condim")
   UI(obs_jnt, "observable_joints") UI(app_sites, "appendage_sites") UI(force_sites, "sensor_force_sites") UI(touch_sites, "sensor_touch_sites") UI(wing_jnt, "wing_jnt")
   UD(body_pos, "body_pos") UD(body_quat, "body_quat") UD(body_ipos, "body_ipos") UD(body_iquat, "body_iquat") UD(body_mass, "body_mass")

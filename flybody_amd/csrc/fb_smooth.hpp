@@ -256,9 +256,15 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
     }
   }
   for (int t = lane; t < M.ntendon; t += FB_WAVE) {
+    int adr = M.tendon_adr[t], num = M.tendon_num[t];
+    int qa[FB_MAXWRAP]; real cf[FB_MAXWRAP], qv[FB_MAXWRAP];
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) { int kk = (k < num) ? adr + k : 0; qa[k] = M.wrap_qadr[kk]; cf[k] = M.wrap_coef[kk]; }
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qpos[qa[k]];
     real L = 0;
-    for (int k = M.tendon_adr[t]; k < M.tendon_adr[t] + M.tendon_num[t]; k++)
-      L += M.wrap_coef[k] * w.qpos[M.jnt_qposadr[M.dof_jntid[M.wrap_dofid[k]]]];
+#pragma unroll
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < num) L += cf[k]*qv[k];
     w.ten_length[t] = L;
   }
   SYNC();

@@ -24,6 +24,7 @@
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
 #define FB_NPROF 32
+#define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
 
@@ -66,6 +67,9 @@ struct DevModel {
   const int *tendon_adr, *tendon_num, *wrap_dofid;
   const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
   const int *adh_act;        // [nadh] actuator ids with body transmission
+  const int *wrap_qadr;      // [nwrap] qpos address of the (hinge/slide) joint a tendon wrap reads
+  const int *act_wn, *act_wdof, *act_lenadr;   // flattened transmission: [nu] dof count, [nu][FB_MAXWRAP] dofs (padded with 0), [nu] qpos address (joint) / tendon id
+  const real *act_wcoef;     // [nu][FB_MAXWRAP] moment arms (padded with 0)
   const int *action_to_ctrl;
   const int *pair_geom1, *pair_geom2, *pair_condim;
   const int *obs_jnt, *app_sites, *force_sites, *touch_sites, *wing_jnt;
