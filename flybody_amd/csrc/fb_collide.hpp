@@ -278,12 +278,13 @@ FBD void c_plane_cylinder(LaneContacts<real>& lc, const real* ppos, const real* 
 }
 
 template <typename real>
-FB_STAGE_B void narrow_phase(const DevModel<real>& M, const WS<real>& w, int p, LaneContacts<real>& lc) {
+FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p, LaneContacts<real>& lc) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   real margin = M.pair_margin[p];
-  const real *p1 = w.gxpos + 3*g1, *p2 = w.gxpos + 3*g2;
-  const real *m1 = w.gxmat + 9*g1, *m2 = w.gxmat + 9*g2;
+  const real *p1 = w.gxpos() + 3*g1, *p2 = w.gxpos() + 3*g2;
+  const real *m1 = w.gxmat() + 9*g1, *m2 = w.gxmat() + 9*g2;
   const real *s1 = M.geom_size + 3*g1, *s2 = M.geom_size + 3*g2;
   if (t1 == GEOM_PLANE) {
     real n[3] = {m1[2], m1[5], m1[8]};
@@ -334,9 +335,9 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     if (p < M.npair) {
       int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
       real margin = M.pair_margin[p];
-      real dif[3]; sub3(dif, w.gxpos + 3*g2, w.gxpos + 3*g1);
+      real dif[3]; sub3(dif, w.gxpos() + 3*g2, w.gxpos() + 3*g1);
       if (M.geom_type[g1] == GEOM_PLANE) {
-        const real* m1 = w.gxmat + 9*g1;
+        const real* m1 = w.gxmat() + 9*g1;
         real n[3] = {m1[2], m1[5], m1[8]};
         hit = dot3(dif, n) <= M.geom_rbound[g2] + margin;
       } else {
@@ -346,34 +347,35 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     }
     unsigned long long bal = __ballot(hit);
     int idx = ncand + __popcll(bal & lt_mask);
-    if (hit && idx < maxcand) w.cand[idx] = p;
+    if (hit && idx < maxcand) w.cand()[idx] = p;
     ncand += __popcll(bal);
   }
   if (ncand > maxcand) ncand = maxcand;
   SYNC();
   PROF(25);
-  // ---- narrow phase
+  // ---- narrow phase (not inlined: it gets a copy of the descriptor, the caller's stays in registers)
+  const WS<real> wc = w;
   int ncon = 0;
   for (int base = 0; base < ncand; base += FB_WAVE) {
     LaneContacts<real> lc; lc.n = 0;
     int c = base + lane, p = -1;
-    if (c < ncand) { p = w.cand[c]; narrow_phase(M, w, p, lc); }
+    if (c < ncand) { p = w.cand()[c]; narrow_phase(M, wc, p, lc); }
     int off = ncon + wave_excl_scan(lc.n, lane);
     for (int k = 0; k < lc.n; k++) {
       int ci = off + k;
       if (ci >= FB_MAXCON_) break;
-      w.con_dist[ci] = lc.dist[k];
-      copy3(w.con_pos + 3*ci, lc.pos + 3*k);
+      w.con_dist()[ci] = lc.dist[k];
+      copy3(w.con_pos() + 3*ci, lc.pos + 3*k);
       real f[9];
       copy3(f, lc.nrm + 3*k); f[3] = f[4] = f[5] = f[6] = f[7] = f[8] = 0;
       makeframe(f);
-      for (int q = 0; q < 9; q++) w.con_frame[9*ci + q] = f[q];
-      w.con_pair[ci] = p;
+      for (int q = 0; q < 9; q++) w.con_frame()[9*ci + q] = f[q];
+      w.con_pair()[ci] = p;
     }
     ncon += wave_sum_i(lc.n);
   }
   if (ncon > FB_MAXCON_) ncon = FB_MAXCON_;
-  if (lane == 0) { w.istate[IS_NCON] = ncon; w.istate[IS_NCAND] = ncand; }
+  if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; }
   SYNC();
   PROF(26);
 }

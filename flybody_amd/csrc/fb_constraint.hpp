@@ -55,7 +55,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     int j = base + lane;
     int side = 0; real dist = 0;
     if (j < M.njnt && M.jnt_limited[j] && M.jnt_type[j] == JNT_HINGE) {
-      real value = w.qpos[M.jnt_qposadr[j]];
+      real value = w.qpos()[M.jnt_qposadr[j]];
       real dlo = value - M.jnt_range[2*j], dhi = M.jnt_range[2*j+1] - value;
       if (dlo < M.jnt_margin[j]) { side = -1; dist = dlo; }
       else if (dhi < M.jnt_margin[j]) { side = 1; dist = dhi; }
@@ -65,23 +65,23 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     if (has) {
       int dof = M.jnt_dofadr[j];
       int len = M.dof_depth[dof] + 1;
-      w.efc_type[r] = CN_LIMIT; w.efc_id[r] = j;
-      w.efc_bA[r] = M.jnt_bodyid[j]; w.efc_lA[r] = len; w.efc_bB[r] = 0; w.efc_lB[r] = 0;
-      w.efc_pos[r] = dist; w.efc_margin[r] = M.jnt_margin[j];
-      for (int s = 0; s < FB_MAXCH; s++) { w.efc_J[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0; w.efc_J[JIDX(1, s, r)] = 0; }
+      w.efc_type()[r] = CN_LIMIT; w.efc_id()[r] = j;
+      w.efc_bA()[r] = M.jnt_bodyid[j]; w.efc_lA()[r] = len; w.efc_bB()[r] = 0; w.efc_lB()[r] = 0;
+      w.efc_pos()[r] = dist; w.efc_margin()[r] = M.jnt_margin[j];
+      for (int s = 0; s < FB_MAXCH; s++) { w.efc_J()[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0; w.efc_J()[JIDX(1, s, r)] = 0; }
       real K, B, imp;
       kbi(M, M.jnt_solref + 2*j, M.jnt_solimp + 5*j, dist, M.jnt_margin[j], false, K, B, imp);
-      w.efc_K[r] = K; w.efc_B[r] = B; w.efc_imp[r] = imp; w.efc_mu[r] = 0;
-      w.efc_R[r] = fmax(FB_MINV, (1 - imp)*M.dof_invweight0[dof]/imp);
+      w.efc_K()[r] = K; w.efc_B()[r] = B; w.efc_imp()[r] = imp; w.efc_mu()[r] = 0;
+      w.efc_R()[r] = fmax(FB_MINV, (1 - imp)*M.dof_invweight0[dof]/imp);
     }
     nlimit += wave_sum_i(has);
   }
   // ---- contacts: lane == contact
-  int ncon = w.istate[IS_NCON];
+  int ncon = w.istate()[IS_NCON];
   int dim = 0, p = 0; real dist = 0, incl = 0;
   if (lane < ncon) {
-    p = w.con_pair[lane];
-    dist = w.con_dist[lane];
+    p = w.con_pair()[lane];
+    dist = w.con_dist()[lane];
     incl = M.pair_margin[p] - M.pair_gap[p];
     if (dist < incl) dim = (M.pair_condim[p] == 1) ? 1 : 3;
   }
@@ -94,13 +94,13 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     nefc = __shfl(adr, first, 64);
     if (lane >= first) dim = 0;
   }
-  if (lane < ncon) { w.con_efc[lane] = dim ? adr : -1; w.con_dim[lane] = dim; }
+  if (lane < ncon) { w.con_efc()[lane] = dim ? adr : -1; w.con_dim()[lane] = dim; }
   if (dim) {
     int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
     int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-    const real* pos = w.con_pos + 3*lane;
-    const real* frame = w.con_frame + 9*lane;
-    real off[3]; sub3(off, pos, w.com);
+    const real* pos = w.con_pos() + 3*lane;
+    const real* frame = w.con_frame() + 9*lane;
+    real off[3]; sub3(off, pos, w.com());
     real K, B, imp;
     kbi(M, M.pair_solref + 2*p, M.pair_solimp + 5*p, dist, incl, false, K, B, imp);
     real tran = M.body_invweight0[2*b1] + M.body_invweight0[2*b2];
@@ -111,13 +111,13 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     real R2 = R1*fr[0]*fr[0]/(fr[1]*fr[1]);
     for (int k = 0; k < dim; k++) {
       int r = adr + k;
-      w.efc_type[r] = (dim == 1) ? CN_FRICTIONLESS : CN_ELLIPTIC; w.efc_id[r] = lane;
-      w.efc_bA[r] = b1; w.efc_bB[r] = b2;
-      w.efc_lA[r] = M.body_chlen[b1]; w.efc_lB[r] = M.body_chlen[b2];
-      w.efc_pos[r] = dist; w.efc_margin[r] = incl;
-      w.efc_K[r] = (k == 0) ? K : (real)0; w.efc_B[r] = B; w.efc_imp[r] = imp;
-      w.efc_R[r] = (k == 0) ? R0 : (k == 1 ? R1 : R2);
-      w.efc_mu[r] = mu;
+      w.efc_type()[r] = (dim == 1) ? CN_FRICTIONLESS : CN_ELLIPTIC; w.efc_id()[r] = lane;
+      w.efc_bA()[r] = b1; w.efc_bB()[r] = b2;
+      w.efc_lA()[r] = M.body_chlen[b1]; w.efc_lB()[r] = M.body_chlen[b2];
+      w.efc_pos()[r] = dist; w.efc_margin()[r] = incl;
+      w.efc_K()[r] = (k == 0) ? K : (real)0; w.efc_B()[r] = B; w.efc_imp()[r] = imp;
+      w.efc_R()[r] = (k == 0) ? R0 : (k == 1 ? R1 : R2);
+      w.efc_mu()[r] = mu;
     }
     for (int side = 0; side < 2; side++) {
       int body = side ? b2 : b1;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
         real c[5][6];
 #pragma unroll
         for (int u = 0; u < 5; u++) {
-          const real* cp = w.cdof + 6*((s0 + u < len) ? ch[s0 + u] : 0);
+          const real* cp = w.cdof() + 6*((s0 + u < len) ? ch[s0 + u] : 0);
 #pragma unroll
           for (int k = 0; k < 6; k++) c[u][k] = cp[k];
         }
@@ -143,14 +143,14 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
             real t[3]; cross3(t, c[u], off);
             jp[0] = c[u][3] + t[0]; jp[1] = c[u][4] + t[1]; jp[2] = c[u][5] + t[2];
           }
-          for (int k = 0; k < dim; k++) w.efc_J[JIDX(side, sl, adr + k)] = sgn*dot3(frame + 3*k, jp);
+          for (int k = 0; k < dim; k++) w.efc_J()[JIDX(side, sl, adr + k)] = sgn*dot3(frame + 3*k, jp);
         }
       }
     }
   }
-  if (lane == 0) { w.istate[IS_NEFC] = nefc; w.istate[IS_NLIMIT] = nlimit; }
+  if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; }
   SYNC();
-  for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D[r] = (real)1 / w.efc_R[r];
+  for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D()[r] = (real)1 / w.efc_R()[r];
 }
 
 // the Delassus matrix is symmetric: packed lower triangle, element (r, c), r >= c, at r(r+1)/2 + c
@@ -162,19 +162,19 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
 // ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
 template <typename real>
 __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
-  int nefc = w.istate[IS_NEFC];
+  int nefc = w.istate()[IS_NEFC];
   if (nefc == 0) return;
   for (int base = 0; base < nefc; base += FB_WAVE) {
     int r = base + lane;
     if (r < nefc) {
       for (int side = 0; side < 2; side++) {
-        int body = side ? w.efc_bB[r] : w.efc_bA[r];
-        int len = side ? w.efc_lB[r] : w.efc_lA[r];
+        int body = side ? w.efc_bB()[r] : w.efc_bA()[r];
+        int len = side ? w.efc_lB()[r] : w.efc_lA()[r];
         int chain[FB_MAXCH], rowadr[FB_MAXCH];
         load_chain(M, body, chain);
         real y[FB_MAXCH];
 #pragma unroll
-        for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
+        for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
         // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
 #pragma unroll
         for (int s = FB_MAXCH - 1; s >= 1; s--) {
@@ -188,30 +188,32 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
         for (int s = 0; s < FB_MAXCH; s++) {
           real v = 0;
           if (s < len) v = y[s] * sqrt(w.lDinv[chain[s]]);
-          w.efc_Y[JIDX(side, s, r)] = v;
+          w.efc_Y()[JIDX(side, s, r)] = v;
         }
       }
     }
   }
   SYNC();
   // AR lives in LDS when it fits, otherwise in the environment's global workspace
-  if (nefc <= LdsCfg<real>::AR_ROWS) d_build_AR(M, w, w.lAR, nefc, lane);
-  else d_build_AR(M, w, w.AR, nefc, lane);
+  const WS<real> wc = w;                 // the callee is not inlined: hand it a copy, the caller's descriptor stays in registers
+  if (nefc <= LdsCfg<real>::AR_ROWS) d_build_AR(M, wc, w.lAR, nefc, lane);
+  else d_build_AR(M, wc, w.AR(), nefc, lane);
 }
 
 template <typename real, typename ARP>
-FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+FB_STAGE_B void d_build_AR(const DevModel<real>& M_, const WS<real>& w_, ARP AR, int nefc, int lane) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;
     bool valid = c < nefc;
     real yA[FB_MAXCH], yB[FB_MAXCH];
     int bA = 0, bB = 0, lA = 0, lB = 0;
-    if (valid) { bA = w.efc_bA[c]; bB = w.efc_bB[c]; lA = w.efc_lA[c]; lB = w.efc_lB[c]; }
+    if (valid) { bA = w.efc_bA()[c]; bB = w.efc_bB()[c]; lA = w.efc_lA()[c]; lB = w.efc_lB()[c]; }
 #pragma unroll
     for (int s = 0; s < FB_MAXCH; s++) {
-      yA[s] = valid ? w.efc_Y[JIDX(0, s, c)] : (real)0;
-      yB[s] = valid ? w.efc_Y[JIDX(1, s, c)] : (real)0;
+      yA[s] = valid ? w.efc_Y()[JIDX(0, s, c)] : (real)0;
+      yB[s] = valid ? w.efc_Y()[JIDX(1, s, c)] : (real)0;
     }
     if (nefc <= FB_WAVE) {
       // every row's Y, bodies and chain lengths are in the registers of lane == row: the row loop broadcasts them with
@@ -237,7 +239,7 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
           if (s < rlB) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
         }
         if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
-          if (c == r) acc += w.efc_R[r];
+          if (c == r) acc += w.efc_R()[r];
           AR[ARIDX(r, c)] = acc;
         }
       }
@@ -245,22 +247,22 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
     for (int r = 0; r < nefc; r++) {
       real acc = 0;
       for (int side = 0; side < 2; side++) {
-        int rb = side ? w.efc_bB[r] : w.efc_bA[r];
-        int rl = side ? w.efc_lB[r] : w.efc_lA[r];
+        int rb = side ? w.efc_bB()[r] : w.efc_bA()[r];
+        int rl = side ? w.efc_lB()[r] : w.efc_lA()[r];
         if (rl == 0) continue;
         int cmA = min(min(M.body_common[rb*M.nbody + bA], lA), rl);
         int cmB = min(min(M.body_common[rb*M.nbody + bB], lB), rl);
 #pragma unroll
         for (int s = 0; s < FB_MAXCH; s++) {
           if (s < rl) {
-            real yr = w.efc_Y[JIDX(side, s, r)];
+            real yr = w.efc_Y()[JIDX(side, s, r)];
             if (s < cmA) acc += yr*yA[s];
             if (s < cmB) acc += yr*yB[s];
           }
         }
       }
       if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
-        if (c == r) acc += w.efc_R[r];
+        if (c == r) acc += w.efc_R()[r];
         AR[ARIDX(r, c)] = acc;
       }
     }
@@ -271,16 +273,16 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, i
 // ------------------------------------------------------------------ adhesion + actuator forces
 template <typename real>
 __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator()[i] = 0;
   SYNC();
   for (int i = lane; i < M.nu; i += FB_WAVE) {
-    real ctrl = w.ctrl[i];
+    real ctrl = w.ctrl()[i];
     if (M.act_ctrllimited[i]) ctrl = clampr(ctrl, M.act_ctrlrange[2*i], M.act_ctrlrange[2*i+1]);
     real input = ctrl;
     int aa = M.act_actadr[i];
     if (aa >= 0) {
-      w.act_dot[aa] = (ctrl - w.act[aa]) / fmax(FB_MINV, M.act_dynprm[i]);
-      input = w.act[aa];
+      w.act_dot()[aa] = (ctrl - w.act()[aa]) / fmax(FB_MINV, M.act_dynprm[i]);
+      input = w.act()[aa];
     }
     // flattened transmission record (fb_engine.hip): every dof / moment arm with one round of independent loads
     int tt = M.act_trntype[i], wn = M.act_wn[i], la = M.act_lenadr[i];
@@ -288,32 +290,32 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) { wd[k] = M.act_wdof[FB_MAXWRAP*i + k]; wc[k] = M.act_wcoef[FB_MAXWRAP*i + k]; }
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qvel[wd[k]];
-    real lq = w.qpos[tt == TRN_JOINT ? la : 0];
+    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qvel()[wd[k]];
+    real lq = w.qpos()[tt == TRN_JOINT ? la : 0];
     real length = 0, vel = 0;
     if (tt == TRN_JOINT) length = lq;
-    else if (tt == TRN_TENDON) length = w.ten_length[la];
+    else if (tt == TRN_TENDON) length = w.ten_length()[la];
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) vel += wc[k]*qv[k];
     real force = M.act_gainprm[3*i]*input;
     if (M.act_biastype[i] == 1) force += M.act_biasprm[3*i] + M.act_biasprm[3*i+1]*length + M.act_biasprm[3*i+2]*vel;
     if (M.act_forcelimited[i]) force = clampr(force, M.act_forcerange[2*i], M.act_forcerange[2*i+1]);
-    w.act_force[i] = force;
+    w.act_force()[i] = force;
     // joint / tendon transmissions own their dofs (checked at model load): plain stores over the zeroed array
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) w.qfrc_actuator[wd[k]] = wc[k]*force;
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) w.qfrc_actuator()[wd[k]] = wc[k]*force;
   }
   SYNC();
   // adhesion (body transmission): pull along the mean contact normal of the body's contacts.
   // lane == contact holds the two bodies, lane == adhesion actuator holds (body, force); both are broadcast by readlane.
-  int ncon = w.istate[IS_NCON];
+  int ncon = w.istate()[IS_NCON];
   int cb1 = 0, cb2 = 0;
   if (lane < ncon) {
-    int p = w.con_pair[lane];
+    int p = w.con_pair()[lane];
     cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
   }
   int aid = -1; real aforce = 0;
-  if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force[ai]; }
+  if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force()[ai]; }
   for (int a = 0; a < M.nadh; a++) {
     int id = rdlane(aid, a);
     real force = rdlane(aforce, a);
@@ -326,18 +328,18 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
       int c = __ffsll((long long)bal) - 1;
       bal &= bal - 1;
       int b1c = rdlane(cb1, c), b2c = rdlane(cb2, c);
-      real off[3]; sub3(off, w.con_pos + 3*c, w.com);
-      const real* nrm = w.con_frame + 9*c;
+      real off[3]; sub3(off, w.con_pos() + 3*c, w.com());
+      const real* nrm = w.con_frame() + 9*c;
       // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
       for (int side = 0; side < 2; side++) {
         int body = side ? b2c : b1c;
         if (body <= 0) continue;
         if (lane < M.body_chlen[body]) {
           int dof = M.body_chain[body*FB_MAXCH + lane];
-          const real* cd = w.cdof + 6*dof;
+          const real* cd = w.cdof() + 6*dof;
           real t[3]; cross3(t, cd, off);
           real jp[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-          w.qfrc_actuator[dof] += (side ? scale : -scale)*dot3(nrm, jp);
+          w.qfrc_actuator()[dof] += (side ? scale : -scale)*dot3(nrm, jp);
         }
       }
     }
@@ -441,10 +443,10 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   R3<double> res;
   rla.v0 = 0; rla.v1 = 0; rla.v2 = 0;
   R3<int> rtype;
-  r3_load<S>(f, w.efc_force, nefc, lane, (real)0);
-  r3_load<S>(rb, w.efc_b, nefc, lane, (real)0);
-  r3_load<S>(rR, w.efc_R, nefc, lane, (real)0);
-  r3_load<S>(rtype, w.efc_type, nefc, lane, 0);
+  r3_load<S>(f, w.efc_force(), nefc, lane, (real)0);
+  r3_load<S>(rb, w.efc_b(), nefc, lane, (real)0);
+  r3_load<S>(rR, w.efc_R(), nefc, lane, (real)0);
+  r3_load<S>(rtype, w.efc_type(), nefc, lane, 0);
   rdiag.v0 = (lane < nefc) ? AR[ARIDX(lane, lane)] : (real)1;
   rdiag.v1 = (!S && lane + 64 < nefc) ? AR[ARIDX(lane + 64, lane + 64)] : (real)1;
   rdiag.v2 = (!S && lane + 128 < nefc) ? AR[ARIDX(lane + 128, lane + 128)] : (real)1;
@@ -454,7 +456,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
       a0[q] = 1; a1[q] = 1;
-      if (r < nefc && w.efc_type[r] == CN_ELLIPTIC) { const real* fr = M.pair_friction + 5*w.con_pair[w.efc_id[r]]; a0[q] = fr[0]; a1[q] = fr[1]; }
+      if (r < nefc && w.efc_type()[r] == CN_ELLIPTIC) { const real* fr = M.pair_friction + 5*w.con_pair()[w.efc_id()[r]]; a0[q] = fr[0]; a1[q] = fr[1]; }
     }
     rfr0.v0 = a0[0]; rfr0.v1 = a0[1]; rfr0.v2 = a0[2]; rfr1.v0 = a1[0]; rfr1.v1 = a1[1]; rfr1.v2 = a1[2];
   }
@@ -480,7 +482,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
       for (int u = 0; u < 13; u++) t[u][q] = 0;
-      bool first = r < nefc && w.efc_type[r] == CN_ELLIPTIC && w.con_efc[w.efc_id[r]] == r;
+      bool first = r < nefc && w.efc_type()[r] == CN_ELLIPTIC && w.con_efc()[w.efc_id()[r]] == r;
       if (first) {
         real a00 = AR[ARIDX(r, r)], a01 = AR[ARIDX(r + 1, r)], a02 = AR[ARIDX(r + 2, r)];
         real a11 = AR[ARIDX(r + 1, r + 1)], a12 = AR[ARIDX(r + 2, r + 1)], a22 = AR[ARIDX(r + 2, r + 2)];
@@ -621,12 +623,12 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     if (improvement*scale < M.tolerance) break;
   }
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
-  if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[31] += bt_[4]; pp_[16] += bt_[0]; pp_[22] += bt_[1]; pp_[23] += bt_[2]; }
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[31] += bt_[4]; pp_[16] += bt_[0]; pp_[22] += bt_[1]; pp_[23] += bt_[2]; }
 #endif
   PROF(P_PGS);
   // ---- noslip: friction dims only, regularisation removed; lane == contact keeps its row address
-  int ncon = w.istate[IS_NCON];
-  int my_efc = (lane < ncon && w.con_dim[lane] > 1) ? w.con_efc[lane] : -1;
+  int ncon = w.istate()[IS_NCON];
+  int my_efc = (lane < ncon && w.con_dim()[lane] > 1) ? w.con_efc()[lane] : -1;
   for (int it = 0; it < M.noslip_iterations; it++) {
     real improvement = 0;
     for (int c = 0; c < ncon; c++) {
@@ -659,10 +661,10 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     if (improvement*scale < M.noslip_tolerance) break;
   }
   PROF(P_NOSLIP);
-  if (lane < nefc) w.efc_force[lane] = f.v0;
+  if (lane < nefc) w.efc_force()[lane] = f.v0;
   if (!S) {
-    if (lane + 64 < nefc) w.efc_force[lane + 64] = f.v1;
-    if (lane + 128 < nefc) w.efc_force[lane + 128] = f.v2;
+    if (lane + 64 < nefc) w.efc_force()[lane + 64] = f.v1;
+    if (lane + 128 < nefc) w.efc_force()[lane + 128] = f.v2;
   }
   return niter;
 }
@@ -670,11 +672,11 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
 template <typename real>
 __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS<real>& w, int lane) {
   // returns true when lx holds J^T f and the caller must run the M^-1 solve before d_constraint_b
-  int nefc = w.istate[IS_NEFC];
+  int nefc = w.istate()[IS_NEFC];
   int nv = M.nv;
   if (nefc == 0) {
-    for (int i = lane; i < nv; i += FB_WAVE) { w.lx[i] = 0; w.qfrc_constraint[i] = 0; }
-    if (lane == 0) w.istate[IS_NITER] = 0;
+    for (int i = lane; i < nv; i += FB_WAVE) { w.lx[i] = 0; w.qfrc_constraint()[i] = 0; }
+    if (lane == 0) w.istate()[IS_NITER] = 0;
     SYNC();
     return false;
   }
@@ -684,8 +686,8 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   for (int r = lane; r < nefc; r += FB_WAVE) {
     real vel = 0, ja = 0, jw = 0;
     for (int side = 0; side < 2; side++) {
-      int body = side ? w.efc_bB[r] : w.efc_bA[r];
-      int len = side ? w.efc_lB[r] : w.efc_lA[r];
+      int body = side ? w.efc_bB()[r] : w.efc_bA()[r];
+      int len = side ? w.efc_lB()[r] : w.efc_lA()[r];
       int ch[FB_MAXCH];
       load_chain(M, body, ch);
 #pragma unroll
@@ -694,58 +696,58 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
 #pragma unroll
         for (int u = 0; u < 5; u++) {
           int sl = s0 + u; int dof = (sl < len) ? ch[sl] : 0;
-          jv[u] = w.efc_J[JIDX(side, sl, r)]; qv[u] = w.qvel[dof]; qs[u] = w.qacc_smooth[dof]; qw[u] = w.qacc_ws[dof];
+          jv[u] = w.efc_J()[JIDX(side, sl, r)]; qv[u] = w.qvel()[dof]; qs[u] = w.qacc_smooth()[dof]; qw[u] = w.qacc_ws()[dof];
         }
 #pragma unroll
         for (int u = 0; u < 5; u++) if (s0 + u < len) { vel += jv[u]*qv[u]; ja += jv[u]*qs[u]; jw += jv[u]*qw[u]; }
       }
     }
-    real aref = -w.efc_B[r]*vel - w.efc_K[r]*w.efc_imp[r]*(w.efc_pos[r] - w.efc_margin[r]);
-    w.efc_vel[r] = vel; w.efc_aref[r] = aref; w.efc_b[r] = ja - aref; w.efc_jar[r] = jw - aref;
+    real aref = -w.efc_B()[r]*vel - w.efc_K()[r]*w.efc_imp()[r]*(w.efc_pos()[r] - w.efc_margin()[r]);
+    w.efc_vel()[r] = vel; w.efc_aref()[r] = aref; w.efc_b()[r] = ja - aref; w.efc_jar()[r] = jw - aref;
   }
   SYNC();
   // ---- warm start: force implied by the previous acceleration (primal map)
   for (int r = lane; r < nefc; r += FB_WAVE) {
-    int type = w.efc_type[r];
-    if (type != CN_ELLIPTIC) { real jar = w.efc_jar[r]; w.efc_force[r] = jar < 0 ? -w.efc_D[r]*jar : (real)0; }
+    int type = w.efc_type()[r];
+    if (type != CN_ELLIPTIC) { real jar = w.efc_jar()[r]; w.efc_force()[r] = jar < 0 ? -w.efc_D()[r]*jar : (real)0; }
     else {
-      int c = w.efc_id[r];
-      if (w.con_efc[c] != r) continue;        // first row of the contact handles the block
-      const real* fr = M.pair_friction + 5*w.con_pair[c];
-      real mu = w.efc_mu[r];
-      real j0 = w.efc_jar[r], j1 = w.efc_jar[r+1], j2 = w.efc_jar[r+2];
+      int c = w.efc_id()[r];
+      if (w.con_efc()[c] != r) continue;        // first row of the contact handles the block
+      const real* fr = M.pair_friction + 5*w.con_pair()[c];
+      real mu = w.efc_mu()[r];
+      real j0 = w.efc_jar()[r], j1 = w.efc_jar()[r+1], j2 = w.efc_jar()[r+2];
       real U0 = j0*mu, U1 = j1*fr[0], U2 = j2*fr[1];
       real N = U0, T = sqrt(U1*U1 + U2*U2);
       real f0, f1, f2;
       if (N >= mu*T || (T <= 0 && N >= 0)) { f0 = f1 = f2 = 0; }
-      else if (mu*N + T <= 0 || (T <= 0 && N < 0)) { f0 = -w.efc_D[r]*j0; f1 = -w.efc_D[r+1]*j1; f2 = -w.efc_D[r+2]*j2; }
+      else if (mu*N + T <= 0 || (T <= 0 && N < 0)) { f0 = -w.efc_D()[r]*j0; f1 = -w.efc_D()[r+1]*j1; f2 = -w.efc_D()[r+2]*j2; }
       else {
-        real Dm = w.efc_D[r] / fmax(FB_MINV, mu*mu*(1 + mu*mu));
+        real Dm = w.efc_D()[r] / fmax(FB_MINV, mu*mu*(1 + mu*mu));
         real NT = N - mu*T;
         f0 = -Dm*NT*mu;
         f1 = -f0/T*U1*fr[0];
         f2 = -f0/T*U2*fr[1];
       }
-      w.efc_force[r] = f0; w.efc_force[r+1] = f1; w.efc_force[r+2] = f2;
+      w.efc_force()[r] = f0; w.efc_force()[r+1] = f1; w.efc_force()[r+2] = f2;
     }
   }
   SYNC();
   int niter;
   if (nefc <= LdsCfg<real>::AR_ROWS) niter = d_pgs<real, const FB_LDS real*, true>(M, w, (const FB_LDS real*)w.lAR, nefc, lane);
-  else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR, nefc, lane);
-  else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR, nefc, lane);
-  if (lane == 0) w.istate[IS_NITER] = niter;
+  else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane);
+  else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
+  if (lane == 0) w.istate()[IS_NITER] = niter;
   SYNC();
   if (nefc <= FB_WAVE) {
     // ---- qfrc_constraint = J^T f, one lane per dof: lane == row keeps (force, last dof of each chain) in registers and
     // broadcasts them with v_readlane; dof i collects J[side][depth(i)][r] f_r from every row whose chain runs through it
     // (the chain's last dof lies in i's DFS subtree).  Same summation order as the row-major loop, no global read-modify-write.
-    real fr = (lane < nefc) ? w.efc_force[lane] : (real)0;
+    real fr = (lane < nefc) ? w.efc_force()[lane] : (real)0;
     int eA = -1, eB = -1;
     if (lane < nefc) {
-      int lA = w.efc_lA[lane], lB = w.efc_lB[lane];
-      if (lA > 0) eA = M.body_chain[w.efc_bA[lane]*FB_MAXCH + lA - 1];
-      if (lB > 0) eB = M.body_chain[w.efc_bB[lane]*FB_MAXCH + lB - 1];
+      int lA = w.efc_lA()[lane], lB = w.efc_lB()[lane];
+      if (lA > 0) eA = M.body_chain[w.efc_bA()[lane]*FB_MAXCH + lA - 1];
+      if (lB > 0) eB = M.body_chain[w.efc_bB()[lane]*FB_MAXCH + lB - 1];
     }
     int dep[2], nd[2]; real acc[2] = {0, 0};
 #pragma unroll
@@ -758,34 +760,34 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
       for (int q = 0; q < 2; q++) {
         int i = lane + q*FB_WAVE;
         bool onA = nd[q] >= 0 && ea >= i && ea <= i + nd[q], onB = nd[q] >= 0 && eb >= i && eb <= i + nd[q];
-        real ja = w.efc_J[JIDX(0, dep[q], r)], jb = w.efc_J[JIDX(1, dep[q], r)];
+        real ja = w.efc_J()[JIDX(0, dep[q], r)], jb = w.efc_J()[JIDX(1, dep[q], r)];
         if (onA) acc[q] += ja*f;
         if (onB) acc[q] += jb*f;
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; if (i < nv) { w.qfrc_constraint[i] = acc[q]; w.lx[i] = acc[q]; } }
+    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; if (i < nv) { w.qfrc_constraint()[i] = acc[q]; w.lx[i] = acc[q]; } }
     SYNC();
   } else {
-  for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint[i] = 0;
+  for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint()[i] = 0;
   SYNC();
   // ---- qfrc_constraint = J^T f : lane == chain slot, a dof is owned by the lane of its depth
   if (lane < FB_MAXCH) {
     for (int r = 0; r < nefc; r++) {
-      real fr = w.efc_force[r];
+      real fr = w.efc_force()[r];
       if (fr == 0) continue;
       for (int side = 0; side < 2; side++) {
-        int len = side ? w.efc_lB[r] : w.efc_lA[r];
+        int len = side ? w.efc_lB()[r] : w.efc_lA()[r];
         if (lane < len) {
-          int body = side ? w.efc_bB[r] : w.efc_bA[r];
+          int body = side ? w.efc_bB()[r] : w.efc_bA()[r];
           int dof = M.body_chain[body*FB_MAXCH + lane];
-          w.qfrc_constraint[dof] += w.efc_J[JIDX(side, lane, r)]*fr;
+          w.qfrc_constraint()[dof] += w.efc_J()[JIDX(side, lane, r)]*fr;
         }
       }
     }
   }
   SYNC();
-  for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint[i];
+  for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint()[i];
   SYNC();
   }
   PROF(P_CFIN);
@@ -795,6 +797,6 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
 // qacc = qacc_smooth + M^-1 J^T f (lx), also saved as the next warm start
 template <typename real>
 __device__ __forceinline__ void d_constraint_b(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nv; i += FB_WAVE) { real a = w.qacc_smooth[i] + w.lx[i]; w.qacc[i] = a; w.qacc_ws[i] = a; }
+  for (int i = lane; i < M.nv; i += FB_WAVE) { real a = w.qacc_smooth()[i] + w.lx[i]; w.qacc()[i] = a; w.qacc_ws()[i] = a; }
   SYNC();
 }

@@ -296,14 +296,14 @@ extern "C" int fb_model_dim(const fb_model* m, const char* name) {
 // ------------------------------------------------------------------ kernels
 template <typename real>
 struct Batch {
-  real* rarena; int* iarena; WSOff off;
+  real* rarena; int* iarena;
   float *obs, *reward, *discount; int* step_type;
   int n_env, nobs;
 };
 
 
 template <typename real>
-__global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(DevModel<real> M, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+__global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
   __shared__ real s_LD[FB_EPB][FB_LDS_SCRATCH];
   __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
@@ -316,6 +316,8 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
   __shared__ uint32_t s_gk[FB_MAXGEN*FB_MAXCH];
   __shared__ uint32_t s_gm[FB_MAXGEN*FB_MAXCH*2];
+  // the model lives in constant memory: its fields (sizes, table pointers, workspace offsets) are scalar loads
+  const DevModel<real>& M = as_constant(*Mp);
   int tid = threadIdx.x;
   for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) {
     s_depth[i] = (uint8_t)M.dof_depth[i]; s_cl[i] = (uint8_t)M.dof_cl[i]; s_gen[i] = (uint8_t)M.dof_gen[i]; s_madr[i] = (uint16_t)M.dof_Madr[i];
@@ -326,9 +328,10 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
   int slot = blockIdx.x*FB_EPB + wave;
   if (slot >= nslot) return;
-  int env = env_ids ? env_ids[slot] : slot;
+  int env = uniform_int(env_ids ? env_ids[slot] : slot);
   WS<real> w;
-  ws_bind(w, B.off, B.rarena + (size_t)env*B.off.nreal, B.iarena + (size_t)env*B.off.nint);
+  w.o = (const FB_CONST WSOff*)&M.off;
+  w.rb = (FB_GLOBAL real*)(B.rarena + (size_t)env*M.off.nreal); w.ib = (FB_GLOBAL int*)(B.iarena + (size_t)env*M.off.nint);
   w.lLD = (FB_LDS real*)s_LD[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
   w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
   w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
 #endif
   d_run(M, w, env, mode, nsub, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
-  if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
 #endif
 }
 
@@ -352,13 +355,15 @@ struct fb_batch {
   int* d_ids = nullptr;
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
+  DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
+  void* dM = nullptr;                 // the model struct in device memory (the kernels read it through the constant path)
   void *ref_qpos = nullptr, *ref_qvel = nullptr;
   bool have_ref = false, have_wbpg = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; int timed_launches = 0; bool timing = false;
 };
 
-template <typename real, typename T>
-static int upload(fb_batch* b, const T* src, size_t n, const real** dst) {
+template <typename real, typename T, typename P>
+static int upload(fb_batch* b, const T* src, size_t n, P* dst) {
   std::vector<real> tmp(n ? n : 1);
   for (size_t k = 0; k < n; k++) tmp[k] = (real)src[k];
   void* p;
@@ -368,7 +373,8 @@ static int upload(fb_batch* b, const T* src, size_t n, const real** dst) {
   *dst = (const real*)p;
   return 0;
 }
-static int upload_i(fb_batch* b, const int* src, size_t n, const int** dst) {
+template <typename P>
+static int upload_i(fb_batch* b, const int* src, size_t n, P* dst) {
   void* p;
   HIPCHK(hipMalloc(&p, (n ? n : 1)*sizeof(int)));
   if (n) HIPCHK(hipMemcpy(p, src, n*sizeof(int), hipMemcpyHostToDevice));
@@ -456,8 +462,8 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
   HIPCHK(hipSetDevice(device));
   fb_batch* b = new fb_batch();
   b->m = m; b->n_env = n_env; b->device = device; b->precision = precision;
-  if (precision == 64) { if (build_devmodel<double>(b, b->M64)) return -1; compute_offsets(b->M64, b->off); }
-  else { if (build_devmodel<float>(b, b->M32)) return -1; compute_offsets(b->M32, b->off); }
+  if (precision == 64) { if (build_devmodel<double>(b, b->M64)) return -1; compute_offsets(b->M64, b->off); b->M64.off = b->off; }
+  else { if (build_devmodel<float>(b, b->M32)) return -1; compute_offsets(b->M32, b->off); b->M32.off = b->off; }
   size_t rs = precision == 64 ? 8 : 4;
   HIPCHK(hipMalloc(&b->rarena, (size_t)n_env*b->off.nreal*rs));
   HIPCHK(hipMemset(b->rarena, 0, (size_t)n_env*b->off.nreal*rs));
@@ -528,7 +534,7 @@ extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const
   HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
   HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
   b->nobs = nobs;
-#define SETREF(M) M.ref_qpos = (decltype(M.ref_qpos))b->ref_qpos; M.ref_qvel = (decltype(M.ref_qvel))b->ref_qvel; M.T = T; \
+#define SETREF(M) M.ref_qpos = (decltype(M.timestep)*)b->ref_qpos; M.ref_qvel = (decltype(M.timestep)*)b->ref_qvel; M.T = T; \
   M.future_steps = future_steps; M.episode_steps = episode_steps; M.nobs = nobs; \
   M.terminal_com_dist = (decltype(M.terminal_com_dist))terminal_com_dist; M.time_limit = (decltype(M.time_limit))time_limit;
   SETREF(b->M64) SETREF(b->M32)
@@ -609,12 +615,23 @@ extern "C" int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds)
 
 static int launch(fb_batch* b, int mode, const float* action, const int* ids, int n, int nsub, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  // the device copy of the model struct follows the host copy (setters only touch the host copy); a changed model is rare,
+  // so the refresh simply waits for the device to be idle
+  const void* hM = b->precision == 64 ? (const void*)&b->M64 : (const void*)&b->M32;
+  void* hD = b->precision == 64 ? (void*)&b->M64_dev : (void*)&b->M32_dev;
+  size_t nM = b->precision == 64 ? sizeof(b->M64) : sizeof(b->M32);
+  if (!b->dM) { HIPCHK(hipMalloc(&b->dM, nM)); memset(hD, 0xff, nM); }
+  if (memcmp(hM, hD, nM) != 0) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(b->dM, hM, nM, hipMemcpyHostToDevice));
+    memcpy(hD, hM, nM);
+  }
   if (b->precision == 64) {
-    Batch<double> B = {(double*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
-    hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, b->M64, B, action, ids, mode, nsub, n);
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
-    Batch<float> B = {(float*)b->rarena, b->iarena, b->off, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
-    hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, b->M32, B, action, ids, mode, nsub, n);
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   HIPCHK(hipGetLastError());
   if (b->timing) b->timed_launches++;

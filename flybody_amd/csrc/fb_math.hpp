@@ -179,6 +179,25 @@ template <typename T> FBD FB_LDS_AS T* uniform_ptr(FB_LDS_AS T* p) {
 }
 FBD int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
+// any pointer flavour (generic / global / constant / LDS) to SGPRs
+#ifdef FB_EMULATE
+template <typename P> FBD P uniform_p(P p) { return p; }
+#else
+template <typename P> FBD P uniform_p(P p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (P)(((unsigned long long)hi << 32) | lo);
+}
+#endif
+// A struct that sits in read-only device memory and is addressed uniformly: tell the compiler (constant address space),
+// its fields then come in through the scalar cache and may be re-read or kept across fences freely.
+#ifdef FB_EMULATE
+template <typename T> FBD const T& as_constant(const T& r) { return r; }
+#else
+template <typename T> FBD const T& as_constant(const T& r) {
+  return *(const T*)(const __attribute__((address_space(4))) T*)uniform_ptr(&r);
+}
+#endif
 
 // ---- wavefront (64-lane) collectives -------------------------------------------------
 #ifdef FB_EMULATE

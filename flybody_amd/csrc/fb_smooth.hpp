@@ -27,13 +27,28 @@
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
 #define PROF_BEGIN() long long prof_t_ = clock64()
 #define PROF_RESET() prof_t_ = clock64()
-#define PROF(id) do { long long now_ = clock64(); if (lane == 0) { long long* pp_ = (long long*)w.prof; pp_[id] += now_ - prof_t_; } prof_t_ = clock64(); } while (0)
+#define PROF(id) do { long long now_ = clock64(); if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[id] += now_ - prof_t_; } prof_t_ = clock64(); } while (0)
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_RESET() do {} while (0)
 #define PROF(id) do {} while (0)
 #endif
 enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_ACT, P_ACC, P_CSETUP, P_PGS, P_NOSLIP, P_CFIN, P_SENS, P_EULER, P_EPI };
+
+// Non-inlined stages get the workspace descriptor by reference (it arrives through memory, so per lane): move its
+// wave-uniform base pointers back to SGPRs.  Callers pass a COPY so that the kernel's own descriptor never escapes.
+template <typename real>
+__device__ __forceinline__ WS<real> ws_uniform(const WS<real>& w_) {
+  WS<real> w = w_;
+  w.rb = uniform_p(w.rb); w.ib = uniform_p(w.ib); w.o = uniform_p(w.o);
+  w.lLD = uniform_p(w.lLD); w.lDinv = uniform_p(w.lDinv); w.lx = uniform_p(w.lx); w.lAR = uniform_p(w.lAR);
+  w.ldepth = uniform_p(w.ldepth); w.lcl = uniform_p(w.lcl); w.lgen = uniform_p(w.lgen); w.lmadr = uniform_p(w.lmadr);
+  w.lgk = uniform_p(w.lgk); w.lgm = uniform_p(w.lgm);
+#ifndef FB_EMULATE
+  w.nlevel = __builtin_amdgcn_readfirstlane(w.nlevel);
+#endif
+  return w;
+}
 
 // ------------------------------------------------------------------ chain gathers
 // Walking a root->leaf dof chain with `load index, then load data` per slot is a string of dependent memory round trips.
@@ -113,13 +128,13 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
       for (int k = 0; k < 3; k++) pos[k] = S[7*par + k];
       for (int k = 0; k < 4; k++) quat[k] = S[7*par + 3 + k];
       if (free_jnt) {
-        const real* q = w.qpos + (int)R[36];
+        const real* q = w.qpos() + (int)R[36];
         pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
         quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
         normquat(quat);
-        copy3(w.xanchor + 3*ja, pos);
+        copy3(w.xanchor() + 3*ja, pos);
         real ax[3] = {0, 0, 1};
-        rotvecquat(w.xaxis + 3*ja, ax, quat);
+        rotvecquat(w.xaxis() + 3*ja, ax, quat);
       } else {
         real t[3], qn[4];
         rotvecquat(t, R + 4, quat);
@@ -135,8 +150,8 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
           real anc[3], t[3], qn[4];
           rotvecquat(t, R + 18 + 6*k, quat);
           add3(anc, t, pos);
-          copy3(w.xanchor + 3*j, anc);
-          rotvecquat(w.xaxis + 3*j, R + 21 + 6*k, quat);
+          copy3(w.xanchor() + 3*j, anc);
+          rotvecquat(w.xaxis() + 3*j, R + 21 + 6*k, quat);
           mulquat(qn, quat, qloc);
           quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
           rotvecquat(t, R + 18 + 6*k, quat);
@@ -148,13 +163,13 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
       for (int k = 0; k < 4; k++) S[7*b + 3 + k] = quat[k];
       real mat[9], t[3], qi[4];
       quat2mat(mat, quat);
-      copy3(w.xpos + 3*b, pos);
-      for (int k = 0; k < 4; k++) w.xquat[4*b + k] = quat[k];
-      for (int k = 0; k < 9; k++) w.xmat[9*b + k] = mat[k];
+      copy3(w.xpos() + 3*b, pos);
+      for (int k = 0; k < 4; k++) w.xquat()[4*b + k] = quat[k];
+      for (int k = 0; k < 9; k++) w.xmat()[9*b + k] = mat[k];
       mulmat3(t, mat, R + 11);
-      add3(w.xipos + 3*b, pos, t);
+      add3(w.xipos() + 3*b, pos, t);
       mulquat(qi, quat, R + 14);
-      quat2mat(w.ximat + 9*b, qi);
+      quat2mat(w.ximat() + 9*b, qi);
     }
     SYNC();
   }
@@ -168,16 +183,16 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
     real q[4] = {1, 0, 0, 0};
     int jt = M.jnt_type[j], qa = M.jnt_qposadr[j];
-    if (jt == JNT_HINGE) axisangle2quat(q, M.jnt_axis + 3*j, w.qpos[qa] - M.qpos0[qa]);
-    else if (jt == JNT_BALL) { for (int k = 0; k < 4; k++) q[k] = w.qpos[qa + k]; normquat(q); }
+    if (jt == JNT_HINGE) axisangle2quat(q, M.jnt_axis + 3*j, w.qpos()[qa] - M.qpos0[qa]);
+    else if (jt == JNT_BALL) { for (int k = 0; k < 4; k++) q[k] = w.qpos()[qa + k]; normquat(q); }
     for (int k = 0; k < 4; k++) JQ[4*j + k] = q[k];
   }
   if (lane == 0) {
     // world body: identity frame
     for (int k = 0; k < 7; k++) S[k] = (k == 3) ? (real)1 : (real)0;
-    for (int k = 0; k < 3; k++) { w.xpos[k] = 0; w.xipos[k] = 0; }
-    for (int k = 0; k < 4; k++) w.xquat[k] = (k == 0) ? (real)1 : (real)0;
-    for (int k = 0; k < 9; k++) { real v = (k % 4 == 0) ? (real)1 : (real)0; w.xmat[k] = v; w.ximat[k] = v; }
+    for (int k = 0; k < 3; k++) { w.xpos()[k] = 0; w.xipos()[k] = 0; }
+    for (int k = 0; k < 4; k++) w.xquat()[k] = (k == 0) ? (real)1 : (real)0;
+    for (int k = 0; k < 9; k++) { real v = (k % 4 == 0) ? (real)1 : (real)0; w.xmat()[k] = v; w.ximat()[k] = v; }
   }
   SYNC();
   fk_pass(M, w, S, JQ, lane, 1, M.fk_dmax, lane);
@@ -188,38 +203,38 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   for (int g = lane; g < M.ngeom; g += FB_WAVE) {
     int b = M.geom_bodyid[g];
     real t[3], q[4];
-    mulmat3(t, w.xmat + 9*b, M.geom_pos + 3*g);
-    add3(w.gxpos + 3*g, w.xpos + 3*b, t);
-    mulquat(q, w.xquat + 4*b, M.geom_quat + 4*g);
-    quat2mat(w.gxmat + 9*g, q);
+    mulmat3(t, w.xmat() + 9*b, M.geom_pos + 3*g);
+    add3(w.gxpos() + 3*g, w.xpos() + 3*b, t);
+    mulquat(q, w.xquat() + 4*b, M.geom_quat + 4*g);
+    quat2mat(w.gxmat() + 9*g, q);
   }
   for (int s = lane; s < M.nsite; s += FB_WAVE) {
     int b = M.site_bodyid[s];
     real t[3], q[4];
-    mulmat3(t, w.xmat + 9*b, M.site_pos + 3*s);
-    add3(w.sxpos + 3*s, w.xpos + 3*b, t);
-    mulquat(q, w.xquat + 4*b, M.site_quat + 4*s);
-    quat2mat(w.sxmat + 9*s, q);
+    mulmat3(t, w.xmat() + 9*b, M.site_pos + 3*s);
+    add3(w.sxpos() + 3*s, w.xpos() + 3*b, t);
+    mulquat(q, w.xquat() + 4*b, M.site_quat + 4*s);
+    quat2mat(w.sxmat() + 9*s, q);
   }
   PROF(26);
   // centre of mass of the (single) kinematic tree
   real c[3] = {0, 0, 0};
-  for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos + 3*b, M.body_mass[b]);
+  for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos() + 3*b, M.body_mass[b]);
   c[0] = wave_sum(c[0]); c[1] = wave_sum(c[1]); c[2] = wave_sum(c[2]);
-  if (lane == 0) { real inv = (real)1 / M.totalmass; w.com[0] = c[0]*inv; w.com[1] = c[1]*inv; w.com[2] = c[2]*inv; }
+  if (lane == 0) { real inv = (real)1 / M.totalmass; w.com()[0] = c[0]*inv; w.com()[1] = c[1]*inv; w.com()[2] = c[2]*inv; }
   SYNC();
 }
 
 // ------------------------------------------------------------------ cinert, cdof, tendons
 template <typename real>
 __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
-  const real com[3] = {w.com[0], w.com[1], w.com[2]};
+  const real com[3] = {w.com()[0], w.com()[1], w.com()[2]};
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real* c = w.cinert + 10*b;
+    real* c = w.cinert() + 10*b;
     if (b == 0) { for (int k = 0; k < 10; k++) c[k] = 0; continue; }
-    const real* R = w.ximat + 9*b; const real* I = M.body_inertia + 3*b;
+    const real* R = w.ximat() + 9*b; const real* I = M.body_inertia + 3*b;
     real mass = M.body_mass[b];
-    real dif[3]; sub3(dif, w.xipos + 3*b, com);
+    real dif[3]; sub3(dif, w.xipos() + 3*b, com);
     real t00 = 0, t11 = 0, t22 = 0, t01 = 0, t02 = 0, t12 = 0;
     for (int k = 0; k < 3; k++) {
       t00 += R[0+k]*I[k]*R[0+k]; t11 += R[3+k]*I[k]*R[3+k]; t22 += R[6+k]*I[k]*R[6+k];
@@ -235,24 +250,24 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
   }
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int j = M.dof_jntid[i], b = M.dof_bodyid[i];
-    real off[3]; sub3(off, com, w.xanchor + 3*j);
-    real* c = w.cdof + 6*i;
+    real off[3]; sub3(off, com, w.xanchor() + 3*j);
+    real* c = w.cdof() + 6*i;
     if (M.jnt_type[j] == JNT_FREE) {
       int k = i - M.jnt_dofadr[j];
       if (k < 3) { for (int q = 0; q < 6; q++) c[q] = 0; c[3 + k] = 1; }
       else {
-        const real* R = w.xmat + 9*b;
+        const real* R = w.xmat() + 9*b;
         real ax[3] = {R[k-3], R[3+k-3], R[6+k-3]};
         copy3(c, ax); cross3(c + 3, ax, off);
       }
     } else if (M.jnt_type[j] == JNT_BALL) {
       // three rotations about the body axes through the anchor
       int k = i - M.jnt_dofadr[j];
-      const real* R = w.xmat + 9*b;
+      const real* R = w.xmat() + 9*b;
       real ax[3] = {R[k], R[3+k], R[6+k]};
       copy3(c, ax); cross3(c + 3, ax, off);
     } else {
-      copy3(c, w.xaxis + 3*j); cross3(c + 3, w.xaxis + 3*j, off);
+      copy3(c, w.xaxis() + 3*j); cross3(c + 3, w.xaxis() + 3*j, off);
     }
   }
   for (int t = lane; t < M.ntendon; t += FB_WAVE) {
@@ -261,11 +276,11 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) { int kk = (k < num) ? adr + k : 0; qa[k] = M.wrap_qadr[kk]; cf[k] = M.wrap_coef[kk]; }
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qpos[qa[k]];
+    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qpos()[qa[k]];
     real L = 0;
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) if (k < num) L += cf[k]*qv[k];
-    w.ten_length[t] = L;
+    w.ten_length()[t] = L;
   }
   SYNC();
 }
@@ -311,11 +326,11 @@ __device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real*
 // ------------------------------------------------------------------ composite inertia + mass matrix
 template <typename real>
 __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
-  subtree_sum<10>(M, w.cinert, w.crb, lane);
+  subtree_sum<10>(M, w.cinert(), w.crb(), lane);
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int adr = M.dof_Madr[i];
     real buf[6];
-    mulinertvec(buf, w.crb + 10*M.dof_bodyid[i], w.cdof + 6*i);
+    mulinertvec(buf, w.crb() + 10*M.dof_bodyid[i], w.cdof() + 6*i);
     real arm = M.dof_armature[i];
     // row i of M: entries for the ancestors of dof i = the first depth(i)+1 slots of its body's chain (slot depth(i) is i itself)
     int ch[FB_MAXCH]; load_chain(M, M.dof_bodyid[i], ch);
@@ -326,7 +341,7 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
       real c[5][6];
 #pragma unroll
       for (int u = 0; u < 5; u++) {
-        const real* cp = w.cdof + 6*((s0 + u <= di) ? ch[s0 + u] : 0);
+        const real* cp = w.cdof() + 6*((s0 + u <= di) ? ch[s0 + u] : 0);
 #pragma unroll
         for (int k = 0; k < 6; k++) c[u][k] = cp[k];
       }
@@ -336,7 +351,7 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
         if (sl <= di) {
           real v = dot6(c[u], buf);
           if (sl == di) v += arm;
-          w.qM[adr + (di - sl)] = v;
+          w.qM()[adr + (di - sl)] = v;
         }
       }
     }
@@ -390,13 +405,13 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
 }
 
 template <typename real>
-FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const real* qM, const real* diag_add, real hscale,
+FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
                          FB_LDS real* RM, FB_LDS real* Dinv, int lane) {
-  const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
-  qM = uniform_ptr(qM); diag_add = uniform_ptr(diag_add); RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); Dinv = uniform_p(Dinv);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
-  const FB_LDS uint32_t* gm = uniform_ptr(w.lgm);          // locals: a fence must not force reloading them from the WS struct
+  const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
   // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
   int fw[FB_FSLOT];
   real acc[FB_FSLOT];
@@ -536,13 +551,13 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const re
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
 FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
-  const DevModel<real>& M = *uniform_ptr(&M_); const WS<real>& w = *uniform_ptr(&w_);
-  RM = uniform_ptr(RM); Dinv = uniform_ptr(Dinv); x = uniform_ptr(x);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  RM = uniform_p(RM); Dinv = uniform_p(Dinv); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
-  const FB_LDS uint32_t* gk = uniform_ptr(w.lgk);
-  const FB_LDS uint16_t* lmadr = uniform_ptr(w.lmadr);
-  const int* fwd = uniform_ptr(M.fwd_tab);
+  const FB_LDS uint32_t* gk = w.lgk;
+  const FB_LDS uint16_t* lmadr = w.lmadr;
+  const FB_GLOBAL int* fwd = M.fwd_tab.p;
   int jd[2], dep[2], cl[2], gen[2], base[2], rowt[2]; real a_[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -638,15 +653,15 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
     real v[6] = {0, 0, 0, 0, 0, 0};
     int n = M.body_chlen[b];
     int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6<4>(ch, n, M.chmax, w.cdof, w.qvel, v);
-    for (int k = 0; k < 6; k++) w.cvel[6*b + k] = v[k];
+    chain_axpy6<4>(ch, n, M.chmax, w.cdof(), w.qvel(), v);
+    for (int k = 0; k < 6; k++) w.cvel()[6*b + k] = v[k];
   }
   SYNC();
   // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i: the parent body's velocity plus the earlier dofs of the
   // same body (free joint: its rotational axes see the three translational dofs; ball joint: none of its own dofs)
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int j = M.dof_jntid[i], b = M.dof_bodyid[i];
-    real* cd = w.cdof_dot + 6*i;
+    real* cd = w.cdof_dot() + 6*i;
     int first = M.body_dofadr[b], nsame;
     if (M.jnt_type[j] == JNT_FREE) {
       int k = i - M.jnt_dofadr[j];
@@ -655,14 +670,14 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
     } else if (M.jnt_type[j] == JNT_BALL) nsame = M.jnt_dofadr[j] - first;
     else nsame = i - first;
     real v[6];
-    const real* pv = w.cvel + 6*M.body_parent[b];
+    const real* pv = w.cvel() + 6*M.body_parent[b];
     for (int k = 0; k < 6; k++) v[k] = pv[k];
     for (int s = 0; s < nsame; s++) {                 // at most 5 (free joint), usually 0..2
-      real qv = w.qvel[first + s];
-      const real* c = w.cdof + 6*(first + s);
+      real qv = w.qvel()[first + s];
+      const real* c = w.cdof() + 6*(first + s);
       for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
     }
-    crossmotion(cd, v, w.cdof + 6*i);
+    crossmotion(cd, v, w.cdof() + 6*i);
   }
   SYNC();
 }
@@ -670,9 +685,9 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
 // 6-D velocity of a frame (pos, rot) rigidly attached to `body`, expressed in that frame
 template <typename real>
 FBD void object_velocity(const WS<real>& w, int body, const real* pos, const real* rot, real* lvel) {
-  const real* cv = w.cvel + 6*body;
+  const real* cv = w.cvel() + 6*body;
   real dif[3], lin[3], t[3];
-  sub3(dif, pos, w.com);
+  sub3(dif, pos, w.com());
   cross3(t, dif, cv);
   sub3(lin, cv + 3, t);
   mulmatT3(lvel, rot, cv);
@@ -690,7 +705,7 @@ __device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, 
   real blunt = gf[1], slender = gf[2], angc = gf[3], kutta = gf[4], magnus = gf[5];
   const real* vmass = gf + 6; const real* vinert = gf + 9;
   real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-  object_velocity(w, b, w.gxpos + 3*g, w.gxmat + 9*g, lvel);
+  object_velocity(w, b, w.gxpos() + 3*g, w.gxmat() + 9*g, lvel);
   const real* om = lvel; const real* v = lvel + 3;
   real plin[3], pang[3], t[3];
   for (int k = 0; k < 3; k++) { plin[k] = M.density*vmass[k]*v[k]; pang[k] = M.density*vinert[k]*om[k]; }
@@ -726,9 +741,9 @@ __device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, 
   for (int k = 0; k < 3; k++) { lfrc[k] -= draga*om[k]; lfrc[3+k] += mag[k] + kf[k] - dragl*v[k]; }
   for (int k = 0; k < 6; k++) lfrc[k] *= gf[0];
   real trq[3], frc[3], off[3];
-  mulmat3(trq, w.gxmat + 9*g, lfrc);
-  mulmat3(frc, w.gxmat + 9*g, lfrc + 3);
-  sub3(off, w.gxpos + 3*g, w.com);
+  mulmat3(trq, w.gxmat() + 9*g, lfrc);
+  mulmat3(frc, w.gxmat() + 9*g, lfrc + 3);
+  sub3(off, w.gxpos() + 3*g, w.com());
   cross3(t, off, frc);
   out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
   out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
@@ -740,14 +755,14 @@ __device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real
   // per-body fluid wrench about the tree CoM, stored in cfrc_ext as [torque; force] (scratch use)
   bool fluid = (M.density > 0 || M.viscosity > 0);
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real* out = w.cfrc_ext + 6*b;
+    real* out = w.cfrc_ext() + 6*b;
     for (int k = 0; k < 6; k++) out[k] = 0;
     if (!fluid || b == 0 || M.body_mass[b] < FB_MINV) continue;
     int fg = M.body_fluid_geom[b];
     if (fg >= 0) { ellipsoid_fluid_wrench(M, w, b, fg, out); continue; }
     const real* box = M.body_box + 3*b;
     real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-    object_velocity(w, b, w.xipos + 3*b, w.ximat + 9*b, lvel);
+    object_velocity(w, b, w.xipos() + 3*b, w.ximat() + 9*b, lvel);
     if (M.viscosity > 0) {
       real diam = (box[0] + box[1] + box[2]) / (real)3;
       for (int k = 0; k < 3; k++) {
@@ -766,26 +781,26 @@ __device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real
       lfrc[2] -= M.density*b2*(b04 + b14)*fabs(lvel[2])*lvel[2]/(real)64;
     }
     real trq[3], frc[3], off[3], t[3];
-    mulmat3(trq, w.ximat + 9*b, lfrc);
-    mulmat3(frc, w.ximat + 9*b, lfrc + 3);
+    mulmat3(trq, w.ximat() + 9*b, lfrc);
+    mulmat3(frc, w.ximat() + 9*b, lfrc + 3);
     // move the wrench to the CoM reference point: torque += off x force
-    sub3(off, w.xipos + 3*b, w.com);
+    sub3(off, w.xipos() + 3*b, w.com());
     cross3(t, off, frc);
     out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
     out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
   }
   SYNC();
-  if (fluid) subtree_sum<6>(M, w.cfrc_ext, w.cacc, lane);       // cacc is free scratch until the sensor stage
+  if (fluid) subtree_sum<6>(M, w.cfrc_ext(), w.cacc(), lane);       // cacc is free scratch until the sensor stage
   // qfrc_passive[i] = spring + damper + cdof_i . (sum of fluid wrenches over the dof's subtree)
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int j = M.dof_jntid[i];
-    real f = -M.dof_damping[i]*w.qvel[i];
+    real f = -M.dof_damping[i]*w.qvel()[i];
     if (M.jnt_type[j] == JNT_HINGE && M.jnt_stiffness[j] != 0) {
       int qa = M.jnt_qposadr[j];
-      f -= M.jnt_stiffness[j]*(w.qpos[qa] - M.qpos_spring[qa]);
+      f -= M.jnt_stiffness[j]*(w.qpos()[qa] - M.qpos_spring[qa]);
     }
-    if (fluid) f += dot6(w.cdof + 6*i, w.cacc + 6*M.dof_bodyid[i]);
-    w.qfrc_passive[i] = f;
+    if (fluid) f += dot6(w.cdof() + 6*i, w.cacc() + 6*M.dof_bodyid[i]);
+    w.qfrc_passive()[i] = f;
   }
   SYNC();
 }
@@ -795,19 +810,19 @@ template <typename real>
 __device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
-    real* out = w.cfrc + 6*b;
+    real* out = w.cfrc() + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
     int n = M.body_chlen[b];
     int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6<4>(ch, n, M.chmax, w.cdof_dot, w.qvel, a);
+    chain_axpy6<4>(ch, n, M.chmax, w.cdof_dot(), w.qvel(), a);
     real t[6], t1[6], t2[6];
-    mulinertvec(t, w.cinert + 10*b, a);
-    mulinertvec(t1, w.cinert + 10*b, w.cvel + 6*b);
-    crossforce(t2, w.cvel + 6*b, t1);
+    mulinertvec(t, w.cinert() + 10*b, a);
+    mulinertvec(t1, w.cinert() + 10*b, w.cvel() + 6*b);
+    crossforce(t2, w.cvel() + 6*b, t1);
     for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k];
   }
   SYNC();
-  subtree_sum<6>(M, w.cfrc, w.cacc, lane);
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_bias[i] = dot6(w.cdof + 6*i, w.cacc + 6*M.dof_bodyid[i]);
+  subtree_sum<6>(M, w.cfrc(), w.cacc(), lane);
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_bias()[i] = dot6(w.cdof() + 6*i, w.cacc() + 6*M.dof_bodyid[i]);
   SYNC();
 }

@@ -13,8 +13,8 @@ __device__ __forceinline__ void d_sensor_vel(const DevModel<real>& M, const WS<r
   if (lane == 0) {
     int s = M.site_thorax;
     real lvel[6];
-    object_velocity(w, M.site_bodyid[s], w.sxpos + 3*s, w.sxmat + 9*s, lvel);
-    for (int k = 0; k < 3; k++) { w.sens[3 + k] = lvel[k]; w.sens[6 + k] = lvel[3 + k]; }
+    object_velocity(w, M.site_bodyid[s], w.sxpos() + 3*s, w.sxmat() + 9*s, lvel);
+    for (int k = 0; k < 3; k++) { w.sens()[3 + k] = lvel[k]; w.sens()[6 + k] = lvel[3 + k]; }
   }
   SYNC();
 }
@@ -57,21 +57,21 @@ FBD real ray_site(const real* pos, const real* mat, const real* size, int type, 
 // acceleration-stage sensors: accelerometer (thorax site), 6 force sensors, 6 touch sensors
 template <typename real>
 __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
-  int ncon = w.istate[IS_NCON];
+  int ncon = w.istate()[IS_NCON];
   // wrench of each active contact about the tree CoM, in the lane that owns the contact (at most 64 contacts)
   int cb1 = -1, cb2 = -1;
   real cw[6] = {0, 0, 0, 0, 0, 0}, cfn = 0;
   if (lane < ncon) {
-    int adr = w.con_efc[lane];
+    int adr = w.con_efc()[lane];
     if (adr >= 0) {
-      int p = w.con_pair[lane];
+      int p = w.con_pair()[lane];
       cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
-      cfn = w.efc_force[adr];
+      cfn = w.efc_force()[adr];
       real lf[3] = {cfn, 0, 0};
-      if (w.con_dim[lane] > 1) { lf[1] = w.efc_force[adr+1]; lf[2] = w.efc_force[adr+2]; }
+      if (w.con_dim()[lane] > 1) { lf[1] = w.efc_force()[adr+1]; lf[2] = w.efc_force()[adr+2]; }
       real r[3];
-      mulmatT3(cw + 3, w.con_frame + 9*lane, lf);
-      sub3(r, w.con_pos + 3*lane, w.com);
+      mulmatT3(cw + 3, w.con_frame() + 9*lane, lf);
+      sub3(r, w.con_pos() + 3*lane, w.com());
       cross3(cw, r, cw + 3);
     }
   }
@@ -89,36 +89,36 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
         for (int k = 0; k < 6; k++) acc[k] += sgn*wr[k];
       }
     }
-    if (b < M.nbody) for (int k = 0; k < 6; k++) w.cfrc_ext[6*b + k] = acc[k];
+    if (b < M.nbody) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
   }
   SYNC();
   // body accelerations (chain walk, now including qacc) and body forces
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
-    real* out = w.cfrc + 6*b;
-    if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc[k] = a[k]; } continue; }
+    real* out = w.cfrc() + 6*b;
+    if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc()[k] = a[k]; } continue; }
     int n = M.body_chlen[b];
     int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6x2<2>(ch, n, M.chmax, w.cdof_dot, w.qvel, w.cdof, w.qacc, a);
-    for (int k = 0; k < 6; k++) w.cacc[6*b + k] = a[k];
+    chain_axpy6x2<2>(ch, n, M.chmax, w.cdof_dot(), w.qvel(), w.cdof(), w.qacc(), a);
+    for (int k = 0; k < 6; k++) w.cacc()[6*b + k] = a[k];
     real t[6], t1[6], t2[6];
-    mulinertvec(t, w.cinert + 10*b, a);
-    mulinertvec(t1, w.cinert + 10*b, w.cvel + 6*b);
-    crossforce(t2, w.cvel + 6*b, t1);
-    for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k] - w.cfrc_ext[6*b + k];
+    mulinertvec(t, w.cinert() + 10*b, a);
+    mulinertvec(t1, w.cinert() + 10*b, w.cvel() + 6*b);
+    crossforce(t2, w.cvel() + 6*b, t1);
+    for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k] - w.cfrc_ext()[6*b + k];
   }
   SYNC();
   if (lane == 0) {
     int s = M.site_thorax, b = M.site_bodyid[s];
-    const real* ca = w.cacc + 6*b;
+    const real* ca = w.cacc() + 6*b;
     real dif[3], t[3], lin[3], la[3], lvel[6], cor[3];
-    sub3(dif, w.sxpos + 3*s, w.com);
+    sub3(dif, w.sxpos() + 3*s, w.com());
     cross3(t, dif, ca);
     sub3(lin, ca + 3, t);
-    mulmatT3(la, w.sxmat + 9*s, lin);
-    object_velocity(w, b, w.sxpos + 3*s, w.sxmat + 9*s, lvel);
+    mulmatT3(la, w.sxmat() + 9*s, lin);
+    object_velocity(w, b, w.sxpos() + 3*s, w.sxmat() + 9*s, lvel);
     cross3(cor, lvel, lvel + 3);
-    for (int k = 0; k < 3; k++) w.sens[k] = la[k] + cor[k];
+    for (int k = 0; k < 3; k++) w.sens()[k] = la[k] + cor[k];
   }
   // force sensors: interaction force of the site's body = subtree sum of body forces
   if (lane >= 8 && lane < 8 + M.nforce) {
@@ -126,8 +126,8 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     int s = M.force_sites[k], b = M.site_bodyid[s];
     real acc[3] = {0, 0, 0};
     int n = M.body_nsub[b];
-    for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
-    mulmatT3(w.sens + 9 + 3*k, w.sxmat + 9*s, acc);
+    for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc() + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
+    mulmatT3(w.sens() + 9 + 3*k, w.sxmat() + 9*s, acc);
   }
   {
     bool on = lane >= 16 && lane < 16 + M.ntouch;
@@ -139,11 +139,11 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
       real fn = rdlane(cfn, c);
       if (rb1 < 0 || fn <= 0) continue;
       if (b != rb1 && b != rb2) continue;
-      real ray[3]; copy3(ray, w.con_frame + 9*c);
+      real ray[3]; copy3(ray, w.con_frame() + 9*c);
       if (b == rb2) scl3(ray, ray, (real)-1);
-      if (ray_site(w.sxpos + 3*s, w.sxmat + 9*s, M.site_size + 3*s, M.site_type[s], w.con_pos + 3*c, ray) >= 0) sum += fn;
+      if (ray_site(w.sxpos() + 3*s, w.sxmat() + 9*s, M.site_size + 3*s, M.site_type[s], w.con_pos() + 3*c, ray) >= 0) sum += fn;
     }
-    if (on) w.sens[9 + 3*M.nforce + k] = sum;
+    if (on) w.sens()[9 + 3*M.nforce + k] = sum;
   }
   SYNC();
 }
@@ -157,35 +157,35 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
     if (aa < 0) continue;
     if (M.act_dyntype[i] == DYN_FILTEREXACT) {
       real tau = fmax(FB_MINV, M.act_dynprm[i]);
-      w.act[aa] += w.act_dot[aa]*tau*(1 - exp(-h/tau));
-    } else w.act[aa] += h*w.act_dot[aa];
+      w.act()[aa] += w.act_dot()[aa]*tau*(1 - exp(-h/tau));
+    } else w.act()[aa] += h*w.act_dot()[aa];
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel[i] += h*w.lx[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel()[i] += h*w.lx[i];
   SYNC();
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
     int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
     if (M.jnt_type[j] == JNT_FREE) {
-      for (int k = 0; k < 3; k++) w.qpos[qa+k] += h*w.qvel[da+k];
-      real ax[3] = {w.qvel[da+3], w.qvel[da+4], w.qvel[da+5]};
+      for (int k = 0; k < 3; k++) w.qpos()[qa+k] += h*w.qvel()[da+k];
+      real ax[3] = {w.qvel()[da+3], w.qvel()[da+4], w.qvel()[da+5]};
       real n = normalize3(ax);
-      real q[4] = {w.qpos[qa+3], w.qpos[qa+4], w.qpos[qa+5], w.qpos[qa+6]}, qr[4], res[4];
+      real q[4] = {w.qpos()[qa+3], w.qpos()[qa+4], w.qpos()[qa+5], w.qpos()[qa+6]}, qr[4], res[4];
       axisangle2quat(qr, ax, n*h);
       normquat(q);
       mulquat(res, q, qr);
       normquat(res);
-      for (int k = 0; k < 4; k++) w.qpos[qa+3+k] = res[k];
+      for (int k = 0; k < 4; k++) w.qpos()[qa+3+k] = res[k];
     } else if (M.jnt_type[j] == JNT_BALL) {
-      real ax[3] = {w.qvel[da], w.qvel[da+1], w.qvel[da+2]};
+      real ax[3] = {w.qvel()[da], w.qvel()[da+1], w.qvel()[da+2]};
       real n = normalize3(ax);
-      real q[4] = {w.qpos[qa], w.qpos[qa+1], w.qpos[qa+2], w.qpos[qa+3]}, qr[4], res[4];
+      real q[4] = {w.qpos()[qa], w.qpos()[qa+1], w.qpos()[qa+2], w.qpos()[qa+3]}, qr[4], res[4];
       axisangle2quat(qr, ax, n*h);
       normquat(q);
       mulquat(res, q, qr);
       normquat(res);
-      for (int k = 0; k < 4; k++) w.qpos[qa+k] = res[k];
-    } else w.qpos[qa] += h*w.qvel[da];
+      for (int k = 0; k < 4; k++) w.qpos()[qa+k] = res[k];
+    } else w.qpos()[qa] += h*w.qvel()[da];
   }
-  if (lane == 0) w.simtime[0] += h;
+  if (lane == 0) w.simtime()[0] += h;
   SYNC();
 }
 
@@ -194,18 +194,18 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
 // a launch and reloaded at the start of the next one (once per control step, not per substep).
 template <typename real>
 __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD[i] = w.lLD[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv[i] = w.lDinv[i];
-  int nefc = w.istate[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.AR[i] = w.lAR[i];
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv()[i] = w.lDinv[i];
+  int nefc = w.istate()[IS_NEFC];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.AR()[i] = w.lAR[i];
   SYNC();
 }
 template <typename real>
 __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv[i];
-  int nefc = w.istate[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lAR[i] = w.AR[i];
+  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD()[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv()[i];
+  int nefc = w.istate()[IS_NEFC];
+  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lAR[i] = w.AR()[i];
   SYNC();
 }
 
@@ -216,8 +216,8 @@ template <typename real> struct RefView { const real* q; int stride, T, episode_
 template <typename real> FBD RefView<real> ref_view(const DevModel<real>& M, const WS<real>& w) {
   RefView<real> r;
   if (M.ds_qpos) {
-    r.stride = 7 + M.ds_nj; r.q = M.ds_qpos + (size_t)w.istate[IS_DS_OFF]*r.stride; r.T = w.istate[IS_DS_LEN];
-    r.episode_steps = w.istate[IS_EPSTEPS]; r.sx = w.dsshift[0]; r.sy = w.dsshift[1];
+    r.stride = 7 + M.ds_nj; r.q = M.ds_qpos + (size_t)w.istate()[IS_DS_OFF]*r.stride; r.T = w.istate()[IS_DS_LEN];
+    r.episode_steps = w.istate()[IS_EPSTEPS]; r.sx = w.dsshift()[0]; r.sy = w.dsshift()[1];
   } else { r.q = M.ref_qpos; r.stride = 7; r.T = M.T; r.episode_steps = M.episode_steps; r.sx = 0; r.sy = 0; }
   return r;
 }
@@ -232,42 +232,42 @@ template <typename real> FBD void ref_root(const RefView<real>& r, int idx, real
 template <typename real>
 __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
   int thorax = M.site_bodyid[M.site_thorax];
-  const real* R = w.xmat + 9*thorax;
-  const real* tp = w.xpos + 3*thorax;
-  int step = w.istate[IS_STEP];
+  const real* R = w.xmat() + 9*thorax;
+  const real* tp = w.xpos() + 3*thorax;
+  int step = w.istate()[IS_STEP];
   int o = 0;
   if (lane < 3) obs[o + lane] = (float)sm[lane];
   o += 3;
-  for (int i = lane; i < M.na; i += FB_WAVE) obs[o + i] = (float)w.act[i];
+  for (int i = lane; i < M.na; i += FB_WAVE) obs[o + i] = (float)w.act()[i];
   o += M.na;
   for (int k = lane; k < M.napp; k += FB_WAVE) {
-    real dif[3], e[3]; sub3(dif, w.sxpos + 3*M.app_sites[k], tp);
+    real dif[3], e[3]; sub3(dif, w.sxpos() + 3*M.app_sites[k], tp);
     mulmatT3(e, R, dif);
     for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
   }
   o += 3*M.napp;
-  if (M.task == 2) { if (lane < 3) obs[o + lane] = (float)w.qvel[M.nv - 3 + lane]; o += 3; }      // ball_qvel (walk_on_ball.py:84-90)
+  if (M.task == 2) { if (lane < 3) obs[o + lane] = (float)w.qvel()[M.nv - 3 + lane]; o += 3; }      // ball_qvel (walk_on_ball.py:84-90)
   for (int k = lane; k < 3*M.nforce; k += FB_WAVE) obs[o + k] = (float)sm[9 + k];
   o += 3*M.nforce;
   if (lane < 3) obs[o + lane] = (float)sm[3 + lane];
   o += 3;
   for (int k = lane; k < M.nobsjnt; k += FB_WAVE) {
     int j = M.obs_jnt[k];
-    obs[o + k] = (float)w.qpos[M.jnt_qposadr[j]];
-    obs[o + M.nobsjnt + k] = (float)w.qvel[M.jnt_dofadr[j]];
+    obs[o + k] = (float)w.qpos()[M.jnt_qposadr[j]];
+    obs[o + M.nobsjnt + k] = (float)w.qvel()[M.jnt_dofadr[j]];
   }
   o += 2*M.nobsjnt;
   int nf = (M.task == 2) ? 0 : M.future_steps + 1;        // walk_on_ball has no reference observables
   const RefView<real> rv = ref_view(M, w);
   for (int k = lane; k < nf; k += FB_WAVE) {
     real rr[7]; ref_root(rv, step + k, rr);
-    real dif[3], e[3]; sub3(dif, rr, w.qpos);
+    real dif[3], e[3]; sub3(dif, rr, w.qpos());
     mulmatT3(e, R, dif);
     for (int q = 0; q < 3; q++) obs[o + 3*k + q] = (float)e[q];
   }
   o += 3*nf;
   if (nf > 0) {
-    const real* q = w.qpos + 3;
+    const real* q = w.qpos() + 3;
     real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
     real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2};
     for (int k = lane; k < nf; k += FB_WAVE) {
@@ -318,9 +318,9 @@ __device__ __forceinline__ void d_walk_pre(const DevModel<real>& M, const WS<rea
   for (int k = lane; k < M.nu; k += FB_WAVE) {
     float a = action[k];
     if (a != a) a = 0.f;
-    w.ctrl[M.action_to_ctrl[k]] = (real)a;
+    w.ctrl()[M.action_to_ctrl[k]] = (real)a;
   }
-  if (lane < FB_NSENS) w.sens_acc[lane] = 0;
+  if (lane < FB_NSENS) w.sens_acc()[lane] = 0;
   SYNC();
 }
 
@@ -336,24 +336,24 @@ template <typename real> FBD real quat_dist_short_arc(const real* a, const real*
 template <typename real>
 __device__ __forceinline__ real d_walk_training_reward(const DevModel<real>& M, const WS<real>& w, int step, int lane) {
   const int nj = M.ds_nj, ns = M.ds_ns;
-  int len = w.istate[IS_DS_LEN];
+  int len = w.istate()[IS_DS_LEN];
   if (step >= len) step = len - 1;
-  size_t row = (size_t)w.istate[IS_DS_OFF] + step;
+  size_t row = (size_t)w.istate()[IS_DS_OFF] + step;
   const real* rq = M.ds_qpos + row*(7 + nj); const real* rvel = M.ds_qvel + row*(6 + nj);
   const real* r2s = M.ds_r2s + row*3*ns; const real* rjq = M.ds_jq + row*4*nj;
-  const real* root_quat = w.qpos + 3;
+  const real* root_quat = w.qpos() + 3;
   real n2 = root_quat[0]*root_quat[0] + root_quat[1]*root_quat[1] + root_quat[2]*root_quat[2] + root_quat[3]*root_quat[3];
   real qinv[4] = {root_quat[0]/n2, -root_quat[1]/n2, -root_quat[2]/n2, -root_quat[3]/n2};
   real d_com = 0, d_qvel = 0, d_site = 0, d_quat = 0;
-  if (lane < 3) { real e = w.qpos[lane] - (rq[lane] - (lane < 2 ? w.dsshift[lane] : (real)0)); d_com = e*e; }
-  if (lane < 6) { real e = w.qvel[lane] - rvel[lane]; d_qvel = e*e; }
+  if (lane < 3) { real e = w.qpos()[lane] - (rq[lane] - (lane < 2 ? w.dsshift()[lane] : (real)0)); d_com = e*e; }
+  if (lane < 6) { real e = w.qvel()[lane] - rvel[lane]; d_qvel = e*e; }
   if (lane == 0) { real e = quat_dist_short_arc(root_quat, rq + 3); d_quat = e*e; }
   for (int k = lane; k < nj; k += FB_WAVE) {
     int j = M.ds_jid[k];
-    real e = w.qvel[M.jnt_dofadr[j]] - rvel[6 + k]; d_qvel += e*e;
+    real e = w.qvel()[M.jnt_dofadr[j]] - rvel[6 + k]; d_qvel += e*e;
     // joint orientation quaternion (quaternions.py:310-333) of the egocentric joint axis: axis-angle(qpos) * z2vec(axis)
     real ax[3], qz[4], qa[4], jq[4];
-    rotvecquat(ax, w.xaxis + 3*j, qinv);
+    rotvecquat(ax, w.xaxis() + 3*j, qinv);
     real an = norm3(ax);
     real vx = ax[0]/an, vy = ax[1]/an, vz = ax[2]/an;
     real s = sqrt(vx*vx + vy*vy), zang = atan2(s, vz);          // z x v = (-vy, vx, 0)
@@ -361,14 +361,14 @@ __device__ __forceinline__ real d_walk_training_reward(const DevModel<real>& M, 
     if (s > (real)1e-12) { cx /= s; cy /= s; } else { cx = 1; cy = 0; }
     real zs = sin(zang/2);
     qz[0] = cos(zang/2); qz[1] = cx*zs; qz[2] = cy*zs; qz[3] = 0;
-    real ang = w.qpos[M.jnt_qposadr[j]], sh = sin(ang/2);
+    real ang = w.qpos()[M.jnt_qposadr[j]], sh = sin(ang/2);
     qa[0] = cos(ang/2); qa[1] = vx*sh; qa[2] = vy*sh; qa[3] = vz*sh;
     mulquat(jq, qa, qz);
     real eq = quat_dist_short_arc(jq, rjq + 4*k); d_quat += eq*eq;
   }
   for (int k = lane; k < ns; k += FB_WAVE) {
     real df[3], ego[3];
-    sub3(df, w.sxpos + 3*M.ds_sid[k], w.qpos);
+    sub3(df, w.sxpos() + 3*M.ds_sid[k], w.qpos());
     rotvecquat(ego, df, qinv);
     for (int c = 0; c < 3; c++) { real e = ego[c] - r2s[3*k + c]; d_site += e*e; }
   }
@@ -377,41 +377,41 @@ __device__ __forceinline__ real d_walk_training_reward(const DevModel<real>& M, 
   real f0 = (real)20*exp(-(real)0.5/(s_com*s_com)*d_com), f1 = exp(-(real)0.5/(s_qvel*s_qvel)*d_qvel);
   real f2 = exp(-(real)0.5/(s_site*s_site)*d_site), f3 = exp(-(real)0.5/(s_quat*s_quat)*d_quat);
   real rw = 1;
-  for (int k = 0; k < 6; k++) { int qa = M.jnt_qposadr[M.wing_jnt[k]]; rw *= tolerance_linear(w.qpos[qa] - M.qpos_spring[qa], (real)3); }
-  if (lane == 0) { w.rfac[0] = f0; w.rfac[1] = f1; w.rfac[2] = f2; w.rfac[3] = f3; w.rfac[4] = rw; }
+  for (int k = 0; k < 6; k++) { int qa = M.jnt_qposadr[M.wing_jnt[k]]; rw *= tolerance_linear(w.qpos()[qa] - M.qpos_spring[qa], (real)3); }
+  if (lane == 0) { w.rfac()[0] = f0; w.rfac()[1] = f1; w.rfac()[2] = f2; w.rfac()[3] = f3; w.rfac()[4] = rw; }
   return f0*f1*f2*f3*rw;
 }
 
 // walk_imitation reward / termination / observation (base.py:212-225, walk_imitation.py:152-203)
 template <typename real>
 __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
-  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
-  int stepc = w.istate[IS_STEP] + 1;
+  if (lane < FB_NSENS) w.sens_acc()[lane] = w.sens_acc()[lane] / (real)M.nsubstep;
+  int stepc = w.istate()[IS_STEP] + 1;
   SYNC();
-  if (lane == 0) w.istate[IS_STEP] = stepc;
+  if (lane == 0) w.istate()[IS_STEP] = stepc;
   real qn = 0;
-  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc()[i]*w.qacc()[i];
   qn = wave_sum(qn);
   SYNC();
-  real linvel = norm3(w.sens + 6), angvel = norm3(w.sens + 3);
-  int tstep = (int)floor(w.simtime[0] / M.control_timestep + (real)0.5);
+  real linvel = norm3(w.sens() + 6), angvel = norm3(w.sens() + 3);
+  int tstep = (int)floor(w.simtime()[0] / M.control_timestep + (real)0.5);
   const RefView<real> rv = ref_view(M, w);
   real rroot[7]; ref_root(rv, stepc, rroot);
-  real dif[3]; sub3(dif, rroot, w.qpos);
+  real dif[3]; sub3(dif, rroot, w.qpos());
   real com_dist = norm3(dif);
   bool traj_end = (tstep == rv.episode_steps);
   real rew = 1;
   if (M.ds_qpos) rew = d_walk_training_reward(M, w, tstep, lane);
   bool term = (linvel > (real)50) || (angvel > (real)200) || traj_end || (com_dist > M.terminal_com_dist) ||
               (sqrt(qn) > (real)1e14) || (qn != qn);
-  bool terminating = term || (w.simtime[0] >= M.time_limit);
-  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  bool terminating = term || (w.simtime()[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc(), obs, lane);
   if (lane == 0) {
     *reward = (float)rew;
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
-    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
-    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+    w.istate()[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate()[IS_RESET_NEXT] = terminating ? 1 : 0;
   }
   SYNC();
 }
@@ -420,13 +420,13 @@ __device__ __forceinline__ void d_walk_post(const DevModel<real>& M, const WS<re
 // episode init: default pose with retracted wings (fruitfly.py:390-405); no reference trajectory
 template <typename real>
 __device__ __forceinline__ void d_ball_init(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = M.qpos0[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
-  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
-  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel()[i] = 0; w.qacc()[i] = 0; w.qacc_ws()[i] = 0; }
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act()[i] = 0; w.act_dot()[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl()[i] = 0;
   SYNC();
-  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
-  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
+  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos()[qa] = M.qpos_spring[qa]; }
+  if (lane == 0) { w.istate()[IS_STEP] = 0; w.istate()[IS_RESET_NEXT] = 0; w.simtime()[0] = 0; }
   SYNC();
 }
 
@@ -434,26 +434,26 @@ __device__ __forceinline__ void d_ball_init(const DevModel<real>& M, const WS<re
 // termination on sensor velocities / qacc (:75-80); discount 0 on termination (base.py:206-210)
 template <typename real>
 __device__ __forceinline__ void d_ball_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
-  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
-  int stepc = w.istate[IS_STEP] + 1;
+  if (lane < FB_NSENS) w.sens_acc()[lane] = w.sens_acc()[lane] / (real)M.nsubstep;
+  int stepc = w.istate()[IS_STEP] + 1;
   SYNC();
-  if (lane == 0) w.istate[IS_STEP] = stepc;
+  if (lane == 0) w.istate()[IS_STEP] = stepc;
   real qn = 0;
-  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc()[i]*w.qacc()[i];
   qn = wave_sum(qn);
   SYNC();
-  real linvel = norm3(w.sens + 6), angvel = norm3(w.sens + 3);
-  const real* bv = w.qvel + M.nv - 3;
+  real linvel = norm3(w.sens() + 6), angvel = norm3(w.sens() + 3);
+  const real* bv = w.qvel() + M.nv - 3;
   real r = tolerance_linear(bv[0], (real)6)*tolerance_linear(bv[1] + (real)5, (real)6)*tolerance_linear(bv[2], (real)6);
   bool term = (linvel > (real)50) || (angvel > (real)200) || (sqrt(qn) > (real)1e14) || (qn != qn);
-  bool terminating = term || (w.simtime[0] >= M.time_limit);
-  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  bool terminating = term || (w.simtime()[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc(), obs, lane);
   if (lane == 0) {
     *reward = (float)r;
     *discount = term ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
-    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
-    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+    w.istate()[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate()[IS_RESET_NEXT] = terminating ? 1 : 0;
   }
   SYNC();
 }
@@ -463,29 +463,29 @@ template <typename real>
 __device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<real>& w, int env, int lane) {
   if (M.ds_qpos) {
     // initialize_episode_mjcf (walk_imitation.py:92-111): the snippet of this episode, keyed by (seed, global env, episode)
-    int episode = w.istate[IS_EPISODE];
+    int episode = w.istate()[IS_EPISODE];
     double u = (double)hash_uniform(M.seed, (unsigned)(M.ds_env_base + env), (unsigned)episode);
     int k = (int)(u*M.ds_nselect); if (k >= M.ds_nselect) k = M.ds_nselect - 1;
     int traj = M.ds_select[k];
     int off = M.ds_offset[traj], len = M.ds_offset[traj + 1] - off;
     const real* q0 = M.ds_qpos + (size_t)off*(7 + M.ds_nj);
-    for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 2) ? (real)0 : ((i < 7) ? q0[i] : M.qpos0[i]);
+    for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = (i < 2) ? (real)0 : ((i < 7) ? q0[i] : M.qpos0[i]);
     SYNC();
-    for (int j = lane; j < M.ds_nj; j += FB_WAVE) w.qpos[M.jnt_qposadr[M.ds_jid[j]]] = q0[7 + j];     // every mocap joint (:118)
+    for (int j = lane; j < M.ds_nj; j += FB_WAVE) w.qpos()[M.jnt_qposadr[M.ds_jid[j]]] = q0[7 + j];     // every mocap joint (:118)
     int snippet = len - M.future_steps - 1;
     if (lane == 0) {
-      w.istate[IS_DS_OFF] = off; w.istate[IS_DS_LEN] = len; w.istate[IS_EPISODE] = episode + 1;
-      w.istate[IS_EPSTEPS] = M.max_episode_steps < snippet ? M.max_episode_steps : snippet;
-      w.dsshift[0] = q0[0]; w.dsshift[1] = q0[1];
+      w.istate()[IS_DS_OFF] = off; w.istate()[IS_DS_LEN] = len; w.istate()[IS_EPISODE] = episode + 1;
+      w.istate()[IS_EPSTEPS] = M.max_episode_steps < snippet ? M.max_episode_steps : snippet;
+      w.dsshift()[0] = q0[0]; w.dsshift()[1] = q0[1];
     }
   } else
-  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = 0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
-  for (int i = lane; i < M.na; i += FB_WAVE) { w.act[i] = 0; w.act_dot[i] = 0; }
-  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel()[i] = 0; w.qacc()[i] = 0; w.qacc_ws()[i] = 0; }
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act()[i] = 0; w.act_dot()[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl()[i] = 0;
   SYNC();
-  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos[qa] = M.qpos_spring[qa]; }
-  if (lane == 0) { w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0; }
+  if (lane < 6) { int qa = M.jnt_qposadr[M.wing_jnt[lane]]; w.qpos()[qa] = M.qpos_spring[qa]; }
+  if (lane == 0) { w.istate()[IS_STEP] = 0; w.istate()[IS_RESET_NEXT] = 0; w.simtime()[0] = 0; }
   SYNC();
 }
 
@@ -493,23 +493,23 @@ __device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<re
 // wings from the WBPG at a per-episode phase
 template <typename real>
 __device__ __forceinline__ void d_flight_init(const DevModel<real>& M, const WS<real>& w, int env, int lane) {
-  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel[i] = (i < 3) ? M.ref_qvel[i] : (real)0; w.qacc[i] = 0; w.qacc_ws[i] = 0; }
-  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl[i] = 0;
-  int episode = w.istate[IS_EPISODE];
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel()[i] = (i < 3) ? M.ref_qvel[i] : (real)0; w.qacc()[i] = 0; w.qacc_ws()[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl()[i] = 0;
+  int episode = w.istate()[IS_EPISODE];
   SYNC();
   real phase0 = (real)hash_uniform(M.seed, (unsigned)env, (unsigned)episode);
-  int fidx = wave_argmin_absdiff(M.wb_freqs, M.wb_nfreq, M.wb_base_freq, false, lane);
+  int fidx = wave_argmin_absdiff((const real*)M.wb_freqs, M.wb_nfreq, M.wb_base_freq, false, lane);
   int o = M.wb_offset[fidx], n = M.wb_offset[fidx + 1] - o;
   int st = wave_argmin_absdiff(M.wb_phase + o, n, phase0, false, lane);
   if (lane < 6) {
     int j = M.wing_jnt[lane];
     real q0 = M.wb_traj[6*(o + st) + lane], q1 = M.wb_traj[6*(o + st + 1) + lane];
-    w.qpos[M.jnt_qposadr[j]] = q0; w.qvel[M.jnt_dofadr[j]] = (q1 - q0)/M.control_timestep;
+    w.qpos()[M.jnt_qposadr[j]] = q0; w.qvel()[M.jnt_dofadr[j]] = (q1 - q0)/M.control_timestep;
   }
   if (lane == 0) {
-    w.istate[IS_STEP] = 0; w.istate[IS_RESET_NEXT] = 0; w.simtime[0] = 0;
-    w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.istate[IS_EPISODE] = episode + 1; w.wbfreq[0] = M.wb_base_freq;
+    w.istate()[IS_STEP] = 0; w.istate()[IS_RESET_NEXT] = 0; w.simtime()[0] = 0;
+    w.istate()[IS_WB_STEP] = st; w.istate()[IS_WB_FREQ] = fidx; w.istate()[IS_EPISODE] = episode + 1; w.wbfreq()[0] = M.wb_base_freq;
   }
   SYNC();
 }
@@ -520,12 +520,12 @@ template <typename real>
 __device__ __forceinline__ void d_flight_pre(const DevModel<real>& M, const WS<real>& w, const float* action, int lane) {
   float au = action[M.user_idx]; if (au != au) au = 0.f;
   real ctrl_freq = M.wb_base_freq*(1 + M.wb_rel_range*(real)au);
-  int fidx = w.istate[IS_WB_FREQ], st = w.istate[IS_WB_STEP];
-  real filt = w.wbfreq[0];
+  int fidx = w.istate()[IS_WB_FREQ], st = w.istate()[IS_WB_STEP];
+  real filt = w.wbfreq()[0];
   int o = M.wb_offset[fidx], n = M.wb_offset[fidx + 1] - o;
   st = (st + 1) % n;
   filt = (M.wb_rate == 0) ? ctrl_freq : filt*M.wb_rate + ctrl_freq*(1 - M.wb_rate);
-  int fnew = wave_argmin_absdiff(M.wb_freqs, M.wb_nfreq, filt, false, lane);
+  int fnew = wave_argmin_absdiff((const real*)M.wb_freqs, M.wb_nfreq, filt, false, lane);
   if (fnew != fidx) {
     real cur = M.wb_phase[o + st]; cur = cur - floor(cur);
     int o2 = M.wb_offset[fnew], n2 = M.wb_offset[fnew + 1] - o2;
@@ -536,24 +536,24 @@ __device__ __forceinline__ void d_flight_pre(const DevModel<real>& M, const WS<r
   for (int k = lane; k < M.nu; k += FB_WAVE) {
     float a = action[k]; if (a != a) a = 0.f;
     real v = (real)a;
-    for (int q = 0; q < 6; q++) if (M.wing_act_idx[q] == k) v += M.wb_traj[6*(o + st) + q] - w.qpos[M.jnt_qposadr[M.wing_jnt[q]]];
-    w.ctrl[M.action_to_ctrl[k]] = v;
+    for (int q = 0; q < 6; q++) if (M.wing_act_idx[q] == k) v += M.wb_traj[6*(o + st) + q] - w.qpos()[M.jnt_qposadr[M.wing_jnt[q]]];
+    w.ctrl()[M.action_to_ctrl[k]] = v;
   }
-  if (lane < FB_NSENS) w.sens_acc[lane] = 0;
-  if (lane == 0) { w.istate[IS_WB_STEP] = st; w.istate[IS_WB_FREQ] = fidx; w.wbfreq[0] = filt; }
+  if (lane < FB_NSENS) w.sens_acc()[lane] = 0;
+  if (lane == 0) { w.istate()[IS_WB_STEP] = st; w.istate()[IS_WB_FREQ] = fidx; w.wbfreq()[0] = filt; }
   SYNC();
 }
 
 // flight_imitation reward / termination / observation (flight_imitation.py:170-212)
 template <typename real>
 __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<real>& w, float* obs, float* reward, float* discount, int* step_type, int lane) {
-  if (lane < FB_NSENS) w.sens_acc[lane] = w.sens_acc[lane] / (real)M.nsubstep;
-  int prev = w.istate[IS_STEP];
+  if (lane < FB_NSENS) w.sens_acc()[lane] = w.sens_acc()[lane] / (real)M.nsubstep;
+  int prev = w.istate()[IS_STEP];
   int stepc = prev + 1;
   SYNC();
-  if (lane == 0) w.istate[IS_STEP] = stepc;
+  if (lane == 0) w.istate()[IS_STEP] = stepc;
   real qn = 0;
-  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc[i]*w.qacc[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) qn += w.qacc()[i]*w.qacc()[i];
   qn = wave_sum(qn);
   SYNC();
   // ghost pose: set from ref[prev] before the physics and advanced by its velocity over the control step
@@ -570,10 +570,10 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
   }
   real off[3], dif[3];
   rotvecquat(off, M.com_offset, tmpq);
-  for (int k = 0; k < 3; k++) dif[k] = gp[k] + off[k] - w.com[k];
+  for (int k = 0; k < 3; k++) dif[k] = gp[k] + off[k] - w.com()[k];
   real r_disp = tolerance_linear((real)norm3(dif), (real)0.4);
   int idx = stepc < M.T ? stepc : M.T - 1;
-  const real* q = w.qpos + 3;
+  const real* q = w.qpos() + 3;
   real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
   real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2}, dq[4];
   mulquat(dq, qi, M.ref_qpos + 7*idx + 3);
@@ -581,19 +581,19 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
   real x = 2*(dq[0]/nq)*(dq[0]/nq) - 1; if (x > 1) x = 1;
   real r_quat = tolerance_linear((real)acos(x), (real)3.14159265358979323846);
   int thorax = M.site_bodyid[M.site_thorax];
-  real height = w.xpos[3*thorax + 2];
-  real cd[3]; sub3(cd, M.ref_qpos + 7*idx, w.qpos);
-  int tstep = (int)floor(w.simtime[0] / M.control_timestep + (real)0.5);
+  real height = w.xpos()[3*thorax + 2];
+  real cd[3]; sub3(cd, M.ref_qpos + 7*idx, w.qpos());
+  int tstep = (int)floor(w.simtime()[0] / M.control_timestep + (real)0.5);
   bool traj_end = (tstep == M.episode_steps);
   bool term = (height < (real)0.2) || (norm3(cd) > M.terminal_com_dist) || traj_end || (sqrt(qn) > (real)1e14) || (qn != qn);
-  bool terminating = term || (w.simtime[0] >= M.time_limit);
-  d_pack_obs(M, w, w.sens_acc, obs, lane);
+  bool terminating = term || (w.simtime()[0] >= M.time_limit);
+  d_pack_obs(M, w, w.sens_acc(), obs, lane);
   if (lane == 0) {
     *reward = (float)(r_disp*r_quat);
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
-    w.istate[IS_STEP_TYPE] = terminating ? 2 : 1;
-    w.istate[IS_RESET_NEXT] = terminating ? 1 : 0;
+    w.istate()[IS_STEP_TYPE] = terminating ? 2 : 1;
+    w.istate()[IS_RESET_NEXT] = terminating ? 1 : 0;
   }
   SYNC();
 }
@@ -611,7 +611,7 @@ enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
 template <typename real>
 __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, const float* action,
                       float* obs, float* reward, float* discount, int* step_type, int lane) {
-  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && w.istate[IS_RESET_NEXT] != 0);
+  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && w.istate()[IS_RESET_NEXT] != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
   bool actuate = true, damp = false;
   int nsub = (mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep, sub = 0;
@@ -635,8 +635,8 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         PROF_BEGIN();
         if (actuate) d_actuation(M, w, lane);
         else {
-          for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator[i] = 0;
-          for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot[i] = 0;
+          for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator()[i] = 0;
+          for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot()[i] = 0;
           SYNC();
         }
         PROF(P_ACT);
@@ -644,20 +644,20 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
       case ST_ACC_PRE: {
         PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) {
-          real f = w.qfrc_passive[i] - w.qfrc_bias[i] + w.qfrc_actuator[i];
-          w.qfrc_smooth[i] = f; w.lx[i] = f;
+          real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.qfrc_actuator()[i];
+          w.qfrc_smooth()[i] = f; w.lx[i] = f;
         }
         SYNC();
         PROF(24);
         ret = ST_ACC_POST; pc = ST_SOLVE; break; }
       case ST_SOLVE: {
         PROF_BEGIN();
-        d_solve(M, w, w.lLD, w.lDinv, w.lx, lane);
+        { const WS<real> wc = w; d_solve(M, wc, w.lLD, w.lDinv, w.lx, lane); }
         PROF(P_ACC);
         pc = ret; break; }
       case ST_ACC_POST: {
         PROF_BEGIN();
-        for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth[i] = w.lx[i];
+        for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx[i];
         SYNC();
         PROF(24);
         pc = ST_CONSTR_A; break; }
@@ -677,13 +677,14 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
       case ST_EULER_PRE: {
         // the factor of M is dead after the constraint solve: its LDS slot is reused for M + h*D
         PROF_BEGIN();
-        for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth[i] + w.qfrc_constraint[i];
+        for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth()[i] + w.qfrc_constraint()[i];
         SYNC();
         PROF(24);
         damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
-        d_factor(M, w, w.qM, damp ? M.dof_damping : (const real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDinv, lane);
+        const WS<real> wc = w;
+        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDinv, lane);
         PROF(P_FACTOR);
         pc = fret; break; }
       case ST_EULER_SOLVE:
@@ -711,7 +712,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         pc = single_pass ? ST_ACT : ST_SUBEND; break; }
       case ST_SUBEND: {
         PROF_BEGIN();
-        if (env_logic) { if (lane < FB_NSENS) w.sens_acc[lane] += w.sens[lane]; SYNC(); }
+        if (env_logic) { if (lane < FB_NSENS) w.sens_acc()[lane] += w.sens()[lane]; SYNC(); }
         sub++;
         PROF(26);
         pc = (sub < nsub) ? ST_ACT : ST_DONE; break; }
@@ -721,8 +722,8 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   PROF_BEGIN();
   if (env_logic) {
     if (resetting) {
-      d_pack_obs(M, w, w.sens, obs, lane);
-      if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate[IS_STEP_TYPE] = 0; }
+      d_pack_obs(M, w, w.sens(), obs, lane);
+      if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate()[IS_STEP_TYPE] = 0; }
       SYNC();
     } else if (M.task == 1) d_flight_post(M, w, obs, reward, discount, step_type, lane);
     else if (M.task == 2) d_ball_post(M, w, obs, reward, discount, step_type, lane);

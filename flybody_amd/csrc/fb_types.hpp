@@ -37,66 +37,29 @@ enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
        IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_N = 16 };
 
-// Constant tables shared by all environments (device pointers).
-template <typename real>
-struct DevModel {
-  int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep;
-  int nobsjnt, napp, nforce, ntouch, site_thorax, nadh;
-  int iterations, noslip_iterations;
-  real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
-  // topology
-  const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_nsub, *body_depth;
-  const int *body_path;      // [nbody][FB_MAXDEPTH] ancestors from the tree root down to the body
-  const int *body_chlen;     // [nbody] number of dofs on the root->body chain
-  const int *body_chain;     // [nbody][FB_MAXCH] dof ids on that chain, root first
-  const int *body_common;    // [nbody][nbody] number of shared chain dofs
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
-  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_depth;
-  const int *dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
-  const int *dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
-  const int *lvl_dof, *lvl_start; int nlevel;   // dofs grouped by depth
-  const int *dof_cl;         // [nv] length of the unbranched chain below the dof
-  const int *dof_gen;        // [nv] index of a dof outside the trunk whose subtree branches ("general" dof) or -1
-  const int *gen_k, *gen_m;  // [FB_MAXGEN][FB_MAXCH] descendants of a general dof on a level: 4 dof ids (u8) / 4 row starts (u16)
-  const int *fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
-  const int *fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
-  int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
-  int chmax;                 // longest dof chain of any body
-  int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
-  const int *geom_type, *geom_bodyid, *site_bodyid, *site_type;
-  const int *tendon_adr, *tendon_num, *wrap_dofid;
-  const int *act_trntype, *act_trnid, *act_dyntype, *act_biastype, *act_ctrllimited, *act_forcelimited, *act_actadr;
-  const int *adh_act;        // [nadh] actuator ids with body transmission
-  const int *wrap_qadr;      // [nwrap] qpos address of the (hinge/slide) joint a tendon wrap reads
-  const int *act_wn, *act_wdof, *act_lenadr;   // flattened transmission: [nu] dof count, [nu][FB_MAXWRAP] dofs (padded with 0), [nu] qpos address (joint) / tendon id
-  const real *act_wcoef;     // [nu][FB_MAXWRAP] moment arms (padded with 0)
-  const int *action_to_ctrl;
-  const int *pair_geom1, *pair_geom2, *pair_condim;
-  const int *obs_jnt, *app_sites, *force_sites, *touch_sites, *wing_jnt;
-  // constants
-  const real *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_box;
-  const real *body_rec;      // [nbody][FB_BODYREC] flattened kinematics record of a body (fb_engine.hip)
-  const real *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_solref, *jnt_solimp, *jnt_margin;
-  const real *qpos0, *qpos_spring, *dof_armature, *dof_damping, *dof_invweight0;
-  const real *geom_pos, *geom_quat, *geom_size, *geom_rbound, *geom_fluid;
-  const real *site_pos, *site_quat, *site_size;
-  const real *wrap_coef;
-  const real *act_dynprm, *act_gainprm, *act_biasprm, *act_ctrlrange, *act_forcerange;
-  const real *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
-  // env-level (walk_imitation)
-  const real *ref_qpos, *ref_qvel;
-  int T, future_steps, episode_steps, nobs;
-  real terminal_com_dist, time_limit;
-  // flight task (task == 1): action layout, CoM offset, wing-beat pattern generator tables
-  int task, nact, user_idx; unsigned seed;
-  const int *wing_act_idx, *body_fluid_geom;
-  real com_offset[3];
-  const real *wb_traj, *wb_phase, *wb_freqs; const int* wb_offset; int wb_nfreq;
-  real wb_base_freq, wb_rel_range, wb_rate;
-  // walk_imitation training mode: reference dataset (fb_batch_set_walk_dataset)
-  const real *ds_qpos, *ds_qvel, *ds_r2s, *ds_jq;
-  const int *ds_offset, *ds_jid, *ds_sid, *ds_select;
-  int ds_nj, ds_ns, ds_ntraj, ds_nselect, ds_env_base, max_episode_steps;
+
+// Address spaces are part of the pointer types.  Pointers that come out of a struct in memory carry no provenance the
+// compiler could use, and a generic pointer compiles to flat_load / flat_store: 64-bit VALU address arithmetic per access
+// and a wait on BOTH memory counters (LDS reads behind an outstanding flat load stall).  Typed as global (1) the same
+// access is global_load with a scalar base; the model struct itself sits in constant (4) memory and its fields arrive by
+// s_load into SGPRs.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FB_EMULATE)
+#define FB_GLOBAL __attribute__((address_space(1)))
+#define FB_CONST __attribute__((address_space(4)))
+#else
+#define FB_GLOBAL
+#define FB_CONST
+#endif
+#ifdef FB_EMULATE
+#define FB_HD
+#else
+#define FB_HD __host__ __device__
+#endif
+// device pointer to a table in global memory (same size and layout as a plain pointer)
+template <typename T> struct GP {
+  FB_GLOBAL T* p;
+  FB_HD __forceinline__ operator T*() const { return (T*)p; }
+  FB_HD __forceinline__ GP& operator=(T* q) { p = (FB_GLOBAL T*)q; return *this; }
 };
 
 // Per-environment real arrays: X(name, element count expression in terms of DevModel M)
@@ -129,6 +92,69 @@ struct WSOff {
   uint32_t nreal, nint;
 };
 
+// Constant tables shared by all environments (device pointers).
+template <typename real>
+struct DevModel {
+  int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep;
+  int nobsjnt, napp, nforce, ntouch, site_thorax, nadh;
+  int iterations, noslip_iterations;
+  real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
+  // topology
+  GP<const int> body_parent, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_nsub, body_depth;
+  GP<const int> body_path;      // [nbody][FB_MAXDEPTH] ancestors from the tree root down to the body
+  GP<const int> body_chlen;     // [nbody] number of dofs on the root->body chain
+  GP<const int> body_chain;     // [nbody][FB_MAXCH] dof ids on that chain, root first
+  GP<const int> body_common;    // [nbody][nbody] number of shared chain dofs
+  GP<const int> jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
+  GP<const int> dof_bodyid, dof_jntid, dof_parentid, dof_Madr, dof_depth;
+  GP<const int> dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
+  GP<const int> dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
+  GP<const int> lvl_dof, lvl_start; int nlevel;   // dofs grouped by depth
+  GP<const int> dof_cl;         // [nv] length of the unbranched chain below the dof
+  GP<const int> dof_gen;        // [nv] index of a dof outside the trunk whose subtree branches ("general" dof) or -1
+  GP<const int> gen_k, gen_m;  // [FB_MAXGEN][FB_MAXCH] descendants of a general dof on a level: 4 dof ids (u8) / 4 row starts (u16)
+  GP<const int> fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
+  GP<const int> fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
+  int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
+  int chmax;                 // longest dof chain of any body
+  int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
+  GP<const int> geom_type, geom_bodyid, site_bodyid, site_type;
+  GP<const int> tendon_adr, tendon_num, wrap_dofid;
+  GP<const int> act_trntype, act_trnid, act_dyntype, act_biastype, act_ctrllimited, act_forcelimited, act_actadr;
+  GP<const int> adh_act;        // [nadh] actuator ids with body transmission
+  GP<const int> wrap_qadr;      // [nwrap] qpos address of the (hinge/slide) joint a tendon wrap reads
+  GP<const int> act_wn, act_wdof, act_lenadr;   // flattened transmission: [nu] dof count, [nu][FB_MAXWRAP] dofs (padded with 0), [nu] qpos address (joint) / tendon id
+  GP<const real> act_wcoef;     // [nu][FB_MAXWRAP] moment arms (padded with 0)
+  GP<const int> action_to_ctrl;
+  GP<const int> pair_geom1, pair_geom2, pair_condim;
+  GP<const int> obs_jnt, app_sites, force_sites, touch_sites, wing_jnt;
+  // constants
+  GP<const real> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0, body_box;
+  GP<const real> body_rec;      // [nbody][FB_BODYREC] flattened kinematics record of a body (fb_engine.hip)
+  GP<const real> jnt_pos, jnt_axis, jnt_stiffness, jnt_range, jnt_solref, jnt_solimp, jnt_margin;
+  GP<const real> qpos0, qpos_spring, dof_armature, dof_damping, dof_invweight0;
+  GP<const real> geom_pos, geom_quat, geom_size, geom_rbound, geom_fluid;
+  GP<const real> site_pos, site_quat, site_size;
+  GP<const real> wrap_coef;
+  GP<const real> act_dynprm, act_gainprm, act_biasprm, act_ctrlrange, act_forcerange;
+  GP<const real> pair_friction, pair_solref, pair_solimp, pair_margin, pair_gap;
+  // env-level (walk_imitation)
+  GP<const real> ref_qpos, ref_qvel;
+  int T, future_steps, episode_steps, nobs;
+  real terminal_com_dist, time_limit;
+  // flight task (task == 1): action layout, CoM offset, wing-beat pattern generator tables
+  int task, nact, user_idx; unsigned seed;
+  GP<const int> wing_act_idx, body_fluid_geom;
+  real com_offset[3];
+  GP<const real> wb_traj, wb_phase, wb_freqs; GP<const int> wb_offset; int wb_nfreq;
+  real wb_base_freq, wb_rel_range, wb_rate;
+  // walk_imitation training mode: reference dataset (fb_batch_set_walk_dataset)
+  GP<const real> ds_qpos, ds_qvel, ds_r2s, ds_jq;
+  GP<const int> ds_offset, ds_jid, ds_sid, ds_select;
+  int ds_nj, ds_ns, ds_ntraj, ds_nselect, ds_env_base, max_episode_steps;
+  WSOff off;                 // layout of one environment's workspace row (fb_engine.hip: compute_offsets)
+};
+
 // LDS pointers carry their address space in the type so that every access compiles to ds_read /
 // ds_write (a generic pointer would fall back to flat_* instructions and their global-class latency)
 #ifdef FB_EMULATE
@@ -146,20 +172,13 @@ struct WS {
   FB_LDS real *lLD, *lDinv, *lx, *lAR;     // lLD: row-major factor, 1/D on the diagonal (see fb_smooth.hpp)
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
   const FB_LDS uint8_t *ldepth, *lcl, *lgen; const FB_LDS uint16_t *lmadr; const FB_LDS uint32_t *lgk, *lgm; int nlevel;
-#define X(name, n) real* name;
+  // global arrays of this environment: base of its arena row + the model's offset table.  The base is wave-uniform
+  // (SGPRs), the offsets are s_load'ed from the model, so an access is global_load with a scalar base address.
+  FB_GLOBAL real* rb; FB_GLOBAL int* ib; const FB_CONST WSOff* o;
+#define X(name, n) __device__ __forceinline__ real* name() const { return (real*)(rb + o->name); }
   FB_WS_REAL(X)
 #undef X
-#define X(name, n) int* name;
+#define X(name, n) __device__ __forceinline__ int* name() const { return (int*)(ib + o->name); }
   FB_WS_INT(X)
 #undef X
 };
-
-template <typename real>
-__device__ __forceinline__ void ws_bind(WS<real>& w, const WSOff& o, real* rbase, int* ibase) {
-#define X(name, n) w.name = rbase + o.name;
-  FB_WS_REAL(X)
-#undef X
-#define X(name, n) w.name = ibase + o.name;
-  FB_WS_INT(X)
-#undef X
-}
