@@ -621,7 +621,11 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     }
     niter = it + 1;
     if (improvement*scale < M.tolerance) break;
+    // the sweeps are one long dependent chain that hardly uses the SIMD: let this wave win issue arbitration against the
+    // throughput-bound stages of its neighbours (measured -3%); the progress-based priority is restored after the loop
+    if (it == 0) FB_SETPRIO(3);
   }
+  FB_SETPRIO(uniform_int(w.istate()[IS_PRIO]));
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[31] += bt_[4]; pp_[16] += bt_[0]; pp_[22] += bt_[1]; pp_[23] += bt_[2]; }
 #endif

@@ -299,6 +299,7 @@ struct Batch {
   real* rarena; int* iarena;
   float *obs, *reward, *discount; int* step_type;
   int n_env, nobs;
+  int* sched;                 // [FB_NSCHED] progress counters, zeroed before every launch
 };
 
 
@@ -339,7 +340,8 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   long long t0_ = clock64(), r0_ = wall_clock64();
 #endif
-  d_run(M, w, env, mode, nsub, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  if (lane == 0) w.istate()[IS_PRIO] = 0;
+  d_run(M, w, env, mode, nsub, nslot, B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
 #endif
@@ -353,6 +355,7 @@ struct fb_batch {
   void* rarena = nullptr; int* iarena = nullptr;
   float *obs = nullptr, *reward = nullptr, *discount = nullptr; int* step_type = nullptr;
   int* d_ids = nullptr;
+  int* sched = nullptr;
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
@@ -473,6 +476,7 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
   HIPCHK(hipMalloc((void**)&b->discount, n_env*sizeof(float)));
   HIPCHK(hipMalloc((void**)&b->step_type, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->d_ids, n_env*sizeof(int)));
+  HIPCHK(hipMalloc((void**)&b->sched, FB_NSCHED*sizeof(int)));
   HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->discount, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->step_type, 0, n_env*sizeof(int)));
@@ -495,7 +499,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->ref_qpos, b->ref_qvel};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->ref_qpos, b->ref_qvel};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -626,11 +630,12 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
     HIPCHK(hipMemcpy(b->dM, hM, nM, hipMemcpyHostToDevice));
     memcpy(hD, hM, nM);
   }
+  HIPCHK(hipMemsetAsync(b->sched, 0, FB_NSCHED*sizeof(int), st));
   if (b->precision == 64) {
-    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->sched};
     hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
-    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs};
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->sched};
     hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   HIPCHK(hipGetLastError());

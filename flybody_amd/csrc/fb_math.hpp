@@ -159,7 +159,7 @@ template <typename real> FBD real clampr(real x, real lo, real hi) { return x < 
 #define FB_LDS_AS
 #else
 #define FB_OPAQUE(x) asm volatile("" : "+v"(x))
-#define FB_SETPRIO(p) do { if ((p) == 0) __builtin_amdgcn_s_setprio(0); else if ((p) == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); } while (0)
+#define FB_SETPRIO(p) do { int p_ = (p); if (p_ <= 0) __builtin_amdgcn_s_setprio(0); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); } while (0)
 #define FB_LDS_AS __attribute__((address_space(3)))
 #endif
 

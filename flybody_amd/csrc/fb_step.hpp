@@ -656,7 +656,7 @@ template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const 
 }
 
 template <typename real>
-__device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, const float* action,
+__device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
                       float* obs, float* reward, float* discount, int* step_type, int lane) {
   bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && w.istate()[IS_RESET_NEXT] != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
@@ -757,6 +757,17 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
       case ST_SUBEND: {
         PROF_BEGIN();
         if (env_logic) { if (lane < FB_NSENS) w.sens_acc()[lane] += w.sens()[lane]; SYNC(); }
+        // Tail-aware issue priority.  The launch ends when its slowest environment ends, and every environment is resident
+        // from the start, so a wave that trails the others is on the critical path.  Each wave counts itself into the
+        // substep's progress counter; the more waves were there before it, the higher its priority for the next substep.
+        if (sched && sub < FB_NSCHED) {
+          int before = 0;
+          if (lane == 0) before = atomicAdd(sched + sub, 1);
+          before = uniform_int(before);
+          int prio = (4*before < 2*nslot) ? 0 : (8*before < 7*nslot ? 1 : (32*before < 31*nslot ? 2 : 3));
+          if (lane == 0) w.istate()[IS_PRIO] = prio;
+          FB_SETPRIO(prio);
+        }
         sub++;
         PROF(26);
         pc = (sub < nsub) ? ST_ACT : ST_DONE; break; }

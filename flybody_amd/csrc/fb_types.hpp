@@ -24,6 +24,7 @@
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
 #define FB_NPROF 32
+#define FB_NSCHED 64          // progress counters of one launch (one per substep)
 #define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 128
@@ -35,7 +36,7 @@ enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 // istate slots
 enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
-       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_N = 16 };
+       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_PRIO = 14, IS_N = 16 };
 
 
 // Address spaces are part of the pointer types.  Pointers that come out of a struct in memory carry no provenance the
