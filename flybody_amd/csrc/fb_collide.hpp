@@ -326,29 +326,52 @@ template <typename real>
 __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   PROF_BEGIN();
-  // ---- mid phase: bounding spheres
+  // ---- mid phase: bounding spheres.  The spheres {centre, radius} of all geoms and the normals of the planes are staged
+  // in LDS first (slot of the Delassus matrix, not live yet), the pair list is a packed word per pair fetched four wave
+  // passes at a time: ~10 global round trips per substep instead of two dependent ones for each of the 34 passes.
+  FB_LDS real* G = w.lAR;
+  for (int g = lane; g < M.ngeom; g += FB_WAVE) {
+    const real* c = w.gxpos() + 3*g;
+    real x = c[0], y = c[1], z = c[2], rb = M.geom_rbound[g];
+    G[4*g] = x; G[4*g + 1] = y; G[4*g + 2] = z; G[4*g + 3] = rb;
+  }
+  for (int k = lane; k < M.nplane; k += FB_WAVE) {
+    const real* m1 = w.gxmat() + 9*M.plane_geoms[k];
+    real nx = m1[2], ny = m1[5], nz = m1[8];
+    FB_LDS real* o = G + 4*(M.ngeom + k);
+    o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 0;
+  }
+  SYNC();
   int ncand = 0;
   const int maxcand = 2*FB_MAXCON_ + 64;
-  for (int base = 0; base < M.npair; base += FB_WAVE) {
-    int p = base + lane;
-    bool hit = false;
-    if (p < M.npair) {
-      int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-      real margin = M.pair_margin[p];
-      real dif[3]; sub3(dif, w.gxpos() + 3*g2, w.gxpos() + 3*g1);
-      if (M.geom_type[g1] == GEOM_PLANE) {
-        const real* m1 = w.gxmat() + 9*g1;
-        real n[3] = {m1[2], m1[5], m1[8]};
-        hit = dot3(dif, n) <= M.geom_rbound[g2] + margin;
+  for (int base = 0; base < M.npair; base += 4*FB_WAVE) {
+    int pw[4]; real mg[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int p = base + u*FB_WAVE + lane, ps = p < M.npair ? p : 0;
+      pw[u] = M.pair_word[ps]; mg[u] = M.pair_margin[ps];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int p = base + u*FB_WAVE + lane;
+      if (base + u*FB_WAVE >= M.npair) break;
+      int g1 = pw[u] & 1023, g2 = (pw[u] >> 10) & 1023, ns = pw[u] >> 20;
+      const FB_LDS real* c1 = G + 4*g1; const FB_LDS real* c2 = G + 4*g2;
+      real dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+      bool hit;
+      if (ns) {
+        const FB_LDS real* n = G + 4*ns;
+        hit = dif[0]*n[0] + dif[1]*n[1] + dif[2]*n[2] <= c2[3] + mg[u];
       } else {
-        real bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+        real bound = c1[3] + c2[3] + mg[u];
         hit = dot3(dif, dif) <= bound*bound;
       }
+      hit = hit && p < M.npair;
+      unsigned long long bal = __ballot(hit);
+      int idx = ncand + __popcll(bal & lt_mask);
+      if (hit && idx < maxcand) w.cand()[idx] = p;
+      ncand += __popcll(bal);
     }
-    unsigned long long bal = __ballot(hit);
-    int idx = ncand + __popcll(bal & lt_mask);
-    if (hit && idx < maxcand) w.cand()[idx] = p;
-    ncand += __popcll(bal);
   }
   if (ncand > maxcand) ncand = maxcand;
   SYNC();

@@ -35,6 +35,7 @@ struct fb_model {
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
   std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
+  std::vector<int> pair_word, plane_geoms;
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
@@ -214,6 +215,20 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
   for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
+  // collision mid phase: one packed word per candidate pair; the geoms' bounding spheres (and the plane normals) are
+  // staged in LDS (the Delassus-matrix slot, free at that point of the step), fb_collide.hpp: d_collision
+  {
+    const int *g1 = m->i("pair_geom1"), *g2 = m->i("pair_geom2"), *gt = m->i("geom_type");
+    std::vector<int> slot(m->ngeom, 0);
+    for (int g = 0; g < m->ngeom; g++) if (gt[g] == GEOM_PLANE) { m->plane_geoms.push_back(g); slot[g] = m->ngeom + (int)m->plane_geoms.size() - 1; }
+    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<float>::AR_ELEMS) { delete m; return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
+    m->pair_word.assign(std::max(m->npair, 1), 0);
+    for (int q = 0; q < m->npair; q++) {
+      if (gt[g2[q]] == GEOM_PLANE) { delete m; return fail("fb_model_load: a plane must be the first geom of a pair"); }
+      m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20);
+    }
+    if (m->plane_geoms.empty()) m->plane_geoms.push_back(0);
+  }
   // flattened actuator transmissions and tendon wraps: one padded record per actuator / wrap, so that the kernel fetches
   // them with a fixed number of independent loads instead of walking tendon_adr -> wrap_dofid -> dof_jntid -> jnt_qposadr
   {
@@ -425,6 +440,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(wrap_qadr, wrap_qadr) UV(act_wn, act_wn) UV(act_wdof, act_wdof) UV(act_lenadr, act_lenadr)
   if (upload<real>(b, m->act_wcoef.data(), m->act_wcoef.size(), &M.act_wcoef)) return -1;
   UI(pair_geom1, "pair_geom1") UI(pair_geom2, "pair_geom2") UI(pair_condim, "pair_condim")
+  UV(pair_word, pair_word) UV(plane_geoms, plane_geoms)
+  { const int* gt_ = m->i("geom_type"); int np_ = 0; for (int g = 0; g < m->ngeom; g++) np_ += gt_[g] == GEOM_PLANE; M.nplane = np_; }
   UI(obs_jnt, "observable_joints") UI(app_sites, "appendage_sites") UI(force_sites, "sensor_force_sites") UI(touch_sites, "sensor_touch_sites") UI(wing_jnt, "wing_jnt")
   UD(body_pos, "body_pos") UD(body_quat, "body_quat") UD(body_ipos, "body_ipos") UD(body_iquat, "body_iquat") UD(body_mass, "body_mass")
   UD(body_inertia, "body_inertia") UD(body_invweight0, "body_invweight0")

@@ -612,6 +612,12 @@ enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
 // Every stage of the step is compiled as a function of its own: the register allocator then works on one stage at a
 // time instead of on the whole state machine (measured: the fully inlined kernel is ~25% slower).  A stage receives the
 // model (constant memory) and a copy of the workspace descriptor; it moves the descriptor's pointers back to SGPRs.
+// trailing-wave priority thresholds, in 32nds of the launch's environments (see ST_SUBEND)
+#ifndef FB_PRIO_T1
+#define FB_PRIO_T1 16
+#define FB_PRIO_T2 28
+#define FB_PRIO_T3 31
+#endif
 #ifndef FB_INL_C
 #define FB_INL_C 1
 #endif
@@ -764,7 +770,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
           int before = 0;
           if (lane == 0) before = atomicAdd(sched + sub, 1);
           before = uniform_int(before);
-          int prio = (4*before < 2*nslot) ? 0 : (8*before < 7*nslot ? 1 : (32*before < 31*nslot ? 2 : 3));
+          int prio = (32*before < FB_PRIO_T1*nslot) ? 0 : (32*before < FB_PRIO_T2*nslot ? 1 : (32*before < FB_PRIO_T3*nslot ? 2 : 3));
           if (lane == 0) w.istate()[IS_PRIO] = prio;
           FB_SETPRIO(prio);
         }
