@@ -1,4 +1,3 @@
 cd /root/repo
-python tools/quick_bench.py flybody_amd/libflybody_hip.so 32 4096 30 2>&1 | grep prec
-python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 4096 15 2>&1 | grep prec
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+python bench.py 2>&1 | tail -1
