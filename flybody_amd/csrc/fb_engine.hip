@@ -315,6 +315,7 @@ struct Batch {
   float *obs, *reward, *discount; int* step_type;
   int n_env, nobs;
   int* sched;                 // [FB_NSCHED] progress counters, zeroed before every launch
+  int* cost;                  // [n_env] duration of the environment's last control step (wall-clock ticks), input of k_order
 };
 
 
@@ -355,11 +356,59 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   long long t0_ = clock64(), r0_ = wall_clock64();
 #endif
+#ifdef FB_EMULATE
+  long long life0_ = 0;
+#else
+  long long life0_ = wall_clock64();
+#endif
   if (lane == 0) w.istate()[IS_PRIO] = 0;
   d_run(M, w, env, mode, nsub, nslot, B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
 #endif
+  // how long this environment's control step took: the next launch starts the slow environments first (k_order)
+  if (mode == MODE_STEP && B.cost && lane == 0) {
+#ifdef FB_EMULATE
+    B.cost[env] = (int)(((unsigned)env*2654435761u) >> 16);        // no clock on the host: an arbitrary permutation exercises the path
+#else
+    B.cost[env] = (int)(wall_clock64() - life0_);
+#endif
+  }
+}
+
+// Launch order for the next control step: environments sorted by the duration of their last step, longest first (counting
+// sort over 256 duration bins, one workgroup).  Contact configurations persist from step to step, so the last duration
+// predicts the next one well, and a launch with more environments than resident waves (FP64 build: 2048 slots per GPU)
+// no longer ends with a few slow environments that started late: longest-processing-time-first packing.
+#define FB_ORDER_THREADS 256
+__global__ void __launch_bounds__(FB_ORDER_THREADS) k_order(const int* cost, int* order, int n) {
+  __shared__ int s_red[FB_ORDER_THREADS];
+  __shared__ int s_hist[256];
+  int tid = threadIdx.x;
+  int mx = 1;
+  for (int e = tid; e < n; e += FB_ORDER_THREADS) mx = cost[e] > mx ? cost[e] : mx;
+  s_red[tid] = mx; s_hist[tid & 255] = 0;
+  __syncthreads();
+  for (int st = FB_ORDER_THREADS/2; st >= 1; st >>= 1) {
+    if (tid < st) s_red[tid] = s_red[tid] > s_red[tid + st] ? s_red[tid] : s_red[tid + st];
+    __syncthreads();
+  }
+  mx = s_red[0];
+  __syncthreads();
+  // bin 0 = longest
+  for (int e = tid; e < n; e += FB_ORDER_THREADS) {
+    int c = cost[e]; c = c < 0 ? 0 : c;
+    int bin = 255 - (int)(((long long)c*255)/mx);
+    atomicAdd(&s_hist[bin], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { int h = s_hist[k]; s_hist[k] = acc; acc += h; } }
+  __syncthreads();
+  for (int e = tid; e < n; e += FB_ORDER_THREADS) {
+    int c = cost[e]; c = c < 0 ? 0 : c;
+    int bin = 255 - (int)(((long long)c*255)/mx);
+    order[atomicAdd(&s_hist[bin], 1)] = e;
+  }
 }
 
 // ------------------------------------------------------------------ batch
@@ -371,6 +420,7 @@ struct fb_batch {
   float *obs = nullptr, *reward = nullptr, *discount = nullptr; int* step_type = nullptr;
   int* d_ids = nullptr;
   int* sched = nullptr;
+  int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true;
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
@@ -494,6 +544,10 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
   HIPCHK(hipMalloc((void**)&b->step_type, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->d_ids, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->sched, FB_NSCHED*sizeof(int)));
+  HIPCHK(hipMalloc((void**)&b->cost, n_env*sizeof(int)));
+  HIPCHK(hipMemset(b->cost, 0, n_env*sizeof(int)));
+  HIPCHK(hipMalloc((void**)&b->order, n_env*sizeof(int)));
+  { const char* e_ = getenv("FB_NO_REORDER"); b->reorder = !(e_ && e_[0] == '1'); }
   HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->discount, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->step_type, 0, n_env*sizeof(int)));
@@ -516,7 +570,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->ref_qpos, b->ref_qvel};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -648,13 +702,16 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
     memcpy(hD, hM, nM);
   }
   HIPCHK(hipMemsetAsync(b->sched, 0, FB_NSCHED*sizeof(int), st));
+  const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder;
+  if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
   if (b->precision == 64) {
-    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->sched};
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
     hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
-    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->sched};
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
     hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
+  if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
   HIPCHK(hipGetLastError());
   if (b->timing) b->timed_launches++;
   return 0;

@@ -32,8 +32,9 @@ def main():
     for prec in (32, 64):
         env = flight_imitation(n_env=8192, precision=prec)
         out.append(dict(config='configs[3]: flight_imitation 8192 envs, random actions, WBPG + ellipsoid wing forces', dtype=f'f{prec}', **rollout(env, 12, K))); del env
-    env = walk_on_ball(n_env=4096, precision=32)
-    out.append(dict(config='8(f)2: walk_on_ball 4096 envs, random actions', dtype='f32', **rollout(env, 59, K))); del env
+    for prec in (32, 64):
+        env = walk_on_ball(n_env=4096, precision=prec)
+        out.append(dict(config='8(f)2: walk_on_ball 4096 envs, random actions', dtype=f'f{prec}', **rollout(env, 59, K))); del env
     # training-mode walk_imitation on a synthetic dataset recorded from the CPU oracle (the figshare data is not available offline)
     from flybody_amd.model_blob import load_npz, pack_model
     from flybody_amd.trajectory_loaders import ArrayWalkingTrajectoryLoader
@@ -41,15 +42,16 @@ def main():
     from _synthetic_dataset import make_dataset
     arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'walk_imitation.npz'))
     ds = make_dataset(fbo.OracleModel(pack_model(arr)), arr, n_traj=8, length=160)
-    env = walk_imitation(ref_path=ArrayWalkingTrajectoryLoader(ds), terminal_com_dist=0.3, n_env=4096, precision=32)
-    out.append(dict(config=f'8(f)1: walk_imitation training mode 4096 envs ({ds.n_traj} synthetic snippets, {len(ds.joint_names)} mocap joints, DeepMimic reward)',
-                    dtype='f32', **rollout(env, 59, K, scale=0.3))); del env
+    for prec in (32, 64):
+        env = walk_imitation(ref_path=ArrayWalkingTrajectoryLoader(ds), terminal_com_dist=0.3, n_env=4096, precision=prec)
+        out.append(dict(config=f'8(f)1: walk_imitation training mode 4096 envs ({ds.n_traj} synthetic snippets, {len(ds.joint_names)} mocap joints, DeepMimic reward)',
+                        dtype=f'f{prec}', **rollout(env, 59, K, scale=0.3))); del env
     for o in out:
         print(json.dumps(o))
     # config 3: DMPO training loop (separate process: it owns the torch RNG / HIP graphs)
-    for ls in (1, 8):
+    for ls, prec in ((1, 32), (8, 32), (1, 64)):
         r = subprocess.run([sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', '4096', '--iters', str(30 if quick else 60), '--learner-steps', str(ls),
-                            '--min-replay', '8192'], cwd=ROOT, capture_output=True, text=True)
+                            '--min-replay', '8192', '--precision', str(prec)], cwd=ROOT, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         print(line[-1] if line else json.dumps({'config': 'configs[2] DMPO', 'error': r.stderr[-300:]}))
 

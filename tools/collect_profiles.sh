@@ -1,6 +1,8 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): kernel-trace stats of the default bench command plus the two
-# PMC passes the MI355X guide prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+# Run on the GPU box (via gpurun): kernel-trace stats of the default bench command plus the PMC passes the MI355X guide
+# prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass; counters never together with API traces).  The default
+# bench launches both builds of the step kernel -- k_fly<double> (headline leg) and k_fly<float> (f32_mode leg) -- and
+# every summary below is kept per kernel.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r1}
@@ -11,21 +13,39 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
-import csv, json, sys, os
+import csv, json, sys, os, collections
 out, tag = sys.argv[1], sys.argv[2]
-def vals(path, name):
-    rows = [r for r in csv.DictReader(open(path)) if 'k_fly' in r['Kernel_Name'] and r['Counter_Name'] == name]
-    v = [float(r['Counter_Value']) for r in rows][6:]        # skip reset + warm-up launches
-    return sum(v)/len(v)
-f = vals(os.path.join(out, 'pmc_fetch', 'f_counter_collection.csv'), 'FETCH_SIZE')
-w = vals(os.path.join(out, 'pmc_write', 'w_counter_collection.csv'), 'WRITE_SIZE')
+KER = {'f64': 'k_fly<double>', 'f32': 'k_fly<float>'}
+def counters(path):
+    acc = {k: collections.defaultdict(list) for k in KER}
+    if not os.path.exists(path): return acc
+    for r in csv.DictReader(open(path)):
+        for k, name in KER.items():
+            if name in r['Kernel_Name']: acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+def mean_tail(v, skip=6):                     # skip the reset launch and the warm-up launches
+    v = v[skip:] if len(v) > skip + 2 else v
+    return sum(v)/max(len(v), 1)
+f = counters(os.path.join(out, 'pmc_fetch', 'f_counter_collection.csv'))
+w = counters(os.path.join(out, 'pmc_write', 'w_counter_collection.csv'))
+s1 = counters(os.path.join(out, 'pmc_sq1', 's_counter_collection.csv'))
+s2 = counters(os.path.join(out, 'pmc_sq2', 's_counter_collection.csv'))
 stats = [r for r in csv.DictReader(open(os.path.join(out, 'trace', 'bench_kernel_stats.csv'))) if 'k_fly' in r['Name']]
-summary = {'tag': tag, 'kernel_stats': stats, 'FETCH_SIZE_KB_per_launch': f, 'WRITE_SIZE_KB_per_launch': w,
-           'bytes_per_launch': (f + w)*1024, 'bytes_per_launch_fetch_x2': (2*f + w)*1024,
-           'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over steady-state k_fly launches; '
-                     'FETCH_SIZE is NOT doubled (the gfx950 half-count applies to 16 B/lane streams, this kernel reads 4 B/lane)'}
+summary = {'tag': tag, 'kernel_stats': stats, 'per_kernel': {}}
+src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 10 --warmup 5`, mean over the steady-state '
+       'launches of the kernel; FETCH_SIZE is NOT doubled (the gfx950 half-count applies to 16 B/lane streams, this kernel reads 4-8 B/lane)')
+for k in KER:
+    fk = mean_tail(f[k].get('FETCH_SIZE', [0])); wk = mean_tail(w[k].get('WRITE_SIZE', [0]))
+    d = {'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk, 'bytes_per_launch': (fk + wk)*1024}
+    for acc in (s1, s2):
+        for name, v in acc[k].items(): d[name] = mean_tail(v)
+    summary['per_kernel'][k] = d
+    json.dump({'bytes_per_launch': d['bytes_per_launch'], 'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk,
+               'source': f'profiles/{tag}/summary.json: ' + src}, open(os.path.join(out, f'pmc_traffic_{k}.json'), 'w'), indent=1)
 json.dump(summary, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
-print(json.dumps({k: summary[k] for k in ('FETCH_SIZE_KB_per_launch', 'WRITE_SIZE_KB_per_launch', 'bytes_per_launch')}))
+for k, d in summary['per_kernel'].items(): print(k, json.dumps({n: round(v, 1) for n, v in d.items()}))
 for s in stats: print(s['Name'][:40], s['Calls'], s['AverageNs'])
 PY
