@@ -519,8 +519,11 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
 #endif
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
   real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
+  // solver options into registers: a read of the model inside the sweep loop would sit on the critical path of every sweep
+  const int max_it = M.iterations, max_noslip = M.noslip_iterations;
+  const real tol_scaled = M.tolerance, noslip_tol = M.noslip_tolerance;
   int niter = 0;
-  for (int it = 0; it < M.iterations; it++) {
+  for (int it = 0; it < max_it; it++) {
     real improvement = 0;
     for (int i = 0; i < nefc;) {
       int type = r3_get<S>(rtype, i);
@@ -620,7 +623,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
       }
     }
     niter = it + 1;
-    if (improvement*scale < M.tolerance) break;
+    if (improvement*scale < tol_scaled) break;
     // the sweeps are one long dependent chain that hardly uses the SIMD: let this wave win issue arbitration against the
     // throughput-bound stages of its neighbours (measured -3%); the progress-based priority is restored after the loop
     if (it == 0) FB_SETPRIO(3);
@@ -633,7 +636,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // ---- noslip: friction dims only, regularisation removed; lane == contact keeps its row address
   int ncon = w.istate()[IS_NCON];
   int my_efc = (lane < ncon && w.con_dim()[lane] > 1) ? w.con_efc()[lane] : -1;
-  for (int it = 0; it < M.noslip_iterations; it++) {
+  for (int it = 0; it < max_noslip; it++) {
     real improvement = 0;
     for (int c = 0; c < ncon; c++) {
       int i = rdlane(my_efc, c);
@@ -662,7 +665,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
       for (int j = 0; j < 2; j++)
         if (del[j] != 0) { res_axpy<S>(res, AR, i+1+j, nefc, del[j], lane); r3_set<S>(f, i+1+j, lane, fq[j]); }
     }
-    if (improvement*scale < M.noslip_tolerance) break;
+    if (improvement*scale < noslip_tol) break;
   }
   PROF(P_NOSLIP);
   if (lane < nefc) w.efc_force()[lane] = f.v0;

@@ -195,7 +195,11 @@ template <typename P> FBD P uniform_p(P p) {
 template <typename T> FBD const T& as_constant(const T& r) { return r; }
 #else
 template <typename T> FBD const T& as_constant(const T& r) {
-  return *(const T*)(const __attribute__((address_space(4))) T*)uniform_ptr(&r);
+  const __attribute__((address_space(4))) T* p4 = (const __attribute__((address_space(4))) T*)uniform_ptr(&r);
+  // opaque to the optimiser: otherwise the generic -> constant -> generic round trip is folded away in places and the
+  // loads behind it fall back to flat_load
+  asm volatile("" : "+s"(p4));
+  return *(const T*)p4;
 }
 #endif
 
