@@ -101,7 +101,7 @@ class _Physics:
 class BatchedFlyEnv:
     """n_env walk_imitation environments stepped in lock-step by one kernel launch per control step."""
 
-    def __init__(self, n_env: int = 1, device: int = 0, precision: int = 32, terminal_com_dist: float = 0.3,
+    def __init__(self, n_env: int = 1, device: int = 0, precision: int = 64, terminal_com_dist: float = 0.3,
                  joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation',
                  wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0):
         arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
@@ -244,7 +244,7 @@ class BatchedFlyEnv:
 
 def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False, disable_wings: bool = True,
                    traj_indices: Optional[Sequence[int]] = None, random_state=None, terminal_com_dist: float = 0.3,
-                   joint_filter: float = 0.01, n_env: int = 1, device: int = 0, precision: int = 32, seed: int = 0,
+                   joint_filter: float = 0.01, n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0,
                    env_id_base: int = 0) -> BatchedFlyEnv:
     """Same keyword surface as flybody/fly_envs.py:100-106, plus n_env / device / precision / seed / env_id_base.
 
@@ -267,7 +267,7 @@ def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False
 
 
 def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, random_state=None, n_env: int = 1, device: int = 0,
-                 precision: int = 32) -> BatchedFlyEnv:
+                 precision: int = 64) -> BatchedFlyEnv:
     """Tethered fly walking on a floating ball: same keyword surface as flybody/fly_envs.py:158-191, plus n_env / device /
     precision.  Observation = the walker observables + `ball_qvel`; reward = product of linear tolerances on the ball's
     angular velocity around the target (0, -5, 0) rad/s (tasks/walk_on_ball.py:62-73); 2 s episodes."""
@@ -280,7 +280,7 @@ def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, rand
 def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,
                      disable_legs: bool = True, traj_indices: Optional[Sequence[int]] = None, randomize_start_step: bool = True,
                      joint_filter: float = 0.0, future_steps: int = 5, random_state=None, terminal_com_dist: float = 2.0,
-                     n_env: int = 1, device: int = 0, precision: int = 32, seed: int = 0) -> BatchedFlyEnv:
+                     n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0) -> BatchedFlyEnv:
     """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed."""
     if ref_path is not None:
         raise NotImplementedError('HDF5 flight datasets are a "next" row (SURVEY.md 8f); inference mode is implemented')
