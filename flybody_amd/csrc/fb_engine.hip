@@ -221,7 +221,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     const int *g1 = m->i("pair_geom1"), *g2 = m->i("pair_geom2"), *gt = m->i("geom_type");
     std::vector<int> slot(m->ngeom, 0);
     for (int g = 0; g < m->ngeom; g++) if (gt[g] == GEOM_PLANE) { m->plane_geoms.push_back(g); slot[g] = m->ngeom + (int)m->plane_geoms.size() - 1; }
-    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<float>::AR_ELEMS) { delete m; return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
+    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS) { delete m; return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
     m->pair_word.assign(std::max(m->npair, 1), 0);
     for (int q = 0; q < m->npair; q++) {
       if (gt[g2[q]] == GEOM_PLANE) { delete m; return fail("fb_model_load: a plane must be the first geom of a pair"); }
@@ -320,12 +320,13 @@ struct Batch {
 
 
 template <typename real>
-__global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
-  __shared__ real s_LD[FB_EPB][FB_LDS_SCRATCH];
-  __shared__ real s_Dinv[FB_EPB][FB_MAXNV];
-  __shared__ real s_x[FB_EPB][FB_MAXNV];
-  __shared__ real s_AR[FB_EPB][LdsCfg<real>::AR_ELEMS];
+  constexpr int EPB = LdsCfg<real>::EPB;
+  __shared__ real s_LD[EPB][FB_LDS_SCRATCH];
+  __shared__ real s_Dinv[EPB][FB_MAXNV];
+  __shared__ real s_x[EPB][FB_MAXNV];
+  __shared__ real s_AR[EPB][LdsCfg<real>::AR_ELEMS];
   // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
   __shared__ uint8_t s_depth[FB_MAXNV];
   __shared__ uint8_t s_cl[FB_MAXNV];
@@ -336,14 +337,14 @@ __global__ void __launch_bounds__(FB_WAVE*FB_EPB, (sizeof(real) == 4 ? 4 : 2)) k
   // the model lives in constant memory: its fields (sizes, table pointers, workspace offsets) are scalar loads
   const DevModel<real>& M = as_constant(*Mp);
   int tid = threadIdx.x;
-  for (int i = tid; i < M.nv; i += FB_WAVE*FB_EPB) {
+  for (int i = tid; i < M.nv; i += FB_WAVE*EPB) {
     s_depth[i] = (uint8_t)M.dof_depth[i]; s_cl[i] = (uint8_t)M.dof_cl[i]; s_gen[i] = (uint8_t)M.dof_gen[i]; s_madr[i] = (uint16_t)M.dof_Madr[i];
   }
-  for (int i = tid; i < FB_MAXGEN*FB_MAXCH; i += FB_WAVE*FB_EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
+  for (int i = tid; i < FB_MAXGEN*FB_MAXCH; i += FB_WAVE*EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
   // the wave index is wave-uniform: say so (v_readfirstlane), otherwise every per-environment base address is 64-bit VALU math
   int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
-  int slot = blockIdx.x*FB_EPB + wave;
+  int slot = blockIdx.x*EPB + wave;
   if (slot >= nslot) return;
   int env = uniform_int(env_ids ? env_ids[slot] : slot);
   WS<real> w;
@@ -706,10 +707,10 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
   if (b->precision == 64) {
     Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
-    hipLaunchKernelGGL((k_fly<double>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
+    hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
     Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
-    hipLaunchKernelGGL((k_fly<float>), dim3((n + FB_EPB - 1)/FB_EPB), dim3(FB_WAVE*FB_EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
+    hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
   HIPCHK(hipGetLastError());

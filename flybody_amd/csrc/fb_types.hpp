@@ -11,10 +11,10 @@
 #include <stdint.h>
 
 #define FB_WAVE 64
-#define FB_EPB 4            // environments (wavefronts) per workgroup; they share the LDS topology tables
+#define FB_EPB 4            // environments (wavefronts) per workgroup of the FP32 build (LdsCfg<real>::EPB); they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
 #define FB_MAXGEN 16       // dofs whose subtree branches (free joint, head, ...)
-#define FB_LDS_SCRATCH 1344  // reals in the per-environment LDS row of the factor (also staging space for the tree passes)
+#define FB_LDS_SCRATCH 1328  // reals in the per-environment LDS row of the factor (also staging space for the tree passes)
 #define FB_BODYREC 40       // reals per body kinematics record
 #define FB_MAXTRUNK 6       // dofs of the unbranched chain at the tree root (free joint) handled wave-parallel
 #define FB_FSLOT 18        // factor work list: off-diagonal entries of M owned by one lane
@@ -27,7 +27,7 @@
 #define FB_NSCHED 64          // progress counters of one launch (one per substep)
 #define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
-#define FB_MAXNV 128
+#define FB_MAXNV 112
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -167,7 +167,15 @@ struct DevModel {
 #endif
 
 // LDS copy of the (packed symmetric) Delassus matrix: AR_ROWS*(AR_ROWS+1)/2 <= AR_ELEMS
-template <typename real> struct LdsCfg { static constexpr int AR_ROWS = 36; static constexpr int AR_ELEMS = 666; };
+// Workgroup shape.  LDS is what limits residency: 160 KB per CU hold 16 FP32 environments (4 workgroups of 4) but only
+// 8 FP64 ones.  The FP64 build therefore runs ONE environment per workgroup, sized to exactly 1/8 of the LDS: a wave
+// slot is then recycled as soon as its own environment finishes instead of when the slowest of four does, which matters
+// because a 4096-batch is two rounds of 2048 resident FP64 environments (with 4 per workgroup the step was ~9 % longer).
+template <typename real> struct LdsCfg {
+  static constexpr int EPB = sizeof(real) == 8 ? 1 : FB_EPB;
+  static constexpr int AR_ROWS = sizeof(real) == 8 ? 29 : 36;
+  static constexpr int AR_ELEMS = AR_ROWS*(AR_ROWS + 1)/2;
+};
 
 template <typename real>
 struct WS {
