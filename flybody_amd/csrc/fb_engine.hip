@@ -794,6 +794,8 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
     case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;
     case FB_STEP_TYPE: *f = {3, 0, 1, b->step_type}; break;
+    case FB_STEP_TICKS: *f = {3, 0, 1, b->cost}; break;
+    case FB_LAUNCH_ORDER: *f = {3, 0, 1, b->order}; break;
     default: return fail("unknown field");
   }
   return 0;

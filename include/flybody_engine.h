@@ -57,6 +57,9 @@ enum {
   FB_GEOM_XPOS = 27,  /* [n_env][ngeom][3] */
   FB_GEOM_XMAT = 28,  /* [n_env][ngeom][9] */
   FB_CVEL = 29,       /* [n_env][nbody][6] spatial velocity [angular, linear] about the tree CoM */
+  FB_STEP_TICKS = 30, /* [n_env] int32: duration of the environment's last control step on the GPU (100 MHz ticks) */
+  FB_LAUNCH_ORDER = 31, /* [n_env] int32: environment ids in the order the next full-batch step launches them
+                           (longest last step first; scheduling only, results do not depend on it) */
   FB_REWARD_FACTORS = 26, /* [n_env][5] training-mode reward factors (com, qvel, root2site, joint_quat, wings) */
   FB_PROF = 25,       /* [n_env][48] int32 pairs = 24 int64 per-phase cycle counters (profiling builds) */
   FB_NFIELD

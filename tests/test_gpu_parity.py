@@ -209,3 +209,25 @@ def test_flight_rollout_parity_fp64(oracle_model):
     assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-8
     assert _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-8
     assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-2)
+
+
+def test_launch_order_on_gpu(gpu_model, reference_traj):
+    """Scheduling state of the step kernel: every environment records the duration of its control step (100 MHz ticks),
+    and k_order sorts the next launch longest-first.  Results do not depend on the order (same actions, same states)."""
+    import torch
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    n = 512
+    B = engine.Batch(gpu_model, n, precision=64)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    a = torch.from_numpy(np.tile(np.random.default_rng(0).uniform(-0.3, 0.3, 59).astype(np.float32), (n, 1))).cuda()
+    for _ in range(3):
+        B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    order = B.get('LAUNCH_ORDER').ravel(); ticks = B.get('STEP_TICKS').ravel()
+    assert sorted(order.tolist()) == list(range(n))
+    assert ticks.min() > 1000 and ticks.max() < 100_000_000            # between 10 us and 1 s
+    c = ticks[order].astype(np.int64)
+    assert np.all(c[:-1] >= c[1:] - (ticks.max() // 255 + 1))
+    q = B.get('QPOS')
+    assert np.array_equal(q, np.tile(q[0], (n, 1)))

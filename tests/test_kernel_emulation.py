@@ -128,3 +128,25 @@ def test_flight_imitation_matches_oracle(emu_lib):
     assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-9 and _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-9
     assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-2)
     assert not np.array_equal(B.get('QPOS')[0], B.get('QPOS')[1])       # a different initial wing phase per environment
+
+
+def test_launch_order_is_longest_first_permutation(emu_model, reference_traj):
+    """k_order (fb_engine.hip): after a full-batch step the next launch order is a permutation of the environments, sorted
+    by the duration of their last step, longest first, up to the 256-bin resolution of the counting sort.  (On the host
+    there is no GPU clock; the emulation build records an arbitrary per-environment number, which is all the sort needs.)
+    The order is scheduling only: environments that get the same actions stay bit-identical whatever their position."""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    n = 37
+    B = engine.Batch(emu_model, n, precision=64)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    a = np.tile(np.random.default_rng(0).uniform(-0.3, 0.3, 59).astype(np.float32), (n, 1))
+    for _ in range(3):
+        B.step_ptr(a.ctypes.data)
+    order = B.get('LAUNCH_ORDER').ravel(); ticks = B.get('STEP_TICKS').ravel()
+    assert sorted(order.tolist()) == list(range(n))
+    assert len(set(ticks.tolist())) > n // 2
+    c = ticks[order].astype(np.int64)
+    assert np.all(c[:-1] >= c[1:] - (ticks.max() // 255 + 1))
+    q = B.get('QPOS')
+    assert np.array_equal(q, np.tile(q[0], (n, 1)))
