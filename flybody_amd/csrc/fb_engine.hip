@@ -33,7 +33,7 @@ struct fb_model {
   std::map<std::string, const BlobEntry*> idx;
   // host-side derived tables
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
-  std::vector<int> body_nsub, body_depth, body_path, body_chlen, body_chain, body_common, dof_depth, dof_anc, dof_ndesc, lvl_dof, lvl_start, adh_act;
+  std::vector<int> body_nsub, body_depth, body_chlen, body_chain, body_common, dof_depth, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, plane_geoms;
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
@@ -96,8 +96,6 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
       if (a != b) { delete m; return fail("fb_model_load: bodies are not in DFS order"); }
     }
   }
-  m->body_path.assign((size_t)nb*FB_MAXDEPTH, 0);
-  for (int b = 1; b < nb; b++) { int a = b; for (int d = m->body_depth[b] - 1; d >= 0; d--) { m->body_path[(size_t)b*FB_MAXDEPTH + d] = a; a = parent[a]; } }
   m->dof_depth.assign(nv, 0);
   for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { n_++; a = dofpar[a]; } m->dof_depth[k] = n_; }
   m->body_chlen.assign(nb, 0); m->body_chain.assign((size_t)nb*FB_MAXCH, 0);
@@ -211,8 +209,6 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
       m->fac_w[o] = (base & 0x1fff) | (dep << 13) | (m->dof_cl[e.i] << 18) | (ee << 23) | (int)((unsigned)(e.gen ? m->dof_gen[e.i] : 15) << 28);
     }
   }
-  m->dof_anc.assign((size_t)nv*FB_MAXCH, 0);
-  for (int k = 0; k < nv; k++) { int a = dofpar[k], n_ = 0; while (a >= 0) { m->dof_anc[(size_t)k*FB_MAXCH + n_] = a; n_++; a = dofpar[a]; } }
   const int* trn = m->i("actuator_trntype");
   for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
   // collision mid phase: one packed word per candidate pair; the geoms' bounding spheres (and the plane normals) are
@@ -471,11 +467,11 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
 #define UI(field, name) { const int* s_ = m->i(name, &c); if (upload_i(b, s_, c, &M.field)) return -1; }
 #define UV(field, vec) { if (upload_i(b, m->vec.data(), m->vec.size(), &M.field)) return -1; }
 #define UD(field, name) { const double* s_ = m->d(name, &c); if (upload<real>(b, s_, c, &M.field)) return -1; }
-  UI(body_parent, "body_parent") UI(body_jntadr, "body_jntadr") UI(body_jntnum, "body_jntnum") UI(body_dofadr, "body_dofadr") UI(body_dofnum, "body_dofnum")
-  UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_path, body_path) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
+  UI(body_parent, "body_parent") UI(body_dofadr, "body_dofadr")
+  UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
-  UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_parentid, "dof_parentid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(dof_anc, dof_anc) UV(dof_ndesc, dof_ndesc) UV(lvl_dof, lvl_dof) UV(lvl_start, lvl_start) UV(body_fluid_geom, body_fluid_geom)
+  UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
+  UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom)
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
@@ -484,7 +480,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];
   M.nlevel = m->nlevel;
   UI(geom_type, "geom_type") UI(geom_bodyid, "geom_bodyid") UI(site_bodyid, "site_bodyid") UI(site_type, "site_type")
-  UI(tendon_adr, "tendon_adr") UI(tendon_num, "tendon_num") UI(wrap_dofid, "wrap_dofid")
+  UI(tendon_adr, "tendon_adr") UI(tendon_num, "tendon_num")
   UI(act_trntype, "actuator_trntype") UI(act_trnid, "actuator_trnid") UI(act_dyntype, "actuator_dyntype") UI(act_biastype, "actuator_biastype")
   UI(act_ctrllimited, "actuator_ctrllimited") UI(act_forcelimited, "actuator_forcelimited") UI(act_actadr, "actuator_actadr")
   UV(adh_act, adh_act) UI(action_to_ctrl, "action_to_ctrl")
@@ -494,11 +490,11 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(pair_word, pair_word) UV(plane_geoms, plane_geoms)
   { const int* gt_ = m->i("geom_type"); int np_ = 0; for (int g = 0; g < m->ngeom; g++) np_ += gt_[g] == GEOM_PLANE; M.nplane = np_; }
   UI(obs_jnt, "observable_joints") UI(app_sites, "appendage_sites") UI(force_sites, "sensor_force_sites") UI(touch_sites, "sensor_touch_sites") UI(wing_jnt, "wing_jnt")
-  UD(body_pos, "body_pos") UD(body_quat, "body_quat") UD(body_ipos, "body_ipos") UD(body_iquat, "body_iquat") UD(body_mass, "body_mass")
+  UD(body_mass, "body_mass")
   UD(body_inertia, "body_inertia") UD(body_invweight0, "body_invweight0")
   if (upload<real>(b, m->body_box.data(), m->body_box.size(), &M.body_box)) return -1;
   if (upload<real>(b, m->body_rec.data(), m->body_rec.size(), &M.body_rec)) return -1;
-  UD(jnt_pos, "jnt_pos") UD(jnt_axis, "jnt_axis") UD(jnt_stiffness, "jnt_stiffness") UD(jnt_range, "jnt_range") UD(jnt_solref, "jnt_solref")
+  UD(jnt_axis, "jnt_axis") UD(jnt_stiffness, "jnt_stiffness") UD(jnt_range, "jnt_range") UD(jnt_solref, "jnt_solref")
   UD(jnt_solimp, "jnt_solimp") UD(jnt_margin, "jnt_margin") UD(qpos0, "qpos0") UD(qpos_spring, "qpos_spring")
   UD(dof_armature, "dof_armature") UD(dof_damping, "dof_damping") UD(dof_invweight0, "dof_invweight0")
   UD(geom_pos, "geom_pos") UD(geom_quat, "geom_quat") UD(geom_size, "geom_size") UD(geom_rbound, "geom_rbound") UD(geom_fluid, "geom_fluid")

@@ -12,7 +12,7 @@
 #include "fb_types.hpp"
 #include "fb_math.hpp"
 
-// Wavefront-level synchronisation.  A workgroup holds FB_EPB independent environments (one per
+// Wavefront-level synchronisation.  A workgroup holds LdsCfg<real>::EPB independent environments (one per
 // wave); the lanes of one wave exchange data through LDS / the environment's global row, so only a
 // memory fence is needed (a wave executes its own memory instructions in order) -- never an
 // s_barrier, which would couple unrelated environments.

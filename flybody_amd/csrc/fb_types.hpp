@@ -101,16 +101,14 @@ struct DevModel {
   int iterations, noslip_iterations;
   real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
   // topology
-  GP<const int> body_parent, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_nsub, body_depth;
-  GP<const int> body_path;      // [nbody][FB_MAXDEPTH] ancestors from the tree root down to the body
+  GP<const int> body_parent, body_dofadr, body_nsub, body_depth;
   GP<const int> body_chlen;     // [nbody] number of dofs on the root->body chain
   GP<const int> body_chain;     // [nbody][FB_MAXCH] dof ids on that chain, root first
   GP<const int> body_common;    // [nbody][nbody] number of shared chain dofs
   GP<const int> jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
-  GP<const int> dof_bodyid, dof_jntid, dof_parentid, dof_Madr, dof_depth;
-  GP<const int> dof_anc;        // [nv][FB_MAXCH] a-th ancestor of each dof (a = 0: parent)
+  GP<const int> dof_bodyid, dof_jntid, dof_Madr, dof_depth;
   GP<const int> dof_ndesc;      // [nv] number of descendant dofs (a DFS-contiguous range i+1 .. i+ndesc)
-  GP<const int> lvl_dof, lvl_start; int nlevel;   // dofs grouped by depth
+  int nlevel;                   // number of dof depth levels
   GP<const int> dof_cl;         // [nv] length of the unbranched chain below the dof
   GP<const int> dof_gen;        // [nv] index of a dof outside the trunk whose subtree branches ("general" dof) or -1
   GP<const int> gen_k, gen_m;  // [FB_MAXGEN][FB_MAXCH] descendants of a general dof on a level: 4 dof ids (u8) / 4 row starts (u16)
@@ -120,7 +118,7 @@ struct DevModel {
   int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
   GP<const int> geom_type, geom_bodyid, site_bodyid, site_type;
-  GP<const int> tendon_adr, tendon_num, wrap_dofid;
+  GP<const int> tendon_adr, tendon_num;
   GP<const int> act_trntype, act_trnid, act_dyntype, act_biastype, act_ctrllimited, act_forcelimited, act_actadr;
   GP<const int> adh_act;        // [nadh] actuator ids with body transmission
   GP<const int> wrap_qadr;      // [nwrap] qpos address of the (hinge/slide) joint a tendon wrap reads
@@ -132,9 +130,9 @@ struct DevModel {
   GP<const int> plane_geoms; int nplane;   // geoms of type plane (their normals are staged behind the bounding spheres)
   GP<const int> obs_jnt, app_sites, force_sites, touch_sites, wing_jnt;
   // constants
-  GP<const real> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0, body_box;
+  GP<const real> body_mass, body_inertia, body_invweight0, body_box;
   GP<const real> body_rec;      // [nbody][FB_BODYREC] flattened kinematics record of a body (fb_engine.hip)
-  GP<const real> jnt_pos, jnt_axis, jnt_stiffness, jnt_range, jnt_solref, jnt_solimp, jnt_margin;
+  GP<const real> jnt_axis, jnt_stiffness, jnt_range, jnt_solref, jnt_solimp, jnt_margin;
   GP<const real> qpos0, qpos_spring, dof_armature, dof_damping, dof_invweight0;
   GP<const real> geom_pos, geom_quat, geom_size, geom_rbound, geom_fluid;
   GP<const real> site_pos, site_quat, site_size;
