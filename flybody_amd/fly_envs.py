@@ -149,11 +149,10 @@ class BatchedFlyEnv:
         if self.task_name == 'flight_imitation':
             # the flight loaders hand over a CoM trajectory; the task converts it to the root joint
             # (set_next_trajectory re-centres x,y: trajectory_loaders.py:172-173; com2root: flight_imitation.py:93-99)
-            from .mjcf_compile import qrot
+            from .task_utils import com2root
             q = s['qpos'].copy(); q[:, :2] -= q[0, :2]
-            off = self.model.arrays['com_offset']
-            for i in range(len(q)):
-                q[i, :3] = q[i, :3] + qrot(q[i, 3:7] / np.linalg.norm(q[i, 3:7]), -off)
+            quat = q[:, 3:7] / np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+            q[:, :3] = com2root(q[:, :3], quat, offset=self.model.arrays['com_offset'])
             s = {'qpos': q, 'qvel': s['qvel']}
         self.batch.set_reference(s['qpos'], s['qvel'], future_steps=self.future_steps,
                                  terminal_com_dist=self.terminal_com_dist, time_limit=self.time_limit)

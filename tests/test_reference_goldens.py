@@ -141,3 +141,40 @@ def test_fluid_analysis_api_components_match_reference(G):
         comps, lfrc = ellipsoid_local(G['fl_lvel'][c], size, gf, dens, visc)
         got = np.concatenate([comps[k] for k in ('fA', 'gA', 'fM', 'fK', 'fD', 'fV', 'gD', 'gV')])
         assert np.allclose(got, G['fl_components'][c], rtol=1e-11, atol=1e-18) and np.allclose(lfrc, G['fl_local_force'][c], rtol=1e-11, atol=1e-18)
+
+
+def test_task_utils_match_reference(G):
+    """flybody_amd/task_utils.py against the reference's flybody/tasks/task_utils.py (action maps of the CanonicalSpecWrapper
+    path, CoM <-> root conversion of the flight task, wing-angle convention)."""
+    from flybody_amd import task_utils as T
+
+    class Spec:
+        minimum, maximum = G['tu_spec'][0], G['tu_spec'][1]
+        shape = (G['tu_spec'].shape[1],)
+    a_real, a_can = G['tu_a_real'], G['tu_a_can']
+    assert np.allclose(T.real2canonical(a_real, Spec), G['tu_real2canonical'], rtol=1e-13, atol=1e-13)
+    assert np.allclose(T.real2canonical(a_real, Spec, clip=False), G['tu_real2canonical_noclip'], rtol=1e-13, atol=1e-13)
+    assert np.allclose(T.canonical2real(a_can, Spec), G['tu_canonical2real'], rtol=1e-13, atol=1e-13)
+    assert np.allclose(T.canonical2real(a_can, Spec, clip=False), G['tu_canonical2real_noclip'], rtol=1e-13, atol=1e-13)
+    rq, off = G['tu_root_qpos'], G['tu_offset']
+    assert np.allclose(T.root2com(rq), G['tu_root2com'], atol=1e-14)
+    assert np.allclose(T.root2com(rq, off), G['tu_root2com_off'], atol=1e-14)
+    assert np.allclose(T.com2root(rq[:, :3], rq[:, 3:]), G['tu_com2root'], atol=1e-14)
+    assert np.allclose(T.com2root(rq[:, :3], rq[:, 3:], off), G['tu_com2root_off'], atol=1e-14)
+    assert np.allclose([T.neg_quat(q) for q in G['q_in1'][:4]], G['tu_neg_quat'])
+    assert np.allclose(T.wing_qpos_to_conventional(G['tu_wing_qpos']), G['tu_wing_conventional'], atol=1e-14)
+    assert np.allclose(T.wing_qpos_to_conventional(G['tu_wing_qpos'], 30.0), G['tu_wing_conventional_30'], atol=1e-14)
+    # round trips, and the compiled model carries the same CoM offset the reference hard-codes
+    assert np.allclose(T.canonical2real(T.real2canonical(a_real, Spec), Spec), np.clip(a_real, Spec.minimum, Spec.maximum))
+    assert np.allclose(T.com2root(T.root2com(rq), rq[:, 3:]), rq[:, :3], atol=1e-14)
+    from flybody_amd.model_blob import load_npz
+    arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
+    assert np.allclose(arr['com_offset'], T._COM_OFFSET)
+
+
+def test_trainer_action_map_is_canonical2real(G):
+    """The DMPO trainer maps canonical policy outputs to environment actions on the GPU as a_min + 0.5 (a + 1) a_scale
+    (train_dmpo.Trainer.iterate, dmpo/evaluator.py); the same expression in float64 is the reference's canonical2real."""
+    lo, hi = G['tu_spec'][0], G['tu_spec'][1]
+    a = np.clip(G['tu_a_can'], -1, 1)
+    assert np.allclose(lo + 0.5*(a + 1.0)*(hi - lo), G['tu_canonical2real'], rtol=1e-13, atol=1e-13)

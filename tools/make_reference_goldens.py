@@ -2,7 +2,7 @@
 """Generate tests/golden/reference_functions.npz by IMPORTING the reference (read-only checkout at /root/reference).
 
 Only the numpy parts of the reference run without MuJoCo / dm_control: quaternions.py, tasks/rewards.py,
-tasks/pattern_generators.py, tasks/constants.py, and -- with `dm_control` stubbed out -- the force-component
+tasks/pattern_generators.py, tasks/constants.py, tasks/task_utils.py, and -- with `dm_control` stubbed out -- the force-component
 functions of ellipsoid_fluid_model.py and tasks/synthetic_trajectories.py (whose only MuJoCo call, mju_quat2Vel,
 is stubbed with the axis-angle formula and is exercised with yaw_speed = 0 and != 0).  The vectors pin this
 repository's restatements of exactly those functions (tests/test_reference_goldens.py); the rigid-body step itself
@@ -47,6 +47,7 @@ def main():
     _stub_dm_control()
     fluid = _load('flybody/ellipsoid_fluid_model.py', 'ref_fluid')
     synth = _load('flybody/tasks/synthetic_trajectories.py', 'ref_synth')
+    tutil = _load('flybody/tasks/task_utils.py', 'ref_task_utils')
     rng = np.random.default_rng(12345)
     out = {}
 
@@ -119,6 +120,23 @@ def main():
     out.update(fl_size=size, fl_coefs=coefs, fl_dens_visc=np.array([dens, visc]), fl_lvel=np.array(lv), fl_virtual=np.array(vm),
                fl_local_force=np.array(tot), fl_components=np.array(comp),
                fl_max_moment=np.array([fluid.mji_ellipsoid_max_moment(size, k) for k in range(3)]))
+
+    # ---- task helpers (flybody/tasks/task_utils.py): action maps, CoM <-> root, wing angle convention
+    class _Spec:
+        pass
+    spec = _Spec(); spec.minimum = rng.uniform(-2, -0.2, 11); spec.maximum = rng.uniform(0.1, 1.5, 11); spec.shape = (11,)
+    a_real = rng.uniform(-2.5, 2.0, (5, 7, 11)); a_can = rng.uniform(-1.3, 1.3, (5, 7, 11))
+    rq = np.concatenate([rng.normal(size=(9, 3)), q1[:9]], axis=1)
+    off = np.array([0.01, -0.02, 0.03])
+    wq = rng.uniform(-1.5, 1.5, (6, 6))
+    out.update(tu_spec=np.stack([spec.minimum, spec.maximum]), tu_a_real=a_real, tu_a_can=a_can,
+               tu_real2canonical=tutil.real2canonical(a_real.copy(), spec), tu_real2canonical_noclip=tutil.real2canonical(a_real.copy(), spec, clip=False),
+               tu_canonical2real=tutil.canonical2real(a_can.copy(), spec), tu_canonical2real_noclip=tutil.canonical2real(a_can.copy(), spec, clip=False),
+               tu_root_qpos=rq, tu_offset=off,
+               tu_root2com=np.array([tutil.root2com(r) for r in rq]), tu_root2com_off=np.array([tutil.root2com(r, off) for r in rq]),
+               tu_com2root=tutil.com2root(rq[:, :3], rq[:, 3:]), tu_com2root_off=tutil.com2root(rq[:, :3], rq[:, 3:], off),
+               tu_neg_quat=np.array([tutil.neg_quat(q) for q in q1[:4]]),
+               tu_wing_qpos=wq, tu_wing_conventional=tutil.wing_qpos_to_conventional(wq), tu_wing_conventional_30=tutil.wing_qpos_to_conventional(wq, 30.0))
 
     # ---- task constants (flybody/tasks/constants.py)
     out['const_terminal'] = np.array([consts._TERMINAL_LINVEL, consts._TERMINAL_ANGVEL, consts._TERMINAL_QACC])
