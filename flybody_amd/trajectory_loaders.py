@@ -146,6 +146,25 @@ class InferenceWalkingTrajectoryLoader:
         return []
 
 
+class InferenceFlightTrajectoryLoader:
+    """Drop-in for inference mode of the flight task (trajectory_loaders.py:144-182): a settable CoM trajectory, returned
+    as the pair (com_qpos, com_qvel) with x, y measured from the first frame.  Default: the reference's synthetic
+    straight flight (200 steps at 20 cm/s, 1 cm above the origin, body pitched by -47.5 degrees)."""
+
+    def __init__(self):
+        from .reference import constant_speed_trajectory
+        self.set_next_trajectory(*constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5,
+                                                            control_timestep=2e-4))
+
+    def set_next_trajectory(self, com_qpos, com_qvel):
+        q = np.array(com_qpos, float)
+        q[:, :2] -= q[0, :2]
+        self._com_qpos, self._com_qvel = q, np.asarray(com_qvel, float)
+
+    def get_trajectory(self, traj_idx=None):
+        return self._com_qpos, self._com_qvel
+
+
 def walker_features(qpos, qvel, xaxis, site_xpos, joint_ids, site_ids, jnt_qposadr, jnt_dofadr):
     """get_walker_features (tasks/rewards.py:37-63) from plain state arrays, flat layout of rewards.reward_factors_deep_mimic."""
     from .rewards import joint_orientation_quat, mult_quat

@@ -178,3 +178,17 @@ def test_trainer_action_map_is_canonical2real(G):
     lo, hi = G['tu_spec'][0], G['tu_spec'][1]
     a = np.clip(G['tu_a_can'], -1, 1)
     assert np.allclose(lo + 0.5*(a + 1.0)*(hi - lo), G['tu_canonical2real'], rtol=1e-13, atol=1e-13)
+
+
+def test_inference_trajectory_loaders_match_reference(G):
+    """Default trajectories and set/get semantics of the inference-time loaders (trajectory_loaders.py:144-182,267-309)."""
+    from flybody_amd.trajectory_loaders import InferenceFlightTrajectoryLoader, InferenceWalkingTrajectoryLoader
+    wl, fl = InferenceWalkingTrajectoryLoader(), InferenceFlightTrajectoryLoader()
+    assert np.allclose(wl.get_trajectory(0)['qpos'], G['tl_walk_qpos'], atol=1e-13)
+    assert np.allclose(wl.get_trajectory(0)['qvel'], G['tl_walk_qvel'], atol=1e-12)
+    assert [len(wl.get_joint_names()), len(wl.get_site_names())] == G['tl_names'].tolist()
+    q, v = fl.get_trajectory(0)
+    assert np.allclose(q, G['tl_flight_qpos'], atol=1e-13) and np.allclose(v, G['tl_flight_qvel'], atol=1e-11)
+    shifted = q.copy(); shifted[:, :2] += np.array([0.7, -0.4])
+    fl.set_next_trajectory(shifted, v)
+    assert np.allclose(fl.get_trajectory(0)[0], G['tl_flight_recentred'], atol=1e-13)

@@ -138,6 +138,18 @@ def main():
                tu_neg_quat=np.array([tutil.neg_quat(q) for q in q1[:4]]),
                tu_wing_qpos=wq, tu_wing_conventional=tutil.wing_qpos_to_conventional(wq), tu_wing_conventional_30=tutil.wing_qpos_to_conventional(wq, 30.0))
 
+    # ---- inference-time trajectory loaders (flybody/tasks/trajectory_loaders.py:144-182,267-309); h5py is only needed by the
+    # HDF5 classes of that module and is stubbed
+    sys.modules.setdefault('h5py', types.ModuleType('h5py'))
+    tl = _load('flybody/tasks/trajectory_loaders.py', 'ref_traj_loaders')
+    wl = tl.InferenceWalkingTrajectoryLoader(); fl = tl.InferenceFlightTrajectoryLoader()
+    out.update(tl_walk_qpos=wl.get_trajectory(0)['qpos'], tl_walk_qvel=wl.get_trajectory(0)['qvel'],
+               tl_flight_qpos=fl.get_trajectory(0)[0], tl_flight_qvel=fl.get_trajectory(0)[1])
+    shifted = fl.get_trajectory(0)[0].copy(); shifted[:, :2] += np.array([0.7, -0.4])
+    fl.set_next_trajectory(shifted, fl.get_trajectory(0)[1])
+    out['tl_flight_recentred'] = fl.get_trajectory(0)[0]
+    out['tl_names'] = np.array([len(wl.get_joint_names()), len(wl.get_site_names())])
+
     # ---- task constants (flybody/tasks/constants.py)
     out['const_terminal'] = np.array([consts._TERMINAL_LINVEL, consts._TERMINAL_ANGVEL, consts._TERMINAL_QACC])
     np.savez_compressed(OUT, **out)
