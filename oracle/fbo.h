@@ -6,6 +6,10 @@
  * specialised to the fruit-fly model class (free root + hinge tree, fixed tendons,
  * plane/sphere/capsule/ellipsoid/cylinder geoms, elliptic cones, PGS + noslip).
  *
+ * Third-party algorithm: MuJoCo (C engine) via dm_control; the reference requires dm_control WITHOUT a version pin
+ * (pyproject.toml:10), mujoco is a transitive unpinned dependency.  Restated here: the published MuJoCo 3.x forward /
+ * constraint / PGS / collision pipeline ("Computation" chapter of the MuJoCo documentation).
+ *
  * PARITY STATUS: "parity unpinned".  MuJoCo is not importable in the build container and the
  * reference pins no trajectory; the oracle is pinned against the
  * reference's model-constant tests (tests/test_flybare.py) and physical invariants only.
