@@ -1,0 +1,8 @@
+#!/bin/bash
+# Profiling build of the engine (per-phase s_memtime counters, FB_PROF field): used by tools/phase_profile.py and
+# tools/tail_profile.py only, never by the package.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DFB_PROFILE \
+  -o "$R/flybody_amd/libflybody_hip_prof.so" "$R/flybody_amd/csrc/fb_engine.hip"
+echo "built $R/flybody_amd/libflybody_hip_prof.so"
