@@ -19,7 +19,10 @@ sys.path.insert(0, ROOT)
 # words read + written per env control step (qpos 109 + qvel 108 + act 59 in and out; action 59 in;
 # obs 741 + reward/discount/step_type 3 out).  State words are 4 B (f32 build) or 8 B (f64 build), action/obs/reward are f32.
 ALGO_BYTES_PER_ENV_STEP = {32: 5420.0, 64: 2*276*8.0 + (59 + 741 + 3)*4.0}
-ALGO_FLOP_PER_ENV_STEP = 9.0e6         # SURVEY.md 8(d) provisional estimate
+# instrumented count of the FP64 CPU oracle (tools/flopcount/count_flops.py, profiles/r1/oracle_flop_count.jsonl): adds,
+# multiplies, divisions and square roots of one walk_imitation control step, mean over 200 steps in contact under the
+# bench's action distribution; replaces SURVEY.md 8(d)'s provisional 9 MFLOP
+ALGO_FLOP_PER_ENV_STEP = 3.44e6
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}
 
@@ -168,7 +171,7 @@ def main():
                          'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': algo_bytes,
                          'note': 'SURVEY 8(d): the path is vector-ALU/latency bound, not HBM bound; '
-                                 'valu_frac uses the provisional 9 MFLOP/env-step estimate',
+                                 'valu_frac uses the instrumented 3.44 MFLOP/env-step of the CPU oracle',
                          'valu_achieved_tflops': ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12,
                          'valu_peak_tflops': VALU_PEAK_TFLOPS[args.precision],
                          'valu_frac': ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12 / VALU_PEAK_TFLOPS[args.precision]},
