@@ -94,10 +94,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+    # functional testing of the N > 1 path on a one-GPU box: FB_BENCH_DEVICE pins every rank to one device and
+    # FB_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a device under RCCL); never set by the driver
+    backend = os.environ.get('FB_BENCH_BACKEND', 'nccl')
+    if 'FB_BENCH_DEVICE' in os.environ:
+        local_rank = int(os.environ['FB_BENCH_DEVICE'])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     n_env = args.envs_per_gpu
     model = engine.Model.from_asset('walk_imitation')
     qp, qv = default_walking_reference()
@@ -134,7 +142,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            t = torch.tensor([dt], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         finite = bool(np.isfinite(batch.get('QPOS')).all())

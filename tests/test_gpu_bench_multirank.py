@@ -1,0 +1,31 @@
+"""bench.py's N > 1 path (one process per GPU under torch.distributed.run, barrier, MAX-over-ranks timing, whole-job
+aggregate) exercised on a ONE-GPU box: two ranks pinned to cuda:0 with the gloo backend (FB_BENCH_DEVICE / FB_BENCH_BACKEND
+exist for exactly this).  The driver's real multi-GPU runs use RCCL; environments are sharded with no data-path collective,
+so the only things the backend carries are the barrier and one scalar reduction."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['dtype'] == 'f64'
+    assert out['config']['global_envs'] == 512 and out['config']['state_finite']
+    assert abs(out['value'] - 512*4/(out['ms_per_step']*4/1e3)) < 1e-6*out['value']       # whole-job aggregate over both ranks
