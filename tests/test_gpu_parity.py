@@ -231,3 +231,31 @@ def test_launch_order_on_gpu(gpu_model, reference_traj):
     assert np.all(c[:-1] >= c[1:] - (ticks.max() // 255 + 1))
     q = B.get('QPOS')
     assert np.array_equal(q, np.tile(q[0], (n, 1)))
+
+
+@pytest.mark.parametrize('precision', [64, 32])
+def test_solver_paths_by_system_size_gpu(gpu_model, oracle_model, walk_arrays, precision):
+    """Same as tests/test_kernel_emulation.py::test_solver_paths_by_system_size, on the GPU: Delassus matrix in LDS, small
+    system from the global row, wide system (> 64 rows) -- all three against the oracle's constraint forces."""
+    from flybody_amd import engine
+    from conftest import random_state
+    cases = [(1, 0.14), (1, 0.135), (1, 0.13), (1, 0.125), (3, 0.12)]     # nefc 24, 36, 54, 66, 114
+    B = engine.Batch(gpu_model, len(cases), precision=precision)
+    ods, Q, V = [], [], []
+    for seed, z in cases:
+        q, v = random_state(walk_arrays, np.random.default_rng(seed), z=z)
+        if precision == 32:
+            q = q.astype(np.float32).astype(float); v = v.astype(np.float32).astype(float)
+        od = _oracle(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+        ods.append(od); Q.append(q); V.append(v)
+    B.set('QPOS', np.array(Q)); B.set('QVEL', np.array(V))
+    B.forward()
+    nefc = [int(od.scalar('nefc')) for od in ods]
+    assert min(nefc) <= 29 and any(36 < n <= 64 for n in nefc) and max(nefc) > 64
+    if precision == 64:
+        assert B.get('NEFC').ravel().tolist() == nefc
+    for e, od in enumerate(ods):
+        n = nefc[e]
+        assert _rel(B.get('QACC')[e], od.field('qacc')) < (1e-6 if precision == 64 else 3e-2), (e, n)
+        if precision == 64:
+            assert _rel(B.get('EFC_FORCE')[e][:n], od.field('efc_force')[:n]) < 1e-6, (e, n)
