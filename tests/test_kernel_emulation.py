@@ -180,3 +180,18 @@ def test_solver_paths_by_system_size(emu_model, oracle_model, walk_arrays, preci
         assert _rel(B.get('QACC')[e], od.field('qacc')) < tol, (e, n)
         if precision == 64:
             assert _rel(B.get('EFC_FORCE')[e][:n], od.field('efc_force')[:n]) < 1e-6, (e, n)
+
+
+def test_maximum_system_size_is_capped_like_the_oracle(emu_model, oracle_model, walk_arrays):
+    """Edge case: a fly pushed far into the floor produces more candidate contacts than the 64-contact / 192-row capacity.
+    Kernel and oracle keep the same first 64 contacts (pair order) and agree on the solve at the cap."""
+    from flybody_amd import engine
+    from oracle import fbo
+    q, v = random_state(walk_arrays, np.random.default_rng(1), z=0.05)
+    od = fbo.OracleData(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+    B = engine.Batch(emu_model, 1, precision=64); B.set('QPOS', q); B.set('QVEL', v); B.forward()
+    assert int(od.scalar('ncon')) == 64 and int(od.scalar('nefc')) == 192
+    assert int(B.get('NCON')[0, 0]) == 64 and int(B.get('NEFC')[0, 0]) == 192
+    assert np.isfinite(B.get('QACC')).all()
+    assert _rel(B.get('QACC')[0], od.field('qacc')) < 1e-8
+    assert _rel(B.get('EFC_FORCE')[0][:192], od.field('efc_force')[:192]) < 1e-8
