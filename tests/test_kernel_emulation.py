@@ -195,3 +195,34 @@ def test_maximum_system_size_is_capped_like_the_oracle(emu_model, oracle_model, 
     assert np.isfinite(B.get('QACC')).all()
     assert _rel(B.get('QACC')[0], od.field('qacc')) < 1e-8
     assert _rel(B.get('EFC_FORCE')[0][:192], od.field('efc_force')[:192]) < 1e-8
+
+
+def test_ragged_partial_reset_and_bad_ids(emu_model, reference_traj):
+    """Ragged input: a reset of an arbitrary subset restarts exactly those environments (their state equals a fresh
+    environment's, the others keep stepping from where they were); ids outside the batch and empty lists are refused."""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    n = 7                                                        # not a multiple of the workgroup size
+    B = engine.Batch(emu_model, n, precision=64)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    q_fresh = B.get('QPOS')[0].copy()
+    a = np.tile(np.random.default_rng(2).uniform(-0.3, 0.3, 59).astype(np.float32), (n, 1))
+    for _ in range(2):
+        B.step_ptr(a.ctypes.data)
+    q_stepped = B.get('QPOS').copy()
+    ids = [5, 0, 2]
+    B.reset(ids)
+    q = B.get('QPOS'); sc = B.get('STEP_COUNT').ravel(); st = B.get('STEP_TYPE').ravel()
+    for e in range(n):
+        if e in ids:
+            assert np.array_equal(q[e], q_fresh) and sc[e] == 0 and st[e] == 0
+        else:
+            assert np.array_equal(q[e], q_stepped[e]) and sc[e] == 2
+    B.step_ptr(a.ctypes.data)
+    assert B.get('STEP_COUNT').ravel().tolist() == [1 if e in ids else 3 for e in range(n)]
+    with pytest.raises(engine.EngineError):
+        B.reset([0, n])
+    with pytest.raises(engine.EngineError):
+        B.reset([-1])
+    with pytest.raises(engine.EngineError):
+        B.reset(np.zeros(0, np.int32))
