@@ -22,7 +22,7 @@ class DMPOConfig:
     discount: float = 0.99
     min_replay_size: int = 10_000
     max_replay_size: int = 4_000_000
-    samples_per_insert: float = 15.0
+    samples_per_insert: Optional[float] = 15.0      # None: only the min_replay_size gate (reverb MinSize limiter)
     target_policy_update_period: int = 101
     target_critic_update_period: int = 107
     policy_lr: float = 1e-4
@@ -30,6 +30,11 @@ class DMPOConfig:
     dual_lr: float = 1e-3
     clipping: bool = True
     max_grad_norm: float = 40.0
+
+    @property
+    def samples_per_insert_error_buffer(self) -> float:
+        """10 % rate tolerance of the reference's limiter (ray_distributed_dmpo.py:81-83)."""
+        return self.min_replay_size * 0.1 * (self.samples_per_insert or 0.0)
 
 
 class DMPOLearner:
@@ -42,10 +47,12 @@ class DMPOLearner:
         self.critic_params = list(self.online.critic.parameters())
         self.dual_params = list(self.loss.parameters())
         cap = self.device.type == 'cuda'          # capturable optimizers: the update can live in a HIP graph
-        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr, capturable=cap)
-        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr, capturable=cap)
-        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr, capturable=cap)
-        self._graph_fb = None; self._graph_opt = None; self._static = None
+        # fused (multi-tensor) Adam on the GPU: one kernel per optimizer instead of ~10 per parameter tensor
+        kw = dict(capturable=True, fused=True) if cap else {}
+        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr, **kw)
+        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr, **kw)
+        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr, **kw)
+        self._graph_fb = None; self._graph_opt = None; self._static = None; self._sampler = None
         self.num_steps = 0
         # one flat gradient buffer; every parameter's .grad is a view into it
         allp = self.policy_params + self.critic_params + self.dual_params
@@ -69,21 +76,59 @@ class DMPOLearner:
 
     # ---- HIP-graph path: the ~200 small kernels of one learner step are replayed as two graphs
     # (forward+backward | clip+Adam) with the single gradient all-reduce between them.
-    def enable_graphs(self, example_batch):
-        assert self.device.type == 'cuda'
+    def _trainable_state(self):
+        """Every tensor a learner step writes: parameters, dual variables and the optimizers' moment / step tensors."""
+        out = [p.data for p in self.policy_params + self.critic_params + self.dual_params]
+        for opt in (self.policy_opt, self.critic_opt, self.dual_opt):
+            for p in opt.param_groups[0]['params']:
+                out += [v for _, v in sorted(opt.state.get(p, {}).items()) if torch.is_tensor(v)]
+        return out
+
+    def warmup_and_capture(self, example_batch, capture: bool = True, sampler=None):
+        """Warm-up (allocations, lazy optimizer state) and, on the GPU, capture of the step as HIP graphs -- WITHOUT touching
+        the training state: the warm-up updates run on the real tensors (the graphs must record their addresses) and are
+        rolled back in place afterwards, so parameters, duals, Adam moments and step counts are exactly what they were.
+        On several ranks the warm-up gradients are rank-local and never reduced; rolling them back is what keeps the
+        replicas identical."""
+        saved_p = [t.clone() for t in self._trainable_state()]      # optimizer state may not exist yet: those tensors start at 0
+        n_saved = len(saved_p)
         self._static = [t.clone() for t in example_batch]
-        s = torch.cuda.Stream(device=self.device)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):                       # warm-up (allocations, optimizer state)
-                self._forward_backward(self._static); self._apply_gradients()
-        torch.cuda.current_stream().wait_stream(s)
-        self._graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_fb):
-            self._static_stats = self._forward_backward(self._static)
-        self._graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_opt):
-            self._apply_gradients()
+        self._sampler = sampler if capture else None
+        if self.device.type == 'cuda':
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    self._forward_backward(self._static); self._apply_gradients()
+            torch.cuda.current_stream().wait_stream(s)
+            if capture:
+                self._graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_fb):
+                    # with a sampler the replay draw (uniform indices from the device-side fill level + five gathers) is part
+                    # of the graph: a learner step is then two graph launches and one all-reduce, no per-step tensor work
+                    self._static_stats = self._forward_backward(sampler() if sampler is not None else self._static)
+                self._graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_opt):
+                    self._apply_gradients()
+        else:
+            self._forward_backward(self._static); self._apply_gradients()
+        with torch.no_grad():
+            state = self._trainable_state()
+            n_param = len(self.policy_params + self.critic_params + self.dual_params)
+            if n_saved == len(state):
+                for t, sv in zip(state, saved_p):
+                    t.copy_(sv)
+            else:                                                   # optimizer state was created by the warm-up: parameters back, moments / steps to zero
+                for t, sv in zip(state[:n_param], saved_p[:n_param]):
+                    t.copy_(sv)
+                for t in state[n_param:]:
+                    t.zero_()
+            self.flat_grad.zero_()
+
+    def enable_graphs(self, example_batch, sampler=None):
+        """sampler: optional zero-argument callable returning a batch with capturable device ops only (NStepReplay.sample)."""
+        assert self.device.type == 'cuda'
+        self.warmup_and_capture(example_batch, capture=True, sampler=sampler)
 
     def _allreduce(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -96,12 +141,14 @@ class DMPOLearner:
             torch.nn.utils.clip_grad_norm_(self.critic_params, self.cfg.max_grad_norm)
         self.critic_opt.step(); self.policy_opt.step(); self.dual_opt.step()
 
-    def step(self, batch) -> Dict[str, torch.Tensor]:
+    def step(self, batch=None) -> Dict[str, torch.Tensor]:
+        """One update.  `batch` may be omitted when the graphs were captured with a sampler."""
         self._sync_targets()
         self.num_steps += 1
         if self._graph_fb is not None:
-            for dst, src in zip(self._static, batch):
-                dst.copy_(src)
+            if self._sampler is None:
+                for dst, src in zip(self._static, batch):
+                    dst.copy_(src)
             self._graph_fb.replay(); self._allreduce(); self._graph_opt.replay()
             return self._static_stats
         stats = self._forward_backward(batch)
@@ -116,8 +163,9 @@ class DMPOLearner:
         with torch.no_grad():
             t_mean, t_std = self.target.policy(o_t)
             sampled = t_mean[None] + t_std[None] * torch.randn(N, B, t_mean.shape[-1], device=self.device)
-            tiled = o_t[None].expand(N, B, o_t.shape[-1]).reshape(N * B, -1)
-            q_t_logits = self.target.critic(tiled, sampled.reshape(N * B, -1))
+            # N sampled actions per next observation: the observation half of the critic's first layer is computed once
+            # per observation, not once per (sample, observation) pair (networks.Critic.forward_samples)
+            q_t_logits = self.target.critic.forward_samples(o_t, sampled).reshape(N * B, -1)
             logp = torch.log_softmax(q_t_logits.view(N, B, -1), dim=-1)
             avg_logits = torch.logsumexp(logp, dim=0)
             sampled_q = self.target.critic.mean_q(q_t_logits).view(N, B)
@@ -133,7 +181,9 @@ class DMPOLearner:
 
     @torch.no_grad()
     def act(self, obs, deterministic: bool = False):
-        mean, std = self.online.policy(obs)
+        """Actors run the TARGET policy: the reference exposes `target_observation_network` / `target_policy_network` to
+        its actors and evaluator (agents/learning_dmpo.py:96-101)."""
+        mean, std = self.target.policy(obs)
         a = mean if deterministic else mean + std * torch.randn_like(mean)
         return a.clamp(-1.0, 1.0)
 

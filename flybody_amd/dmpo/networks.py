@@ -82,6 +82,21 @@ class Critic(nn.Module):
         x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
         return self.logits(self.torso(x))
 
+    def forward_samples(self, obs, actions):
+        """Logits [N, B, atoms] for N actions per observation (obs [B, O], actions [N, B, A]).  Same function as
+        `forward` on the tiled inputs; the first layer is split into its observation and action halves so that the
+        observation half (741 of the 800 input columns) is multiplied once per observation instead of once per pair."""
+        t = self.torso
+        no = obs.shape[-1]
+        h_o = F.linear(obs, t.first.weight[:, :no], t.first.bias)                        # [B, H]
+        h_a = F.linear(actions.clamp(-1.0, 1.0), t.first.weight[:, no:])                 # [N, B, H]
+        h = torch.tanh(t.norm(h_o[None] + h_a))
+        for i, lin in enumerate(t.rest):
+            h = lin(h)
+            if t.activate_final or i < len(t.rest) - 1:
+                h = F.elu(h)
+        return self.logits(h)
+
     def mean_q(self, logits):
         return (F.softmax(logits, dim=-1) * self.values).sum(-1)
 

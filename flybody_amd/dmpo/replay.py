@@ -1,8 +1,13 @@
-"""On-GPU n-step accumulator + uniform FIFO replay for batched environments.
+"""On-GPU n-step accumulator + uniform FIFO replay for batched environments, and the sample-to-insert rate limiter.
 
-Replaces the Reverb table (uniform sampler, FIFO remover; flybody/agents/ray_distributed_dmpo.py:67-105)
-and Acme's NStepTransitionAdder(n_step=5, discount=0.99) (ray_distributed_dmpo.py:374-380).  All storage
-is preallocated on the device that steps the environments; nothing crosses PCIe.
+Replaces the Reverb table (uniform sampler, FIFO remover, `SampleToInsertRatio` limiter;
+flybody/agents/ray_distributed_dmpo.py:67-105) and Acme's NStepTransitionAdder(n_step=5, discount=0.99)
+(ray_distributed_dmpo.py:374-380).  All storage is preallocated on the device that steps the environments; nothing
+crosses PCIe and -- unlike a host-driven adder -- nothing synchronises with the host: the number of transitions a control
+step produces depends on which environments started / ended an episode, so the write cursor, the fill level and the
+insert count are DEVICE scalars and every append has a static shape (rows that carry no transition are steered into a
+per-environment trash row behind the ring).  `add` and `sample` are therefore HIP-graph capturable and can be queued
+behind the physics kernel without stalling the launch thread.
 """
 from __future__ import annotations
 
@@ -14,37 +19,62 @@ class NStepReplay:
                  device='cpu', seed: int = 0):
         self.n_env, self.n, self.gamma, self.capacity, self.device = n_env, n_step, discount, capacity, torch.device(device)
         f = dict(dtype=torch.float32, device=self.device)
-        self.obs = torch.zeros(capacity, obs_dim, **f); self.next_obs = torch.zeros(capacity, obs_dim, **f)
-        self.action = torch.zeros(capacity, action_dim, **f)
-        self.reward = torch.zeros(capacity, **f); self.discount = torch.zeros(capacity, **f)
-        self.size = 0; self.head = 0; self.inserted = 0
-        # rolling window of the last n steps of every environment
+        rows = capacity + n_env                      # [capacity, capacity + n_env): trash rows, one per environment
+        self.obs = torch.zeros(rows, obs_dim, **f); self.next_obs = torch.zeros(rows, obs_dim, **f)
+        self.action = torch.zeros(rows, action_dim, **f)
+        self.reward = torch.zeros(rows, **f); self.discount = torch.zeros(rows, **f)
+        i64 = dict(dtype=torch.long, device=self.device)
+        self._head = torch.zeros((), **i64); self._size = torch.zeros((), **i64); self._inserted = torch.zeros((), **i64)
+        self._cap = torch.tensor(capacity, **i64)
+        self._trash = capacity + torch.arange(n_env, **i64)
+        self._env = torch.arange(n_env, **i64)
+        # ring of the last n steps of every environment (slot = control step mod n: no data movement per step)
         self.w_obs = torch.zeros(n_step, n_env, obs_dim, **f); self.w_act = torch.zeros(n_step, n_env, action_dim, **f)
         self.w_rew = torch.zeros(n_step, n_env, **f); self.w_disc = torch.zeros(n_step, n_env, **f)
-        self.w_len = torch.zeros(n_env, dtype=torch.long, device=self.device)    # valid steps in the window
-        self.gen = torch.Generator(device=self.device); self.gen.manual_seed(seed)
+        self.w_len = torch.zeros(n_env, **i64)       # valid steps in the window
+        self._t = 0                                   # control steps added (host counter; the ring slot is t mod n)
+        # CPU: own generator (reproducible tests).  GPU: the device's default generator (seeded per rank by the trainer),
+        # whose Philox offsets torch advances correctly when `sample` is replayed from a captured graph.
+        self.gen = None
+        if self.device.type == 'cpu':
+            self.gen = torch.Generator(device=self.device); self.gen.manual_seed(seed)
 
-    def _append(self, obs, act, rew, disc, nxt):
-        k = obs.shape[0]
-        if k == 0:
-            return
-        idx = (self.head + torch.arange(k, device=self.device)) % self.capacity
-        self.obs[idx] = obs; self.action[idx] = act; self.reward[idx] = rew; self.discount[idx] = disc; self.next_obs[idx] = nxt
-        self.head = (self.head + k) % self.capacity
-        self.size = min(self.capacity, self.size + k); self.inserted += k
+    # host views of the device counters (these synchronise; the training loop does not call them per step)
+    @property
+    def size(self) -> int:
+        return int(self._size)
 
-    def _emit(self, start: int, mask, next_obs):
-        """n-step transition starting `start` steps back in the window (oldest first ordering)."""
-        if not bool(mask.any()):
-            return
+    @property
+    def head(self) -> int:
+        return int(self._head)
+
+    @property
+    def inserted(self) -> int:
+        return int(self._inserted)
+
+    def _append(self, mask, obs, act, rew, disc, nxt):
+        """Appends the rows where `mask` is set, in environment order (static shapes: the others go to the trash rows)."""
+        m = mask.to(torch.long)
+        pos = torch.cumsum(m, 0) - m                                  # exclusive prefix count
+        idx = torch.where(mask, (self._head + pos) % self._cap, self._trash)
+        self.obs.index_copy_(0, idx, obs); self.action.index_copy_(0, idx, act); self.next_obs.index_copy_(0, idx, nxt)
+        self.reward.index_copy_(0, idx, rew); self.discount.index_copy_(0, idx, disc)
+        k = m.sum()
+        self._head.copy_((self._head + k) % self._cap)
+        self._size.copy_(torch.minimum(self._size + k, self._cap)); self._inserted.add_(k)
+
+    def _emit(self, length, mask, next_obs):
+        """n-step transition over the last `length[e]` steps of the window (length >= 1 where mask is set)."""
         n = self.n
         R = torch.zeros(self.n_env, device=self.device); D = torch.ones(self.n_env, device=self.device)
-        for k in range(start, n):
-            R = R + D * self.w_rew[k]
-            D = D * self.w_disc[k] * self.gamma
+        for back in range(n - 1, -1, -1):             # oldest step first
+            slot = (self._t - back) % n
+            use = back < length
+            R = torch.where(use, R + D * self.w_rew[slot], R)
+            D = torch.where(use, D * self.w_disc[slot] * self.gamma, D)
         D = D / self.gamma        # Acme: total discount = prod(env discounts) * gamma^(m-1); the learner multiplies by gamma once more
-        sel = mask.nonzero(as_tuple=True)[0]
-        self._append(self.w_obs[start, sel], self.w_act[start, sel], R[sel], D[sel], next_obs[sel])
+        start = (self._t - (length - 1).clamp(min=0)) % n              # ring slot of the transition's first step, per environment
+        self._append(mask, self.w_obs[start, self._env], self.w_act[start, self._env], R, D, next_obs)
 
     def add(self, obs, action, reward, discount, next_obs, first, last):
         """One control step of every environment.
@@ -56,19 +86,68 @@ class NStepReplay:
         transition starts at the episode's first observation; at LAST the shorter tails are flushed.
         """
         n = self.n
+        first = first.view(-1); last = last.view(-1)
         valid = ~first
-        self.w_obs = torch.roll(self.w_obs, -1, 0); self.w_act = torch.roll(self.w_act, -1, 0)
-        self.w_rew = torch.roll(self.w_rew, -1, 0); self.w_disc = torch.roll(self.w_disc, -1, 0)
-        self.w_obs[-1] = obs; self.w_act[-1] = action; self.w_rew[-1] = reward; self.w_disc[-1] = discount
+        self._t += 1
+        slot = self._t % n
+        self.w_obs[slot] = obs; self.w_act[slot] = action; self.w_rew[slot] = reward.view(-1); self.w_disc[slot] = discount.view(-1)
         self.w_len = torch.where(valid, (self.w_len + 1).clamp(max=n), torch.zeros_like(self.w_len))
-        for start in range(n):                       # oldest valid entry of each window
-            self._emit(start, valid & (self.w_len == n - start), next_obs)
+        self._emit(self.w_len, valid, next_obs)          # the transition that ends at this step
         ended = valid & last
-        if bool(ended.any()):
-            for start in range(1, n):                # shorter tails
-                self._emit(start, ended & (self.w_len > n - start), next_obs)
-            self.w_len = torch.where(ended, torch.zeros_like(self.w_len), self.w_len)
+        for cut in range(1, n):                          # shorter tails of an episode that just ended (oldest first)
+            self._emit(self.w_len - cut, ended & (self.w_len > cut), next_obs)
+        self.w_len = torch.where(ended, torch.zeros_like(self.w_len), self.w_len)
 
     def sample(self, batch_size: int):
-        idx = torch.randint(0, self.size, (batch_size,), device=self.device, generator=self.gen)
+        u = torch.rand(batch_size, device=self.device, generator=self.gen)
+        idx = (u * self._size.to(torch.float32)).to(torch.long).clamp_(max=self.capacity - 1)
+        idx = torch.minimum(idx, (self._size - 1).clamp(min=0))
         return self.obs[idx], self.action[idx], self.reward[idx], self.discount[idx], self.next_obs[idx]
+
+
+class SampleToInsertRatio:
+    """Reverb's `rate_limiters.SampleToInsertRatio(samples_per_insert, min_size_to_sample, error_buffer)`
+    (ray_distributed_dmpo.py:82-87: 15 samples per insert, 10 000 items before the first sample, error buffer 15 000)
+    for a loop in which ONE thread both inserts and samples.
+
+    Reverb keeps  diff = inserts * samples_per_insert - samples  inside  [offset - error_buffer, offset + error_buffer]
+    with  offset = samples_per_insert * min_size_to_sample : an insert blocks while diff is above the window, a sample
+    blocks while it is below (or while fewer than min_size_to_sample items exist).  Here the actor side cannot block --
+    a control step of the whole batch inserts ~n_env items at once -- so after every control step the learner runs as
+    many updates as the window allows: `learner_steps_allowed` returns that number.  The counts are kept on the host
+    from rank-independent quantities (control steps * n_env inserted items, learner steps * batch sampled items), so
+    every rank of a data-parallel job takes the same decisions without a collective.
+    """
+
+    def __init__(self, samples_per_insert: float, min_size_to_sample: int, error_buffer: float):
+        if samples_per_insert <= 0:
+            raise ValueError('samples_per_insert must be > 0')
+        self.spi = float(samples_per_insert); self.min_size = int(min_size_to_sample)
+        offset = self.spi * self.min_size
+        # Reverb requires error_buffer >= max(1, samples_per_insert)
+        self.error_buffer = max(float(error_buffer), 1.0, self.spi)
+        self.min_diff = offset - self.error_buffer; self.max_diff = offset + self.error_buffer
+        self.inserts = 0; self.samples = 0
+
+    def insert(self, n_items: int):
+        self.inserts += int(n_items)
+
+    def learner_steps_allowed(self, batch_size: int) -> int:
+        """Updates of `batch_size` samples each that may run now (sampling stays at or above the lower edge of the window)."""
+        if self.inserts < self.min_size:
+            return 0
+        room = self.inserts * self.spi - self.samples - self.min_diff
+        return max(0, int(room // batch_size))
+
+    def sample(self, n_items: int):
+        self.samples += int(n_items)
+
+    @property
+    def achieved_samples_per_insert(self) -> float:
+        return self.samples / max(1, self.inserts)
+
+    def state_dict(self):
+        return dict(inserts=self.inserts, samples=self.samples)
+
+    def load_state_dict(self, sd):
+        self.inserts = int(sd['inserts']); self.samples = int(sd['samples'])

@@ -20,14 +20,20 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .dmpo import (Checkpointer, Counter, DMPOConfig, DMPOLearner, MetricsLogger, MPOLoss, NStepReplay, Snapshotter, evaluate,
-                   make_networks)
+from .dmpo import (Checkpointer, Counter, DMPOConfig, DMPOLearner, MetricsLogger, MPOLoss, NStepReplay, SampleToInsertRatio,
+                   Snapshotter, evaluate, make_networks)
 from .dmpo.losses import PenalizationCostRealActions
 from .fly_envs import BatchedFlyEnv, walk_imitation
 
 
 class Trainer:
-    def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=1, seed=0,
+    """learner_steps_per_env_step=None (default): the number of updates after each control step of the batch comes from the
+    reference's rate limiter, SampleToInsertRatio(config.samples_per_insert = 15, min_size_to_sample = config.min_replay_size,
+    error_buffer = 10 % tolerance) -- with 4096 environments and batch 256 that is 240 updates per control step, i.e. the learner
+    sets the pace exactly as in the reference.  An integer fixes the count instead (throughput runs); the gate on
+    min_replay_size stays.  config.samples_per_insert = None means "no ratio" (reverb MinSize): one update per control step."""
+
+    def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=None, seed=0,
                  config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None,
                  directory=None, checkpoint_to_load=None, time_delta_minutes=30.0, checkpoint_max_to_keep=1):
         self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
@@ -55,6 +61,12 @@ class Trainer:
         self.replay = NStepReplay(n_env, nobs, nu, min(replay_capacity, config.max_replay_size), config.n_step, config.discount,
                                   device=self.device, seed=seed + self.rank)
         self.lsteps_per = learner_steps_per_env_step
+        # Reverb limiter of the reference (ray_distributed_dmpo.py:82-87).  Its counts are rank-independent (control steps *
+        # n_env, learner steps * batch), so every rank takes the same learn / don't-learn decision without a collective.
+        if config.samples_per_insert is None and self.lsteps_per is None:
+            self.lsteps_per = 1
+        self.limiter = SampleToInsertRatio(config.samples_per_insert or 1.0, min(config.min_replay_size, self.replay.capacity // 2),
+                                           config.samples_per_insert_error_buffer)
         self.use_graphs = os.environ.get('FB_LEARNER_GRAPHS', '1') == '1'
         self.views = self.env.reset_all()
         self.obs = self.views['obs'].clone()
@@ -62,7 +74,11 @@ class Trainer:
         # checkpoints / policy snapshots / metrics (rank 0 writes; every rank restores so that replicas stay identical)
         self.counter = Counter(); self.checkpointer = self.snapshotter = None; self.logger = MetricsLogger(None)
         self._ep_return = torch.zeros(n_env, device=self.device); self._ep_len = torch.zeros(n_env, device=self.device)
+        # finished-episode statistics accumulate on the device and are read back every 64 control steps
+        self._fin_n = torch.zeros((), device=self.device); self._fin_ret = torch.zeros((), device=self.device)
+        self._fin_len = torch.zeros((), device=self.device)
         self._last_return = 0.0; self._last_length = 0.0; self._t_learn = None
+        self._eval_kw = dict(ref_path=ref_path, traj_indices=traj_indices, terminal_com_dist=terminal_com_dist, seed=seed)
         if directory is not None:
             ck = Checkpointer(directory, self.learner, self.counter, time_delta_minutes, checkpoint_max_to_keep)
             restored = ck.restore(checkpoint_to_load) if (checkpoint_to_load or ck._files()) else None
@@ -82,24 +98,37 @@ class Trainer:
         self.replay.add(self.obs, canon, v['reward'], v['discount'], nxt, first, last)
         self.obs = nxt
         self.env_steps += self.env.n_env
-        # actor-side counters (acme EnvironmentLoop): steps, finished episodes, last mean episode return / length
+        # actor-side counters (acme EnvironmentLoop): steps, finished episodes, last mean episode return / length.
+        # Everything stays on the device; one read-back every 64 control steps.
         live = st.view(-1) != 0
-        self._ep_return += torch.where(live, v['reward'].view(-1), torch.zeros_like(self._ep_return)); self._ep_len += live.float()
+        zero = torch.zeros_like(self._ep_return)
+        self._ep_return += torch.where(live, v['reward'].view(-1), zero); self._ep_len += live.float()
         fin = last.view(-1)
-        nfin = int(fin.sum()) if self.env_steps % (64*self.env.n_env) == 0 else 0        # host sync only every 64 control steps
-        if nfin:
-            self._last_return = float(self._ep_return[fin].mean()); self._last_length = float(self._ep_len[fin].mean())
-            self.counter.increment(actor_episodes=nfin)
-        self._ep_return[fin] = 0; self._ep_len[fin] = 0
+        self._fin_n += fin.sum(); self._fin_ret += torch.where(fin, self._ep_return, zero).sum()
+        self._fin_len += torch.where(fin, self._ep_len, zero).sum()
+        self._ep_return = torch.where(fin, zero, self._ep_return); self._ep_len = torch.where(fin, zero, self._ep_len)
+        if (self.env_steps // self.env.n_env) % 64 == 0:
+            nfin = int(self._fin_n)
+            if nfin:
+                self._last_return = float(self._fin_ret) / nfin; self._last_length = float(self._fin_len) / nfin
+                self.counter.increment(actor_episodes=nfin)
+                self._fin_n.zero_(); self._fin_ret.zero_(); self._fin_len.zero_()
         self.counter.increment(actor_steps=self.env.n_env*self.world)
+        self.limiter.insert(self.env.n_env)
         stats = None
-        if learn and self.replay.size >= min(self.cfg.min_replay_size, self.replay.capacity // 2):
+        B = self.cfg.batch_size
+        allowed = self.limiter.learner_steps_allowed(B) if learn else 0
+        if self.lsteps_per is not None:
+            allowed = self.lsteps_per if (learn and self.limiter.inserts >= self.limiter.min_size) else 0
+        if allowed > 0:
             if self.use_graphs and self.learner._graph_fb is None:
-                self.learner.enable_graphs(self.replay.sample(self.cfg.batch_size))
-            for _ in range(self.lsteps_per):
-                stats = self.learner.step(self.replay.sample(self.cfg.batch_size)); self.learner_steps += 1
+                self.learner.enable_graphs(self.replay.sample(B), sampler=lambda: self.replay.sample(B))
+            sampled_in_graph = self.learner._sampler is not None
+            for _ in range(allowed):
+                stats = self.learner.step(None if sampled_in_graph else self.replay.sample(B))
+            self.learner_steps += allowed; self.limiter.sample(allowed * B)
             now = time.time()
-            self.counter.increment(learner_steps=self.lsteps_per, learner_walltime=(now - self._t_learn) if self._t_learn else 0.0)
+            self.counter.increment(learner_steps=allowed, learner_walltime=(now - self._t_learn) if self._t_learn else 0.0)
             self._t_learn = now
             if self.checkpointer is not None:
                 self.checkpointer.save()
@@ -112,8 +141,10 @@ class Trainer:
 
     def evaluate(self, n_env=64, episodes_per_env=1):
         """Greedy-policy evaluation on a separate small batch (the reference's evaluator actor)."""
-        env = BatchedFlyEnv(n_env=n_env, device=self.local_rank, precision=self.env.batch.precision,
-                            terminal_com_dist=self.env.terminal_com_dist) if not hasattr(self, '_eval_env') else self._eval_env
+        # same task as the training environments: reference dataset, snippet selection, termination distance (so that the
+        # evaluator's episode return IS the imitation reward when training with ref_path)
+        env = walk_imitation(n_env=n_env, device=self.local_rank, precision=self.env.batch.precision,
+                             env_id_base=10_000_000 + self.rank*n_env, **self._eval_kw) if not hasattr(self, '_eval_env') else self._eval_env
         self._eval_env = env
         return evaluate(env, lambda o: self.learner.act(o, deterministic=True), self.a_min, self.a_scale, episodes_per_env)
 
@@ -122,14 +153,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--iters', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10); ap.add_argument('--precision', type=int, default=32)
-    ap.add_argument('--learner-steps', type=int, default=1, help='learner steps per control step of the batch')
+    ap.add_argument('--gpus', type=int, default=None, help='started bare with --gpus N > 1: re-execute under torch.distributed.run with N ranks')
+    ap.add_argument('--learner-steps', type=int, default=None,
+                    help='fixed number of learner steps per control step of the batch (default: set by the sample-to-insert limiter)')
+    ap.add_argument('--samples-per-insert', type=float, default=15.0, help='reference: 15 (train_dmpo_ray.py:114); <= 0: no ratio')
     ap.add_argument('--min-replay', type=int, default=10_000)
     ap.add_argument('--ref-path', default=None, help='walking dataset (.hdf5 or .npz): training-mode reward')
     ap.add_argument('--directory', default=None, help='checkpoints / policy snapshots / metrics go here; resumes from the newest checkpoint')
     ap.add_argument('--checkpoint-to-load', default=None); ap.add_argument('--checkpoint-minutes', type=float, default=30.0)
     a = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and (a.gpus or 1) > 1:
+        import socket, subprocess, sys
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), '-m', 'flybody_amd.train_dmpo'] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1')))
+    spi = a.samples_per_insert if a.samples_per_insert > 0 else None
     tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
-                 config=DMPOConfig(min_replay_size=a.min_replay), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
+                 config=DMPOConfig(min_replay_size=a.min_replay, samples_per_insert=spi), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
                  ref_path=a.ref_path, directory=a.directory, checkpoint_to_load=a.checkpoint_to_load, time_delta_minutes=a.checkpoint_minutes)
     for _ in range(a.warmup):
         tr.iterate()
@@ -149,7 +191,9 @@ def main():
     if tr.rank == 0:
         out = {'metric': 'env steps/sec + learner steps/sec, walk_imitation DMPO on-GPU training', 'n_gpus': tr.world,
                'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
-               'envs_per_gpu': a.envs, 'learner_steps_per_env_step': a.learner_steps, 'batch_size': tr.cfg.batch_size,
+               'envs_per_gpu': a.envs, 'learner_steps_per_env_step': (tr.learner_steps - l0) / max(1, a.iters), 'batch_size': tr.cfg.batch_size,
+               'samples_per_insert': {'configured': spi if a.learner_steps is None else None, 'achieved': tr.limiter.achieved_samples_per_insert,
+                                      'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
                'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'dtype': f'f{a.precision} physics / f32 learner',
                'reward': 'inference mode (== 1): synthetic reference, throughput run' if a.ref_path is None else f'training mode (DeepMimic factors) on {a.ref_path}',
                'stats': {k: float(v) for k, v in (stats or {}).items() if k in ('critic_loss', 'policy_loss', 'dual_temperature', 'kl_q_rel')}}

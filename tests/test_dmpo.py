@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from conftest import ROOT
-from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, categorical_td_loss, l2_project, make_networks
+from flybody_amd.dmpo import (DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, SampleToInsertRatio, categorical_td_loss, l2_project,
+                              make_networks)
 
 
 def test_network_shapes_and_sizes():
@@ -122,9 +123,71 @@ def test_nstep_replay_matches_reference_adder():
     for t in range(10):
         small.add(torch.full((2, 2), float(t)), torch.zeros(2, 1), torch.ones(2), torch.ones(2), torch.zeros(2, 2),
                   torch.zeros(2, dtype=torch.bool), torch.zeros(2, dtype=torch.bool))
-    assert small.size == 8 and float(small.obs.min()) == 6.0
+    assert small.size == 8 and float(small.obs[:small.capacity].min()) == 6.0      # (rows behind `capacity` are the trash rows)
     o, a, r, d, no = small.sample(64)
     assert o.shape == (64, 2) and float(o.min()) >= 6.0
+
+
+def test_first_rows_clear_the_window_and_counters_live_on_the_device():
+    """A FIRST row (auto-reset step) carries no transition and restarts the n-step window of that environment only."""
+    rep = NStepReplay(2, 1, 1, capacity=64, n_step=3, discount=0.5)
+    z = lambda *v: torch.tensor(v, dtype=torch.float32)
+    f = lambda *v: torch.tensor(v, dtype=torch.bool)
+    for t in range(4):
+        rep.add(z(10 + t, 20 + t)[:, None], torch.zeros(2, 1), z(1, 1), z(1, 1), z(11 + t, 21 + t)[:, None], f(False, t == 2), f(False, False))
+    assert torch.is_tensor(rep._size) and rep.size == 4 + 3 and rep.inserted == 7
+    env1 = sorted((float(rep.obs[i]), round(float(rep.reward[i]), 4)) for i in range(rep.size) if float(rep.obs[i]) >= 20)
+    # env 1: steps t=0,1 give windows starting at obs 20 (lengths 1, 2); t=2 is FIRST (nothing); t=3 starts over at obs 23
+    assert env1 == [(20.0, 1.0), (20.0, 1.5), (23.0, 1.0)]
+    env0 = sorted((float(rep.obs[i]), round(float(rep.reward[i]), 4)) for i in range(rep.size) if float(rep.obs[i]) < 20)
+    assert env0 == [(10.0, 1.0), (10.0, 1.5), (10.0, 1.75), (11.0, 1.75)]
+
+
+def test_sample_to_insert_ratio_limiter():
+    """Reverb SampleToInsertRatio(15, min_size 10 000, error buffer 15 000) as configured at ray_distributed_dmpo.py:77-87."""
+    cfg = DMPOConfig()
+    assert cfg.samples_per_insert == 15.0 and cfg.samples_per_insert_error_buffer == 15_000.0
+    lim = SampleToInsertRatio(cfg.samples_per_insert, cfg.min_replay_size, cfg.samples_per_insert_error_buffer)
+    lim.insert(4096); lim.insert(4096)
+    assert lim.learner_steps_allowed(256) == 0                      # fewer than min_size_to_sample items
+    lim.insert(4096)
+    k0 = lim.learner_steps_allowed(256)
+    assert k0 == int((12288*15 - (150_000 - 15_000)) // 256)        # down to the lower edge of the window
+    lim.sample(k0*256)
+    assert lim.learner_steps_allowed(256) == 0
+    total = k0
+    for _ in range(200):                                            # steady state: 4096 inserts -> 240 updates of 256 samples
+        lim.insert(4096); k = lim.learner_steps_allowed(256); lim.sample(k*256); total += k
+        assert 239 <= k <= 241
+    assert abs(lim.achieved_samples_per_insert - 15.0) < 0.3
+    sd = lim.state_dict(); lim2 = SampleToInsertRatio(15.0, 10_000, 15_000.0); lim2.load_state_dict(sd)
+    assert lim2.learner_steps_allowed(256) == lim.learner_steps_allowed(256)
+
+
+def test_warmup_leaves_training_state_untouched():
+    """enable_graphs' warm-up updates are rolled back in place (they used to be 3 real, un-reduced Adam steps)."""
+    torch.manual_seed(0)
+    nets = make_networks(20, 4, policy_sizes=(32, 32), critic_sizes=(32, 32))
+    L = DMPOLearner(nets, MPOLoss(4), DMPOConfig(batch_size=16, num_samples=5))
+    batch = (torch.randn(16, 20), torch.rand(16, 4) * 2 - 1, torch.ones(16), torch.ones(16), torch.randn(16, 20))
+    before = [p.detach().clone() for p in list(L.online.parameters()) + list(L.loss.parameters())]
+    L.warmup_and_capture(batch, capture=False)
+    after = list(L.online.parameters()) + list(L.loss.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(after, before))
+    for opt in (L.policy_opt, L.critic_opt, L.dual_opt):
+        for st in opt.state.values():
+            assert all(float(v.abs().sum()) == 0 for v in st.values() if torch.is_tensor(v))      # moments and step counts back at zero
+    # after real steps the roll-back restores the (non-zero) optimizer state as well
+    for _ in range(3):
+        L.step(batch)
+    snap = [t.clone() for t in L._trainable_state()]
+    L.warmup_and_capture(batch, capture=False)
+    assert all(torch.equal(a, b) for a, b in zip(L._trainable_state(), snap))
+    # critic forward on N samples per observation == forward on the tiled inputs
+    obs = torch.randn(6, 20); acts = torch.randn(5, 6, 4)
+    a = nets.critic.forward_samples(obs, acts)
+    b = nets.critic(obs[None].expand(5, 6, 20).reshape(30, 20), acts.reshape(30, 4)).view(5, 6, -1)
+    assert torch.allclose(a, b, atol=1e-5)
 
 
 def test_learner_step_mechanics():
@@ -159,12 +222,17 @@ g = torch.Generator().manual_seed(100 + rank)            # different data shard 
 batch = (torch.randn(8, 12, generator=g), torch.rand(8, 3, generator=g) * 2 - 1, torch.ones(8), torch.ones(8), torch.randn(8, 12, generator=g))
 torch.manual_seed(7)                                     # same action-sampling noise on both ranks
 L.step(batch)
-flat = torch.cat([p.detach().flatten() for p in L.online.parameters()])
+grad1 = L.flat_grad.clone()
+# the graph warm-up runs on rank-local data without a reduction: it must leave every replica where it was
+L.warmup_and_capture(batch, capture=False)
+for k in range(3):
+    torch.manual_seed(8 + k); L.step(batch)
+flat = torch.cat([p.detach().flatten() for p in list(L.online.parameters()) + list(L.loss.parameters())])
 out = [torch.zeros_like(flat) for _ in range(world)]
 dist.all_gather(out, flat)
 if rank == 0:
     assert torch.equal(out[0], out[1]), 'replicas diverged after the all-reduced step'
-    torch.save(L.flat_grad.clone(), %(out)r)
+    torch.save(grad1, %(out)r)
 dist.barrier(); dist.destroy_process_group()
 """
 
