@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -41,27 +42,116 @@ struct fb_model {
   std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom;
   double totalmass;
+  // A missing or ill-typed array is an error of the caller's blob, never a reason to take the process down: the accessors
+  // throw, every extern "C" entry point that reads the model catches and returns -1 with the message in fb_last_error().
+  // fb_model_load checks every array the engine reads (name, type, minimum length) up front, so a loaded model cannot throw.
   const double* d(const char* n, size_t* cnt = nullptr) const {
     auto it = idx.find(n);
-    if (it == idx.end() || it->second->dtype != 0) { fprintf(stderr, "flybody_engine: missing f64 array %s\n", n); abort(); }
+    if (it == idx.end() || it->second->dtype != 0) throw std::runtime_error(std::string("model blob: missing f64 array '") + n + "'");
     if (cnt) *cnt = it->second->nbytes/8;
     return (const double*)(blob.data() + it->second->offset);
   }
   const int* i(const char* n, size_t* cnt = nullptr) const {
     auto it = idx.find(n);
-    if (it == idx.end() || it->second->dtype != 1) { fprintf(stderr, "flybody_engine: missing i32 array %s\n", n); abort(); }
+    if (it == idx.end() || it->second->dtype != 1) throw std::runtime_error(std::string("model blob: missing i32 array '") + n + "'");
     if (cnt) *cnt = it->second->nbytes/4;
     return (const int*)(blob.data() + it->second->offset);
   }
+  void need(const char* n, int dtype, size_t min_count) const {
+    auto it = idx.find(n);
+    if (it == idx.end()) throw std::runtime_error(std::string("model blob: missing array '") + n + "'");
+    if ((int)it->second->dtype != dtype) throw std::runtime_error(std::string("model blob: array '") + n + "' has the wrong type (expected " + (dtype ? "i32" : "f64") + ")");
+    size_t c = it->second->nbytes/(dtype ? 4 : 8);
+    if (c < min_count) throw std::runtime_error(std::string("model blob: array '") + n + "' has " + std::to_string(c) + " elements, expected at least " + std::to_string(min_count));
+  }
 };
 
+#define FB_GUARD_BEGIN try {
+#define FB_GUARD_END } catch (const std::exception& e_) { return fail(e_.what()); }
+
+// Build identity of this shared object (the GPU test log / smoke() print it, so a log shows which binary ran)
+#ifndef FB_BUILD_ID
+#define FB_BUILD_ID "unversioned"
+#endif
+extern "C" const char* fb_version(void) {
+#ifdef FB_EMULATE
+  return "flybody_engine 2 (host emulation build, " FB_BUILD_ID ")";
+#else
+  return "flybody_engine 2 (gfx950, " FB_BUILD_ID ")";
+#endif
+}
+
+static int model_load_impl(fb_model* m, size_t n);
+
 extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
+  if (!out) return fail("fb_model_load: null output pointer");
+  *out = nullptr;
   if (!blob || n < 8 || memcmp(blob, "FBM1", 4) != 0) return fail("fb_model_load: bad blob magic");
   fb_model* m = new fb_model();
-  m->blob.assign((const char*)blob, (const char*)blob + n);
+  int rc;
+  try {
+    m->blob.assign((const char*)blob, (const char*)blob + n);
+    rc = model_load_impl(m, n);
+  } catch (const std::exception& e_) { rc = fail(std::string("fb_model_load: ") + e_.what()); }
+  if (rc != 0) { delete m; return rc; }
+  *out = m;
+  return 0;
+}
+
+// every array the engine reads, with its element type and the minimum length the model's dimensions imply
+static void check_model_arrays(const fb_model* m) {
+  const size_t nq = m->nq, nv = m->nv, nb = m->nbody, nj = m->njnt, ng = m->ngeom, ns = m->nsite, nu = m->nu, nt = m->ntendon, np = m->npair;
+  struct Req { const char* name; int dtype; size_t n; };
+  size_t nwrap = 0; { size_t c = 0; m->i("wrap_dofid", &c); nwrap = c; }
+  const Req req[] = {
+    {"body_mass", 0, nb}, {"body_inertia", 0, 3*nb}, {"body_invweight0", 0, 2*nb}, {"body_pos", 0, 3*nb}, {"body_quat", 0, 4*nb},
+    {"body_ipos", 0, 3*nb}, {"body_iquat", 0, 4*nb}, {"jnt_pos", 0, 3*nj}, {"jnt_axis", 0, 3*nj}, {"jnt_stiffness", 0, nj},
+    {"jnt_range", 0, 2*nj}, {"jnt_solref", 0, 2*nj}, {"jnt_solimp", 0, 5*nj}, {"jnt_margin", 0, nj}, {"qpos0", 0, nq}, {"qpos_spring", 0, nq},
+    {"dof_armature", 0, nv}, {"dof_damping", 0, nv}, {"dof_invweight0", 0, nv}, {"geom_pos", 0, 3*ng}, {"geom_quat", 0, 4*ng},
+    {"geom_size", 0, 3*ng}, {"geom_rbound", 0, ng}, {"geom_fluid", 0, 12*ng}, {"site_pos", 0, 3*ns}, {"site_quat", 0, 4*ns}, {"site_size", 0, 3*ns},
+    {"wrap_coef", 0, nwrap}, {"actuator_dynprm", 0, nu}, {"actuator_gainprm", 0, 3*nu}, {"actuator_biasprm", 0, 3*nu},
+    {"actuator_ctrlrange", 0, 2*nu}, {"actuator_forcerange", 0, 2*nu}, {"pair_friction", 0, 5*np}, {"pair_solref", 0, 2*np},
+    {"pair_solimp", 0, 5*np}, {"pair_margin", 0, np}, {"pair_gap", 0, np}, {"opt_timestep", 0, 1}, {"opt_control_timestep", 0, 1},
+    {"opt_gravity", 0, 3}, {"opt_density", 0, 1}, {"opt_viscosity", 0, 1}, {"opt_impratio", 0, 1}, {"opt_tolerance", 0, 1},
+    {"opt_noslip_tolerance", 0, 1}, {"stat_meaninertia", 0, 1}, {"com_offset", 0, 3},
+    {"body_parent", 1, nb}, {"body_dofadr", 1, nb}, {"body_dofnum", 1, nb}, {"body_jntadr", 1, nb}, {"body_jntnum", 1, nb},
+    {"jnt_type", 1, nj}, {"jnt_qposadr", 1, nj}, {"jnt_dofadr", 1, nj}, {"jnt_bodyid", 1, nj}, {"jnt_limited", 1, nj},
+    {"dof_bodyid", 1, nv}, {"dof_jntid", 1, nv}, {"dof_parentid", 1, nv}, {"dof_Madr", 1, nv + 1}, {"geom_type", 1, ng}, {"geom_bodyid", 1, ng},
+    {"site_bodyid", 1, ns}, {"site_type", 1, ns}, {"tendon_adr", 1, nt}, {"tendon_num", 1, nt}, {"actuator_trntype", 1, nu},
+    {"actuator_trnid", 1, nu}, {"actuator_dyntype", 1, nu}, {"actuator_biastype", 1, nu}, {"actuator_ctrllimited", 1, nu},
+    {"actuator_forcelimited", 1, nu}, {"actuator_actadr", 1, nu}, {"action_to_ctrl", 1, nu}, {"pair_geom1", 1, np}, {"pair_geom2", 1, np},
+    {"pair_condim", 1, np}, {"observable_joints", 1, 0}, {"appendage_sites", 1, 0}, {"sensor_force_sites", 1, 0}, {"sensor_touch_sites", 1, 0},
+    {"wing_jnt", 1, 6}, {"wing_action_idx", 1, 0}, {"task_id", 1, 1}, {"user_action_idx", 1, 1}, {"sensor_site_thorax", 1, 1},
+    {"opt_iterations", 1, 1}, {"opt_noslip_iterations", 1, 1}, {"wrap_dofid", 1, 0},
+  };
+  for (const Req& r : req) m->need(r.name, r.dtype, r.n);
+  // index ranges the kernels rely on
+  auto in_range = [&](const char* name, size_t cnt, int lo, int hi) {
+    const int* v = m->i(name);
+    for (size_t k = 0; k < cnt; k++) if (v[k] < lo || v[k] >= hi) throw std::runtime_error(std::string("model blob: '") + name + "' holds an index out of range");
+  };
+  in_range("body_parent", nb, -1, (int)nb); in_range("dof_bodyid", nv, 0, (int)nb); in_range("dof_jntid", nv, 0, (int)nj);
+  in_range("jnt_qposadr", nj, 0, (int)nq); in_range("jnt_dofadr", nj, 0, (int)nv); in_range("jnt_bodyid", nj, 0, (int)nb);
+  in_range("geom_bodyid", ng, 0, (int)nb); in_range("site_bodyid", ns, 0, (int)nb); in_range("pair_geom1", np, 0, (int)ng); in_range("pair_geom2", np, 0, (int)ng);
+  in_range("action_to_ctrl", nu, 0, (int)nu); in_range("wrap_dofid", nwrap, 0, (int)nv);
+  { size_t c = 0; m->i("observable_joints", &c); in_range("observable_joints", c, 0, (int)nj); }
+  { size_t c = 0; m->i("appendage_sites", &c); in_range("appendage_sites", c, 0, (int)ns); }
+  { size_t c = 0; m->i("sensor_force_sites", &c); in_range("sensor_force_sites", c, 0, (int)ns); }
+  { size_t c = 0; m->i("sensor_touch_sites", &c); in_range("sensor_touch_sites", c, 0, (int)ns); }
+  in_range("wing_jnt", 6, 0, (int)nj); in_range("sensor_site_thorax", 1, 0, (int)ns);
+}
+
+static int model_load_impl(fb_model* m, size_t n) {
   uint32_t narr; memcpy(&narr, m->blob.data() + 4, 4);
+  if (narr > 4096 || 8 + (size_t)narr*sizeof(BlobEntry) > n) return fail("fb_model_load: corrupt table of contents");
   const BlobEntry* e = (const BlobEntry*)(m->blob.data() + 8);
-  for (uint32_t k = 0; k < narr; k++) m->idx[std::string(e[k].name)] = e + k;
+  for (uint32_t k = 0; k < narr; k++) {
+    if (!memchr(e[k].name, 0, sizeof(e[k].name))) return fail("fb_model_load: unterminated array name");
+    if (e[k].dtype > 1) return fail(std::string("fb_model_load: array '") + e[k].name + "' has an unknown element type");
+    if (e[k].offset > n || e[k].nbytes > n - e[k].offset) return fail(std::string("fb_model_load: array '") + e[k].name + "' lies outside the blob");
+    if (e[k].offset % 8 != 0) return fail(std::string("fb_model_load: array '") + e[k].name + "' is misaligned");
+    m->idx[std::string(e[k].name)] = e + k;
+  }
   size_t c;
   m->d("qpos0", &c); m->nq = (int)c;
   m->i("dof_bodyid", &c); m->nv = (int)c;
@@ -76,7 +166,10 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   m->i("appendage_sites", &c); m->napp = (int)c;
   m->i("sensor_force_sites", &c); m->nforce = (int)c;
   m->i("sensor_touch_sites", &c); m->ntouch = (int)c;
+  if (m->nq <= 0 || m->nv <= 0 || m->nbody <= 1 || m->njnt <= 0) return fail("fb_model_load: empty model");
+  check_model_arrays(m);
   m->nM = m->i("dof_Madr")[m->nv];
+  if (!(m->d("opt_timestep")[0] > 0) || !(m->d("opt_control_timestep")[0] >= m->d("opt_timestep")[0])) return fail("fb_model_load: bad timestep / control timestep");
   m->nsubstep = (int)floor(m->d("opt_control_timestep")[0] / m->d("opt_timestep")[0] + 0.5);
   const int* actadr = m->i("actuator_actadr");
   m->na = 0; for (int k = 0; k < m->nu; k++) if (actadr[k] >= 0) m->na++;
@@ -88,12 +181,12 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int b = 1; b < nb; b++) m->body_depth[b] = m->body_depth[parent[b]] + 1;
   for (int b = nb - 1; b > 0; b--) m->body_nsub[parent[b]] += m->body_nsub[b];
   for (int b = 1; b < nb; b++) {
-    if (m->body_depth[b] > FB_MAXDEPTH) { delete m; return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
-    if (nb > 2*FB_WAVE || 10*nb + 6*m->nv > FB_LDS_SCRATCH || 7*nb + 4*m->njnt > FB_LDS_SCRATCH) { delete m; return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
+    if (m->body_depth[b] > FB_MAXDEPTH) { return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
+    if (nb > 2*FB_WAVE || 10*nb + 6*m->nv > FB_LDS_SCRATCH || 7*nb + 4*m->njnt > FB_LDS_SCRATCH) { return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
     // DFS contiguity: every body in (b, b+nsub) must descend from b
     for (int d = b + 1; d < b + m->body_nsub[b]; d++) {
       int a = d; while (a > b) a = parent[a];
-      if (a != b) { delete m; return fail("fb_model_load: bodies are not in DFS order"); }
+      if (a != b) { return fail("fb_model_load: bodies are not in DFS order"); }
     }
   }
   m->dof_depth.assign(nv, 0);
@@ -104,8 +197,8 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     if (a <= 0) continue;
     int last = dofadr[a] + dofnum[a] - 1;
     int len = m->dof_depth[last] + 1;
-    if (len > FB_MAXCH) { delete m; return fail("fb_model_load: dof chain longer than FB_MAXCH"); }
-    if (m->nM > FB_MAXNM || m->nv > FB_MAXNV) { delete m; return fail("fb_model_load: model exceeds the LDS capacity constants FB_MAXNM / FB_MAXNV"); }
+    if (len > FB_MAXCH) { return fail("fb_model_load: dof chain longer than FB_MAXCH"); }
+    if (m->nM > FB_MAXNM || m->nv > FB_MAXNV) { return fail("fb_model_load: model exceeds the LDS capacity constants FB_MAXNM / FB_MAXNV"); }
     m->body_chlen[b] = len;
     for (int k = last, s = len - 1; k >= 0; k = dofpar[k], s--) m->body_chain[(size_t)b*FB_MAXCH + s] = k;
   }
@@ -121,7 +214,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int k = 0; k < nv; k++)
     for (int q = k + 1; q <= k + m->dof_ndesc[k]; q++) {
       int a = q; while (a > k) a = dofpar[a];
-      if (a != k) { delete m; return fail("fb_model_load: dofs are not in DFS order"); }
+      if (a != k) { return fail("fb_model_load: dofs are not in DFS order"); }
     }
   m->nlevel = 0;
   for (int k = 0; k < nv; k++) if (m->dof_depth[k] + 1 > m->nlevel) m->nlevel = m->dof_depth[k] + 1;
@@ -129,7 +222,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   for (int d = 0; d < m->nlevel; d++) {
     m->lvl_start[d] = (int)m->lvl_dof.size();
     for (int k = 0; k < nv; k++) if (m->dof_depth[k] == d) m->lvl_dof.push_back(k);
-    if ((int)m->lvl_dof.size() - m->lvl_start[d] > FB_WAVE) { delete m; return fail("fb_model_load: more than 64 dofs on one depth level"); }
+    if ((int)m->lvl_dof.size() - m->lvl_start[d] > FB_WAVE) { return fail("fb_model_load: more than 64 dofs on one depth level"); }
   }
   m->lvl_start[m->nlevel] = (int)m->lvl_dof.size();
   // The factor is stored ROW-major like qM: row k = [1/D[k], L[k,parent], L[k,grandparent], ...] at dof_Madr[k].
@@ -138,8 +231,8 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   const int* madr = m->i("dof_Madr");
   {
     int adr = 0;
-    for (int k = 0; k < nv; k++) { if (madr[k] != adr) { delete m; return fail("fb_model_load: dof_Madr does not match the dof tree"); } adr += m->dof_depth[k] + 1; }
-    if (adr != m->nM) { delete m; return fail("fb_model_load: dof_Madr does not match the dof tree"); }
+    for (int k = 0; k < nv; k++) { if (madr[k] != adr) { return fail("fb_model_load: dof_Madr does not match the dof tree"); } adr += m->dof_depth[k] + 1; }
+    if (adr != m->nM) { return fail("fb_model_load: dof_Madr does not match the dof tree"); }
   }
   // pure-chain length below each dof (descendants i+1 .. i+cl are one unbranched chain).  The unbranched chain
   // that starts at dof 0 is the "trunk" (the free joint): its rows are handled wave-parallel.  Other dofs whose
@@ -155,7 +248,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     m->ntrunk = (nroots == 1) ? std::min(m->dof_cl[0] + 1, FB_MAXTRUNK) : 0;
     m->dof_gen.assign(nv, -1);
     for (int k = m->ntrunk; k < nv; k++) if (m->dof_ndesc[k] > m->dof_cl[k]) m->dof_gen[k] = m->ngen++;
-    if (m->ngen > 15 || m->ngen > FB_MAXGEN) { delete m; return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
+    if (m->ngen > 15 || m->ngen > FB_MAXGEN) { return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
     m->gen_k.assign((size_t)FB_MAXGEN*FB_MAXCH, -1);            // 4 descendant dof ids per (general dof, level), 0xff = none
     m->gen_m.assign((size_t)FB_MAXGEN*FB_MAXCH*2, -1);          // ... and their row starts, 4 x u16, 0xffff = none
     for (int k = 0; k < nv; k++) {
@@ -165,7 +258,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
         for (int t = m->lvl_start[d]; t < m->lvl_start[d + 1]; t++) {
           int q = m->lvl_dof[t];
           if (q > k && q <= k + m->dof_ndesc[k]) {
-            if (cnt == 4) { delete m; return fail("fb_model_load: a branching dof has more than 4 descendants on one level"); }
+            if (cnt == 4) { return fail("fb_model_load: a branching dof has more than 4 descendants on one level"); }
             pk = (pk & ~(0xffu << (8*cnt))) | ((unsigned)q << (8*cnt));
             pm = (pm & ~(0xffffull << (16*cnt))) | ((unsigned long long)madr[q] << (16*cnt));
             cnt++;
@@ -199,12 +292,12 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
         bool room = e.gen ? (ngs[l] < FB_FGEN) : (ncs[l] < FB_FSLOT - FB_FGEN || ngs[l] < FB_FGEN);
         if (room && (best < 0 || load[l] < load[best])) best = l;
       }
-      if (best < 0) { delete m; return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
+      if (best < 0) { return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
       int slot;
       if (e.gen || ncs[best] >= FB_FSLOT - FB_FGEN) slot = ngs[best]++; else slot = FB_FGEN + ncs[best]++;
       load[best] += e.work;
       int dep = m->dof_depth[e.i], base = madr[e.i] - dep*(dep + 1)/2, ee = dep - m->dof_depth[e.j];
-      if (base < -4096 || base > 4095 || dep > 30) { delete m; return fail("fb_model_load: factor work list field overflow"); }
+      if (base < -4096 || base > 4095 || dep > 30) { return fail("fb_model_load: factor work list field overflow"); }
       size_t o = (size_t)slot*FB_WAVE + best;
       m->fac_w[o] = (base & 0x1fff) | (dep << 13) | (m->dof_cl[e.i] << 18) | (ee << 23) | (int)((unsigned)(e.gen ? m->dof_gen[e.i] : 15) << 28);
     }
@@ -217,10 +310,10 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     const int *g1 = m->i("pair_geom1"), *g2 = m->i("pair_geom2"), *gt = m->i("geom_type");
     std::vector<int> slot(m->ngeom, 0);
     for (int g = 0; g < m->ngeom; g++) if (gt[g] == GEOM_PLANE) { m->plane_geoms.push_back(g); slot[g] = m->ngeom + (int)m->plane_geoms.size() - 1; }
-    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS) { delete m; return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
+    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS) { return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
     m->pair_word.assign(std::max(m->npair, 1), 0);
     for (int q = 0; q < m->npair; q++) {
-      if (gt[g2[q]] == GEOM_PLANE) { delete m; return fail("fb_model_load: a plane must be the first geom of a pair"); }
+      if (gt[g2[q]] == GEOM_PLANE) { return fail("fb_model_load: a plane must be the first geom of a pair"); }
       m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20);
     }
     if (m->plane_geoms.empty()) m->plane_geoms.push_back(0);
@@ -234,7 +327,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     const double* wc = m->d("wrap_coef", &c_);
     m->wrap_qadr.assign(std::max<size_t>(nw_, 1), 0);
     for (size_t k = 0; k < nw_; k++) m->wrap_qadr[k] = jqa[djnt[wd[k]]];
-    for (int t = 0; t < m->ntendon; t++) if (tnum[t] > FB_MAXWRAP) { delete m; return fail("fb_model_load: tendon with more than FB_MAXWRAP joints"); }
+    for (int t = 0; t < m->ntendon; t++) if (tnum[t] > FB_MAXWRAP) { return fail("fb_model_load: tendon with more than FB_MAXWRAP joints"); }
     m->act_wn.assign(m->nu, 0); m->act_lenadr.assign(m->nu, 0);
     m->act_wdof.assign((size_t)m->nu*FB_MAXWRAP, 0); m->act_wcoef.assign((size_t)m->nu*FB_MAXWRAP, 0.0);
     std::vector<int> owner(m->nv, -1);
@@ -249,7 +342,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
       // the kernel scatters joint / tendon actuator forces with plain stores (one lane per actuator): dofs must not be shared
       for (int q = 0; q < n_; q++) {
         int dq = m->act_wdof[(size_t)k*FB_MAXWRAP + q];
-        if (owner[dq] >= 0) { delete m; return fail("fb_model_load: two joint/tendon actuators drive the same dof"); }
+        if (owner[dq] >= 0) { return fail("fb_model_load: two joint/tendon actuators drive the same dof"); }
         owner[dq] = k;
       }
     }
@@ -265,7 +358,7 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
     for (int b = 0; b < nb; b++) {
       double* R = m->body_rec.data() + (size_t)b*FB_BODYREC;
       int jn = bjn[b], ja = bja[b];
-      if (jn > 3) { delete m; return fail("fb_model_load: more than 3 joints on one body"); }
+      if (jn > 3) { return fail("fb_model_load: more than 3 joints on one body"); }
       bool fr = jn > 0 && jt[ja] == JNT_FREE;
       R[0] = parent[b]; R[1] = ja; R[2] = jn; R[3] = fr ? 1 : 0;
       for (int k = 0; k < 3; k++) { R[4 + k] = bp[3*b + k]; R[11 + k] = bip[3*b + k]; }
@@ -287,13 +380,13 @@ extern "C" int fb_model_load(const void* blob, size_t n, fb_model** out) {
   { const double* gfl = m->d("geom_fluid"); const int* gb = m->i("geom_bodyid");
     for (int g = 0; g < m->ngeom; g++) if (gfl[12*g] > 0) m->body_fluid_geom[gb[g]] = g; }
   (void)dofbody;
-  *out = m;
   return 0;
 }
 
 extern "C" void fb_model_destroy(fb_model* m) { delete m; }
 
 extern "C" int fb_model_dim(const fb_model* m, const char* name) {
+  if (!m || !name) return -1;
 #define X(f) if (!strcmp(name, #f)) return m->f
   X(nq); X(nv); X(nbody); X(njnt); X(ngeom); X(nsite); X(nu); X(na); X(ntendon); X(npair); X(nM); X(nsubstep);
   X(nobsjnt); X(napp); X(nforce); X(ntouch);
@@ -417,7 +510,7 @@ struct fb_batch {
   float *obs = nullptr, *reward = nullptr, *discount = nullptr; int* step_type = nullptr;
   int* d_ids = nullptr;
   int* sched = nullptr;
-  int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true;
+  int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true;
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
@@ -520,7 +613,11 @@ static void compute_offsets(const DevModel<real>& M, WSOff& o) {
   o.nreal = (r + 15u) & ~15u; o.nint = (i + 15u) & ~15u;
 }
 
+static int batch_create_impl(fb_batch* b);
+
 extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int precision, fb_batch** out) {
+  if (!out) return fail("fb_batch_create: null output pointer");
+  *out = nullptr;
   if (!m || n_env <= 0) return fail("fb_batch_create: bad arguments");
   if (precision != 32 && precision != 64) return fail("fb_batch_create: precision must be 32 or 64");
   int ndev = 0;
@@ -529,6 +626,15 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
   HIPCHK(hipSetDevice(device));
   fb_batch* b = new fb_batch();
   b->m = m; b->n_env = n_env; b->device = device; b->precision = precision;
+  int rc;
+  try { rc = batch_create_impl(b); } catch (const std::exception& e_) { rc = fail(std::string("fb_batch_create: ") + e_.what()); }
+  if (rc != 0) { std::string keep = g_err; fb_batch_destroy(b); g_err = keep; return rc; }     // every allocation made so far is released
+  *out = b;
+  return 0;
+}
+
+static int batch_create_impl(fb_batch* b) {
+  const fb_model* m = b->m; const int n_env = b->n_env, precision = b->precision;
   if (precision == 64) { if (build_devmodel<double>(b, b->M64)) return -1; compute_offsets(b->M64, b->off); b->M64.off = b->off; }
   else { if (build_devmodel<float>(b, b->M32)) return -1; compute_offsets(b->M32, b->off); b->M32.off = b->off; }
   size_t rs = precision == 64 ? 8 : 4;
@@ -545,6 +651,7 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
   HIPCHK(hipMemset(b->cost, 0, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->order, n_env*sizeof(int)));
   { const char* e_ = getenv("FB_NO_REORDER"); b->reorder = !(e_ && e_[0] == '1'); }
+  b->use_prio = getenv("FB_NO_PRIO") == nullptr;
   HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->discount, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->step_type, 0, n_env*sizeof(int)));
@@ -559,7 +666,6 @@ extern "C" int fb_batch_create(const fb_model* m, int n_env, int device, int pre
     HIPCHK(hipMemcpy2D((char*)b->rarena + (size_t)b->off.qpos*rs, (size_t)b->off.nreal*rs, rows.data(), (size_t)m->nq*rs, (size_t)m->nq*rs, n_env, hipMemcpyHostToDevice));
   }
   b->nobs = 0;
-  *out = b;
   return 0;
 }
 
@@ -567,7 +673,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -581,6 +687,7 @@ extern "C" int fb_batch_set_reference(fb_batch* b, const double* ref_qpos, const
   if (T - future_steps - 1 < 1) return fail("fb_batch_set_reference: trajectory shorter than future_steps + 2");
   HIPCHK(hipSetDevice(b->device));
   (void)hipFree(b->ref_qpos); (void)hipFree(b->ref_qvel); (void)hipFree(b->obs);
+  b->ref_qpos = b->ref_qvel = nullptr; b->obs = nullptr; b->have_ref = false;     // (a failed allocation below must not leave dangling pointers)
   const fb_model* m = b->m;
   int nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
   int max_steps = (int)floor(time_limit / m->d("opt_control_timestep")[0] + 0.5) + 1;
@@ -621,7 +728,7 @@ extern "C" int fb_batch_set_time_limit(fb_batch* b, double time_limit) {
   if (m->i("task_id")[0] != 2) return fail("fb_batch_set_time_limit: only the walk_on_ball task has no reference trajectory");
   HIPCHK(hipSetDevice(b->device));
   int nobs = 3 + m->na + 3*m->napp + 3 + 3*m->nforce + 3 + 2*m->nobsjnt + m->ntouch + 3 + 3;
-  (void)hipFree(b->obs);
+  (void)hipFree(b->obs); b->obs = nullptr;
   HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
   HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
   b->nobs = nobs;
@@ -667,7 +774,7 @@ extern "C" int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds)
   int nj = ds->n_joints, ns = ds->n_sites, future_steps = ds->future_steps;
   int nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
   int max_steps = (int)floor(ds->time_limit / m->d("opt_control_timestep")[0] + 0.5) + 1;
-  (void)hipFree(b->obs);
+  (void)hipFree(b->obs); b->obs = nullptr;
   HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
   HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
   b->nobs = nobs;
@@ -702,10 +809,10 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder;
   if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
   if (b->precision == 64) {
-    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost};
     hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
-    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, getenv("FB_NO_PRIO") ? nullptr : b->sched, b->cost};
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost};
     hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }

@@ -51,6 +51,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
             pass
     L = C.CDLL(path)
     L.fb_last_error.restype = C.c_char_p
+    L.fb_version.restype = C.c_char_p
     L.fb_model_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.fb_model_destroy.argtypes = [C.c_void_p]; L.fb_model_destroy.restype = None
     L.fb_model_dim.argtypes = [C.c_void_p, C.c_char_p]
@@ -72,6 +73,24 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _libs[path] = L
     return L
+
+
+def version(lib_path: Optional[str] = None) -> str:
+    """Build identity of the loaded engine library (fb_version)."""
+    return load_library(lib_path).fb_version().decode()
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources in this tree (csrc/ + the C-ABI header), as embedded into the library at build time."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = [os.path.join(root, 'include', 'flybody_engine.h')]
+    for base, _, names in os.walk(os.path.join(_HERE, 'csrc')):
+        files += [os.path.join(base, f) for f in names if f.endswith(('.hip', '.hpp', '.h'))]
+    h = hashlib.sha1()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:12]
 
 
 def _check(L, rc):

@@ -149,6 +149,10 @@ int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launc
 
 const char* fb_last_error(void);
 
+/* Build identity of the shared object: "flybody_engine <abi> (<target>, <hash of the kernel sources it was built from>)".
+ * smoke() and the GPU tests print it and compare the hash with the sources in the tree, so a log shows which binary ran. */
+const char* fb_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,41 @@ def test_model_load_and_argument_validation(walk_arrays):
     assert b'precision' in M.L.fb_last_error()
 
 
+def test_malformed_blobs_are_errors_not_aborts(walk_arrays):
+    """fb_model_load validates every array it will read (a missing array used to abort() the process)."""
+    import numpy as np
+    from flybody_amd import engine
+    from flybody_amd.model_blob import pack_model
+    L = engine.load_library()
+    assert 'flybody_engine' in engine.version() and engine.source_hash() in engine.version()      # the binary names the sources it was built from
+    h = C.c_void_p()
+
+    def load(arrays):
+        blob = pack_model(arrays)
+        rc = L.fb_model_load(blob, len(blob), C.byref(h))
+        if rc == 0:
+            L.fb_model_destroy(h)
+        return rc, L.fb_last_error().decode()
+
+    assert load(dict(walk_arrays))[0] == 0
+    a = dict(walk_arrays); del a['jnt_solimp']
+    rc, msg = load(a); assert rc != 0 and 'jnt_solimp' in msg
+    a = dict(walk_arrays); a['body_mass'] = np.asarray(a['body_mass'])[:10]
+    rc, msg = load(a); assert rc != 0 and 'body_mass' in msg
+    a = dict(walk_arrays); a['geom_type'] = np.asarray(a['geom_type'], np.float64)
+    rc, msg = load(a); assert rc != 0 and 'geom_type' in msg
+    a = dict(walk_arrays); g = np.asarray(a['pair_geom2']).copy(); g[5] = 10_000; a['pair_geom2'] = g
+    rc, msg = load(a); assert rc != 0 and 'pair_geom2' in msg
+    a = dict(walk_arrays); a['opt_timestep'] = np.float64(0.0)
+    rc, msg = load(a); assert rc != 0 and 'timestep' in msg
+    # truncated blob / corrupt table of contents
+    blob = pack_model(dict(walk_arrays))
+    assert L.fb_model_load(blob[:200], 200, C.byref(h)) != 0
+    assert L.fb_model_load(blob[:len(blob)//2], len(blob)//2, C.byref(h)) != 0 and b'outside the blob' in L.fb_last_error()
+    assert L.fb_model_load(blob, len(blob), None) != 0
+    assert L.fb_model_dim(None, b'nq') == -1
+
+
 def test_no_cpu_fallback(walk_arrays):
     """Without a GPU the product path must raise, not silently compute on the CPU."""
     import torch
