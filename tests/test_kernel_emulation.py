@@ -226,3 +226,33 @@ def test_ragged_partial_reset_and_bad_ids(emu_model, reference_traj):
         B.reset([-1])
     with pytest.raises(engine.EngineError):
         B.reset(np.zeros(0, np.int32))
+
+
+def test_numeric_guards_emulation(emu_model, oracle_model, reference_traj):
+    """NaN actions -> 0 (tasks/walk_imitation.py:148) and the ||qacc|| > 1e14 / non-finite termination with discount 0
+    (tasks/base.py:222-225), kernel source against the oracle (the GPU version is tests/test_gpu_parity.py)."""
+    from flybody_amd import engine
+    from oracle import fbo
+    qp, qv = reference_traj
+    n = 3
+    B = engine.Batch(emu_model, n, precision=64); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    ods = []
+    for _ in range(n):
+        od = fbo.OracleData(oracle_model); od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset(); ods.append(od)
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-0.5, 0.5, (n, 59)).astype(np.float32); a[1, ::3] = np.nan
+    for _ in range(2):
+        B.step_ptr(a.ctypes.data)
+        for e in range(n):
+            ods[e].env_step(a[e].astype(np.float64))
+    Q = B.get('QPOS')
+    assert np.isfinite(Q).all()
+    assert all(_rel(Q[e], ods[e].field('qpos')) < 1e-9 for e in range(n))
+    V = B.get('QVEL'); V[2, 20:40] = 1e18; B.set('QVEL', V); ods[2].field('qvel')[20:40] = 1e18
+    a0 = np.zeros((n, 59), np.float32)
+    B.step_ptr(a0.ctypes.data); ods[2].env_step(a0[2].astype(np.float64))
+    assert B.get('STEP_TYPE').ravel().tolist() == [1, 1, 2] and B.get('DISCOUNT').ravel().tolist() == [1.0, 1.0, 0.0]
+    assert int(ods[2].scalar('step_type')) == 2 and ods[2].scalar('discount') == 0.0
+    B.step_ptr(a0.ctypes.data); ods[2].env_step(a0[2].astype(np.float64))
+    assert B.get('STEP_TYPE').ravel().tolist() == [1, 1, 0] and np.isfinite(B.get('QPOS')).all()
+    assert _rel(B.get('QPOS')[2], ods[2].field('qpos')) < 1e-12
