@@ -416,6 +416,11 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, (sizeof(real) == 4 
   __shared__ real s_Dinv[EPB][FB_MAXNV];
   __shared__ real s_x[EPB][FB_MAXNV];
   __shared__ real s_AR[EPB][LdsCfg<real>::AR_ELEMS];
+#ifdef FB_LDS_PAD
+  // experiment: extra LDS per workgroup halves the number of resident environments (is a phase latency- or issue-bound?)
+  __shared__ real s_pad[FB_LDS_PAD];
+  if (threadIdx.x == 0 && mode == 12345) s_pad[blockIdx.x % FB_LDS_PAD] = 1;
+#endif
   // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
   __shared__ uint8_t s_depth[FB_MAXNV];
   __shared__ uint8_t s_cl[FB_MAXNV];

@@ -1,0 +1,103 @@
+"""Parity against CPU MuJoCo -- the reference's real engine -- through golden vectors recorded by
+`tools/dump_mujoco_golden.py` wherever `mujoco` + `dm_control` + the reference package exist.
+
+STATUS IN THIS REPOSITORY: the golden files are ABSENT (MuJoCo cannot be installed in the build container and the
+reference pins no trajectory), so these tests SKIP and every physics parity statement reads "kernel == in-repo FP64
+oracle; MuJoCo parity unpinned".  Dropping `mujoco_walk_rollout.npz` / `mujoco_model_constants.npz` into tests/golden/
+turns them on without further changes:
+
+  * compiled constants (CPU): sizes, masses, inertias (this pins the head / thorax approximation), M0, invweight0, wing
+    fluid coefficients, actuator parameters against flybody_amd/assets/walk_imitation.npz;
+  * rollout (CPU): the recorded actions replayed through the FP64 oracle; north_star's tolerance 1e-4 relative on qpos /
+    qvel at every one of the 100 control steps, observation / reward / step type next to it;
+  * rollout (GPU, `-m gpu`): the same through the HIP engine's C-ABI.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+ROLL = os.path.join(GOLD, 'mujoco_walk_rollout.npz')
+CONST = os.path.join(GOLD, 'mujoco_model_constants.npz')
+_SKIP = ('MuJoCo golden vectors absent: run tools/dump_mujoco_golden.py where mujoco + dm_control + flybody are installed '
+         'and commit tests/golden/mujoco_*.npz -- until then MuJoCo parity is UNPINNED')
+TOL = 1e-4                                            # BASELINE.json north_star: qpos / qvel within 1e-4 rel over 100 steps
+
+
+def _rel(a, b):
+    a = np.asarray(a, float).ravel(); b = np.asarray(b, float).ravel()
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_golden_dump_script_is_present_and_parses():
+    """The script the goldens come from is part of the repository and at least compiles here."""
+    import ast
+    src = open(os.path.join(ROOT, 'tools', 'dump_mujoco_golden.py')).read()
+    ast.parse(src)
+    for token in ('mujoco.__version__', 'walk_imitation(terminal_com_dist=float(\'inf\'))', 'np.random.seed(0)', 'mj_fullM', 'efc_force'):
+        assert token in src
+
+
+@pytest.mark.skipif(not os.path.exists(CONST), reason=_SKIP)
+def test_compiled_constants_match_mujoco(walk_arrays):
+    g = np.load(CONST)
+    print('MuJoCo', str(g['mujoco_version']))
+    a = walk_arrays
+    ghost = 1                                         # the ghost walker adds one body / one free joint behind the fly
+    nb, nv, nq = len(a['body_mass']), len(a['dof_bodyid']), len(a['qpos0'])
+    assert int(g['nq']) == nq + 7*ghost and int(g['nv']) == nv + 6*ghost and int(g['nu']) == len(a['actuator_trntype'])
+    names = [str(s) for s in g['names_body']]
+    ours = [str(s) for s in a['names_body']]
+    idx = [names.index('walker/' + n) if ('walker/' + n) in names else names.index(n) for n in ours[1:]]
+    assert np.allclose(g['body_mass'][idx], a['body_mass'][1:], rtol=1e-5)
+    assert np.allclose(g['body_inertia'][idx], a['body_inertia'][1:], rtol=1e-4, atol=1e-14)
+    assert np.allclose(g['body_ipos'][idx], a['body_ipos'][1:], atol=1e-7)
+    assert np.allclose(g['dof_M0'][:nv], a['dof_M0'], rtol=1e-5)
+    assert np.allclose(g['dof_invweight0'][:nv], a['dof_invweight0'], rtol=1e-4)
+    assert np.allclose(g['M0_full'][:nv, :nv], a['M0_full'], rtol=1e-5, atol=1e-12)
+    assert np.allclose(g['actuator_gainprm'][:, :3], a['actuator_gainprm'], rtol=1e-9)
+    assert np.allclose(g['actuator_biasprm'][:, :3], a['actuator_biasprm'], rtol=1e-9)
+    assert abs(float(g['opt_timestep']) - float(a['opt_timestep'])) < 1e-15
+    fl = np.asarray(g['geom_fluid']); ours_fl = np.asarray(a['geom_fluid'])
+    assert np.allclose(fl[fl[:, 0] > 0], ours_fl[ours_fl[:, 0] > 0], rtol=1e-5)           # wing ellipsoids: virtual mass / inertia
+
+
+@pytest.mark.skipif(not os.path.exists(ROLL), reason=_SKIP)
+def test_oracle_rollout_matches_mujoco(oracle_model, walk_arrays):
+    from flybody_amd.reference import default_walking_reference
+    from oracle import fbo
+    g = np.load(ROLL)
+    print('MuJoCo', str(g['mujoco_version']))
+    nq, nv = len(walk_arrays['qpos0']), len(walk_arrays['dof_bodyid'])
+    qp, qv = default_walking_reference()
+    od = fbo.OracleData(oracle_model); od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
+    assert _rel(od.field('qpos'), g['qpos0'][:nq]) < 1e-9
+    worst = 0.0
+    for k, act in enumerate(g['action']):
+        od.env_step(act.astype(np.float64))
+        eq, ev = _rel(od.field('qpos'), g['qpos'][k][:nq]), _rel(od.field('qvel'), g['qvel'][k][:nv])
+        worst = max(worst, eq, ev)
+        assert eq < TOL and ev < TOL, (k, eq, ev)
+        assert od.scalar('reward') == g['reward'][k] and int(od.scalar('step_type')) == int(g['step_type'][k])
+    print(f'oracle vs MuJoCo over {len(g["action"])} control steps: worst relative error {worst:.3e}')
+    assert np.allclose(od.field('obs'), g['obs'][-1], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(ROLL), reason=_SKIP)
+def test_engine_rollout_matches_mujoco(walk_arrays):
+    import torch
+    from flybody_amd import engine
+    from flybody_amd.reference import default_walking_reference
+    g = np.load(ROLL)
+    nq, nv = len(walk_arrays['qpos0']), len(walk_arrays['dof_bodyid'])
+    M = engine.Model(walk_arrays); B = engine.Batch(M, 2, precision=64)
+    qp, qv = default_walking_reference()
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    for k, act in enumerate(g['action']):
+        a = torch.from_numpy(np.tile(act.astype(np.float32), (2, 1))).cuda()
+        B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        assert _rel(B.get('QPOS')[0], g['qpos'][k][:nq]) < TOL and _rel(B.get('QVEL')[0], g['qvel'][k][:nv]) < TOL, k
