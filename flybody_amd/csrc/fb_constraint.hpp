@@ -187,7 +187,7 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
 #pragma unroll
         for (int s = 0; s < FB_MAXCH; s++) {
           real v = 0;
-          if (s < len) v = y[s] * sqrt(w.lDinv[chain[s]]);
+          if (s < len) v = y[s] * sqrt(w.lLD[rowadr[s] - s]);          // 1/D of the dof: diagonal slot of its row
           w.efc_Y()[JIDX(side, s, r)] = v;
         }
       }
@@ -740,7 +740,26 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   }
   SYNC();
   int niter;
-  if (nefc <= LdsCfg<real>::AR_ROWS) niter = d_pgs<real, const FB_LDS real*, true>(M, w, (const FB_LDS real*)w.lAR, nefc, lane);
+  if (nefc <= LdsCfg<real>::WIDE_ROWS) {
+    // Delassus matrix in LDS.  A system that does not fit the matrix slot alone borrows the factor row in front of it (the
+    // pool is contiguous): the factor is parked in the environment's global row during the sweeps -- two coalesced passes
+    // instead of a global-memory round trip on the critical path of every row update of a system that is slow already.
+    const bool wide = nefc > LdsCfg<real>::AR_ROWS;
+    if (wide) {
+      for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
+      SYNC();
+      const real* src = w.AR();
+      for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lLD[i] = src[i];
+      SYNC();
+    }
+    const FB_LDS real* arp = wide ? (const FB_LDS real*)w.lLD : (const FB_LDS real*)w.lAR;
+    niter = d_pgs<real, const FB_LDS real*, true>(M, w, arp, nefc, lane);
+    if (wide) {
+      SYNC();
+      for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD()[i];
+      SYNC();
+    }
+  }
   else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane);
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
   if (lane == 0) w.istate()[IS_NITER] = niter;

@@ -182,7 +182,7 @@ static int model_load_impl(fb_model* m, size_t n) {
   for (int b = nb - 1; b > 0; b--) m->body_nsub[parent[b]] += m->body_nsub[b];
   for (int b = 1; b < nb; b++) {
     if (m->body_depth[b] > FB_MAXDEPTH) { return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
-    if (nb > 2*FB_WAVE || 10*nb + 6*m->nv > FB_LDS_SCRATCH || 7*nb + 4*m->njnt > FB_LDS_SCRATCH) { return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
+    if (nb > 2*FB_WAVE || 7*nb + 4*m->njnt > FB_LDS_SCRATCH || m->nM + 1 > FB_LDS_SCRATCH) { return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
     // DFS contiguity: every body in (b, b+nsub) must descend from b
     for (int d = b + 1; d < b + m->body_nsub[b]; d++) {
       int a = d; while (a > b) a = parent[a];
@@ -248,7 +248,7 @@ static int model_load_impl(fb_model* m, size_t n) {
     m->ntrunk = (nroots == 1) ? std::min(m->dof_cl[0] + 1, FB_MAXTRUNK) : 0;
     m->dof_gen.assign(nv, -1);
     for (int k = m->ntrunk; k < nv; k++) if (m->dof_ndesc[k] > m->dof_cl[k]) m->dof_gen[k] = m->ngen++;
-    if (m->ngen > 15 || m->ngen > FB_MAXGEN) { return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
+    if (m->ngen > 15 || m->ngen > FB_MAXGEN || m->ngen > FB_LGEN) { return fail("fb_model_load: more than FB_MAXGEN branching dofs"); }
     m->gen_k.assign((size_t)FB_MAXGEN*FB_MAXCH, -1);            // 4 descendant dof ids per (general dof, level), 0xff = none
     m->gen_m.assign((size_t)FB_MAXGEN*FB_MAXCH*2, -1);          // ... and their row starts, 4 x u16, 0xffff = none
     for (int k = 0; k < nv; k++) {
@@ -310,7 +310,7 @@ static int model_load_impl(fb_model* m, size_t n) {
     const int *g1 = m->i("pair_geom1"), *g2 = m->i("pair_geom2"), *gt = m->i("geom_type");
     std::vector<int> slot(m->ngeom, 0);
     for (int g = 0; g < m->ngeom; g++) if (gt[g] == GEOM_PLANE) { m->plane_geoms.push_back(g); slot[g] = m->ngeom + (int)m->plane_geoms.size() - 1; }
-    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS) { return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
+    if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS + FB_MAXNV) { return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
     m->pair_word.assign(std::max(m->npair, 1), 0);
     for (int q = 0; q < m->npair; q++) {
       if (gt[g2[q]] == GEOM_PLANE) { return fail("fb_model_load: a plane must be the first geom of a pair"); }
@@ -409,15 +409,12 @@ struct Batch {
 
 
 template <typename real>
-__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, (sizeof(real) == 4 ? 4 : 2)) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES_PER_SIMD) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
   constexpr int EPB = LdsCfg<real>::EPB;
-  __shared__ real s_LD[EPB][FB_LDS_SCRATCH];
-  __shared__ real s_Dinv[EPB][FB_MAXNV];
-  __shared__ real s_x[EPB][FB_MAXNV];
-  __shared__ real s_AR[EPB][LdsCfg<real>::AR_ELEMS];
+  __shared__ real s_pool[EPB][LdsCfg<real>::POOL];          // [factor row | Delassus matrix | solve vector] of each environment
 #ifdef FB_LDS_PAD
-  // experiment: extra LDS per workgroup halves the number of resident environments (is a phase latency- or issue-bound?)
+  // experiment: extra LDS per workgroup lowers the number of resident environments (is a phase latency- or issue-bound?)
   __shared__ real s_pad[FB_LDS_PAD];
   if (threadIdx.x == 0 && mode == 12345) s_pad[blockIdx.x % FB_LDS_PAD] = 1;
 #endif
@@ -426,15 +423,15 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, (sizeof(real) == 4 
   __shared__ uint8_t s_cl[FB_MAXNV];
   __shared__ uint8_t s_gen[FB_MAXNV];
   __shared__ uint16_t s_madr[FB_MAXNV + 1];
-  __shared__ uint32_t s_gk[FB_MAXGEN*FB_MAXCH];
-  __shared__ uint32_t s_gm[FB_MAXGEN*FB_MAXCH*2];
+  __shared__ uint32_t s_gk[FB_LGEN*FB_MAXCH];
+  __shared__ uint32_t s_gm[FB_LGEN*FB_MAXCH*2];
   // the model lives in constant memory: its fields (sizes, table pointers, workspace offsets) are scalar loads
   const DevModel<real>& M = as_constant(*Mp);
   int tid = threadIdx.x;
   for (int i = tid; i < M.nv; i += FB_WAVE*EPB) {
     s_depth[i] = (uint8_t)M.dof_depth[i]; s_cl[i] = (uint8_t)M.dof_cl[i]; s_gen[i] = (uint8_t)M.dof_gen[i]; s_madr[i] = (uint16_t)M.dof_Madr[i];
   }
-  for (int i = tid; i < FB_MAXGEN*FB_MAXCH; i += FB_WAVE*EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
+  for (int i = tid; i < FB_LGEN*FB_MAXCH; i += FB_WAVE*EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
   // the wave index is wave-uniform: say so (v_readfirstlane), otherwise every per-environment base address is 64-bit VALU math
   int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
@@ -444,7 +441,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, (sizeof(real) == 4 
   WS<real> w;
   w.o = (const FB_CONST WSOff*)&M.off;
   w.rb = (FB_GLOBAL real*)(B.rarena + (size_t)env*M.off.nreal); w.ib = (FB_GLOBAL int*)(B.iarena + (size_t)env*M.off.nint);
-  w.lLD = (FB_LDS real*)s_LD[wave]; w.lDinv = (FB_LDS real*)s_Dinv[wave]; w.lx = (FB_LDS real*)s_x[wave]; w.lAR = (FB_LDS real*)s_AR[wave];
+  w.lLD = (FB_LDS real*)s_pool[wave]; w.lAR = w.lLD + FB_LDS_SCRATCH; w.lx = w.lAR + LdsCfg<real>::AR_ELEMS;
   w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
   w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
   float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;

@@ -138,9 +138,9 @@ template <typename real> FBD void makeframe(real* f) {
 }
 // division on solver hot paths: exact in FP64 (bit-faithful to the oracle), v_rcp_f32 (1 ulp) in FP32
 // FP64: IEEE division costs ~25 dependent instructions (v_div_scale x2, v_rcp_f64, 5 FMAs, v_div_fmas, v_div_fixup) in the
-// middle of the solver's serial chain.  With FB_FAST_DIV64 the quotient is v_rcp_f64 + two Newton steps + one residual
+// middle of the solver's serial chain.  Unless FB_EXACT_DIV64 is defined the quotient is v_rcp_f64 + two Newton steps + one residual
 // correction (<= 1 ulp for the normal-range operands the solver produces, no denormal / overflow handling).
-#if defined(FB_FAST_DIV64) && !defined(FB_EMULATE)
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
 FBD double fb_div(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
@@ -156,7 +156,7 @@ FBD float fb_div(float a, float b) { return a / b; }
 #else
 FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 #endif
-#if defined(FB_FAST_DIV64) && !defined(FB_EMULATE)
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
 FBD double fb_rsqrt(double a) {
   double y = __builtin_amdgcn_rsq(a);
   y = y*__builtin_fma(-0.5*a*y, y, 1.5);

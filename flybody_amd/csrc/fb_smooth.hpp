@@ -41,7 +41,7 @@ template <typename real>
 __device__ __forceinline__ WS<real> ws_uniform(const WS<real>& w_) {
   WS<real> w = w_;
   w.rb = uniform_p(w.rb); w.ib = uniform_p(w.ib); w.o = uniform_p(w.o);
-  w.lLD = uniform_p(w.lLD); w.lDinv = uniform_p(w.lDinv); w.lx = uniform_p(w.lx); w.lAR = uniform_p(w.lAR);
+  w.lLD = uniform_p(w.lLD); w.lx = uniform_p(w.lx); w.lAR = uniform_p(w.lAR);
   w.ldepth = uniform_p(w.ldepth); w.lcl = uniform_p(w.lcl); w.lgen = uniform_p(w.lgen); w.lmadr = uniform_p(w.lmadr);
   w.lgk = uniform_p(w.lgk); w.lgm = uniform_p(w.lgm);
 #ifndef FB_EMULATE
@@ -405,10 +405,14 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
 }
 
 template <typename real>
+FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
+                              FB_LDS real* RM, int lane);
+
+template <typename real>
 FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
-                         FB_LDS real* RM, FB_LDS real* Dinv, int lane) {
+                         FB_LDS real* RM, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
-  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); Dinv = uniform_p(Dinv);
+  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
@@ -444,7 +448,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) FB_OPAQUE(fd[q]);
     // publish the rows of level d (unnormalised) and 1/D
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; Dinv[lane + q*FB_WAVE] = di; }
+    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; }
 #pragma unroll
     for (int s = 0; s < FB_FSLOT; s++) {
       // branch-free: a slot that is not on level d stores to a dummy word behind the factor
@@ -492,6 +496,29 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     PROF(23);
   }
   PROF(18);
+  // the register accumulators are dead from here on (every entry was published, unnormalised, on its own level): the trunk
+  // and the normalisation run as a function of their own, with their own register allocation
+  d_factor_tail(M, w_, qM, diag_add, hscale, RM, lane);
+}
+
+// Second half of the factorisation: the dense Schur complement of the trunk rows (the free joint), the normalisation of
+// the published rows and the small dense LDL of the trunk.  Reads the unnormalised rows from LDS; its only inputs besides
+// them are the packed work words (re-read from the model) and the trunk rows of M.
+template <typename real>
+FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
+                              FB_LDS real* RM, int lane) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM);
+  PROF_BEGIN();
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk);
+  int fd[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    int j = lane + q*FB_WAVE;
+    bool has = j < nv && j >= nT;
+    int dp = has ? w.ldepth[j] : 31, mj = has ? w.lmadr[j] : 0;
+    fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13);
+  }
   // trunk: S[a,b] = M[a,b] - sum_{k >= nT} M~[k,a] M~[k,b] / D[k], then dense LDL (every lane, uniform values)
   real S[FB_NTT];
 #pragma unroll
@@ -524,17 +551,22 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     }
   SYNC();
   // normalise the published rows: L[i,j] = M~[i,j] / D[i]
+  {
+    int fw[FB_FSLOT];
 #pragma unroll
-  for (int s = 0; s < FB_FSLOT; s++) {
-    int wd = fw[s], dep = FW_DEP(wd);
-    if (dep != 31) { int ad = FW_BASE(wd) + dep*(dep + 1)/2; RM[ad + FW_E(wd)] = acc[s]*RM[ad]; }
+    for (int s = 0; s < FB_FSLOT; s++) fw[s] = M.fac_w[s*FB_WAVE + lane];
+#pragma unroll
+    for (int s = 0; s < FB_FSLOT; s++) {
+      int wd = fw[s], dep = FW_DEP(wd);
+      if (dep != 31) { int ad = FW_BASE(wd) + dep*(dep + 1)/2; RM[ad + FW_E(wd)] *= RM[ad]; }
+    }
   }
   // trunk rows: dof k sits at depth k, row start T(k)
 #pragma unroll
   for (int k = FB_MAXTRUNK - 1; k >= 0; k--) {
     if (k < nT) {
       real Dk = S[k*(k + 1)/2 + k], Di = (real)1/Dk;
-      if (lane == 0) { RM[k*(k + 1)/2] = Di; Dinv[k] = Di; }
+      if (lane == 0) RM[k*(k + 1)/2] = Di;
 #pragma unroll
       for (int a = 0; a < k; a++) {
         real Lka = S[k*(k + 1)/2 + a]*Di;
@@ -550,9 +582,9 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
 
 // x <- M^-1 x using the factorisation (everything in LDS)
 template <typename real>
-FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, const FB_LDS real* Dinv, FB_LDS real* x, int lane) {
+FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, FB_LDS real* x, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
-  RM = uniform_p(RM); Dinv = uniform_p(Dinv); x = uniform_p(x);
+  RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gk = w.lgk;
@@ -614,9 +646,9 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
     for (int k = a + 1; k < FB_MAXTRUNK; k++) if (k < nT) xt[a] -= RM[k*(k + 1)/2 + (k - a)]*xt[k];
   // ---- x <- D^-1 x
 #pragma unroll
-  for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT) xt[a] *= Dinv[a];
+  for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT) xt[a] *= RM[a*(a + 1)/2];         // 1/D sits in the diagonal slot of the row
 #pragma unroll
-  for (int q = 0; q < 2; q++) if (dep[q] != 31) a_[q] *= Dinv[jd[q]];
+  for (int q = 0; q < 2; q++) if (dep[q] != 31) a_[q] *= RM[rowt[q] - dep[q]];
   PROF(20);
   // ---- x <- L^-1 x: trunk (uniform), trunk -> every other dof, then level by level
 #pragma unroll

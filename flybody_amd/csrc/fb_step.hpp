@@ -195,7 +195,6 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
 template <typename real>
 __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qLDinv()[i] = w.lDinv[i];
   int nefc = w.istate()[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.AR()[i] = w.lAR[i];
   SYNC();
@@ -203,7 +202,6 @@ __device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<re
 template <typename real>
 __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
   for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD()[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.lDinv[i] = w.qLDinv()[i];
   int nefc = w.istate()[IS_NEFC];
   if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lAR[i] = w.AR()[i];
   SYNC();
@@ -664,10 +662,13 @@ template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const 
 template <typename real>
 __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
                       float* obs, float* reward, float* discount, int* step_type, int lane) {
-  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && w.istate()[IS_RESET_NEXT] != 0);
+  // every selector of the stage machine is wave-uniform: say so (v_readfirstlane), otherwise the interpreter's state lives in
+  // VGPRs + saved exec masks across every stage call and counts against the register budget of all stages
+  mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg);
+  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
   bool actuate = true, damp = false;
-  int nsub = (mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep, sub = 0;
+  int nsub = uniform_int((mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep), sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   const WS<real> wc = w;                  // the stages are separate functions: they read this copy, `w` itself stays in registers
   if (resetting) {
@@ -706,7 +707,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         ret = ST_ACC_POST; pc = ST_SOLVE; break; }
       case ST_SOLVE: {
         PROF_BEGIN();
-        d_solve(M, wc, w.lLD, w.lDinv, w.lx, lane);
+        d_solve(M, wc, w.lLD, w.lx, lane);
         PROF(P_ACC);
         pc = ret; break; }
       case ST_ACC_POST: {
@@ -716,7 +717,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         PROF(24);
         pc = ST_CONSTR_A; break; }
       case ST_CONSTR_A: {
-        bool need = s_constraint_a(M, wc, lane);
+        bool need = uniform_int(s_constraint_a(M, wc, lane) ? 1 : 0) != 0;
         ret = ST_CONSTR_B; pc = need ? ST_SOLVE : ST_CONSTR_B; break; }
       case ST_CONSTR_B: {
         PROF_BEGIN();
@@ -737,7 +738,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
-        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lDinv, lane);
+        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, lane);
         PROF(P_FACTOR);
         pc = fret; break; }
       case ST_EULER_SOLVE:

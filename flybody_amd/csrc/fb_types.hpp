@@ -14,7 +14,9 @@
 #define FB_EPB 4            // environments (wavefronts) per workgroup of the FP32 build (LdsCfg<real>::EPB); they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)
 #define FB_MAXGEN 16       // dofs whose subtree branches (free joint, head, ...)
-#define FB_LDS_SCRATCH 1328  // reals in the per-environment LDS row of the factor (also staging space for the tree passes)
+#define FB_LDS_SCRATCH 1216  // reals in the per-environment LDS row of the factor (fruit fly: 1213 + the dummy slot of the branch-free
+                            // publish); the same row stages the body frames / joint rotations of the kinematics pass (7 nbody + 4 njnt)
+#define FB_LGEN 6           // branching dofs whose per-level descendant lists are staged in LDS (fruit fly: 6; checked at model load)
 #define FB_BODYREC 40       // reals per body kinematics record
 #define FB_MAXTRUNK 6       // dofs of the unbranched chain at the tree root (free joint) handled wave-parallel
 #define FB_FSLOT 18        // factor work list: off-diagonal entries of M owned by one lane
@@ -70,15 +72,15 @@ template <typename T> struct GP {
   X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) X(xmat, 9*M.nbody) X(xipos, 3*M.nbody) X(ximat, 9*M.nbody) \
   X(xanchor, 3*M.njnt) X(xaxis, 3*M.njnt) X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
   X(cinert, 10*M.nbody) X(crb, 10*M.nbody) X(cdof, 6*M.nv) X(cdof_dot, 6*M.nv) X(cvel, 6*M.nbody) \
-  X(qM, M.nM) X(qLD, M.nM) X(qLDinv, M.nv) X(qH, M.nM) X(qHinv, M.nv) \
+  X(qM, M.nM) X(qLD, M.nM) \
   X(qfrc_bias, M.nv) X(qfrc_passive, M.nv) X(qfrc_actuator, M.nv) X(qfrc_smooth, M.nv) X(qacc_smooth, M.nv) \
-  X(qfrc_constraint, M.nv) X(tmpv, M.nv) X(tmpv2, M.nv) X(ten_length, M.ntendon + 1) X(act_force, M.nu) \
+  X(qfrc_constraint, M.nv) X(ten_length, M.ntendon + 1) X(act_force, M.nu) \
   X(con_dist, FB_MAXCON_) X(con_pos, 3*FB_MAXCON_) X(con_frame, 9*FB_MAXCON_) \
   X(efc_J, 2*FB_MAXCH*FB_MAXEFC_) X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) \
   X(efc_pos, FB_MAXEFC_) X(efc_margin, FB_MAXEFC_) X(efc_R, FB_MAXEFC_) X(efc_D, FB_MAXEFC_) X(efc_K, FB_MAXEFC_) \
   X(efc_B, FB_MAXEFC_) X(efc_imp, FB_MAXEFC_) X(efc_aref, FB_MAXEFC_) X(efc_b, FB_MAXEFC_) X(efc_force, FB_MAXEFC_) \
   X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) \
-  X(AR, FB_MAXEFC_*FB_MAXEFC_) \
+  X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2) /* packed lower triangle, only written for systems that do not fit the LDS copy */ \
   X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody)
 
 #define FB_WS_INT(X) \
@@ -164,21 +166,39 @@ struct DevModel {
 #define FB_LDS __attribute__((address_space(3)))
 #endif
 
-// LDS copy of the (packed symmetric) Delassus matrix: AR_ROWS*(AR_ROWS+1)/2 <= AR_ELEMS
-// Workgroup shape.  LDS is what limits residency: 160 KB per CU hold 16 FP32 environments (4 workgroups of 4) but only
-// 8 FP64 ones.  The FP64 build therefore runs ONE environment per workgroup, sized to exactly 1/8 of the LDS: a wave
-// slot is then recycled as soon as its own environment finishes instead of when the slowest of four does, which matters
-// because a 4096-batch is two rounds of 2048 resident FP64 environments (with 4 per workgroup the step was ~9 % longer).
+// LDS budget of one environment (one contiguous pool: [factor row | Delassus matrix | solve vector]) and workgroup shape.
+// LDS is what limits residency: 160 KB per CU, allocated in granules (the budgets below leave room for 1280-byte granules).
+//   * the factor row holds the sparse L^T D L factor (1/D on the diagonal slots -- there is no separate D^-1 array);
+//   * the Delassus matrix is a packed lower triangle of AR_ROWS rows (r(r+1)/2 <= AR_ELEMS).  A larger system (up to
+//     WIDE_ROWS rows: its triangle fits the factor row + the matrix slot together) is solved from LDS as well: the factor is
+//     parked in the environment's global row for the duration of the solver sweeps and reloaded afterwards
+//     (d_constraint_a).  Only beyond WIDE_ROWS does the solver read global memory.
+// FP32: 4 environments per workgroup (they share the elimination-tree tables), 4 workgroups = 16 environments per CU = 4 waves
+// per SIMD (the register budget, 128 VGPRs).
+// FP64, default (FB_F64_DENSE 0): ONE environment per workgroup, 8 per CU = 2 waves per SIMD, sized to exactly 1/8 of the LDS.
+// A BASELINE batch of 4096 environments is then two full rounds of 2048 resident environments, and a single-environment
+// workgroup recycles its slot the moment its environment finishes (k_order starts the slow ones first).
+// FP64, FB_F64_DENSE 1: 4 environments per workgroup, 3 workgroups = 12 per CU = 3 waves per SIMD (168 VGPRs).  Measured on
+// MI355X (profiles/r2/f64_residency.txt): +8 % throughput for batches that are multiples of 3072 (6144: 248 k vs 229 k
+// env-steps/s), but a 4096-batch is then 1.33 rounds and takes 22.0 ms against 19.6 ms -- hence not the default.
+#ifndef FB_F64_DENSE
+#define FB_F64_DENSE 0
+#endif
 template <typename real> struct LdsCfg {
-  static constexpr int EPB = sizeof(real) == 8 ? 1 : FB_EPB;
-  static constexpr int AR_ROWS = sizeof(real) == 8 ? 29 : 36;
+  static constexpr bool F64 = sizeof(real) == 8;
+  static constexpr int EPB = F64 ? (FB_F64_DENSE ? 4 : 1) : FB_EPB;
+  static constexpr int AR_ROWS = F64 ? (FB_F64_DENSE ? 23 : 43) : 46;
   static constexpr int AR_ELEMS = AR_ROWS*(AR_ROWS + 1)/2;
+  static constexpr int POOL = FB_LDS_SCRATCH + AR_ELEMS + FB_MAXNV;
+  static constexpr int WAVES_PER_SIMD = F64 ? (FB_F64_DENSE ? 3 : 2) : 4;      // register budget of every stage function
+  static constexpr int wide_rows() { int r = AR_ROWS; while ((r + 1)*(r + 2)/2 <= FB_LDS_SCRATCH + AR_ELEMS && r + 1 <= FB_WAVE) r++; return r; }
+  static constexpr int WIDE_ROWS = wide_rows();
 };
 
 template <typename real>
 struct WS {
   // LDS-resident hot arrays (per workgroup == per environment)
-  FB_LDS real *lLD, *lDinv, *lx, *lAR;     // lLD: row-major factor, 1/D on the diagonal (see fb_smooth.hpp)
+  FB_LDS real *lLD, *lx, *lAR;     // lLD: row-major factor, 1/D on the diagonal (see fb_smooth.hpp); the three are one contiguous pool [lLD | lAR | lx]
   // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
   const FB_LDS uint8_t *ldepth, *lcl, *lgen; const FB_LDS uint16_t *lmadr; const FB_LDS uint32_t *lgk, *lgm; int nlevel;
   // global arrays of this environment: base of its arena row + the model's offset table.  The base is wave-uniform

@@ -32,14 +32,14 @@ def _kernel(usage, tag):
 def test_fp32_kernel_residency(usage):
     k = _kernel(usage, 'k_flyIf')
     assert k['VGPRs'] <= 128 and k['Occupancy'] == 4                     # 4 waves per SIMD = 16 environments per CU
-    assert 4 * k['LDS Size'] <= LDS_PER_CU                               # 4 workgroups of 4 environments
+    assert 4 * (-(-k['LDS Size'] // 1280) * 1280) <= LDS_PER_CU          # 4 workgroups of 4 environments
     assert k['ScratchSize'] <= 1024                                      # register spills only: no pointer tables in scratch
 
 
 def test_fp64_kernel_residency(usage):
     k = _kernel(usage, 'k_flyId')
     assert k['VGPRs'] <= 256 and k['Occupancy'] == 2                     # 2 waves per SIMD = 8 environments per CU
-    assert 8 * k['LDS Size'] <= LDS_PER_CU                               # 8 single-environment workgroups
+    assert 8 * (-(-k['LDS Size'] // 1280) * 1280) <= LDS_PER_CU          # 8 single-environment workgroups, LDS allocated in granules (<= 1280 B)
     assert k['ScratchSize'] <= 1536
 
 
