@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
   if (lane == 0) w.istate()[IS_PRIO] = 0;
   d_run(M, w, env, mode, nsub, nslot, B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
-  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; }
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; pp_[28] = r0_; /* start tick (replaces the env_post phase counter) */ }
 #endif
   // how long this environment's control step took: the next launch starts the slow environments first (k_order)
   if (mode == MODE_STEP && B.cost && lane == 0) {

@@ -168,6 +168,7 @@ void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, cons
                       double base_freq, double rel_range, double rate, unsigned seed);
 double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode);
 void fbo_env_step(fbo_data* d, const double* action);
+void fbo_env_rollout_batch(fbo_data** ds, int n, const double* actions, int nsteps, int nthreads);
 void fbo_env_step_batch(fbo_data** ds, int n, const double* actions, int nthreads);
 
 /* introspection for tests */

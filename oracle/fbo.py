@@ -49,6 +49,7 @@ def lib():
         L.fbo_env_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint]
         L.fbo_hash_uniform.argtypes = [C.c_uint, C.c_uint, C.c_uint]; L.fbo_hash_uniform.restype = C.c_double
         L.fbo_env_step_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.fbo_env_rollout_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
     return _LIB
 
 
@@ -165,3 +166,12 @@ def step_batch(datas, actions, nthreads=0):
     arr = (C.c_void_p * len(datas))(*[d.h for d in datas])
     a = np.ascontiguousarray(actions, float)
     lib().fbo_env_step_batch(arr, len(datas), a.ctypes.data, nthreads)
+
+
+def rollout_batch(datas, actions, nthreads=0):
+    """actions[n_env][n_steps][nu]: every environment runs its own n_steps control steps, no barrier between steps."""
+    arr = (C.c_void_p * len(datas))(*[d.h for d in datas])
+    a = np.ascontiguousarray(actions, float)
+    assert a.ndim == 3 and a.shape[0] == len(datas)
+    lib().fbo_env_rollout_batch(arr, len(datas), a.ctypes.data, a.shape[1], nthreads)
+

@@ -485,3 +485,19 @@ void fbo_env_step_batch(fbo_data** ds, int n, const double* actions, int nthread
 #endif
   for (int e = 0; e < n; e++) fbo_env_step(ds[e], actions + (size_t)e*ds[e]->m->nu);
 }
+
+/* Throughput driver of the CPU baseline: every environment runs `nsteps` control steps with its own action sequence
+ * actions[e][step][nu]; environments are distributed over the threads dynamically and a thread runs all steps of the
+ * environment it picked before taking the next one -- no barrier per control step, so the spread of the per-step cost
+ * (solver sweeps) does not idle any core (fbo_env_step_batch synchronises after every step: ~1/3 efficiency at 32 threads). */
+void fbo_env_rollout_batch(fbo_data** ds, int n, const double* actions, int nsteps, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int e = 0; e < n; e++) {
+    const int nu = ds[e]->m->nu;
+    for (int k = 0; k < nsteps; k++) fbo_env_step(ds[e], actions + ((size_t)e*nsteps + k)*nu);
+  }
+}
+
