@@ -57,6 +57,7 @@ struct fb_model {
     if (cnt) *cnt = it->second->nbytes/4;
     return (const int*)(blob.data() + it->second->offset);
   }
+  bool has(const char* n, int dtype) const { auto it = idx.find(n); return it != idx.end() && (int)it->second->dtype == dtype; }
   void need(const char* n, int dtype, size_t min_count) const {
     auto it = idx.find(n);
     if (it == idx.end()) throw std::runtime_error(std::string("model blob: missing array '") + n + "'");
@@ -571,6 +572,9 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   UI(wing_act_idx, "wing_action_idx")
+  // leg joints (optional array: models compiled before the flight-with-legs variant do not carry it)
+  if (m->has("leg_joints", 1)) { UI(leg_jnt, "leg_joints") M.nlegjnt = (int)c; for (size_t k = 0; k < c; k++) if (m->i("leg_joints")[k] < 0 || m->i("leg_joints")[k] >= m->njnt) return fail("fb_batch_create: leg_joints out of range"); }
+  else { UV(leg_jnt, adh_act) M.nlegjnt = 0; }
   M.task = m->i("task_id")[0]; M.user_idx = m->i("user_action_idx")[0]; M.nact = m->nu + (M.user_idx >= 0 ? 1 : 0);
   for (int k = 0; k < 3; k++) M.com_offset[k] = (real)m->d("com_offset")[k];
   M.nlevel = m->nlevel;
@@ -790,6 +794,39 @@ extern "C" int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds)
     M.terminal_com_dist = (real)ds->terminal_com_dist; M.time_limit = (real)ds->time_limit; }
   if (b->precision == 64) SETDS(b->M64, double) else SETDS(b->M32, float)
 #undef SETDS
+  b->have_ref = true;
+  return 0;
+}
+
+extern "C" int fb_batch_set_flight_dataset(fb_batch* b, const fb_flight_dataset* ds) {
+  if (!b || !ds || !ds->traj_offset || !ds->qpos || !ds->qvel || !ds->select) return fail("fb_batch_set_flight_dataset: null argument");
+  if (ds->n_traj <= 0 || ds->n_select <= 0 || ds->future_steps < 0) return fail("fb_batch_set_flight_dataset: bad sizes");
+  const fb_model* m = b->m;
+  if (m->i("task_id")[0] != 1) return fail("fb_batch_set_flight_dataset: not a flight_imitation model");
+  for (int k = 0; k < ds->n_select; k++) {
+    int t = ds->select[k];
+    if (t < 0 || t >= ds->n_traj) return fail("fb_batch_set_flight_dataset: selected trajectory out of range");
+    int len = ds->traj_offset[t + 1] - ds->traj_offset[t];
+    // the shortest slice a random start can leave is 51 rows (start < len - 50); it must still hold future_steps + 2 rows
+    if (len < 52 || (ds->randomize_start_step ? 51 : len) - ds->future_steps - 1 < 1) return fail("fb_batch_set_flight_dataset: trajectory too short (needs > 51 rows and future_steps + 2 rows after any start)");
+  }
+  HIPCHK(hipSetDevice(b->device));
+  size_t rows = (size_t)ds->traj_offset[ds->n_traj];
+  int future_steps = ds->future_steps;
+  int nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
+  (void)hipFree(b->obs); b->obs = nullptr;
+  HIPCHK(hipMalloc((void**)&b->obs, (size_t)b->n_env*nobs*sizeof(float)));
+  HIPCHK(hipMemset(b->obs, 0, (size_t)b->n_env*nobs*sizeof(float)));
+  b->nobs = nobs;
+#define SETFD(M, real) { const real *q_, *v_; const int *o_, *se_; \
+    if (upload<real>(b, ds->qpos, rows*7, &q_) || upload<real>(b, ds->qvel, rows*6, &v_) || \
+        upload_i(b, ds->traj_offset, (size_t)ds->n_traj + 1, &o_) || upload_i(b, ds->select, ds->n_select, &se_)) return -1; \
+    M.ds_qpos = q_; M.ds_qvel = v_; M.ds_offset = o_; M.ds_select = se_; M.ds_nj = 0; M.ds_ns = 0; M.ds_ntraj = ds->n_traj; \
+    M.ds_nselect = ds->n_select; M.ds_env_base = ds->env_id_base; M.ds_random_start = ds->randomize_start_step ? 1 : 0; \
+    M.seed = ds->seed; M.future_steps = future_steps; M.nobs = nobs; M.T = 0; M.episode_steps = 0; \
+    M.terminal_com_dist = (real)ds->terminal_com_dist; M.time_limit = (real)ds->time_limit; }
+  if (b->precision == 64) SETFD(b->M64, double) else SETFD(b->M32, float)
+#undef SETFD
   b->have_ref = true;
   return 0;
 }

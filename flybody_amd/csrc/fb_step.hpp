@@ -210,14 +210,21 @@ __device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<rea
 // ------------------------------------------------------------------ reference trajectory of an environment
 // inference mode: one root track shared by all environments (fb_batch_set_reference); training mode: the snippet the
 // environment picked from the dataset at episode start, shifted to start at x = y = 0 (trajectory_loaders.py:249)
-template <typename real> struct RefView { const real* q; int stride, T, episode_steps; real sx, sy; };
+template <typename real> struct RefView { const real *q, *v; int stride, vstride, T, episode_steps; real sx, sy; };
 template <typename real> FBD RefView<real> ref_view(const DevModel<real>& M, const WS<real>& w) {
   RefView<real> r;
   if (M.ds_qpos) {
-    r.stride = 7 + M.ds_nj; r.q = M.ds_qpos + (size_t)w.istate()[IS_DS_OFF]*r.stride; r.T = w.istate()[IS_DS_LEN];
+    r.stride = 7 + M.ds_nj; r.vstride = 6 + M.ds_nj;
+    r.q = M.ds_qpos + (size_t)w.istate()[IS_DS_OFF]*r.stride; r.v = M.ds_qvel + (size_t)w.istate()[IS_DS_OFF]*r.vstride;
+    r.T = w.istate()[IS_DS_LEN];
     r.episode_steps = w.istate()[IS_EPSTEPS]; r.sx = w.dsshift()[0]; r.sy = w.dsshift()[1];
-  } else { r.q = M.ref_qpos; r.stride = 7; r.T = M.T; r.episode_steps = M.episode_steps; r.sx = 0; r.sy = 0; }
+  } else { r.q = M.ref_qpos; r.v = M.ref_qvel; r.stride = 7; r.vstride = 6; r.T = M.T; r.episode_steps = M.episode_steps; r.sx = 0; r.sy = 0; }
   return r;
+}
+template <typename real> FBD void ref_vel(const RefView<real>& r, int idx, real* out6) {
+  if (idx >= r.T) idx = r.T - 1;
+  const real* p = r.v + (size_t)idx*r.vstride;
+  for (int c = 0; c < 6; c++) out6[c] = p[c];
 }
 template <typename real> FBD void ref_root(const RefView<real>& r, int idx, real* out7) {
   if (idx >= r.T) idx = r.T - 1;
@@ -491,12 +498,42 @@ __device__ __forceinline__ void d_walk_init(const DevModel<real>& M, const WS<re
 // wings from the WBPG at a per-episode phase
 template <typename real>
 __device__ __forceinline__ void d_flight_init(const DevModel<real>& M, const WS<real>& w, int env, int lane) {
-  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = (i < 7) ? M.ref_qpos[i] : M.qpos0[i];
-  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel()[i] = (i < 3) ? M.ref_qvel[i] : (real)0; w.qacc()[i] = 0; w.qacc_ws()[i] = 0; }
-  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl()[i] = 0;
   int episode = w.istate()[IS_EPISODE];
+  if (M.ds_qpos) {
+    // HDF5FlightTrajectoryLoader.get_trajectory (trajectory_loaders.py:110-141): a trajectory out of traj_indices and, with
+    // randomize_start_step, a start step in [0, len - 50); the reference draws both from a RandomState, here they are pure
+    // functions of (seed, global environment id, episode).  x / y are re-centred on the first row of the slice.
+    double u = (double)hash_uniform(M.seed, (unsigned)(M.ds_env_base + env), (unsigned)episode);
+    int k = (int)(u*M.ds_nselect); if (k >= M.ds_nselect) k = M.ds_nselect - 1;
+    int traj = M.ds_select[k];
+    int off = M.ds_offset[traj], len = M.ds_offset[traj + 1] - off, start = 0;
+    if (M.ds_random_start) {
+      double u2 = (double)hash_uniform(M.seed ^ 0x5bd1e995u, (unsigned)(M.ds_env_base + env), (unsigned)episode);
+      start = (int)(u2*(len - 50)); if (start > len - 51) start = len - 51; if (start < 0) start = 0;
+    }
+    int T = len - start, lim = (int)floor(M.time_limit / M.control_timestep + (real)0.5);
+    const real* q0 = M.ds_qpos + (size_t)(off + start)*7;
+    if (lane == 0) {
+      w.istate()[IS_DS_OFF] = off + start; w.istate()[IS_DS_LEN] = T;
+      w.istate()[IS_EPSTEPS] = (T < lim ? T : lim) - (M.future_steps + 1);            // flight_imitation.py:101-105
+      // the loader re-centres the CoM track (x, y of the first row -> 0) BEFORE the task converts it to the root joint:
+      // the shift is the CoM position of the first row = root + R(quat) com_offset (task_utils.root2com)
+      real qn[4] = {q0[3], q0[4], q0[5], q0[6]}, co[3];
+      normquat(qn); rotvecquat(co, M.com_offset, qn);
+      w.dsshift()[0] = q0[0] + co[0]; w.dsshift()[1] = q0[1] + co[1];
+    }
+    SYNC();
+  }
+  const RefView<real> rv = ref_view(M, w);
+  real r0[7], v0[6]; ref_root(rv, 0, r0); ref_vel(rv, 0, v0);
+  for (int i = lane; i < M.nq; i += FB_WAVE) w.qpos()[i] = (i < 7) ? r0[i] : M.qpos0[i];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { w.qvel()[i] = (i < 3) ? v0[i] : (real)0; w.qacc()[i] = 0; w.qacc_ws()[i] = 0; }
+  for (int i = lane; i < M.nu; i += FB_WAVE) w.ctrl()[i] = 0;
+  for (int i = lane; i < M.na; i += FB_WAVE) { w.act()[i] = 0; w.act_dot()[i] = 0; }
   SYNC();
-  real phase0 = (real)hash_uniform(M.seed, (unsigned)env, (unsigned)episode);
+  // enabled legs start retracted (flight_imitation.py:142-144)
+  for (int k = lane; k < M.nlegjnt; k += FB_WAVE) { int qa = M.jnt_qposadr[M.leg_jnt[k]]; w.qpos()[qa] = M.qpos_spring[qa]; }
+  real phase0 = (real)hash_uniform(M.seed, (unsigned)(M.ds_env_base + env), (unsigned)episode + 0x40000000u*(M.ds_qpos ? 1u : 0u));
   int fidx = wave_argmin_absdiff((const real*)M.wb_freqs, M.wb_nfreq, M.wb_base_freq, false, lane);
   int o = M.wb_offset[fidx], n = M.wb_offset[fidx + 1] - o;
   int st = wave_argmin_absdiff(M.wb_phase + o, n, phase0, false, lane);
@@ -557,9 +594,10 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
   // ghost pose: set from ref[prev] before the physics and advanced by its velocity over the control step
   // (its ~1e-8 cm gravity sag is neglected)
   real gp[3], gq[4], qr[4], tmpq[4];
-  const real* rv = M.ref_qvel + 6*prev;
-  for (int k = 0; k < 3; k++) gp[k] = M.ref_qpos[7*prev + k] + M.control_timestep*rv[k];
-  for (int k = 0; k < 4; k++) gq[k] = M.ref_qpos[7*prev + 3 + k];
+  const RefView<real> rview = ref_view(M, w);
+  real rp[7], rv[6]; ref_root(rview, prev, rp); ref_vel(rview, prev, rv);
+  for (int k = 0; k < 3; k++) gp[k] = rp[k] + M.control_timestep*rv[k];
+  for (int k = 0; k < 4; k++) gq[k] = rp[3 + k];
   {
     real ax[3] = {rv[3], rv[4], rv[5]};
     real nn = normalize3(ax);
@@ -570,24 +608,27 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
   rotvecquat(off, M.com_offset, tmpq);
   for (int k = 0; k < 3; k++) dif[k] = gp[k] + off[k] - w.com()[k];
   real r_disp = tolerance_linear((real)norm3(dif), (real)0.4);
-  int idx = stepc < M.T ? stepc : M.T - 1;
+  real rnext[7]; ref_root(rview, stepc, rnext);              // (clamped to the last row of the snippet)
   const real* q = w.qpos() + 3;
   real n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
   real qi[4] = {q[0]/n2, -q[1]/n2, -q[2]/n2, -q[3]/n2}, dq[4];
-  mulquat(dq, qi, M.ref_qpos + 7*idx + 3);
+  mulquat(dq, qi, rnext + 3);
   real nq = sqrt(dq[0]*dq[0] + dq[1]*dq[1] + dq[2]*dq[2] + dq[3]*dq[3]);
   real x = 2*(dq[0]/nq)*(dq[0]/nq) - 1; if (x > 1) x = 1;
   real r_quat = tolerance_linear((real)acos(x), (real)3.14159265358979323846);
   int thorax = M.site_bodyid[M.site_thorax];
   real height = w.xpos()[3*thorax + 2];
-  real cd[3]; sub3(cd, M.ref_qpos + 7*idx, w.qpos());
+  real cd[3]; sub3(cd, rnext, w.qpos());
   int tstep = (int)floor(w.simtime()[0] / M.control_timestep + (real)0.5);
-  bool traj_end = (tstep == M.episode_steps);
+  bool traj_end = (tstep == rview.episode_steps);
+  // enabled legs: reward for keeping them retracted (flight_imitation.py:196-203; 1 when the legs are disabled)
+  real r_legs = 1;
+  for (int k = 0; k < M.nlegjnt; k++) { int qa = M.jnt_qposadr[M.leg_jnt[k]]; r_legs *= tolerance_linear(w.qpos()[qa] - M.qpos_spring[qa], (real)4); }
   bool term = (height < (real)0.2) || (norm3(cd) > M.terminal_com_dist) || traj_end || (sqrt(qn) > (real)1e14) || (qn != qn);
   bool terminating = term || (w.simtime()[0] >= M.time_limit);
   d_pack_obs(M, w, w.sens_acc(), obs, lane);
   if (lane == 0) {
-    *reward = (float)(r_disp*r_quat);
+    *reward = (float)(r_disp*r_quat*r_legs);
     *discount = (term && !traj_end) ? 0.0f : 1.0f;
     *step_type = terminating ? 2 : 1;
     w.istate()[IS_STEP_TYPE] = terminating ? 2 : 1;

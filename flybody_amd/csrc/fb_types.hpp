@@ -155,6 +155,8 @@ struct DevModel {
   GP<const real> ds_qpos, ds_qvel, ds_r2s, ds_jq;
   GP<const int> ds_offset, ds_jid, ds_sid, ds_select;
   int ds_nj, ds_ns, ds_ntraj, ds_nselect, ds_env_base, max_episode_steps;
+  int ds_random_start;       // flight dataset: random start step inside the chosen trajectory (trajectory_loaders.py:132-134)
+  GP<const int> leg_jnt; int nlegjnt;     // flight with enabled legs: leg joints are reset to / rewarded at their spring reference
   WSOff off;                 // layout of one environment's workspace row (fb_engine.hip: compute_offsets)
 };
 

@@ -60,6 +60,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_set_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
     L.fb_batch_set_wbpg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32]
     L.fb_batch_set_walk_dataset.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_set_flight_dataset.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_set_time_limit.argtypes = [C.c_void_p, C.c_double]
     L.fb_batch_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -159,6 +160,24 @@ class Batch:
         d = _DS(ds.n_traj, len(keep[5]), len(keep[6]), len(sel), *(a.ctypes.data for a in keep), int(future_steps), float(terminal_com_dist),
                 float(time_limit), int(seed), int(env_id_base))
         _check(self.L, self.L.fb_batch_set_walk_dataset(self.h, C.byref(d)))
+        m = self.model
+        self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
+                     7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)
+
+    def set_flight_dataset(self, offsets, root_qpos, qvel, select=None, future_steps=5, terminal_com_dist=2.0, time_limit=0.6,
+                           randomize_start_step=True, seed: int = 0, env_id_base: int = 0):
+        """flight_imitation on a reference dataset (fb_batch_set_flight_dataset); root_qpos = FlightDataset.root_qpos(com_offset)."""
+        class _FD(C.Structure):
+            _fields_ = [('n_traj', C.c_int32), ('n_select', C.c_int32), ('traj_offset', C.c_void_p), ('qpos', C.c_void_p),
+                        ('qvel', C.c_void_p), ('select', C.c_void_p), ('future_steps', C.c_int32), ('randomize_start_step', C.c_int32),
+                        ('terminal_com_dist', C.c_double), ('time_limit', C.c_double), ('seed', C.c_uint32), ('env_id_base', C.c_int32)]
+        n_traj = len(offsets) - 1
+        sel = np.arange(n_traj, dtype=np.int32) if select is None else np.ascontiguousarray(select, np.int32)
+        keep = [np.ascontiguousarray(offsets, np.int32), np.ascontiguousarray(root_qpos, np.float64), np.ascontiguousarray(qvel, np.float64), sel]
+        assert keep[1].shape == (keep[0][-1], 7) and keep[2].shape == (keep[0][-1], 6)
+        d = _FD(n_traj, len(sel), keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, sel.ctypes.data, int(future_steps),
+                int(bool(randomize_start_step)), float(terminal_com_dist), float(time_limit), int(seed), int(env_id_base))
+        _check(self.L, self.L.fb_batch_set_flight_dataset(self.h, C.byref(d)))
         m = self.model
         self.nobs = (3 + m.dim('na') + 3*m.dim('napp') + 3*m.dim('nforce') + 3 + 2*m.dim('nobsjnt') +
                      7*(future_steps + 1) + m.dim('ntouch') + 3 + 3)

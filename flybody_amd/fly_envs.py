@@ -103,25 +103,43 @@ class BatchedFlyEnv:
 
     def __init__(self, n_env: int = 1, device: int = 0, precision: int = 64, terminal_com_dist: float = 0.3,
                  joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation',
-                 wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0):
-        arrays = engine.load_npz(engine.os.path.join(engine.ASSETS, task + '.npz'))
+                 wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0, force_actuators: bool = False,
+                 use_wings: Optional[bool] = None, use_legs: Optional[bool] = None, dyntype_filterexact: bool = False,
+                 use_mouth: bool = False, use_antennae: bool = False, adhesion_filter: Optional[float] = None):
+        from . import model_zoo
         self.task_name = task
+        # FruitFly._build's configuration space (fruitfly.py:123-386): the compiled tables come from the shipped assets, the
+        # variant cache, or a fresh compile of the reference XML (model_zoo.get_model)
         compiled_filter = 0.0 if task == 'flight_imitation' else 0.01
-        if (joint_filter > 0) != (compiled_filter > 0):
-            raise NotImplementedError('switching the joint filter on/off changes the activation layout: recompile the model '
-                                      'with tools/compile_models.py (needs the reference fruitfly.xml)')
-        if joint_filter > 0 and joint_filter != compiled_filter:
+        same_layout = (joint_filter > 0) == (compiled_filter > 0)
+        cfg = model_zoo.task_config(task, force_actuators=force_actuators, use_wings=use_wings, use_legs=use_legs,
+                                    joint_filter=None if same_layout else joint_filter, adhesion_filter=adhesion_filter,
+                                    dyntype_filterexact=dyntype_filterexact, use_mouth=use_mouth, use_antennae=use_antennae)
+        arrays = model_zoo.get_model(cfg)
+        if same_layout and joint_filter > 0 and joint_filter != compiled_filter:
+            # a different filter TIME CONSTANT keeps the activation layout: patch the table instead of recompiling
             arrays = dict(arrays)
             dyn = arrays['actuator_dynprm'].copy()
             dyn[arrays['actuator_trntype'] != 5] = joint_filter       # fruitfly.py:330-335
             arrays['actuator_dynprm'] = dyn
+        self.config = cfg
         self.model = engine.Model(arrays)
         self.n_env = n_env; self.device = device
         self.batch = engine.Batch(self.model, n_env, device=device, precision=precision)
         self.future_steps = future_steps; self.terminal_com_dist = terminal_com_dist; self.time_limit = time_limit
         self.task = _Task(self); self.physics = _Physics(self)
         self._time = 0.0
-        if task == 'flight_imitation':
+        if task == 'flight_imitation' and traj_loader is not None:
+            # reference dataset (fly_envs.py:71-76): every trajectory lives on the GPU, each environment picks its slice there
+            from .wbpg import build_tables
+            self.batch.set_wbpg(wbpg_tables or build_tables(), seed=seed)
+            ds = traj_loader.dataset
+            self.task._traj_generator = traj_loader
+            self.batch.set_flight_dataset(ds.offsets, ds.root_qpos(arrays['com_offset']), ds.com_qvel, select=traj_loader.traj_indices,
+                                          future_steps=future_steps, terminal_com_dist=terminal_com_dist, time_limit=time_limit,
+                                          randomize_start_step=traj_loader.randomize_start_step, seed=seed, env_id_base=env_id_base)
+            qp = qv = None
+        elif task == 'flight_imitation':
             from .wbpg import build_tables
             self.batch.set_wbpg(wbpg_tables or build_tables(), seed=seed)
             # InferenceFlightTrajectoryLoader default (trajectory_loaders.py:161-163): 200 steps, 20 cm/s, z = 1, pitch -47.5 deg
@@ -258,11 +276,9 @@ def walk_imitation(ref_path: Optional[str] = None, force_actuators: bool = False
             traj_loader = ArrayWalkingTrajectoryLoader(str(ref_path), traj_indices=traj_indices, random_state=random_state)
         else:
             traj_loader = HDF5WalkingTrajectoryLoader(str(ref_path), traj_indices=traj_indices, random_state=random_state)
-    if force_actuators or not disable_wings:
-        raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
                          joint_filter=joint_filter, future_steps=64, time_limit=10.0, seed=seed, traj_loader=traj_loader,
-                         env_id_base=env_id_base)
+                         env_id_base=env_id_base, force_actuators=force_actuators, use_wings=not disable_wings)
 
 
 def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, random_state=None, n_env: int = 1, device: int = 0,
@@ -270,25 +286,35 @@ def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, rand
     """Tethered fly walking on a floating ball: same keyword surface as flybody/fly_envs.py:158-191, plus n_env / device /
     precision.  Observation = the walker observables + `ball_qvel`; reward = product of linear tolerances on the ball's
     angular velocity around the target (0, -5, 0) rad/s (tasks/walk_on_ball.py:62-73); 2 s episodes."""
-    if force_actuators or not disable_wings:
-        raise NotImplementedError('force_actuators / enabled wings need a recompiled model (tools/compile_models.py)')
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=float('inf'), joint_filter=0.01,
-                         future_steps=0, time_limit=2.0, task='walk_on_ball')
+                         future_steps=0, time_limit=2.0, task='walk_on_ball', force_actuators=force_actuators,
+                         use_wings=not disable_wings)
 
 
 def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,
                      disable_legs: bool = True, traj_indices: Optional[Sequence[int]] = None, randomize_start_step: bool = True,
                      joint_filter: float = 0.0, future_steps: int = 5, random_state=None, terminal_com_dist: float = 2.0,
-                     n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0) -> BatchedFlyEnv:
-    """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed."""
+                     n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0, env_id_base: int = 0) -> BatchedFlyEnv:
+    """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed / env_id_base.
+
+    ref_path: the reference's hdf5 flight dataset (needs h5py), its .npz conversion (trajectory_loaders.FlightDataset.save) or an
+    already constructed loader; None = InferenceFlightTrajectoryLoader (the synthetic straight flight)."""
+    traj_loader = None
     if ref_path is not None:
-        raise NotImplementedError('HDF5 flight datasets are a "next" row (SURVEY.md 8f); inference mode is implemented')
-    if force_actuators or not disable_legs:
-        raise NotImplementedError('force_actuators / enabled legs need a recompiled model (tools/compile_models.py)')
+        from .trajectory_loaders import ArrayFlightTrajectoryLoader, HDF5FlightTrajectoryLoader
+        if hasattr(ref_path, 'dataset'):
+            traj_loader = ref_path
+        elif str(ref_path).endswith('.npz'):
+            traj_loader = ArrayFlightTrajectoryLoader(str(ref_path), traj_indices=traj_indices, randomize_start_step=randomize_start_step,
+                                                      random_state=random_state)
+        else:
+            traj_loader = HDF5FlightTrajectoryLoader(str(ref_path), traj_indices=traj_indices, randomize_start_step=randomize_start_step,
+                                                     random_state=random_state)
     tables = None
     if wpg_pattern_path is not None:
         from .wbpg import build_tables
         tables = build_tables(np.load(wpg_pattern_path))
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
                          joint_filter=joint_filter, future_steps=future_steps, time_limit=0.6, task='flight_imitation',
-                         wbpg_tables=tables, seed=seed)
+                         wbpg_tables=tables, seed=seed, traj_loader=traj_loader, env_id_base=env_id_base,
+                         force_actuators=force_actuators, use_legs=not disable_legs)

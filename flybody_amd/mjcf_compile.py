@@ -250,6 +250,7 @@ class TaskConfig:
     joint_filter: float = 0.01
     adhesion_filter: float = 0.007
     dyntype_filterexact: bool = False
+    force_actuators: bool = False      # fruitfly.py:308-327: position actuators -> force actuators (no affine bias, ctrlrange (-1, 1))
     physics_timestep: float = 2e-4
     control_timestep: float = 2e-3
     floor: bool = True                 # dm_control floors.Floor() plane at z=0
@@ -454,6 +455,14 @@ class FlyCompiler:
                 new_q = qmul(dq, qconj(up_raw))
                 self._change_body_frame(B[self.bname[wing]], new_q)
 
+        # force actuators: fruitfly.py:308-327 -- every `general` actuator loses its affine bias and its own ctrlrange (the
+        # single top-level default (-1, 1) applies), gains stay; adhesion actuators are untouched
+        if cfg.force_actuators:
+            for a in self.actuators:
+                if a['_tag'] == 'adhesion':
+                    continue
+                a.pop('biastype', None); a.pop('biasprm', None)
+                a['ctrlrange'] = '-1 1'
         # filters: fruitfly.py:330-340
         dyn = 'filterexact' if cfg.dyntype_filterexact else 'filter'
         for a in self.actuators:
@@ -499,6 +508,11 @@ class FlyCompiler:
         for cls in _ACTION_CLASSES:
             self.action_to_ctrl.extend(ctrl_idx[cls])
         self.ctrl_idx = ctrl_idx
+        # environment-action indices per class (fruitfly.py:360-379): classes in order, user actions last
+        num = {c: len(ctrl_idx[c]) for c in _ACTION_CLASSES}; num['user'] = cfg.num_user_actions
+        self.action_idx = {}; counter = 0
+        for c in _ACTION_CLASSES:
+            self.action_idx[c] = list(range(counter, counter + num[c])); counter += num[c]
 
     def _change_body_frame(self, body: Body, frame_quat):
         # fruitfly.py:90-117 with frame_pos = body.pos
@@ -586,6 +600,54 @@ class FlyCompiler:
         return mass, com, I * scale
 
     # -- compile -----------------------------------------------------------------
+    def _actuator_arrays(self, tname=None):
+        """Per-actuator tables in MuJoCo's conventions.  `tname` (tendon name -> id) is only known to the full compile."""
+        act = dict(trntype=[], trnid=[], dyntype=[], dynprm=[], gainprm=[], biastype=[], biasprm=[],
+                   ctrlrange=[], ctrllimited=[], forcerange=[], forcelimited=[], name=[])
+        for a in self.actuators:
+            act['name'].append(a['name'])
+            if a['_tag'] == 'adhesion':
+                act['trntype'].append(TRN_BODY); act['trnid'].append(self.bname[a['body']])
+                act['biastype'].append(BIAS_NONE); act['biasprm'].append(np.zeros(3))
+            else:
+                if 'joint' in a:
+                    act['trntype'].append(TRN_JOINT); act['trnid'].append(self.jname[a['joint']] if hasattr(self, 'jname') and a['joint'] in getattr(self, 'jname', {}) else -1)
+                else:
+                    act['trntype'].append(TRN_TENDON); act['trnid'].append(tname[a['tendon']] if tname else -1)
+                bt = a.get('biastype', 'none')
+                act['biastype'].append(BIAS_AFFINE if bt == 'affine' else BIAS_NONE)
+                bp = _floats(a.get('biasprm', '0 0 0'))
+                act['biasprm'].append(np.concatenate([bp, np.zeros(3 - len(bp))]))
+            dt = a.get('dyntype', 'none')
+            act['dyntype'].append({'none': DYN_NONE, 'filter': DYN_FILTER, 'filterexact': DYN_FILTEREXACT}[dt])
+            act['dynprm'].append(float(a.get('dynprm', '1').split()[0]))
+            gp = _floats(a.get('gainprm', '1 0 0'))
+            act['gainprm'].append(np.concatenate([gp, np.zeros(3 - len(gp))]))
+            cr = _floats(a.get('ctrlrange', '0 0'))
+            act['ctrlrange'].append(cr)
+            cl = a.get('ctrllimited', 'auto')
+            act['ctrllimited'].append(int((cl == 'true' or cl == 'auto') and 'ctrlrange' in a))
+            fr = _floats(a.get('forcerange', '0 0'))
+            act['forcerange'].append(fr)
+            fl = a.get('forcelimited', 'auto')
+            act['forcelimited'].append(int((fl == 'true' or fl == 'auto') and 'forcerange' in a))
+        return act
+
+    def actuator_spec(self) -> Dict[str, object]:
+        """The part of FruitFly._build the acceptance sweep of the reference checks (tests/test_flywalker.py:36-168):
+        actuator names / types / dynamics / gains / ranges, `_ctrl_indices`, `_action_indices`, the action -> ctrl map and
+        the action spec -- without the (seconds-long) inertia / contact-pair compile."""
+        self.parse_bodies(); self.apply_rewrites()
+        act = self._actuator_arrays(None)
+        out = {k: np.array(v) for k, v in act.items()}
+        out['ctrl_indices'] = {c: (self.ctrl_idx[c] or None) for c in _ACTION_CLASSES}
+        out['action_indices'] = dict(self.action_idx)
+        out['action_to_ctrl'] = np.array(self.action_to_ctrl, int)
+        names = [act['name'][i] for i in self.action_to_ctrl] + [f'user_{k}' for k in range(self.cfg.num_user_actions)]
+        rng = [tuple(act['ctrlrange'][i]) for i in self.action_to_ctrl] + [(-1.0, 1.0)]*self.cfg.num_user_actions
+        out['action_names'] = names; out['action_minimum'] = np.array([r[0] for r in rng]); out['action_maximum'] = np.array([r[1] for r in rng])
+        return out
+
     def compile(self) -> Dict[str, np.ndarray]:
         cfg = self.cfg
         self.parse_bodies()
@@ -781,35 +843,7 @@ class FlyCompiler:
 
         # ---- actuators
         nu = len(self.actuators)
-        act = dict(trntype=[], trnid=[], dyntype=[], dynprm=[], gainprm=[], biastype=[], biasprm=[],
-                   ctrlrange=[], ctrllimited=[], forcerange=[], forcelimited=[], name=[])
-        for a in self.actuators:
-            act['name'].append(a['name'])
-            if a['_tag'] == 'adhesion':
-                act['trntype'].append(TRN_BODY); act['trnid'].append(self.bname[a['body']])
-                act['biastype'].append(BIAS_NONE); act['biasprm'].append(np.zeros(3))
-            else:
-                if 'joint' in a:
-                    act['trntype'].append(TRN_JOINT); act['trnid'].append(self.jname[a['joint']])
-                else:
-                    act['trntype'].append(TRN_TENDON); act['trnid'].append(tname[a['tendon']])
-                bt = a.get('biastype', 'none')
-                act['biastype'].append(BIAS_AFFINE if bt == 'affine' else BIAS_NONE)
-                bp = _floats(a.get('biasprm', '0 0 0'))
-                act['biasprm'].append(np.concatenate([bp, np.zeros(3 - len(bp))]))
-            dt = a.get('dyntype', 'none')
-            act['dyntype'].append({'none': DYN_NONE, 'filter': DYN_FILTER, 'filterexact': DYN_FILTEREXACT}[dt])
-            act['dynprm'].append(float(a.get('dynprm', '1').split()[0]))
-            gp = _floats(a.get('gainprm', '1 0 0'))
-            act['gainprm'].append(np.concatenate([gp, np.zeros(3 - len(gp))]))
-            cr = _floats(a.get('ctrlrange', '0 0'))
-            act['ctrlrange'].append(cr)
-            cl = a.get('ctrllimited', 'auto')
-            act['ctrllimited'].append(int((cl == 'true' or cl == 'auto') and 'ctrlrange' in a))
-            fr = _floats(a.get('forcerange', '0 0'))
-            act['forcerange'].append(fr)
-            fl = a.get('forcelimited', 'auto')
-            act['forcelimited'].append(int((fl == 'true' or fl == 'auto') and 'forcerange' in a))
+        act = self._actuator_arrays(tname)
         act_adr = -np.ones(nu, int)
         na = 0
         for i in range(nu):
@@ -872,6 +906,8 @@ class FlyCompiler:
         m['names_geom'] = np.array([g['name'] for g in geoms]); m['names_site'] = np.array([s['name'] for s in sites])
         m['names_actuator'] = np.array(act['name']); m['names_tendon'] = np.array([t['name'] for t in self.tendons])
         m['observable_joints'] = np.array([self.jname[n] for n in self.observable_joints], int)
+        # leg joints (flight with enabled legs resets them to / rewards them at their spring reference: flight_imitation.py:142-144,196-203)
+        m['leg_joints'] = np.array([i for i, n in enumerate(jnt['name']) if _any_in(_NAME_SUBSTR['legs'], n) and jnt['type'][i] == JNT_HINGE], int)
 
         # ---- reference-configuration quantities (M0, invweight0, springdamper)
         self._set0(m, jnt)

@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
+import dataclasses
+
 import numpy as np
 
 
@@ -144,6 +146,109 @@ class InferenceWalkingTrajectoryLoader:
 
     def get_site_names(self):
         return []
+
+
+@dataclasses.dataclass
+class FlightDataset:
+    """The reference's flight imitation dataset (hdf5 layout of trajectory_loaders.py:89-100: trajectories/<idx>/com_qpos
+    [T, 7], com_qvel [T, 6], timestep_seconds) as flat row-concatenated arrays; `.npz` round trip for machines without h5py."""
+    offsets: np.ndarray         # [n_traj + 1]
+    com_qpos: np.ndarray        # [rows, 7]  CoM position + root quaternion
+    com_qvel: np.ndarray        # [rows, 6]
+    timestep: float = 2e-4
+
+    @property
+    def n_traj(self) -> int:
+        return len(self.offsets) - 1
+
+    def root_qpos(self, com_offset) -> np.ndarray:
+        """Root-joint track of every row (tasks/flight_imitation.py:93-99: com2root of the CoM track)."""
+        from .task_utils import com2root
+        q = self.com_qpos.copy()
+        quat = q[:, 3:7]/np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+        q[:, :3] = com2root(q[:, :3], quat, offset=com_offset)
+        return q
+
+    def save(self, path: str):
+        np.savez_compressed(path, offsets=self.offsets, com_qpos=self.com_qpos, com_qvel=self.com_qvel, timestep=self.timestep)
+
+    @staticmethod
+    def load(path: str) -> 'FlightDataset':
+        with np.load(path, allow_pickle=False) as z:
+            return FlightDataset(z['offsets'].astype(np.int32), z['com_qpos'], z['com_qvel'], float(z['timestep']))
+
+
+class _FlightLoaderBase:
+    """get_trajectory semantics of HDF5FlightTrajectoryLoader (trajectory_loaders.py:110-141)."""
+
+    def __init__(self, dataset: FlightDataset, traj_indices=None, randomize_start_step: bool = True, random_state=None):
+        self.dataset = dataset
+        self._random_state = random_state if random_state is not None else np.random.RandomState(None)
+        self._traj_indices = np.arange(dataset.n_traj) if traj_indices is None else np.asarray(traj_indices)
+        self._randomize_start_step = randomize_start_step
+
+    @property
+    def timestep(self):
+        return self.dataset.timestep
+
+    @property
+    def num_trajectories(self):
+        return self.dataset.n_traj
+
+    @property
+    def traj_indices(self):
+        return self._traj_indices
+
+    @property
+    def randomize_start_step(self):
+        return self._randomize_start_step
+
+    def trajectory_len(self, traj_idx: int) -> int:
+        o = self.dataset.offsets
+        return int(o[traj_idx + 1] - o[traj_idx])
+
+    def get_trajectory(self, traj_idx: Optional[int] = None, start_step: Optional[int] = None, end_step: Optional[int] = None):
+        if traj_idx is None:
+            traj_idx = self._random_state.choice(self._traj_indices)
+        n = self.trajectory_len(traj_idx); o = int(self.dataset.offsets[traj_idx])
+        if self._randomize_start_step:
+            start_step = self._random_state.randint(n - 50); end_step = n
+        else:
+            start_step = 0 if start_step is None else start_step
+            end_step = n if end_step is None else end_step
+        q = self.dataset.com_qpos[o + start_step:o + end_step].copy()
+        q[:, :2] -= q[0, :2]
+        return q, self.dataset.com_qvel[o + start_step:o + end_step]
+
+
+class ArrayFlightTrajectoryLoader(_FlightLoaderBase):
+    """In-memory / .npz flight dataset (tests, synthetic data, converted HDF5 files)."""
+
+    def __init__(self, dataset, traj_indices=None, randomize_start_step: bool = True, random_state=None):
+        if isinstance(dataset, str):
+            dataset = FlightDataset.load(dataset)
+        super().__init__(dataset, traj_indices, randomize_start_step, random_state)
+
+
+class HDF5FlightTrajectoryLoader(_FlightLoaderBase):
+    """Loads the reference's hdf5 flight imitation dataset (figshare) into a FlightDataset."""
+
+    def __init__(self, path: str, traj_indices=None, randomize_start_step: bool = True, random_state=None):
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError('reading the HDF5 flight dataset needs h5py; convert it once to .npz with FlightDataset.save() '
+                              'on a machine that has it and use ArrayFlightTrajectoryLoader') from e
+        with h5py.File(path, 'r') as f:
+            n = len(f['trajectories']); nz = len(str(n))
+            qp, qv, offs = [], [], [0]
+            for idx in range(n):
+                s = f['trajectories'][str(idx).zfill(nz)]
+                qp.append(s['com_qpos'][()]); qv.append(s['com_qvel'][()])
+                assert qp[-1].shape[0] == qv[-1].shape[0]
+                offs.append(offs[-1] + len(qp[-1]))
+            ds = FlightDataset(np.array(offs, np.int32), np.concatenate(qp), np.concatenate(qv), float(f['timestep_seconds'][()]))
+        super().__init__(ds, traj_indices, randomize_start_step, random_state)
 
 
 class InferenceFlightTrajectoryLoader:

@@ -116,6 +116,22 @@ typedef struct fb_walk_dataset {
 } fb_walk_dataset;
 int fb_batch_set_walk_dataset(fb_batch* b, const fb_walk_dataset* ds);
 
+/* flight_imitation with a reference dataset (fly_envs.flight_imitation(ref_path=...), tasks/trajectory_loaders.py:67-141,
+ * tasks/flight_imitation.py:82-110): every trajectory of the dataset, row-concatenated and already converted from the
+ * dataset's CoM track to the root joint (task_utils.com2root); per episode every environment picks a trajectory out of
+ * `select` and -- with randomize_start_step -- a start row in [0, len - 50) on the GPU (pure functions of seed, global env
+ * id and episode number; the reference uses RandomState.choice / randint), re-centres x / y on the first row of the slice
+ * and tracks it.  Replaces fb_batch_set_reference for that mode; fb_batch_set_wbpg is still required.  Host pointers, FP64. */
+typedef struct fb_flight_dataset {
+  int32_t n_traj, n_select;
+  const int32_t* traj_offset;     /* [n_traj + 1] first row of each trajectory */
+  const double* qpos;             /* [rows][7] ROOT position + quaternion */
+  const double* qvel;             /* [rows][6] */
+  const int32_t* select;          /* [n_select] trajectory ids to sample from (traj_indices) */
+  int32_t future_steps, randomize_start_step; double terminal_com_dist, time_limit; uint32_t seed; int32_t env_id_base;
+} fb_flight_dataset;
+int fb_batch_set_flight_dataset(fb_batch* b, const fb_flight_dataset* ds);
+
 /* env.reset() for the listed environments (env_ids == NULL: all).  `stream` is a hipStream_t
  * (NULL = default stream).  Asynchronous. */
 int fb_batch_reset(fb_batch* b, const int32_t* env_ids, int n, void* stream);

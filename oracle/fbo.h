@@ -59,6 +59,7 @@ typedef struct {
   const int *pair_geom1, *pair_geom2, *pair_condim;
   const double *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   const int *observable_joints, *appendage_sites, *sensor_force_sites, *sensor_touch_sites, *wing_jnt;
+  const int* leg_jnt; int nlegjnt;       /* leg joints (flight with enabled legs); optional array of the blob */
   int sensor_site_thorax;
   int any_damping;
   int task_id, user_action_idx; const int* wing_action_idx; const double* com_offset;
@@ -107,6 +108,7 @@ typedef struct {
   int wb_step, wb_freq_idx, episode_count; unsigned seed;
   /* walk_imitation training mode: reference dataset (tasks/trajectory_loaders.py:185-264) + per-episode snippet */
   int ds_ntraj, ds_nj, ds_ns, ds_nselect, ds_traj, ds_off, ds_len; unsigned env_id;
+  int ds_random_start;                     /* flight dataset: random start step (trajectory_loaders.py:132-134) */
   const int *ds_offset, *ds_joint_ids, *ds_site_ids, *ds_select;
   const double *ds_qpos, *ds_qvel, *ds_root2site, *ds_joint_quat;
   double reward_factors[5];
@@ -168,6 +170,9 @@ void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, cons
                       double base_freq, double rel_range, double rate, unsigned seed);
 double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode);
 void fbo_env_step(fbo_data* d, const double* action);
+void fbo_env_set_flight_dataset(fbo_data* d, int n_traj, const int* traj_offset, const double* root_qpos, const double* qvel, const int* select,
+                                int n_select, int future_steps, double terminal_com_dist, double time_limit, int randomize_start_step,
+                                unsigned seed, unsigned env_id);
 void fbo_env_rollout_batch(fbo_data** ds, int n, const double* actions, int nsteps, int nthreads);
 void fbo_env_step_batch(fbo_data** ds, int n, const double* actions, int nthreads);
 

@@ -148,6 +148,17 @@ class OracleData:
                                    a[3].ctypes.data, a[4].ctypes.data, a[5].ctypes.data, a[6].ctypes.data, a[7].ctypes.data, len(sel),
                                    future_steps, float(terminal_com_dist), float(time_limit), seed, env_id)
 
+    def set_flight_dataset(self, offsets, root_qpos, qvel, select=None, future_steps=5, terminal_com_dist=2.0, time_limit=0.6,
+                           randomize_start_step=True, seed=0, env_id=0):
+        L = lib()
+        L.fbo_env_set_flight_dataset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, C.c_int, C.c_uint, C.c_uint]
+        n_traj = len(offsets) - 1
+        sel = np.arange(n_traj, dtype=np.int32) if select is None else np.ascontiguousarray(select, np.int32)
+        a = [np.ascontiguousarray(offsets, np.int32), np.ascontiguousarray(root_qpos, float), np.ascontiguousarray(qvel, float), sel]
+        L.fbo_env_set_flight_dataset(self.h, n_traj, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, len(sel),
+                                     future_steps, float(terminal_com_dist), float(time_limit), int(bool(randomize_start_step)), seed, env_id)
+
     def env_reset(self):
         lib().fbo_env_reset(self.h)
 

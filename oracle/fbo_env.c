@@ -400,12 +400,62 @@ void fbo_env_step(fbo_data* d, const double* action) {
 }
 
 /* ---- flight_imitation: flybody/tasks/flight_imitation.py:82-223, tasks/base.py:274-364 ---- */
+/* flight_imitation(ref_path=...): the dataset (root-converted on the host, task_utils.com2root) -- tasks/trajectory_loaders.py:67-141 */
+void fbo_env_set_flight_dataset(fbo_data* d, int n_traj, const int* traj_offset, const double* root_qpos, const double* qvel, const int* select,
+                                int n_select, int future_steps, double terminal_com_dist, double time_limit, int randomize_start_step,
+                                unsigned seed, unsigned env_id) {
+  const fbo_model* m = d->m;
+  size_t rows = (size_t)traj_offset[n_traj];
+  d->ds_ntraj = n_traj; d->ds_nj = 0; d->ds_ns = 0; d->ds_nselect = n_select; d->seed = seed; d->env_id = env_id;
+  d->ds_random_start = randomize_start_step;
+  d->ds_offset = (const int*)dupmem(traj_offset, sizeof(int)*(n_traj + 1));
+  d->ds_qpos = (const double*)dupmem(root_qpos, sizeof(double)*rows*7);
+  d->ds_qvel = (const double*)dupmem(qvel, sizeof(double)*rows*6);
+  d->ds_select = (const int*)dupmem(select, sizeof(int)*n_select);
+  d->future_steps = future_steps; d->terminal_com_dist = terminal_com_dist; d->time_limit = time_limit;
+  free(d->obs);
+  d->nobs = 3 + m->na + 3*m->napp + 3*m->nforce + 3 + 2*m->nobsjnt + 7*(future_steps + 1) + m->ntouch + 3 + 3;
+  d->obs = (double*)calloc(d->nobs, sizeof(double));
+  d->episode_count = 0; d->reset_next = 1;
+}
+
+/* HDF5FlightTrajectoryLoader.get_trajectory (trajectory_loaders.py:110-141): trajectory out of traj_indices, random start in
+ * [0, len - 50), x / y measured from the first row of the slice.  Draws are pure functions of (seed, environment, episode). */
+static void pick_flight_snippet(fbo_data* d) {
+  double u = fbo_hash_uniform(d->seed, d->env_id, (unsigned)d->episode_count);
+  int k = (int)(u * d->ds_nselect); if (k >= d->ds_nselect) k = d->ds_nselect - 1;
+  d->ds_traj = d->ds_select[k];
+  int off = d->ds_offset[d->ds_traj], len = d->ds_offset[d->ds_traj + 1] - off, start = 0;
+  if (d->ds_random_start) {
+    double u2 = fbo_hash_uniform(d->seed ^ 0x5bd1e995u, d->env_id, (unsigned)d->episode_count);
+    start = (int)(u2 * (len - 50)); if (start > len - 51) start = len - 51; if (start < 0) start = 0;
+  }
+  d->ds_off = off + start; d->ds_len = len - start;
+  int T = d->ds_len;
+  free(d->ref_qpos); free(d->ref_qvel);
+  d->ref_qpos = (double*)malloc(sizeof(double)*7*T); d->ref_qvel = (double*)malloc(sizeof(double)*6*T);
+  /* the loader re-centres the CoM track before the task converts it to the root joint: shift = CoM x, y of the first row */
+  const double* q0 = d->ds_qpos + (size_t)d->ds_off*7;
+  double qn[4] = {q0[3], q0[4], q0[5], q0[6]}, co[3];
+  { double n = sqrt(qn[0]*qn[0] + qn[1]*qn[1] + qn[2]*qn[2] + qn[3]*qn[3]); for (int c = 0; c < 4; c++) qn[c] /= n; }
+  rotvecquat(co, d->m->com_offset, qn);
+  double sh[2] = {q0[0] + co[0], q0[1] + co[1]};
+  for (int t = 0; t < T; t++) {
+    const double* q = d->ds_qpos + (size_t)(d->ds_off + t)*7;
+    for (int c = 0; c < 7; c++) d->ref_qpos[7*t + c] = q[c] - (c < 2 ? sh[c] : 0.0);
+    memcpy(d->ref_qvel + 6*t, d->ds_qvel + (size_t)(d->ds_off + t)*6, sizeof(double)*6);
+  }
+  d->T = T;
+}
+
 static void flight_reset(fbo_data* d) {
   const fbo_model* m = d->m;
   fbo_reset_state(d);
+  if (d->ds_qpos) pick_flight_snippet(d);
   memcpy(d->qpos, d->ref_qpos, sizeof(double)*7);
+  for (int k = 0; k < m->nlegjnt; k++) { int qa = m->jnt_qposadr[m->leg_jnt[k]]; d->qpos[qa] = m->qpos_spring[qa]; }   /* flight_imitation.py:142-144 */
   double wq[6], wv[6];
-  wbpg_reset(d, fbo_hash_uniform(d->seed, 0u, (unsigned)d->episode_count), wq, wv);
+  wbpg_reset(d, fbo_hash_uniform(d->seed, d->env_id, (unsigned)d->episode_count + (d->ds_qpos ? 0x40000000u : 0u)), wq, wv);
   d->episode_count++;
   for (int k = 0; k < 6; k++) {
     int j = m->wing_jnt[k];
@@ -470,7 +520,9 @@ static void flight_step(fbo_data* d, const double* action_in) {
   double qn = 0; for (int i = 0; i < m->nv; i++) qn += d->qacc[i]*d->qacc[i];
   d->reached_traj_end = (step == d->episode_steps);
   d->should_terminate = (height < 0.2) || (com_dist > d->terminal_com_dist) || d->reached_traj_end || (sqrt(qn) > TERMINAL_QACC) || (qn != qn);
-  d->reward = r_disp*r_quat;
+  double r_legs = 1.0;                                    /* flight_imitation.py:196-203 (1 when the legs are disabled) */
+  for (int k = 0; k < m->nlegjnt; k++) { int qa = m->jnt_qposadr[m->leg_jnt[k]]; r_legs *= tolerance_linear(d->qpos[qa] - m->qpos_spring[qa], 4.0); }
+  d->reward = r_disp*r_quat*r_legs;
   d->discount = (d->should_terminate && !d->reached_traj_end) ? 0.0 : 1.0;
   int terminating = d->should_terminate || (d->time >= d->time_limit);
   pack_obs(d, mean);

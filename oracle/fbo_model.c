@@ -73,6 +73,8 @@ int fbo_model_load(const void* blob_in, size_t n, fbo_model** out) {
   m->sensor_force_sites = geti(b, "sensor_force_sites", &m->nforce);
   m->sensor_touch_sites = geti(b, "sensor_touch_sites", &m->ntouch);
   m->wing_jnt = geti(b, "wing_jnt", NULL);
+  { const blob_entry* e = find(b, "leg_joints"); m->nlegjnt = 0; m->leg_jnt = NULL;
+    if (e && e->dtype == 1) { m->leg_jnt = (const int*)((const char*)b + e->offset); m->nlegjnt = (int)(e->nbytes/4); } }
   m->sensor_site_thorax = geti(b, "sensor_site_thorax", NULL)[0];
   m->task_id = geti(b, "task_id", NULL)[0]; m->user_action_idx = geti(b, "user_action_idx", NULL)[0];
   m->wing_action_idx = geti(b, "wing_action_idx", NULL); m->com_offset = getd(b, "com_offset", NULL);
@@ -200,7 +202,7 @@ double fbo_scalar(const fbo_data* d, const char* name) {
 #define X(f) if (!strcmp(name, #f)) return (double)d->f
   X(ncon); X(nefc); X(solver_niter); X(noslip_niter); X(time); X(reward); X(discount); X(step_type);
   X(wb_step); X(wb_freq_idx); X(wb_ctrl_freq); X(episode_count);
-  X(ds_traj); X(ds_off); X(ds_len); X(step_counter); X(episode_steps); X(reset_next); X(should_terminate); X(reached_traj_end); X(nobs);
+  X(ds_traj); X(ds_off); X(ds_len); X(T); X(step_counter); X(episode_steps); X(reset_next); X(should_terminate); X(reached_traj_end); X(nobs);
 #undef X
   return -1e300;
 }

@@ -169,3 +169,72 @@ def test_ellipsoid_fluid_force_analysis_api():
             total_f = sum(comp[n] for n in COMPONENTS if n.startswith('f')); total_g = sum(comp[n] for n in COMPONENTS if n.startswith('g'))
             assert np.allclose(total_f, gxm[g] @ lfrc[3:], rtol=1e-6, atol=1e-14) and np.allclose(total_g, gxm[g] @ lfrc[:3], rtol=1e-6, atol=1e-14)
             assert np.linalg.norm(total_f) > 0
+
+
+@pytest.mark.gpu
+def test_factory_variants_on_gpu():
+    """FruitFly._build's switches through the fly_envs factories (force_actuators, enabled wings / legs, unfiltered joints):
+    spec sizes follow the configuration and the environments step (the compiled variants are committed under assets/variants)."""
+    import torch
+    from flybody_amd.fly_envs import flight_imitation, walk_imitation, walk_on_ball
+    e = walk_imitation(force_actuators=True, terminal_com_dist=float('inf'), n_env=64, precision=32)
+    spec = e.action_spec()
+    names = spec.name.split('\t')
+    lo, hi = np.asarray(spec.minimum), np.asarray(spec.maximum)
+    adh = np.array(['adhere' in n for n in names])
+    assert spec.shape == (59,) and np.all(lo[~adh] == -1) and np.all(hi[~adh] == 1) and np.all(lo[adh] == 0) and np.all(hi[adh] == 1)
+    v = e.reset_all(); a = torch.rand(64, 59, device='cuda')*2 - 1
+    for _ in range(3):
+        v = e.step_tensor(a)
+    torch.cuda.synchronize(); assert torch.isfinite(v['obs']).all()
+    e = walk_imitation(disable_wings=False, terminal_com_dist=float('inf'), n_env=8, precision=64)
+    assert e.action_spec().shape == (65,) and sum(int(np.prod(s.shape)) for s in e.observation_spec().values()) == 741 + 12 + 6     # 6 more joints (pos, vel) and activations
+    ts = e.reset(); ts = e.step(np.zeros(65)); assert ts.reward == 1.0
+    e = walk_imitation(joint_filter=0.0, terminal_com_dist=float('inf'), n_env=8, precision=64)
+    assert e.observation_spec()['walker/actuator_activation'].shape == (6,)          # only the adhesion filters keep a state
+    ts = e.reset(); ts = e.step(np.zeros(59)); assert np.isfinite(ts.observation['walker/joints_pos']).all()
+    e = flight_imitation(disable_legs=False, n_env=8, precision=64)
+    assert e.action_spec().shape == (66,) and e.action_spec().name.split('\t')[-1] == 'user_0'
+    ts = e.reset(); ts = e.step(np.zeros(66)); assert 0.0 <= ts.reward <= 1.0
+    e = walk_on_ball(force_actuators=True, n_env=8, precision=32)
+    ts = e.reset(); ts = e.step(np.zeros(59)); assert np.isfinite(ts.observation['walker/ball_qvel']).all()
+
+
+@pytest.mark.gpu
+def test_flight_dataset_on_gpu(tmp_path):
+    """flight_imitation(ref_path=...) with the dataset resident on the GPU: per-environment trajectory / start-step selection and
+    a tracked episode against the oracle (the emulation version is tests/test_flight_dataset.py)."""
+    import torch
+    from _synthetic_flight_dataset import make_flight_dataset
+    from flybody_amd.fly_envs import flight_imitation
+    from flybody_amd.model_blob import pack_model
+    from flybody_amd.wbpg import build_tables
+    from oracle import fbo
+    ds = make_flight_dataset(); path = str(tmp_path / 'flight.npz'); ds.save(path)
+    n = 16
+    env = flight_imitation(ref_path=path, n_env=n, precision=64, seed=11, env_id_base=40)
+    arrays = env.model.arrays
+    root = ds.root_qpos(arrays['com_offset']); tabs = build_tables()
+    om = fbo.OracleModel(pack_model(arrays)); ods = []
+    for e in range(n):
+        od = fbo.OracleData(om); od.set_wbpg(tabs, seed=11)
+        od.set_flight_dataset(ds.offsets, root, ds.com_qvel, future_steps=5, terminal_com_dist=2.0, time_limit=0.6, randomize_start_step=True,
+                              seed=11, env_id=40 + e)
+        od.env_reset(); ods.append(od)
+    v = env.reset_all(); torch.cuda.synchronize()
+    obs = v['obs'].cpu().numpy()
+    offs = {int(od.scalar('ds_off')) for od in ods}
+    assert len(offs) > 4                                                     # the environments picked different slices
+    for e, od in enumerate(ods):
+        assert np.allclose(obs[e], od.field('obs'), rtol=1e-5, atol=1e-5), e
+    rng = np.random.default_rng(1)
+    for k in range(40):
+        a = rng.uniform(-0.3, 0.3, (n, 12)).astype(np.float32)
+        v = env.step_tensor(torch.from_numpy(a).cuda()); torch.cuda.synchronize()
+        for e, od in enumerate(ods):
+            od.env_step(a[e].astype(np.float64))
+        assert v['step_type'].cpu().numpy().tolist() == [int(od.scalar('step_type')) for od in ods], k
+    Q = env.batch.get('QPOS')
+    for e, od in enumerate(ods):
+        assert np.abs(Q[e] - od.field('qpos')).max() < 1e-7*max(1.0, np.abs(od.field('qpos')).max()), e
+    assert np.allclose(v['reward'].cpu().numpy(), [od.scalar('reward') for od in ods], atol=1e-5)

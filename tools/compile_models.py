@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--xml', default='/root/reference/flybody/fruitfly/assets/fruitfly.xml')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'flybody_amd', 'assets'))
+    ap.add_argument('--variants', action='store_true', help='also (re)build the committed variant cache assets/variants/*.npz (model_zoo.COMMON_VARIANTS)')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     for cfg in (walk_imitation_config(), flight_imitation_config(), walk_on_ball_config()):
@@ -23,6 +24,18 @@ def main():
         print(cfg.name, 'nq', len(m['qpos0']), 'nv', len(m['dof_bodyid']), 'nbody', len(m['body_parent']),
               'nu', len(m['actuator_trntype']), 'ngeom', len(m['geom_type']), 'npair', len(m['pair_geom1']),
               '->', path, os.path.getsize(path), 'bytes')
+    if a.variants:
+        variants(a.xml)
+
+def variants(xml):
+    from flybody_amd import model_zoo
+    os.makedirs(model_zoo.VARIANTS, exist_ok=True)
+    for task, kw in model_zoo.COMMON_VARIANTS:
+        cfg = model_zoo.task_config(task, **kw)
+        path = os.path.join(model_zoo.VARIANTS, model_zoo.config_key(cfg) + '.npz')
+        m = compile_model(xml, cfg); save_model(m, path)
+        print(task, kw, '-> nq', len(m['qpos0']), 'nv', len(m['dof_bodyid']), 'nu', len(m['actuator_trntype']), os.path.basename(path))
+
 
 if __name__ == '__main__':
     main()
