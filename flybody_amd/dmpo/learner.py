@@ -4,12 +4,14 @@ from __future__ import annotations
 
 import copy
 import dataclasses
+import os
 from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
 
-from .losses import MPOLoss, categorical_td_loss
+from . import fused
+from .losses import MPOLoss
 from .networks import DMPONetworks
 
 
@@ -46,20 +48,35 @@ class DMPOLearner:
         self.policy_params = list(self.online.policy.parameters())
         self.critic_params = list(self.online.critic.parameters())
         self.dual_params = list(self.loss.parameters())
-        cap = self.device.type == 'cuda'          # capturable optimizers: the update can live in a HIP graph
-        # fused (multi-tensor) Adam on the GPU: one kernel per optimizer instead of ~10 per parameter tensor
-        kw = dict(capturable=True, fused=True) if cap else {}
-        self.policy_opt = torch.optim.Adam(self.policy_params, lr=config.policy_lr, **kw)
-        self.critic_opt = torch.optim.Adam(self.critic_params, lr=config.critic_lr, **kw)
-        self.dual_opt = torch.optim.Adam(self.dual_params, lr=config.dual_lr, **kw)
         self._graph_fb = None; self._graph_opt = None; self._static = None; self._sampler = None
         self.num_steps = 0
-        # one flat gradient buffer; every parameter's .grad is a view into it
+        # ONE flat parameter buffer and ONE flat gradient buffer: [policy | critic | duals]; every parameter (and its .grad) is
+        # a view.  The gradient buffer is what the single all-reduce of a data-parallel step sends; the parameter buffer is what
+        # the fused clipped-Adam kernel updates (dmpo/fused.py: FlatAdam -- two launches for all 1.17 M parameters).
         allp = self.policy_params + self.critic_params + self.dual_params
-        self.flat_grad = torch.zeros(sum(p.numel() for p in allp), device=self.device)
+        n_all = sum(p.numel() for p in allp)
+        self.flat_param = torch.empty(n_all, device=self.device); self.flat_grad = torch.zeros(n_all, device=self.device)
         off = 0
-        for p in allp:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p); off += p.numel()
+        with torch.no_grad():
+            for p in allp:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view_as(p)
+                p.grad = self.flat_grad[off:off + n].view_as(p); off += n
+        clip = config.max_grad_norm if config.clipping else 0.0
+        self.opt = fused.FlatAdam(self.flat_param, self.flat_grad,
+                                  [sum(p.numel() for p in g) for g in (self.policy_params, self.critic_params, self.dual_params)],
+                                  lrs=[config.policy_lr, config.critic_lr, config.dual_lr], clips=[clip, clip, 0.0],
+                                  floors=[None, None, -18.0])      # the duals are projected to >= -18 (losses_mpo.py: _MIN_LOG_TEMPERATURE)
+        self.fused = self.device.type == 'cuda'       # GPU: fused loss kernels (they fail loudly if the library is missing)
+        if self.fused:
+            fused.lib()
+            # The learner's GEMMs are plain (no bias epilogue) [256 | 5120] x K x [51 .. 512] products.  hipBLASLt's heuristics pick
+            # a 256x256 macro tile for the M = 256, N = 256 ones (one or two workgroups on a 256-CU device: 63-170 us each,
+            # profiles/r2/learner_gemm_probe.txt); rocBLAS runs every shape of this step in 4-40 us.  Process-wide switch.
+            blas = os.environ.get('FB_LEARNER_BLAS', 'hipblas')
+            if blas != 'default':
+                torch.backends.cuda.preferred_blas_library(blas)
 
     def broadcast_parameters(self):
         """Make every rank start from rank 0's weights (replicas then stay identical deterministically)."""
@@ -77,12 +94,8 @@ class DMPOLearner:
     # ---- HIP-graph path: the ~200 small kernels of one learner step are replayed as two graphs
     # (forward+backward | clip+Adam) with the single gradient all-reduce between them.
     def _trainable_state(self):
-        """Every tensor a learner step writes: parameters, dual variables and the optimizers' moment / step tensors."""
-        out = [p.data for p in self.policy_params + self.critic_params + self.dual_params]
-        for opt in (self.policy_opt, self.critic_opt, self.dual_opt):
-            for p in opt.param_groups[0]['params']:
-                out += [v for _, v in sorted(opt.state.get(p, {}).items()) if torch.is_tensor(v)]
-        return out
+        """Every tensor a learner step writes: the flat parameter buffer (parameters + duals) and Adam's moments / step count."""
+        return [self.flat_param] + self.opt.state_tensors()
 
     def warmup_and_capture(self, example_batch, capture: bool = True, sampler=None):
         """Warm-up (allocations, lazy optimizer state) and, on the GPU, capture of the step as HIP graphs -- WITHOUT touching
@@ -90,8 +103,7 @@ class DMPOLearner:
         rolled back in place afterwards, so parameters, duals, Adam moments and step counts are exactly what they were.
         On several ranks the warm-up gradients are rank-local and never reduced; rolling them back is what keeps the
         replicas identical."""
-        saved_p = [t.clone() for t in self._trainable_state()]      # optimizer state may not exist yet: those tensors start at 0
-        n_saved = len(saved_p)
+        saved_p = [t.clone() for t in self._trainable_state()]
         self._static = [t.clone() for t in example_batch]
         self._sampler = sampler if capture else None
         if self.device.type == 'cuda':
@@ -113,16 +125,8 @@ class DMPOLearner:
         else:
             self._forward_backward(self._static); self._apply_gradients()
         with torch.no_grad():
-            state = self._trainable_state()
-            n_param = len(self.policy_params + self.critic_params + self.dual_params)
-            if n_saved == len(state):
-                for t, sv in zip(state, saved_p):
-                    t.copy_(sv)
-            else:                                                   # optimizer state was created by the warm-up: parameters back, moments / steps to zero
-                for t, sv in zip(state[:n_param], saved_p[:n_param]):
-                    t.copy_(sv)
-                for t in state[n_param:]:
-                    t.zero_()
+            for t, sv in zip(self._trainable_state(), saved_p):
+                t.copy_(sv)
             self.flat_grad.zero_()
 
     def enable_graphs(self, example_batch, sampler=None):
@@ -136,10 +140,7 @@ class DMPOLearner:
             self.flat_grad.div_(dist.get_world_size())
 
     def _apply_gradients(self):
-        if self.cfg.clipping:
-            torch.nn.utils.clip_grad_norm_(self.policy_params, self.cfg.max_grad_norm)
-            torch.nn.utils.clip_grad_norm_(self.critic_params, self.cfg.max_grad_norm)
-        self.critic_opt.step(); self.policy_opt.step(); self.dual_opt.step()
+        self.opt.step()              # global-norm clipping per group (policy, critic) + Adam for everything
 
     def step(self, batch=None) -> Dict[str, torch.Tensor]:
         """One update.  `batch` may be omitted when the graphs were captured with a sampler."""
@@ -165,17 +166,27 @@ class DMPOLearner:
             sampled = t_mean[None] + t_std[None] * torch.randn(N, B, t_mean.shape[-1], device=self.device)
             # N sampled actions per next observation: the observation half of the critic's first layer is computed once
             # per observation, not once per (sample, observation) pair (networks.Critic.forward_samples)
-            q_t_logits = self.target.critic.forward_samples(o_t, sampled).reshape(N * B, -1)
-            logp = torch.log_softmax(q_t_logits.view(N, B, -1), dim=-1)
-            avg_logits = torch.logsumexp(logp, dim=0)
-            sampled_q = self.target.critic.mean_q(q_t_logits).view(N, B)
+            q_t_logits = self.target.critic.forward_samples(o_t, sampled)               # [N, B, atoms]
         o_mean, o_std = self.online.policy(o_t)
         q_tm1_logits = self.online.critic(o_tm1, a_tm1)
-        critic_loss = categorical_td_loss(q_tm1_logits, self.online.critic.values, r_t, cfg.discount * d_t, avg_logits).mean()
-        policy_loss, stats = self.loss(o_mean, o_std, t_mean, t_std, sampled, sampled_q)
-        self.flat_grad.zero_()
-        # critic loss trains the critic only; policy loss trains policy + duals (independent graphs)
-        (critic_loss + policy_loss).backward()
+        # categorical TD loss (+ the mean Q of every sampled action, the E-step input) and the MPO loss: fused kernels on the GPU
+        critic_loss, sampled_q = fused.td_loss(q_tm1_logits, q_t_logits, self.online.critic.values, r_t, d_t, cfg.discount)
+        if self.fused:
+            policy_loss, stats = fused.mpo_loss(self.loss, o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        else:
+            policy_loss, stats = self.loss(o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        # critic loss trains the critic only; policy loss trains policy + duals (independent graphs).  The gradients come back
+        # as fresh tensors and land in the flat buffer with ONE multi-tensor copy (backward() into the pre-existing .grad views
+        # would cost an accumulate kernel per parameter tensor plus the zero-fill)
+        allp = self.policy_params + self.critic_params + self.dual_params
+        grads = torch.autograd.grad(critic_loss + policy_loss, allp, allow_unused=True)
+        views = [p.grad for p in allp]
+        if any(g is None for g in grads):                 # (the penalty temperature without action penalization)
+            for v, g in zip(views, grads):
+                if g is None:
+                    v.zero_()
+            views, grads = zip(*[(v, g) for v, g in zip(views, grads) if g is not None])
+        torch._foreach_copy_(list(views), list(grads))
         stats = dict(stats); stats['critic_loss'] = critic_loss.detach(); stats['policy_loss'] = policy_loss.detach()
         return stats
 
@@ -189,10 +200,8 @@ class DMPOLearner:
 
     def state_dict(self):
         return dict(online=self.online.state_dict(), target=self.target.state_dict(), duals=self.loss.state_dict(),
-                    policy_opt=self.policy_opt.state_dict(), critic_opt=self.critic_opt.state_dict(),
-                    dual_opt=self.dual_opt.state_dict(), num_steps=self.num_steps)
+                    adam=self.opt.state_dict(), num_steps=self.num_steps)
 
     def load_state_dict(self, sd):
         self.online.load_state_dict(sd['online']); self.target.load_state_dict(sd['target']); self.loss.load_state_dict(sd['duals'])
-        self.policy_opt.load_state_dict(sd['policy_opt']); self.critic_opt.load_state_dict(sd['critic_opt'])
-        self.dual_opt.load_state_dict(sd['dual_opt']); self.num_steps = sd['num_steps']
+        self.opt.load_state_dict(sd['adam']); self.num_steps = sd['num_steps']

@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
+
 
 def _uniform_fan_out_(w: torch.Tensor, scale: float = 0.333):
     # VarianceScaling(scale, mode='fan_out', distribution='uniform'); torch weight is [out, in]
@@ -34,11 +36,16 @@ class LayerNormMLP(nn.Module):
             _uniform_fan_out_(lin.weight); nn.init.zeros_(lin.bias)
 
     def forward(self, x):
-        h = torch.tanh(self.norm(self.first(x)))
+        return self.tail(F.linear(x, self.first.weight))
+
+    def tail(self, z):
+        """Everything after the first GEMM.  The GEMMs run WITHOUT a bias epilogue (measured on MI355X: hipBLASLt's bias kernels
+        take 63-170 us for the [256 x K] x [K x 256] shapes of this network against 5 us for the plain GEMM,
+        profiles/r2/learner_gemm_probe.txt); bias + LayerNorm + tanh and bias + ELU are one fused kernel each (dmpo/fused.py)."""
+        h = fused.bias_ln_tanh(z, self.first.bias, self.norm)
         for i, lin in enumerate(self.rest):
-            h = lin(h)
-            if self.activate_final or i < len(self.rest) - 1:
-                h = F.elu(h)
+            z = F.linear(h, lin.weight)
+            h = fused.bias_elu(z, lin.bias) if (self.activate_final or i < len(self.rest) - 1) else z + lin.bias
         return h
 
 
@@ -54,8 +61,8 @@ class GaussianHead(nn.Module):
         self.init_scale = init_scale; self.min_scale = min_scale
 
     def forward(self, h):
-        mean = self.mean(h)
-        std = F.softplus(self.scale(h)) * (self.init_scale / math.log(2.0)) + self.min_scale
+        mean = F.linear(h, self.mean.weight) + self.mean.bias
+        std = F.softplus(F.linear(h, self.scale.weight) + self.scale.bias) * (self.init_scale / math.log(2.0)) + self.min_scale
         return mean, std
 
 
@@ -80,7 +87,7 @@ class Critic(nn.Module):
     def forward(self, obs, action):
         # ClipToSpec on canonical actions ([-1, 1] after CanonicalSpecWrapper, train_dmpo_ray.py:89)
         x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
-        return self.logits(self.torso(x))
+        return F.linear(self.torso(x), self.logits.weight) + self.logits.bias
 
     def forward_samples(self, obs, actions):
         """Logits [N, B, atoms] for N actions per observation (obs [B, O], actions [N, B, A]).  Same function as
@@ -88,14 +95,9 @@ class Critic(nn.Module):
         observation half (741 of the 800 input columns) is multiplied once per observation instead of once per pair."""
         t = self.torso
         no = obs.shape[-1]
-        h_o = F.linear(obs, t.first.weight[:, :no], t.first.bias)                        # [B, H]
+        h_o = F.linear(obs, t.first.weight[:, :no])                                      # [B, H]
         h_a = F.linear(actions.clamp(-1.0, 1.0), t.first.weight[:, no:])                 # [N, B, H]
-        h = torch.tanh(t.norm(h_o[None] + h_a))
-        for i, lin in enumerate(t.rest):
-            h = lin(h)
-            if t.activate_final or i < len(t.rest) - 1:
-                h = F.elu(h)
-        return self.logits(h)
+        return F.linear(t.tail(h_o[None] + h_a), self.logits.weight) + self.logits.bias
 
     def mean_q(self, logits):
         return (F.softmax(logits, dim=-1) * self.values).sum(-1)

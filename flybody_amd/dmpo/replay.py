@@ -100,6 +100,9 @@ class NStepReplay:
 
     def sample(self, batch_size: int):
         u = torch.rand(batch_size, device=self.device, generator=self.gen)
+        if self.device.type == 'cuda':
+            from . import fused            # index + five gathers in one launch
+            return tuple(fused.replay_gather(u, self._size, self.capacity, [self.obs, self.action, self.reward, self.discount, self.next_obs]))
         idx = (u * self._size.to(torch.float32)).to(torch.long).clamp_(max=self.capacity - 1)
         idx = torch.minimum(idx, (self._size - 1).clamp(min=0))
         return self.obs[idx], self.action[idx], self.reward[idx], self.discount[idx], self.next_obs[idx]

@@ -174,9 +174,7 @@ def test_warmup_leaves_training_state_untouched():
     L.warmup_and_capture(batch, capture=False)
     after = list(L.online.parameters()) + list(L.loss.parameters())
     assert all(torch.equal(a, b) for a, b in zip(after, before))
-    for opt in (L.policy_opt, L.critic_opt, L.dual_opt):
-        for st in opt.state.values():
-            assert all(float(v.abs().sum()) == 0 for v in st.values() if torch.is_tensor(v))      # moments and step counts back at zero
+    assert all(float(t.abs().sum()) == 0 for t in L.opt.state_tensors())                     # moments and step count back at zero
     # after real steps the roll-back restores the (non-zero) optimizer state as well
     for _ in range(3):
         L.step(batch)
@@ -188,6 +186,30 @@ def test_warmup_leaves_training_state_untouched():
     a = nets.critic.forward_samples(obs, acts)
     b = nets.critic(obs[None].expand(5, 6, 20).reshape(30, 20), acts.reshape(30, 4)).view(5, 6, -1)
     assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_flat_adam_matches_torch_adam_with_clipping():
+    """FlatAdam (the CPU formulation; the GPU kernel is checked against it in tests/test_gpu_learner.py) == torch.optim.Adam
+    preceded by clip_grad_norm_ per parameter group, and the dual floor."""
+    from flybody_amd.dmpo.fused import FlatAdam
+    torch.manual_seed(0)
+    sizes = [37, 12, 5]; n = sum(sizes)
+    p0 = torch.randn(n); flat_p = p0.clone(); flat_g = torch.zeros(n)
+    opt = FlatAdam(flat_p, flat_g, sizes, lrs=[1e-2, 3e-3, 1e-1], clips=[0.5, 0.5, 0.0], floors=[None, None, -0.2])
+    ref = [torch.nn.Parameter(p0[a:b].clone()) for a, b in ((0, 37), (37, 49), (49, 54))]
+    ropts = [torch.optim.Adam([r], lr=lr) for r, lr in zip(ref, (1e-2, 3e-3, 1e-1))]
+    for k in range(6):
+        g = torch.randn(n)*(3.0 if k % 2 else 0.1)
+        flat_g.copy_(g); opt.step()
+        for r, o, (a, b), clip in zip(ref, ropts, ((0, 37), (37, 49), (49, 54)), (0.5, 0.5, None)):
+            r.grad = g[a:b].clone()
+            if clip:
+                torch.nn.utils.clip_grad_norm_([r], clip)
+            o.step()
+        with torch.no_grad():
+            ref[2].clamp_(min=-0.2)
+    assert torch.allclose(flat_p, torch.cat([r.detach() for r in ref]), rtol=1e-5, atol=1e-7)
+    assert float(flat_p[49:].min()) >= -0.2
 
 
 def test_learner_step_mechanics():
@@ -253,9 +275,7 @@ def test_two_rank_gradient_allreduce(tmp_path):
         torch.manual_seed(7)
         L.cfg.clipping = False
         # reproduce backward without the optimizer step
-        for opt in (L.policy_opt, L.critic_opt, L.dual_opt):
-            for grp in opt.param_groups:
-                grp['lr'] = 0.0
+        L.opt.set_lrs([0.0, 0.0, 0.0])
         L.step(batch); grads.append(L.flat_grad.clone())
     want = (grads[0] + grads[1]) / 2
     got = torch.load(out)

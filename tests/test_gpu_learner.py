@@ -1,0 +1,174 @@
+"""The fused learner kernels (include/flybody_learner.h) on the GPU against the plain PyTorch formulation of the same math
+(dmpo/losses.py, torch.nn.functional, torch.optim.Adam) -- values AND gradients -- and the learner step built on them."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=2e-4, atol=1e-6):
+    a = a.detach().float().cpu(); b = b.detach().float().cpu()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
+
+
+def test_library_symbols():
+    import ctypes as C, os, re
+    from conftest import ROOT
+    import __graft_entry__ as g
+    lib = C.CDLL(g.build_learner())
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'flybody_learner.h')).read(), flags=re.S)
+    for s in sorted(set(re.findall(r'\b(fbl_[a-z_0-9]+)\s*\(', hdr))):
+        assert hasattr(lib, s), s
+
+
+def test_td_loss_kernel():
+    from flybody_amd.dmpo import fused
+    from flybody_amd.dmpo.losses import categorical_td_loss
+    torch.manual_seed(0)
+    N, B, K = 20, 256, 51
+    dev = 'cuda'
+    values = torch.linspace(-150, 150, K, device=dev)
+    qt = torch.randn(N, B, K, device=dev)*2; q1 = (torch.randn(B, K, device=dev)*2).requires_grad_(True)
+    r = torch.randn(B, device=dev)*3 + 1; d = (torch.rand(B, device=dev) > 0.1).float(); d[:4] = 0.0
+    r[:3] = 400.0; r[3:6] = -400.0                       # out-of-support targets: clamped onto the end atoms
+    loss, sq = fused.td_loss(q1, qt, values, r, d, 0.99)
+    loss.backward(); g_f = q1.grad.clone(); q1.grad = None
+    logp = torch.log_softmax(qt, -1); avg = torch.logsumexp(logp, 0)
+    ref = categorical_td_loss(q1, values, r, 0.99*d, avg).mean()
+    ref.backward()
+    _close(loss, ref); _close(g_f, q1.grad, rtol=1e-3, atol=1e-8)
+    _close(sq, (torch.softmax(qt, -1)*values).sum(-1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('penal', [True, False])
+def test_mpo_loss_kernel(penal):
+    from flybody_amd.dmpo import MPOLoss, fused
+    from flybody_amd.dmpo.losses import PenalizationCostRealActions
+    torch.manual_seed(1)
+    N, B, D = 20, 256, 59
+    dev = 'cuda'
+    lo = -np.abs(np.random.default_rng(0).normal(size=D)).astype(np.float32) - 0.2; hi = -lo*1.3
+    mk = lambda: MPOLoss(D, epsilon=0.1, epsilon_mean=0.0025, epsilon_stddev=1e-7, action_penalization=penal, epsilon_penalty=0.1,
+                         init_log_temperature=1.5, init_log_alpha_mean=2.0, init_log_alpha_stddev=30.0,
+                         penalization_cost=PenalizationCostRealActions(lo, hi, dev) if penal else None).to(dev)
+    m_f, m_r = mk(), mk()
+    tm = torch.randn(B, D, device=dev)*0.3; ts = torch.rand(B, D, device=dev)*0.5 + 0.2
+    om = (tm + 0.05*torch.randn(B, D, device=dev)).requires_grad_(True); os_ = (ts*(1 + 0.1*torch.randn(B, D, device=dev))).abs().requires_grad_(True)
+    acts = tm[None] + ts[None]*torch.randn(N, B, D, device=dev); q = torch.randn(N, B, device=dev)*3
+    lf, sf = fused.mpo_loss(m_f, om, os_, tm, ts, acts, q)
+    lf.backward(); g = [om.grad.clone(), os_.grad.clone()]; om.grad = None; os_.grad = None
+    lr_, sr = m_r(om, os_, tm, ts, acts, q)
+    lr_.backward()
+    _close(lf, lr_, rtol=1e-4, atol=1e-4)
+    _close(g[0], om.grad, rtol=2e-3, atol=1e-7); _close(g[1], os_.grad, rtol=2e-3, atol=1e-7)
+    for name in ('log_temperature', 'log_alpha_mean', 'log_alpha_stddev') + (('log_penalty_temperature',) if penal else ()):
+        _close(getattr(m_f, name).grad, getattr(m_r, name).grad, rtol=2e-3, atol=1e-6)
+    for k in ('kl_q_rel', 'kl_mean_rel', 'kl_stddev_rel', 'q_min', 'q_max', 'pi_stddev_min', 'pi_stddev_max', 'dual_temperature', 'loss_temperature') + \
+            (('penalty_kl_q_rel',) if penal else ()):
+        _close(sf[k], sr[k], rtol=2e-3, atol=1e-5)
+
+
+def test_flat_adam_kernel():
+    from flybody_amd.dmpo.fused import FlatAdam
+    torch.manual_seed(2)
+    sizes = [352_374, 818_227, 120]; n = sum(sizes)
+    p0 = torch.randn(n)
+    mk = lambda dev: FlatAdam(p0.clone().to(dev), torch.zeros(n, device=dev), sizes, lrs=[1e-4, 1e-4, 1e-3], clips=[40.0, 40.0, 0.0],
+                              floors=[None, None, -18.0])
+    a, b = mk('cuda'), mk('cpu')
+    for k in range(4):
+        g = torch.randn(n)*(0.2 if k % 2 else 0.01)
+        a.g.copy_(g.cuda()); b.g.copy_(g); a.step(); b.step()
+    _close(a.p, b.p, rtol=1e-5, atol=2e-6); _close(a.m, b.m, rtol=1e-4, atol=1e-6); _close(a.v, b.v, rtol=1e-4, atol=1e-9)
+    assert float(a.step_t) == 4.0
+
+
+@pytest.mark.parametrize('M,W', [(256, 256), (5120, 512), (37, 200)])
+def test_fused_layer_kernels(M, W):
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(3)
+    dev = 'cuda'
+    x = torch.randn(M, W, device=dev, requires_grad=True); b = torch.randn(W, device=dev, requires_grad=True)
+    ln = torch.nn.LayerNorm(W).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_()
+    up = torch.randn(M, W, device=dev)
+    y = fused.bias_ln_tanh(x, b, ln); y.backward(up)
+    got = [x.grad.clone(), b.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()]
+    x.grad = b.grad = ln.weight.grad = ln.bias.grad = None
+    yr = torch.tanh(ln(x + b)); yr.backward(up)
+    _close(y, yr, rtol=1e-4, atol=1e-5)
+    for a_, r_ in zip(got, [x.grad, b.grad, ln.weight.grad, ln.bias.grad]):
+        _close(a_, r_, rtol=2e-3, atol=2e-4)
+    x.grad = b.grad = None
+    y = fused.bias_elu(x, b); y.backward(up); got = [x.grad.clone(), b.grad.clone()]; x.grad = b.grad = None
+    yr = F.elu(x + b); yr.backward(up)
+    _close(y, yr, rtol=1e-5, atol=1e-6); _close(got[0], x.grad, rtol=1e-4, atol=1e-6); _close(got[1], b.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_learner_step_fused_equals_unfused():
+    """Five DMPO updates at the reference's shapes with the fused kernels against the same learner on plain PyTorch ops."""
+    from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, make_networks
+    from flybody_amd.dmpo.losses import PenalizationCostRealActions
+    dev = torch.device('cuda', 0)
+    nobs, nu, B = 741, 59, 256
+
+    def make(fused_on):
+        torch.manual_seed(0)
+        loss = MPOLoss(nu, epsilon=0.1, epsilon_mean=0.0025, epsilon_stddev=1e-7, action_penalization=True, epsilon_penalty=0.1,
+                       penalization_cost=PenalizationCostRealActions(-np.ones(nu, np.float32), np.ones(nu, np.float32), dev))
+        L = DMPOLearner(make_networks(nobs, nu), loss, DMPOConfig(), device=dev); L.fused = fused_on
+        return L
+    a, b = make(True), make(False)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for k in range(5):
+        batch = (torch.randn(B, nobs, device=dev, generator=g), torch.rand(B, nu, device=dev, generator=g)*2 - 1, torch.ones(B, device=dev),
+                 torch.ones(B, device=dev), torch.randn(B, nobs, device=dev, generator=g))
+        torch.manual_seed(100 + k); sa = a.step(batch)
+        torch.manual_seed(100 + k); sb = b.step(batch)
+        _close(sa['critic_loss'], sb['critic_loss'], rtol=1e-4); _close(sa['policy_loss'], sb['policy_loss'], rtol=1e-3, atol=1e-3)
+    # Adam's update is scale-free (m / sqrt(v)): a parameter whose gradient is at rounding level moves by +-lr per step in a
+    # direction rounding decides, so single parameters may differ by a few lr after five steps; the bulk must agree
+    diff = (a.flat_param - b.flat_param).abs()
+    n_net = a.flat_param.numel() - 120
+    assert float(diff[:n_net].max()) <= 5*1e-4 + 1e-6 and float(diff[:n_net].mean()) < 2e-6, (float(diff[:n_net].max()), float(diff[:n_net].mean()))
+    _close(a.flat_param[n_net:], b.flat_param[n_net:], rtol=1e-5, atol=1e-4)              # the duals
+    # graphs + in-graph replay sampling
+    from flybody_amd.dmpo import NStepReplay
+    rep = NStepReplay(512, nobs, nu, 20_000, device=dev)
+    obs = torch.randn(512, nobs, device=dev)
+    for t in range(8):
+        rep.add(obs, torch.rand(512, nu, device=dev)*2 - 1, torch.ones(512, device=dev), torch.ones(512, device=dev), obs,
+                torch.zeros(512, dtype=torch.bool, device=dev), torch.zeros(512, dtype=torch.bool, device=dev))
+    sampler = lambda: rep.sample(B)
+    before = a.flat_param.clone()
+    a.enable_graphs(sampler(), sampler=sampler)
+    assert torch.equal(a.flat_param, before)                    # the warm-up is rolled back
+    for _ in range(3):
+        st = a.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in st.values()) and not torch.equal(a.flat_param, before)
+
+
+def test_replay_gather_kernel():
+    from flybody_amd.dmpo import NStepReplay
+    dev = torch.device('cuda', 0)
+    rep = NStepReplay(64, 7, 3, 500, n_step=1, device=dev)
+    for t in range(5):
+        o = torch.full((64, 7), float(t), device=dev) + torch.arange(64, device=dev)[:, None]*0.001
+        rep.add(o, torch.zeros(64, 3, device=dev), torch.full((64,), float(t), device=dev), torch.ones(64, device=dev), o + 0.5,
+                torch.zeros(64, dtype=torch.bool, device=dev), torch.zeros(64, dtype=torch.bool, device=dev))
+    n = rep.size
+    assert n == 5*64
+    o, a, r, d, no = rep.sample(4096)
+    assert o.shape == (4096, 7) and r.shape == (4096,) and float(o.max()) < 5 and float(o.min()) >= 0
+    # every sampled row is a row of the storage, fields stay aligned, and the draw covers the filled part only
+    key = (o[:, 0]*1000).round().long()
+    store = {int(round(float(k)*1000)): i for i, k in enumerate(rep.obs[:n, 0].cpu())}
+    idx = torch.tensor([store[int(k)] for k in key.cpu()])
+    assert torch.equal(rep.next_obs[idx.to(dev)], no) and torch.equal(rep.reward[idx.to(dev)], r)
+    assert idx.max() < n and len(set(idx.tolist())) > 0.9*n
