@@ -48,10 +48,21 @@ def main():
                         dtype=f'f{prec}', **rollout(env, 59, K, scale=0.3))); del env
     for o in out:
         print(json.dumps(o))
-    # config 3: DMPO training loop (separate process: it owns the torch RNG / HIP graphs)
-    for ls, prec in ((1, 32), (8, 32), (1, 64)):
-        r = subprocess.run([sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', '4096', '--iters', str(30 if quick else 60), '--learner-steps', str(ls),
-                            '--min-replay', '8192', '--precision', str(prec)], cwd=ROOT, capture_output=True, text=True)
+    # flight_imitation on a (synthetic) reference dataset resident on the GPU
+    from _synthetic_flight_dataset import make_flight_dataset
+    from flybody_amd.trajectory_loaders import ArrayFlightTrajectoryLoader
+    for prec in (32, 64):
+        env = flight_imitation(ref_path=ArrayFlightTrajectoryLoader(make_flight_dataset(n_traj=16)), n_env=8192, precision=prec)
+        print(json.dumps(dict(config='8(f)1: flight_imitation on a reference dataset, 8192 envs (16 synthetic trajectories, random start steps)', dtype=f'f{prec}',
+                              **rollout(env, 12, K)))); del env
+    # config 3: DMPO training loop (separate process: it owns the torch RNG / HIP graphs).  First the reference's rate limiter
+    # (15 samples per insert: 240 learner steps per control step of 4096 environments -- the learner sets the pace, as in the
+    # reference), then fixed numbers of learner steps per control step (throughput-oriented settings)
+    for ls, prec, iters in ((None, 32, 12 if quick else 24), (1, 32, 30 if quick else 60), (8, 32, 30 if quick else 60), (1, 64, 30 if quick else 60)):
+        cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', '4096', '--iters', str(iters), '--min-replay', '8192', '--precision', str(prec)]
+        if ls is not None:
+            cmd += ['--learner-steps', str(ls)]
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         print(line[-1] if line else json.dumps({'config': 'configs[2] DMPO', 'error': r.stderr[-300:]}))
 

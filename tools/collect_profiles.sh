@@ -5,7 +5,7 @@
 # every summary below is kept per kernel.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
