@@ -523,110 +523,235 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   const int max_it = M.iterations, max_noslip = M.noslip_iterations;
   const real tol_scaled = M.tolerance, noslip_tol = M.noslip_tolerance;
   int niter = 0;
+#ifndef FB_PGS_BRANCHY
+  if (S) {
+  // ---- branch-lean sweep for systems of <= 64 rows (every row lives in lane == row).
+  // Measured on MI355X (tools/microbench/lat.hip, one wave): a dependent FP64 FMA costs ~6 cycles, but a wave-uniform branch
+  // on a VALU result costs ~60-90 (v_cmp -> VCC -> s_cbranch) and a v_readlane feeding the VALU ~35.  The row-type dispatch
+  // therefore runs on a scalar bit mask (SALU only), the ray update and the cone post-processing are selects, and the Newton
+  // iteration on the friction multiplier has ONE exit test per pass.  Same arithmetic, same order, same results.
+  unsigned long long m_first;        // bit i: row i is the first row of an elliptic contact
+  {
+    bool fst = lane < nefc && w.efc_type()[lane] == CN_ELLIPTIC && w.con_efc()[w.efc_id()[lane]] == lane;
+    m_first = __ballot(fst);
+  }
   for (int it = 0; it < max_it; it++) {
     real improvement = 0;
     for (int i = 0; i < nefc;) {
-      int type = r3_get<S>(rtype, i);
-      if (type != CN_ELLIPTIC) {
-        real r0 = (real)r3_get<S>(res, i);
-        real a = r3_get<S>(rdiag, i);
-        real old = r3_get<S>(f, i);
+      if (!((m_first >> i) & 1ull)) {
+        real r0 = (real)rdlane(res.v0, i);
+        real a = rdlane(rdiag.v0, i);
+        real old = rdlane(f.v0, i);
         real fn = old - fb_div(r0, a);
-        if (fn < 0) fn = 0;
+        fn = fn < 0 ? (real)0 : fn;
         real del = fn - old;
         improvement -= (real)0.5*del*del*a + del*r0;
-        if (del != 0) { res_axpy<S>(res, AR, i, nefc, del, lane); r3_set<S>(f, i, lane, fn); }
+        res_axpy<true>(res, AR, i, nefc, del, lane);                 // (del == 0 adds exactly nothing)
+        f.v0 = (lane == i) ? fn : f.v0;
         i += 1;
-      } else {
-        real r0 = (real)r3_get<S>(res, i), o0 = r3_get<S>(f, i), o1 = r3_get<S>(f, i+1), o2 = r3_get<S>(f, i+2);
-        // a contact that carries no force and is separating stays at zero (the ray update below would return 0)
-        if (o0 == 0 && o1 == 0 && o2 == 0 && r0 >= 0) { i += 3; continue; }
-        FB_BT(0);
-        real r1 = (real)r3_get<S>(res, i+1), r2 = (real)r3_get<S>(res, i+2);
-        real A00 = r3_get<S>(cA00, i), A01 = r3_get<S>(cA01, i), A02 = r3_get<S>(cA02, i);
-        real A11 = r3_get<S>(cA11, i), A12 = r3_get<S>(cA12, i), A22 = r3_get<S>(cA22, i);
-        // A*old and the part of the residual that does not depend on this block
-        real Ao0 = A00*o0 + A01*o1 + A02*o2, Ao1 = A01*o0 + A11*o1 + A12*o2, Ao2 = A02*o0 + A12*o1 + A22*o2;
-        real bc1 = r1 - Ao1, bc2 = r2 - Ao2;
-        // ray update: along e1 when the contact is inactive, along the current force otherwise
-        real f0, f1, f2;
-        if (o0 < FB_MINV) {
-          real x = -r0*r3_get<S>(cI00, i);           // 1/A00 (0 when A00 is degenerate: no move)
-          if (o0 + x < 0) x = -o0;
-          f0 = o0 + x; f1 = o1; f2 = o2;
-        } else {
-          real denom = o0*Ao0 + o1*Ao1 + o2*Ao2;
-          real x = 0;
-          if (denom >= FB_MINV) { x = -fb_div(o0*r0 + o1*r1 + o2*r2, denom); if (o0 + x*o0 < 0) x = -1; }
-          f0 = o0 + x*o0; f1 = o1 + x*o1; f2 = o2 + x*o2;
-        }
-        if (f0 < FB_MINV) { f0 = 0; f1 = 0; f2 = 0; }
-        else {
-          FB_BT(1);
-          // friction plane: min 0.5 x'Qx + x'b subject to |x| <= f0 in friction-scaled coordinates
-          real d0 = r3_get<S>(rfr0, i), d1 = r3_get<S>(rfr1, i);
-          real b1 = (bc1 + A01*f0)*d0, b2 = (bc2 + A02*f0)*d1;
-          real ec = r3_get<S>(cEc, i), es = r3_get<S>(cEs, i), R1 = r3_get<S>(cR1, i), R2 = r3_get<S>(cR2, i);
-          real v1 = 0, v2 = 0, la = 0;
-          bool active = false;
-          if (R1 != 0 || R2 != 0) {                   // (both zero: singular friction block, force stays 0)
-            real t1 = ec*b1 + es*b2, t2 = ec*b2 - es*b1;             // b in the eigenbasis
-            real u1 = -t1*R1, u2 = -t2*R2;                           // unconstrained minimiser (multiplier 0)
-            real rr = f0*f0;
-            real val = u1*u1 + u2*u2 - rr;
-            const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*rr + (real)1e-10;
-            if (val >= tolv) {
-              // Newton iteration on the multiplier (FP64: from 0 with the reference's absolute thresholds; FP32:
-              // restarted from the multiplier of the previous sweep, thresholds at single-precision resolution)
-              real E1 = r3_get<S>(cE1, i), E2 = r3_get<S>(cE2, i);
-              bool fresh = true;                      // (u, val, R) are the values at the current multiplier
-              if (sizeof(real) == 4) { real law = r3_get<S>(rla, i); if (law > 0) { la = law; fresh = false; } }
-              for (int k = 1; k < 20; k++) {
-                if (!fresh) {
-                  real a1 = E1 + la, a2 = E2 + la;
-                  if (a1*a2 < (real)1e-10) { u1 = 0; u2 = 0; la = 0; break; }
-                  R1 = fb_div((real)1, a1); R2 = fb_div((real)1, a2);
-                  u1 = -t1*R1; u2 = -t2*R2;
-                  val = u1*u1 + u2*u2 - rr;
-                  if (val < tolv && (sizeof(real) == 8 || val > -tolv)) break;
-                }
-                real deriv = -(real)2*(u1*u1*R1 + u2*u2*R2);
-                real delta = -fb_div(val, deriv);
-                const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
-                if (sizeof(real) == 8) { if (delta < told) break; }
-                else if (fabs(delta) < told) break;
-                la += delta;
-                if (la < 0) la = 0;
-                fresh = false;
-              }
-              active = la != 0;
-            }
-            if (sizeof(real) == 4) r3_set<S>(rla, i, lane, la);
-            if (active) {
-              // put the friction force exactly on the cone boundary
-              real s2 = u1*u1 + u2*u2;
-              if (s2 > FB_MINV*FB_MINV) { real k = f0*fb_rsqrt(s2); u1 *= k; u2 *= k; }
-            }
-            v1 = ec*u1 - es*u2; v2 = es*u1 + ec*u2;
-          }
-          f1 = v1*d0; f2 = v2*d1;
-        }
-        FB_BT(2);
-        real e0 = f0 - o0, e1 = f1 - o1, e2 = f2 - o2;
-        real Ae0 = A00*e0 + A01*e1 + A02*e2, Ae1 = A01*e0 + A11*e1 + A12*e2, Ae2 = A02*e0 + A12*e1 + A22*e2;
-        improvement -= (real)0.5*(e0*Ae0 + e1*Ae1 + e2*Ae2) + (e0*r0 + e1*r1 + e2*r2);
-        // the three rows are read together (a zero delta leaves the residual unchanged, so no test is needed)
-        res_axpy3<S>(res, AR, i, nefc, e0, e1, e2, lane);
-        r3_set<S>(f, i, lane, f0); r3_set<S>(f, i+1, lane, f1); r3_set<S>(f, i+2, lane, f2);
-        FB_BT(3);
-        i += 3;
+        continue;
       }
+      real r0 = (real)rdlane(res.v0, i), o0 = rdlane(f.v0, i), o1 = rdlane(f.v0, i + 1), o2 = rdlane(f.v0, i + 2);
+      // a contact that carries no force and is separating stays at zero (the ray update below would return 0)
+      if (o0 == 0 && o1 == 0 && o2 == 0 && r0 >= 0) { i += 3; continue; }
+      FB_BT(0);
+      real r1 = (real)rdlane(res.v0, i + 1), r2 = (real)rdlane(res.v0, i + 2);
+      real A00 = rdlane(cA00.v0, i), A01 = rdlane(cA01.v0, i), A02 = rdlane(cA02.v0, i);
+      real A11 = rdlane(cA11.v0, i), A12 = rdlane(cA12.v0, i), A22 = rdlane(cA22.v0, i);
+      real Ao0 = A00*o0 + A01*o1 + A02*o2, Ao1 = A01*o0 + A11*o1 + A12*o2, Ao2 = A02*o0 + A12*o1 + A22*o2;
+      real bc1 = r1 - Ao1, bc2 = r2 - Ao2;
+      // ray update, both candidates computed, one selected: along e1 when the contact is inactive, along the current force otherwise
+      const bool inact = o0 < FB_MINV;
+      real xa = -r0*rdlane(cI00.v0, i);
+      xa = (o0 + xa < 0) ? -o0 : xa;
+      real denom = o0*Ao0 + o1*Ao1 + o2*Ao2;
+      const bool dok = denom >= FB_MINV;
+      real xb = -fb_div(o0*r0 + o1*r1 + o2*r2, dok ? denom : (real)1);
+      xb = dok ? ((o0 + xb*o0 < 0) ? (real)-1 : xb) : (real)0;
+      real f0 = inact ? o0 + xa : o0 + xb*o0, f1 = inact ? o1 : o1 + xb*o1, f2 = inact ? o2 : o2 + xb*o2;
+      const bool dead = f0 < FB_MINV;
+      FB_BT(1);
+      // friction plane: min 0.5 x'Qx + x'b subject to |x| <= f0 in friction-scaled coordinates (eigenbasis of Q)
+      real d0 = rdlane(rfr0.v0, i), d1 = rdlane(rfr1.v0, i);
+      real b1 = (bc1 + A01*f0)*d0, b2 = (bc2 + A02*f0)*d1;
+      real ec = rdlane(cEc.v0, i), es = rdlane(cEs.v0, i), R1 = rdlane(cR1.v0, i), R2 = rdlane(cR2.v0, i);
+      const bool sing = (R1 == 0 && R2 == 0);                    // singular friction block: the friction force stays 0
+      real t1 = ec*b1 + es*b2, t2 = ec*b2 - es*b1;
+      real u1 = -t1*R1, u2 = -t2*R2;                              // unconstrained minimiser (multiplier 0)
+      const real rr = f0*f0;
+      real val = u1*u1 + u2*u2 - rr;
+      const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*rr + (real)1e-10;
+      real la = 0;
+      if (!dead && !sing && val >= tolv) {
+        // Newton iteration on the multiplier (FP64: from 0 with the reference's absolute thresholds; FP32: restarted from the
+        // multiplier of the previous sweep, thresholds at single-precision resolution)
+        real E1 = rdlane(cE1.v0, i), E2 = rdlane(cE2.v0, i);
+        bool run = true, deg = false;
+        if (sizeof(real) == 4) {
+          real law = rdlane(rla.v0, i);
+          if (law > 0) {
+            la = law;
+            real a1 = E1 + la, a2 = E2 + la;
+            deg = a1*a2 < (real)1e-10;
+            R1 = fb_div((real)1, a1); R2 = fb_div((real)1, a2);
+            u1 = -t1*R1; u2 = -t2*R2; val = u1*u1 + u2*u2 - rr;
+            run = !(deg || (val < tolv && val > -tolv));
+          }
+        }
+        if (run) {
+          real deriv = -(real)2*(u1*u1*R1 + u2*u2*R2);
+          real delta = -fb_div(val, deriv);
+          real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
+          bool stop = (sizeof(real) == 8) ? (delta < told) : (fabs(delta) < told);
+          for (int k = 1; k < 20 && !stop; k++) {
+            la += delta;
+            la = la < 0 ? (real)0 : la;
+            real a1 = E1 + la, a2 = E2 + la;
+            deg = a1*a2 < (real)1e-10;
+            R1 = fb_div((real)1, a1); R2 = fb_div((real)1, a2);
+            u1 = -t1*R1; u2 = -t2*R2;
+            val = u1*u1 + u2*u2 - rr;
+            deriv = -(real)2*(u1*u1*R1 + u2*u2*R2);
+            delta = -fb_div(val, deriv);
+            told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
+            // one exit test per pass: degenerate block, multiplier found (|u| on the circle), or the step has become negligible
+            stop = deg || (val < tolv && (sizeof(real) == 8 || val > -tolv)) || ((sizeof(real) == 8) ? (delta < told) : (fabs(delta) < told));
+          }
+        }
+        if (deg) { u1 = 0; u2 = 0; la = 0; }
+        // put the friction force exactly on the cone boundary
+        real s2 = u1*u1 + u2*u2;
+        const bool onb = (la != 0) && (s2 > FB_MINV*FB_MINV);
+        real kk = f0*fb_rsqrt(onb ? s2 : (real)1);
+        kk = onb ? kk : (real)1;
+        u1 *= kk; u2 *= kk;
+      }
+      if (sizeof(real) == 4) rla.v0 = (lane == i) ? la : rla.v0;
+      real v1 = ec*u1 - es*u2, v2 = es*u1 + ec*u2;
+      const bool nofr = dead || sing;
+      f0 = dead ? (real)0 : f0;
+      f1 = nofr ? (real)0 : v1*d0; f2 = nofr ? (real)0 : v2*d1;
+      FB_BT(2);
+      real e0 = f0 - o0, e1 = f1 - o1, e2 = f2 - o2;
+      real Ae0 = A00*e0 + A01*e1 + A02*e2, Ae1 = A01*e0 + A11*e1 + A12*e2, Ae2 = A02*e0 + A12*e1 + A22*e2;
+      improvement -= (real)0.5*(e0*Ae0 + e1*Ae1 + e2*Ae2) + (e0*r0 + e1*r1 + e2*r2);
+      res_axpy3<true>(res, AR, i, nefc, e0, e1, e2, lane);
+      f.v0 = (lane == i) ? f0 : ((lane == i + 1) ? f1 : ((lane == i + 2) ? f2 : f.v0));
+      FB_BT(3);
+      i += 3;
     }
     niter = it + 1;
     if (improvement*scale < tol_scaled) break;
-    // the sweeps are one long dependent chain that hardly uses the SIMD: let this wave win issue arbitration against the
-    // throughput-bound stages of its neighbours (measured -3%); the progress-based priority is restored after the loop
     if (it == 0) FB_SETPRIO(3);
+  }
+  } else
+#endif
+  {
+    for (int it = 0; it < max_it; it++) {
+      real improvement = 0;
+      for (int i = 0; i < nefc;) {
+        int type = r3_get<S>(rtype, i);
+        if (type != CN_ELLIPTIC) {
+          real r0 = (real)r3_get<S>(res, i);
+          real a = r3_get<S>(rdiag, i);
+          real old = r3_get<S>(f, i);
+          real fn = old - fb_div(r0, a);
+          if (fn < 0) fn = 0;
+          real del = fn - old;
+          improvement -= (real)0.5*del*del*a + del*r0;
+          if (del != 0) { res_axpy<S>(res, AR, i, nefc, del, lane); r3_set<S>(f, i, lane, fn); }
+          i += 1;
+        } else {
+          real r0 = (real)r3_get<S>(res, i), o0 = r3_get<S>(f, i), o1 = r3_get<S>(f, i+1), o2 = r3_get<S>(f, i+2);
+          // a contact that carries no force and is separating stays at zero (the ray update below would return 0)
+          if (o0 == 0 && o1 == 0 && o2 == 0 && r0 >= 0) { i += 3; continue; }
+          FB_BT(0);
+          real r1 = (real)r3_get<S>(res, i+1), r2 = (real)r3_get<S>(res, i+2);
+          real A00 = r3_get<S>(cA00, i), A01 = r3_get<S>(cA01, i), A02 = r3_get<S>(cA02, i);
+          real A11 = r3_get<S>(cA11, i), A12 = r3_get<S>(cA12, i), A22 = r3_get<S>(cA22, i);
+          // A*old and the part of the residual that does not depend on this block
+          real Ao0 = A00*o0 + A01*o1 + A02*o2, Ao1 = A01*o0 + A11*o1 + A12*o2, Ao2 = A02*o0 + A12*o1 + A22*o2;
+          real bc1 = r1 - Ao1, bc2 = r2 - Ao2;
+          // ray update: along e1 when the contact is inactive, along the current force otherwise
+          real f0, f1, f2;
+          if (o0 < FB_MINV) {
+            real x = -r0*r3_get<S>(cI00, i);           // 1/A00 (0 when A00 is degenerate: no move)
+            if (o0 + x < 0) x = -o0;
+            f0 = o0 + x; f1 = o1; f2 = o2;
+          } else {
+            real denom = o0*Ao0 + o1*Ao1 + o2*Ao2;
+            real x = 0;
+            if (denom >= FB_MINV) { x = -fb_div(o0*r0 + o1*r1 + o2*r2, denom); if (o0 + x*o0 < 0) x = -1; }
+            f0 = o0 + x*o0; f1 = o1 + x*o1; f2 = o2 + x*o2;
+          }
+          if (f0 < FB_MINV) { f0 = 0; f1 = 0; f2 = 0; }
+          else {
+            FB_BT(1);
+            // friction plane: min 0.5 x'Qx + x'b subject to |x| <= f0 in friction-scaled coordinates
+            real d0 = r3_get<S>(rfr0, i), d1 = r3_get<S>(rfr1, i);
+            real b1 = (bc1 + A01*f0)*d0, b2 = (bc2 + A02*f0)*d1;
+            real ec = r3_get<S>(cEc, i), es = r3_get<S>(cEs, i), R1 = r3_get<S>(cR1, i), R2 = r3_get<S>(cR2, i);
+            real v1 = 0, v2 = 0, la = 0;
+            bool active = false;
+            if (R1 != 0 || R2 != 0) {                   // (both zero: singular friction block, force stays 0)
+              real t1 = ec*b1 + es*b2, t2 = ec*b2 - es*b1;             // b in the eigenbasis
+              real u1 = -t1*R1, u2 = -t2*R2;                           // unconstrained minimiser (multiplier 0)
+              real rr = f0*f0;
+              real val = u1*u1 + u2*u2 - rr;
+              const real tolv = (sizeof(real) == 8) ? (real)1e-10 : (real)2e-6*rr + (real)1e-10;
+              if (val >= tolv) {
+                // Newton iteration on the multiplier (FP64: from 0 with the reference's absolute thresholds; FP32:
+                // restarted from the multiplier of the previous sweep, thresholds at single-precision resolution)
+                real E1 = r3_get<S>(cE1, i), E2 = r3_get<S>(cE2, i);
+                bool fresh = true;                      // (u, val, R) are the values at the current multiplier
+                if (sizeof(real) == 4) { real law = r3_get<S>(rla, i); if (law > 0) { la = law; fresh = false; } }
+                for (int k = 1; k < 20; k++) {
+                  if (!fresh) {
+                    real a1 = E1 + la, a2 = E2 + la;
+                    if (a1*a2 < (real)1e-10) { u1 = 0; u2 = 0; la = 0; break; }
+                    R1 = fb_div((real)1, a1); R2 = fb_div((real)1, a2);
+                    u1 = -t1*R1; u2 = -t2*R2;
+                    val = u1*u1 + u2*u2 - rr;
+                    if (val < tolv && (sizeof(real) == 8 || val > -tolv)) break;
+                  }
+                  real deriv = -(real)2*(u1*u1*R1 + u2*u2*R2);
+                  real delta = -fb_div(val, deriv);
+                  const real told = (sizeof(real) == 8) ? (real)1e-10 : (real)1e-6*la + (real)1e-10;
+                  if (sizeof(real) == 8) { if (delta < told) break; }
+                  else if (fabs(delta) < told) break;
+                  la += delta;
+                  if (la < 0) la = 0;
+                  fresh = false;
+                }
+                active = la != 0;
+              }
+              if (sizeof(real) == 4) r3_set<S>(rla, i, lane, la);
+              if (active) {
+                // put the friction force exactly on the cone boundary
+                real s2 = u1*u1 + u2*u2;
+                if (s2 > FB_MINV*FB_MINV) { real k = f0*fb_rsqrt(s2); u1 *= k; u2 *= k; }
+              }
+              v1 = ec*u1 - es*u2; v2 = es*u1 + ec*u2;
+            }
+            f1 = v1*d0; f2 = v2*d1;
+          }
+          FB_BT(2);
+          real e0 = f0 - o0, e1 = f1 - o1, e2 = f2 - o2;
+          real Ae0 = A00*e0 + A01*e1 + A02*e2, Ae1 = A01*e0 + A11*e1 + A12*e2, Ae2 = A02*e0 + A12*e1 + A22*e2;
+          improvement -= (real)0.5*(e0*Ae0 + e1*Ae1 + e2*Ae2) + (e0*r0 + e1*r1 + e2*r2);
+          // the three rows are read together (a zero delta leaves the residual unchanged, so no test is needed)
+          res_axpy3<S>(res, AR, i, nefc, e0, e1, e2, lane);
+          r3_set<S>(f, i, lane, f0); r3_set<S>(f, i+1, lane, f1); r3_set<S>(f, i+2, lane, f2);
+          FB_BT(3);
+          i += 3;
+        }
+      }
+      niter = it + 1;
+      if (improvement*scale < tol_scaled) break;
+      // the sweeps are one long dependent chain that hardly uses the SIMD: let this wave win issue arbitration against the
+      // throughput-bound stages of its neighbours (measured -3%); the progress-based priority is restored after the loop
+      if (it == 0) FB_SETPRIO(3);
+    }
   }
   FB_SETPRIO(uniform_int(w.istate()[IS_PRIO]));
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
