@@ -14,7 +14,7 @@ extern "C" const char* fbl_last_error(void) { return g_lerr.c_str(); }
 #ifndef FB_BUILD_ID
 #define FB_BUILD_ID "unversioned"
 #endif
-extern "C" const char* fbl_version(void) { return "flybody_learner 1 (gfx950, " FB_BUILD_ID ")"; }
+extern "C" const char* fbl_version(void) { return "flybody_learner 2 (gfx950, " FB_BUILD_ID ")"; }
 #define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return lfail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 #define WAVE 64
@@ -22,178 +22,232 @@ extern "C" const char* fbl_version(void) { return "flybody_learner 1 (gfx950, " 
 #define MIN_LOG (-18.0f)   // losses_mpo.py:30 _MPO_FLOAT_EPSILON / _MIN_LOG_TEMPERATURE
 #define FEPS 1e-8f
 
-__device__ __forceinline__ float wsum(float v) { for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE); return v; }
-__device__ __forceinline__ float wmax(float v) { for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE)); return v; }
-__device__ __forceinline__ float wmin(float v) { for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, WAVE)); return v; }
+// Wavefront reductions on the DPP datapath (no LDS crossbar): butterfly inside each row of 16 lanes (quad_perm x2, row_half_mirror,
+// row_mirror), then row_bcast15 / row_bcast31 fold the four rows into lane 63, whose value is read back as a wave-uniform scalar.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+#define WAVE_REDUCE(NAME, OP, IDENT)                                                   \
+  __device__ __forceinline__ float NAME(float v) {                                     \
+    v = OP(v, dpp_f<0xB1, 0xF>(IDENT, v));  /* quad_perm [1,0,3,2] */                    \
+    v = OP(v, dpp_f<0x4E, 0xF>(IDENT, v));  /* quad_perm [2,3,0,1] */                    \
+    v = OP(v, dpp_f<0x141, 0xF>(IDENT, v)); /* row_half_mirror */                        \
+    v = OP(v, dpp_f<0x140, 0xF>(IDENT, v)); /* row_mirror */                             \
+    v = OP(v, dpp_f<0x142, 0xA>(IDENT, v)); /* row_bcast15 -> rows 1, 3 */               \
+    v = OP(v, dpp_f<0x143, 0xC>(IDENT, v)); /* row_bcast31 -> rows 2, 3 */               \
+    return rl(v, 63);                                                                  \
+  }
+__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
+WAVE_REDUCE(wsum, op_add, 0.f)
+WAVE_REDUCE(wmax, fmaxf, -INFINITY)
+WAVE_REDUCE(wmin, fminf, INFINITY)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f/(1.f + expf(-x)); }
 
 // ------------------------------------------------------------------ categorical TD loss
-__global__ void __launch_bounds__(WAVE) k_td(const float* __restrict__ qt, const float* __restrict__ q1, const float* __restrict__ values,
-                                             const float* __restrict__ reward, const float* __restrict__ discount, float gamma, int N, int B, int K,
-                                             float* __restrict__ sampled_q, float* __restrict__ dlogits, float* __restrict__ loss) {
-  const int b = blockIdx.x, k = threadIdx.x;
-  const bool valid = k < K;
+// Four wavefronts per batch row (lane == atom), TD_ROWS rows per workgroup.  The row's work is a chain of dependent wave reductions and
+// transcendentals, so it is the chain that is cut: the N target heads are split over the four waves (each keeps a running
+// logsumexp of log p_n[k]; combined through LDS) and so are the K source atoms of the Cramer projection.  The logits arrive WITHOUT
+// their bias (the GEMMs run without an epilogue): bias_t / bias_1 are added here; the bias gradient (column sum of d_logits) and
+// the batch-mean loss are summed over the workgroup's rows in LDS and leave with one atomic per column and workgroup (same-address
+// atomics cost ~20 ns each on this part, measured: the chain length B / TD_ROWS is what they add to the kernel).
+#define TD_ROWS 4
+__global__ void __launch_bounds__(256*TD_ROWS) k_td(const float* __restrict__ qt, const float* __restrict__ bias_t, const float* __restrict__ q1,
+                                                   const float* __restrict__ bias_1, const float* __restrict__ values, const float* __restrict__ reward,
+                                                   const float* __restrict__ discount, float gamma, int N, int B, int K, float* __restrict__ sampled_q,
+                                                   float* __restrict__ dlogits, float* __restrict__ dbias, float* __restrict__ loss, float* __restrict__ loss_mean) {
+  __shared__ float sM[TD_ROWS][4][WAVE], sS[TD_ROWS][4][WAVE], sT[TD_ROWS][4][WAVE], sD[TD_ROWS][WAVE], sL[TD_ROWS];
+  const int k = threadIdx.x & 63, w = threadIdx.x >> 6, row = w >> 2, wv = w & 3, b = blockIdx.x*TD_ROWS + row;
+  const bool valid = k < K, live = b < B;
   const float NEG = -INFINITY;
   const float vk = valid ? values[k] : 0.f;
-  float Mk = NEG, Sk = 0.f;                                   // running logsumexp over the N samples of log p_n[k]
-  for (int n = 0; n < N; n++) {
-    float x = valid ? qt[((size_t)n*B + b)*K + k] : NEG;
-    float m = wmax(x);
-    float e = valid ? expf(x - m) : 0.f;
-    float s = wsum(e);
-    float logp = x - m - logf(s);
-    float q = wsum(e*vk)/s;
-    if (k == 0) sampled_q[(size_t)n*B + b] = q;
-    if (valid) {
-      if (logp > Mk) { Sk = Sk*expf(Mk - logp) + 1.f; Mk = logp; } else Sk += expf(logp - Mk);
+  const float bt = (valid && bias_t) ? bias_t[k] : 0.f;
+  const float x1 = (valid && live && wv == 0) ? q1[(size_t)b*K + k] + (bias_1 ? bias_1[k] : 0.f) : NEG;
+  const float rb = live ? reward[b] : 0.f, db = live ? gamma*discount[b] : 0.f;
+  float Mk = NEG, Sk = 0.f;                                   // running logsumexp over this wave's samples of log p_n[k]
+  float xn = (valid && live && wv < N) ? qt[((size_t)wv*B + b)*K + k] + bt : NEG;
+  if (live)
+    for (int n = wv; n < N; n += 4) {
+      const float x = xn;
+      if (n + 4 < N) xn = valid ? qt[((size_t)(n + 4)*B + b)*K + k] + bt : NEG;   // the next head's logits are in flight during the reductions
+      float m = wmax(x);
+      float e = valid ? expf(x - m) : 0.f;
+      float s = wsum(e);
+      float logp = x - m - logf(s);
+      float q = wsum(e*vk)/s;
+      if (k == 0) sampled_q[(size_t)n*B + b] = q;
+      if (valid) {
+        if (logp > Mk) { Sk = Sk*expf(Mk - logp) + 1.f; Mk = logp; } else Sk += expf(logp - Mk);
+      }
     }
-  }
-  float avg = valid ? Mk + logf(Sk) : NEG;
+  sM[row][wv][k] = Mk; sS[row][wv][k] = Sk;
+  __syncthreads();
+  float Mx = fmaxf(fmaxf(sM[row][0][k], sM[row][1][k]), fmaxf(sM[row][2][k], sM[row][3][k])), Sx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { float mw = sM[row][q][k]; if (mw > NEG) Sx += sS[row][q][k]*expf(mw - Mx); }
+  float avg = (valid && Mx > NEG) ? Mx + logf(Sx) : NEG;
   float m = wmax(avg);
-  float e = valid ? expf(avg - m) : 0.f;
-  float pt = e/wsum(e);                                       // p_t = softmax(log sum_n p_n)
+  float e = (valid && avg > NEG) ? expf(avg - m) : 0.f;
+  float se = wsum(e);
+  float pt = se > 0.f ? e/se : 0.f;                           // p_t = softmax(log sum_n p_n)
   const float vmin = values[0], vmax = values[K - 1];
-  float z = fminf(fmaxf(reward[b] + gamma*discount[b]*vk, vmin), vmax);
-  // projection onto atom j == lane (acme losses.l2_project)
+  float z = fminf(fmaxf(rb + db*vk, vmin), vmax);
+  // projection onto atom j == lane (acme losses.l2_project); source atoms kk = wv, wv + 4, ... as wave-uniform scalars
   float dpos = (valid && k + 1 < K) ? 1.f/(values[k + 1] - vk) : 0.f;
   float dneg = (valid && k > 0) ? 1.f/(vk - values[k - 1]) : 0.f;
   float target = 0.f;
-  for (int kk = 0; kk < K; kk++) {
-    float pk = __shfl(pt, kk, WAVE), zk = __shfl(z, kk, WAVE);
+  for (int kk = wv; kk < K; kk += 4) {
+    float pk = rl(pt, kk), zk = rl(z, kk);
     float delta = zk - vk;
     float dh = delta >= 0.f ? delta*dpos : -delta*dneg;
     target += fminf(fmaxf(1.f - dh, 0.f), 1.f)*pk;
   }
-  if (!valid) target = 0.f;
-  float x1 = valid ? q1[(size_t)b*K + k] : NEG;
-  float m1 = wmax(x1);
-  float e1 = valid ? expf(x1 - m1) : 0.f;
-  float s1 = wsum(e1);
-  float logq = x1 - m1 - logf(s1);
-  float lb = -wsum(valid ? target*logq : 0.f);
-  float tsum = wsum(target);
-  if (valid) dlogits[(size_t)b*K + k] = (e1/s1*tsum - target)/(float)B;
-  if (k == 0) loss[b] = lb;
+  sT[row][wv][k] = target;
+  __syncthreads();
+  if (wv == 0) {
+    float dl = 0.f, lb = 0.f;
+    if (live) {
+      target = valid ? sT[row][0][k] + sT[row][1][k] + sT[row][2][k] + sT[row][3][k] : 0.f;
+      float m1 = wmax(x1);
+      float e1 = valid ? expf(x1 - m1) : 0.f;
+      float s1 = wsum(e1);
+      float logq = x1 - m1 - logf(s1);
+      lb = -wsum(valid ? target*logq : 0.f);
+      float tsum = wsum(target);
+      if (valid) { dl = (e1/s1*tsum - target)/(float)B; dlogits[(size_t)b*K + k] = dl; }
+      if (k == 0) loss[b] = lb;
+    }
+    sD[row][k] = dl;
+    if (k == 0) sL[row] = lb;
+  }
+  __syncthreads();
+  if (w != 0) return;
+  float cs = 0.f, ls = 0.f;
+#pragma unroll
+  for (int r = 0; r < TD_ROWS; r++) { cs += sD[r][k]; ls += sL[r]; }
+  if (valid && dbias) atomicAdd(dbias + k, cs);
+  if (k == 0 && loss_mean) atomicAdd(loss_mean, ls/(float)B);
 }
 
-extern "C" int fbl_td_loss(const float* q_t_logits, const float* q_tm1_logits, const float* values, const float* reward, const float* discount,
-                           float gamma, int N, int B, int K, float* sampled_q, float* d_logits, float* loss, void* stream) {
+extern "C" int fbl_td_loss(const float* q_t_logits, const float* bias_t, const float* q_tm1_logits, const float* bias_tm1, const float* values,
+                           const float* reward, const float* discount, float gamma, int N, int B, int K, float* sampled_q, float* d_logits,
+                           float* d_bias, float* loss, float* loss_mean, void* stream) {
   if (!q_t_logits || !q_tm1_logits || !values || !reward || !discount || !sampled_q || !d_logits || !loss) return lfail("fbl_td_loss: null argument");
   if (N <= 0 || B <= 0 || K < 2 || K > WAVE) return lfail("fbl_td_loss: need N, B > 0 and 2 <= K <= 64");
-  hipLaunchKernelGGL(k_td, dim3(B), dim3(WAVE), 0, (hipStream_t)stream, q_t_logits, q_tm1_logits, values, reward, discount, gamma, N, B, K, sampled_q, d_logits, loss);
+  hipLaunchKernelGGL(k_td, dim3((B + TD_ROWS - 1)/TD_ROWS), dim3(256*TD_ROWS), 0, (hipStream_t)stream, q_t_logits, bias_t, q_tm1_logits, bias_tm1, values, reward, discount, gamma, N, B, K,
+                     sampled_q, d_logits, d_bias, loss, loss_mean);
   LCHK(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ MPO loss
+// Launch 1 (k_mpo): a wavefront per batch row (MPO_ROWS rows per workgroup) computes the row's E-step weights, the gradients wrt the
+// online mean / stddev and the row's contribution to every batch sum (per-dimension KLs + 12 scalars); the workgroup's rows are
+// summed in LDS and added to the accumulator block with one atomic per slot.  Launch 2 (k_mpo_fin, one wavefront): batch means,
+// dual gradients, loss value, statistics -- and the accumulator block is zero again for the next step.
 enum { WS_LSE = 0, WS_WTQ, WS_KLNP, WS_LSEP, WS_PWTP, WS_KLNPP, WS_LPM, WS_LPS, WS_QMIN, WS_QMAX, WS_SMIN, WS_SMAX, WS_NSCALAR = 16 };
+#define MPO_ROWS 8
 
-__global__ void __launch_bounds__(WAVE) k_mpo(fbl_mpo_args a) {
-  const int b = blockIdx.x, d = threadIdx.x, N = a.N, B = a.B, D = a.D;
+__global__ void __launch_bounds__(WAVE*MPO_ROWS) k_mpo(fbl_mpo_args a) {
+  __shared__ float sA[MPO_ROWS][3][WAVE];
+  const int d = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.x*MPO_ROWS + wv, N = a.N, B = a.B, D = a.D;
   const bool vd = d < D, vn = d < N;
   const float NEG = -INFINITY;
-  const float T = softplus_f(fmaxf(a.log_temperature[0], MIN_LOG)) + FEPS;
-  const float am = vd ? softplus_f(fmaxf(a.log_alpha_mean[d], MIN_LOG)) + FEPS : 0.f;
-  const float as = vd ? softplus_f(fmaxf(a.log_alpha_stddev[d], MIN_LOG)) + FEPS : 0.f;
-  const size_t bd = (size_t)b*D + d;
-  const float om = vd ? a.online_mean[bd] : 0.f, os = vd ? a.online_std[bd] : 1.f, tm = vd ? a.target_mean[bd] : 0.f, ts = vd ? a.target_std[bd] : 1.f;
-  // E-step weights over the N samples: lane n holds sample n
-  float qn = vn ? a.q[(size_t)d*B + b] : NEG;
-  float tq = vn ? qn/T : NEG;
-  float mx = wmax(tq);
-  float e = vn ? expf(tq - mx) : 0.f;
-  float s = wsum(e);
-  float w = e/s;
-  float lse = mx + logf(s);
-  float klnp = wsum(vn ? w*logf((float)N*w + 1e-8f) : 0.f);
-  float wtq = wsum(vn ? w*tq : 0.f);
-  float qmin = wmin(vn ? qn : INFINITY), qmax = wmax(vn ? qn : NEG);
-  // the actions of this row in registers: areg[n] = a[n][b][d]
-  float areg[MAXN];
+  float klm = 0.f, kls = 0.f, scal = 0.f;
+  if (b < B) {
+    const float T = softplus_f(fmaxf(a.log_temperature[0], MIN_LOG)) + FEPS;
+    const float am = vd ? softplus_f(fmaxf(a.log_alpha_mean[d], MIN_LOG)) + FEPS : 0.f;
+    const float as = vd ? softplus_f(fmaxf(a.log_alpha_stddev[d], MIN_LOG)) + FEPS : 0.f;
+    const size_t bd = (size_t)b*D + d;
+    const float om = vd ? a.online_mean[bd] : 0.f, os = vd ? a.online_std[bd] : 1.f, tm = vd ? a.target_mean[bd] : 0.f, ts = vd ? a.target_std[bd] : 1.f;
+    // the actions of this row in registers: areg[n] = a[n][b][d]  (all loads issued before the first reduction)
+    float areg[MAXN];
 #pragma unroll
-  for (int n = 0; n < MAXN; n++) areg[n] = (n < N && vd) ? a.actions[((size_t)n*B + b)*D + d] : 0.f;
-  float W = w, lsep = 0.f, klnpp = 0.f, pwtp = 0.f;
-  if (a.action_penalization) {
-    const float pT = softplus_f(fmaxf(a.log_penalty_temperature[0], MIN_LOG)) + FEPS;
-    const float sc = (vd && a.pen_scale) ? a.pen_scale[d] : 2.f, of = (vd && a.pen_offset) ? a.pen_offset[d] : -1.f;     // defaults: real == a
-    float cn = NEG;
+    for (int n = 0; n < MAXN; n++) areg[n] = (n < N && vd) ? a.actions[((size_t)n*B + b)*D + d] : 0.f;
+    // E-step weights over the N samples: lane n holds sample n
+    float qn = vn ? a.q[(size_t)d*B + b] : NEG;
+    float tq = vn ? qn/T : NEG;
+    float mx = wmax(tq);
+    float e = vn ? expf(tq - mx) : 0.f;
+    float s = wsum(e);
+    float w = e/s;
+    float lse = mx + logf(s);
+    float klnp = wsum(vn ? w*logf((float)N*w + 1e-8f) : 0.f);
+    float wtq = wsum(vn ? w*tq : 0.f);
+    float qmin = wmin(vn ? qn : INFINITY), qmax = wmax(vn ? qn : NEG);
+    float W = w, lsep = 0.f, klnpp = 0.f, pwtp = 0.f;
+    if (a.action_penalization) {
+      const float pT = softplus_f(fmaxf(a.log_penalty_temperature[0], MIN_LOG)) + FEPS;
+      const float sc = (vd && a.pen_scale) ? a.pen_scale[d] : 2.f, of = (vd && a.pen_offset) ? a.pen_offset[d] : -1.f;     // defaults: real == a
+      float cn = NEG;                                           // lane n: -||real action of sample n||
+#pragma unroll
+      for (int n = 0; n < MAXN; n++) {
+        if (n < N) {
+          float r = vd ? 0.5f*(areg[n] + 1.f)*sc + of : 0.f;
+          float c2 = wsum(r*r);
+          cn = d == n ? -sqrtf(c2) : cn;
+        }
+      }
+      float tp = vn ? cn/pT : NEG;
+      float mp = wmax(tp);
+      float ep = vn ? expf(tp - mp) : 0.f;
+      float sp = wsum(ep);
+      float pw = ep/sp;
+      lsep = mp + logf(sp);
+      klnpp = wsum(vn ? pw*logf((float)N*pw + 1e-8f) : 0.f);
+      pwtp = wsum(vn ? pw*tp : 0.f);
+      W = w + pw;
+    }
+    // M-step: decoupled cross-entropies (fixed-stddev mean update, fixed-mean stddev update); lane-local sums over the samples,
+    // ONE reduction over the action dimensions at the end.  W of sample n is a wave-uniform scalar (readlane).
+    const float its = 1.f/ts, ios = 1.f/os;
+    const float c0 = 0.91893853320467274f;                       // 0.5 log(2 pi)
+    const float lts = logf(ts) + c0, los = logf(os) + c0;
+    float gm = 0.f, gs = 0.f, lpm = 0.f, lps = 0.f;
 #pragma unroll
     for (int n = 0; n < MAXN; n++) {
-      if (n < N) {
-        float r = vd ? 0.5f*(areg[n] + 1.f)*sc + of : 0.f;
-        float c2 = wsum(r*r);
-        if (d == n) cn = -sqrtf(c2);
-      }
-    }
-    float tp = vn ? cn/pT : NEG;
-    float mp = wmax(tp);
-    float ep = vn ? expf(tp - mp) : 0.f;
-    float sp = wsum(ep);
-    float pw = ep/sp;
-    lsep = mp + logf(sp);
-    klnpp = wsum(vn ? pw*logf((float)N*pw + 1e-8f) : 0.f);
-    pwtp = wsum(vn ? pw*tp : 0.f);
-    W = w + pw;
-  }
-  // M-step: decoupled cross-entropies (fixed-stddev mean update, fixed-mean stddev update)
-  const float its = 1.f/ts, ios = 1.f/os;
-  const float c0 = 0.91893853320467274f;                       // 0.5 log(2 pi)
-  float gm = 0.f, gs = 0.f, lpm = 0.f, lps = 0.f;
-#pragma unroll
-  for (int n = 0; n < MAXN; n++) {
-    if (n < N) {
-      float Wn = __shfl(W, n, WAVE);
+      const float Wn = n < N ? rl(W, n) : 0.f;
       float dm = areg[n] - om, dt = areg[n] - tm;
       gm += Wn*dm;
       gs += Wn*(dt*dt*ios*ios*ios - ios);
-      float t1 = vd ? -0.5f*(dm*its)*(dm*its) - logf(ts) - c0 : 0.f;
-      float t2 = vd ? -0.5f*(dt*ios)*(dt*ios) - logf(os) - c0 : 0.f;
-      lpm -= Wn*wsum(t1); lps -= Wn*wsum(t2);
+      lpm += Wn*(0.5f*(dm*its)*(dm*its) + lts);
+      lps += Wn*(0.5f*(dt*ios)*(dt*ios) + los);
     }
+    lpm = wsum(vd ? lpm : 0.f); lps = wsum(vd ? lps : 0.f);
+    const float invB = 1.f/(float)B;
+    if (vd) {
+      a.d_online_mean[bd] = (-gm*its*its + am*(om - tm)*its*its)*invB;
+      a.d_online_std[bd] = (-gs + as*(ios - ts*ts*ios*ios*ios))*invB;
+      klm = (tm - om)*(tm - om)*0.5f*its*its;                                         // KL(target || online mean, target std)
+      kls = logf(os*its) + ts*ts*0.5f*ios*ios - 0.5f;                                 // KL(target || target mean, online std)
+    }
+    float smin = wmin(vd ? os : INFINITY), smax = wmax(vd ? os : NEG);
+    float v = 0.f;
+    v = d == WS_LSE ? lse : v; v = d == WS_WTQ ? wtq : v; v = d == WS_KLNP ? klnp : v; v = d == WS_LSEP ? lsep : v; v = d == WS_PWTP ? pwtp : v;
+    v = d == WS_KLNPP ? klnpp : v; v = d == WS_LPM ? lpm : v; v = d == WS_LPS ? lps : v; v = d == WS_QMIN ? qmin : v; v = d == WS_QMAX ? qmax : v;
+    v = d == WS_SMIN ? smin : v; v = d == WS_SMAX ? smax : v;
+    scal = v;
   }
-  const float invB = 1.f/(float)B;
-  if (vd) {
-    a.d_online_mean[bd] = (-gm*its*its + am*(om - tm)*its*its)*invB;
-    a.d_online_std[bd] = (-gs + as*(ios - ts*ts*ios*ios*ios))*invB;
-  }
-  float* ws = a.workspace + (size_t)b*(2*D + WS_NSCALAR);
-  if (vd) {
-    ws[d] = (tm - om)*(tm - om)*0.5f*its*its;                                         // KL(target || online mean, target std)
-    ws[D + d] = logf(os*its) + ts*ts*0.5f*ios*ios - 0.5f;                             // KL(target || target mean, online std)
-  }
-  float smin = wmin(vd ? os : INFINITY), smax = wmax(vd ? os : NEG);
-  if (d == 0) {
-    float* sc = ws + 2*D;
-    sc[WS_LSE] = lse; sc[WS_WTQ] = wtq; sc[WS_KLNP] = klnp; sc[WS_LSEP] = lsep; sc[WS_PWTP] = pwtp; sc[WS_KLNPP] = klnpp;
-    sc[WS_LPM] = lpm; sc[WS_LPS] = lps; sc[WS_QMIN] = qmin; sc[WS_QMAX] = qmax; sc[WS_SMIN] = smin; sc[WS_SMAX] = smax;
-  }
-}
-
-// sums over the batch (four wavefronts split the rows; lane == action dimension / scalar slot), dual gradients, loss value and
-// statistics
-__global__ void __launch_bounds__(1024) k_mpo_reduce(fbl_mpo_args a) {
-  __shared__ float part[3][16][WAVE];
-  const int d = threadIdx.x & 63, wv = threadIdx.x >> 6, N = a.N, B = a.B, D = a.D;
-  const bool vd = d < D;
-  const int stride = 2*D + WS_NSCALAR;
-  float km = 0.f, ks = 0.f, sc = 0.f;
-  const bool minslot = (d == WS_QMIN || d == WS_QMAX || d == WS_SMIN || d == WS_SMAX);       // (batch MEANS of the per-row min / max)
-  (void)minslot;
-#pragma unroll 4
-  for (int b = wv; b < B; b += 16) {
-    const float* ws = a.workspace + (size_t)b*stride;
-    if (vd) { km += ws[d]; ks += ws[D + d]; }
-    if (d < WS_NSCALAR) sc += ws[2*D + d];
-  }
-  part[0][wv][d] = km; part[1][wv][d] = ks; part[2][wv][d] = sc;
+  sA[wv][0][d] = klm; sA[wv][1][d] = kls; sA[wv][2][d] = scal;
   __syncthreads();
   if (wv != 0) return;
-  km = 0.f; ks = 0.f; sc = 0.f;
+  klm = 0.f; kls = 0.f; scal = 0.f;
 #pragma unroll
-  for (int q = 0; q < 16; q++) { km += part[0][q][d]; ks += part[1][q][d]; sc += part[2][q][d]; }
+  for (int w = 0; w < MPO_ROWS; w++) { klm += sA[w][0][d]; kls += sA[w][1][d]; scal += sA[w][2][d]; }
+  float* acc = a.workspace;                                     // [2 D + WS_NSCALAR] sums over the batch
+  if (vd) { atomicAdd(acc + d, klm); atomicAdd(acc + D + d, kls); }
+  if (d <= WS_SMAX) atomicAdd(acc + 2*D + d, scal);
+}
+
+__global__ void __launch_bounds__(WAVE) k_mpo_fin(fbl_mpo_args a) {
+  const int d = threadIdx.x, N = a.N, B = a.B, D = a.D;
+  const bool vd = d < D;
   const float invB = 1.f/(float)B;
-  km *= invB; ks *= invB; sc *= invB;
+  float* acc = a.workspace;
+  float km = vd ? acc[d]*invB : 0.f, ks = vd ? acc[D + d]*invB : 0.f, sc = d < WS_NSCALAR ? acc[2*D + d]*invB : 0.f;
+  if (vd) { acc[d] = 0.f; acc[D + d] = 0.f; }
+  if (d < WS_NSCALAR) acc[2*D + d] = 0.f;
   // clamp the duals in place (MPO.__call__ projects them before use)
   float lam = vd ? fmaxf(a.log_alpha_mean[d], MIN_LOG) : 0.f, las = vd ? fmaxf(a.log_alpha_stddev[d], MIN_LOG) : 0.f;
   if (vd) { a.log_alpha_mean[d] = lam; a.log_alpha_stddev[d] = las; }
@@ -205,10 +259,9 @@ __global__ void __launch_bounds__(1024) k_mpo_reduce(fbl_mpo_args a) {
   float loss_kl_mean = wsum(am*km), loss_kl_std = wsum(as*ks);
   float loss_alpha = wsum(vd ? am*(a.epsilon_mean - km) + as*(a.epsilon_stddev - ks) : 0.f);
   float kl_mean_rel = wsum(vd ? km : 0.f)/((float)D*a.epsilon_mean), kl_std_rel = wsum(vd ? ks : 0.f)/((float)D*a.epsilon_stddev);
-  float v_lse = __shfl(sc, WS_LSE, WAVE), v_wtq = __shfl(sc, WS_WTQ, WAVE), v_klnp = __shfl(sc, WS_KLNP, WAVE);
-  float v_lsep = __shfl(sc, WS_LSEP, WAVE), v_pwtp = __shfl(sc, WS_PWTP, WAVE), v_klnpp = __shfl(sc, WS_KLNPP, WAVE);
-  float v_lpm = __shfl(sc, WS_LPM, WAVE), v_lps = __shfl(sc, WS_LPS, WAVE);
-  float v_qmin = __shfl(sc, WS_QMIN, WAVE), v_qmax = __shfl(sc, WS_QMAX, WAVE), v_smin = __shfl(sc, WS_SMIN, WAVE), v_smax = __shfl(sc, WS_SMAX, WAVE);
+  float am_mean = wsum(am)/(float)D, as_mean = wsum(as)/(float)D;
+  float v_lse = rl(sc, WS_LSE), v_wtq = rl(sc, WS_WTQ), v_klnp = rl(sc, WS_KLNP), v_lsep = rl(sc, WS_LSEP), v_pwtp = rl(sc, WS_PWTP), v_klnpp = rl(sc, WS_KLNPP);
+  float v_lpm = rl(sc, WS_LPM), v_lps = rl(sc, WS_LPS), v_qmin = rl(sc, WS_QMIN), v_qmax = rl(sc, WS_QMAX), v_smin = rl(sc, WS_SMIN), v_smax = rl(sc, WS_SMAX);
   if (d == 0) {
     const float logN = logf((float)N);
     float lt = fmaxf(a.log_temperature[0], MIN_LOG); a.log_temperature[0] = lt;
@@ -227,11 +280,11 @@ __global__ void __launch_bounds__(1024) k_mpo_reduce(fbl_mpo_args a) {
     st[0] = v_lpm + v_lps + loss_kl_mean + loss_kl_std + loss_alpha + loss_T;
     st[1] = v_lpm; st[2] = v_lps; st[3] = loss_kl_mean; st[4] = loss_kl_std; st[5] = loss_alpha; st[6] = loss_T;
     st[7] = v_klnp/a.epsilon; st[8] = pen_rel; st[9] = kl_mean_rel; st[10] = kl_std_rel;
-    st[11] = v_qmin; st[12] = v_qmax; st[13] = v_smin; st[14] = v_smax; st[15] = T;
+    st[11] = v_qmin; st[12] = v_qmax; st[13] = v_smin; st[14] = v_smax; st[15] = T; st[16] = am_mean; st[17] = as_mean;
   }
 }
 
-extern "C" size_t fbl_mpo_workspace_floats(int B, int D) { return (size_t)B*(2*(size_t)D + WS_NSCALAR); }
+extern "C" size_t fbl_mpo_workspace_floats(int B, int D) { (void)B; return 2*(size_t)D + WS_NSCALAR; }
 
 extern "C" int fbl_mpo_loss(const fbl_mpo_args* a, void* stream) {
   if (!a) return lfail("fbl_mpo_loss: null argument");
@@ -240,98 +293,324 @@ extern "C" int fbl_mpo_loss(const fbl_mpo_args* a, void* stream) {
       !a->log_alpha_stddev || !a->d_online_mean || !a->d_online_std || !a->d_log_temperature || !a->d_log_alpha_mean || !a->d_log_alpha_stddev ||
       !a->stats || !a->workspace || (a->action_penalization && (!a->log_penalty_temperature || !a->d_log_penalty_temperature)))
     return lfail("fbl_mpo_loss: null pointer in the argument block");
-  hipLaunchKernelGGL(k_mpo, dim3(a->B), dim3(WAVE), 0, (hipStream_t)stream, *a);
-  hipLaunchKernelGGL(k_mpo_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(k_mpo, dim3((a->B + MPO_ROWS - 1)/MPO_ROWS), dim3(WAVE*MPO_ROWS), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(k_mpo_fin, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, *a);
   LCHK(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ clipped Adam on a flat buffer
+#define NORM_SLOTS 32
+// Step bookkeeping without fences or memsets.  step[0] = completed updates (written by k_adam), step[1] = the update in
+// flight (written by the norm pass: k_gather_flat or k_sqnorm).  The squared group norms are double-buffered on the parity of
+// step[0]: the norm pass of update t accumulates into norms[(t-1) & 1], k_adam(t) reads that half and clears the OTHER one, which
+// is where update t+1 will accumulate.  Within a kernel nobody reads what the same kernel writes.  Each half holds NORM_SLOTS
+// partial sums per segment (workgroup w adds to slot w mod NORM_SLOTS): a same-address atomic costs ~20 ns on this part, so one
+// slot would serialise ~1100 workgroups into ~20 us; k_adam adds the slots up.
 struct AdamSegs { int nseg; long long end[8]; float lr[8], clip[8], floor_[8]; };
 
-__global__ void __launch_bounds__(256) k_sqnorm(const float* __restrict__ g, long long n, AdamSegs sg, float* __restrict__ norms, float* __restrict__ step) {
+__device__ __forceinline__ int seg_of(const AdamSegs& sg, long long i) {
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < 7; q++) if (q + 1 < sg.nseg && i >= sg.end[q]) s = q + 1;
+  return s;
+}
+
+// block-level sum of the per-thread per-segment squares -> one atomic per segment and workgroup
+__device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __restrict__ norms, float* __restrict__ step) {
   __shared__ float red[8][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int par = ((int)step[0]) & 1;
+#pragma unroll
+  for (int s = 0; s < 8; s++) { float t = wsum(acc[s]); if (lane == 0) red[s][wv] = t; }
+  __syncthreads();
+  if (threadIdx.x < 8 && threadIdx.x < nseg)
+    atomicAdd(norms + (par*NORM_SLOTS + (blockIdx.x & (NORM_SLOTS - 1)))*8 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) step[1] = step[0] + 1.f;
+}
+
+__global__ void __launch_bounds__(256) k_sqnorm(const float* __restrict__ g, long long n, AdamSegs sg, float* __restrict__ norms, float* __restrict__ step) {
   float acc[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) acc[s] = 0.f;
   for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
-    float v = g[i]; int s = 0;
-#pragma unroll
-    for (int q = 0; q < 7; q++) if (q + 1 < sg.nseg && i >= sg.end[q]) s = q + 1;
+    float v = g[i]; int s = seg_of(sg, i);
 #pragma unroll
     for (int q = 0; q < 8; q++) if (q == s) acc[q] += v*v;
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int s = 0; s < 8; s++) { float t = wsum(acc[s]); if (lane == 0) red[s][wv] = t; }
-  __syncthreads();
-  if (threadIdx.x < 8 && threadIdx.x < sg.nseg) atomicAdd(norms + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) step[0] += 1.f;
+  norm_commit(acc, sg.nseg, norms, step);
 }
 
+struct AdamOut { float p, m, v; };
+__device__ __forceinline__ AdamOut adam_one(float p, float g, float m, float v, long long i, const AdamSegs& sg, const float* __restrict__ nrm, float b1,
+                                            float b2, float eps, float bc1, float bc2s) {
+  float lr = sg.lr[0], clip = sg.clip[0], fl = sg.floor_[0], nn = nrm[0];
+#pragma unroll
+  for (int q = 1; q < 8; q++) {                                // (static indices only: the segment table stays in scalar registers)
+    const bool in = q < sg.nseg && i >= sg.end[q - 1];
+    lr = in ? sg.lr[q] : lr; clip = in ? sg.clip[q] : clip; fl = in ? sg.floor_[q] : fl; nn = in ? nrm[q] : nn;
+  }
+  if (clip > 0.f) g *= fminf(1.f, clip/(sqrtf(nn) + 1e-6f));
+  AdamOut o;
+  o.m = b1*m + (1.f - b1)*g;
+  o.v = b2*v + (1.f - b2)*g*g;
+  const float denom = sqrtf(o.v)/bc2s + eps;
+  o.p = fmaxf(p - (lr/bc1)*o.m/denom, fl);
+  return o;
+}
+
+// One float4 of p, g, m, v per thread and iteration: the 28 bytes per parameter stream with all of a thread's loads in flight.
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                              const float* __restrict__ step, const float* __restrict__ norms, long long n, AdamSegs sg,
-                                              float b1, float b2, float eps) {
-  const float t = step[0];
+                                              float* __restrict__ step, float* __restrict__ norms, long long n, AdamSegs sg, float b1, float b2, float eps) {
+  __shared__ float sN[NORM_SLOTS*8], nrm[8];
+  const float t = step[1];
+  const int par = ((int)t - 1) & 1;
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
-  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
-    int s = 0;
-#pragma unroll
-    for (int q = 0; q < 7; q++) if (q + 1 < sg.nseg && i >= sg.end[q]) s = q + 1;
-    float lr = sg.lr[0], clip = sg.clip[0], fl = sg.floor_[0], nn = norms[0];
-#pragma unroll
-    for (int q = 1; q < 8; q++) if (q == s) { lr = sg.lr[q]; clip = sg.clip[q]; fl = sg.floor_[q]; nn = norms[q]; }
-    float gi = g[i];
-    if (clip > 0.f) gi *= fminf(1.f, clip/(sqrtf(nn) + 1e-6f));
-    float mi = b1*m[i] + (1.f - b1)*gi;
-    float vi = b2*v[i] + (1.f - b2)*gi*gi;
-    m[i] = mi; v[i] = vi;
-    float denom = sqrtf(vi)/bc2s + eps;
-    float pi = p[i] - (lr/bc1)*mi/denom;
-    p[i] = fmaxf(pi, fl);
+  sN[threadIdx.x] = norms[par*NORM_SLOTS*8 + threadIdx.x];                                  // (blockDim.x == NORM_SLOTS * 8)
+  if (blockIdx.x == 0) norms[(1 - par)*NORM_SLOTS*8 + threadIdx.x] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = t;
+  __syncthreads();
+  if (threadIdx.x < 8) { float a = 0.f; for (int q = 0; q < NORM_SLOTS; q++) a += sN[q*8 + threadIdx.x]; nrm[threadIdx.x] = a; }
+  __syncthreads();
+  const long long n4 = n >> 2;
+  for (long long j = (long long)blockIdx.x*blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x*blockDim.x) {
+    const float4 P = reinterpret_cast<float4*>(p)[j], M = reinterpret_cast<float4*>(m)[j], V = reinterpret_cast<float4*>(v)[j];
+    const float4 G = reinterpret_cast<const float4*>(g)[j];
+    const long long i = j << 2;
+    const AdamOut o0 = adam_one(P.x, G.x, M.x, V.x, i, sg, nrm, b1, b2, eps, bc1, bc2s);
+    const AdamOut o1 = adam_one(P.y, G.y, M.y, V.y, i + 1, sg, nrm, b1, b2, eps, bc1, bc2s);
+    const AdamOut o2 = adam_one(P.z, G.z, M.z, V.z, i + 2, sg, nrm, b1, b2, eps, bc1, bc2s);
+    const AdamOut o3 = adam_one(P.w, G.w, M.w, V.w, i + 3, sg, nrm, b1, b2, eps, bc1, bc2s);
+    reinterpret_cast<float4*>(p)[j] = make_float4(o0.p, o1.p, o2.p, o3.p);
+    reinterpret_cast<float4*>(m)[j] = make_float4(o0.m, o1.m, o2.m, o3.m);
+    reinterpret_cast<float4*>(v)[j] = make_float4(o0.v, o1.v, o2.v, o3.v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                 // tail (n not a multiple of 4)
+    const long long i = (n4 << 2) + threadIdx.x;
+    const AdamOut o = adam_one(p[i], g[i], m[i], v[i], i, sg, nrm, b1, b2, eps, bc1, bc2s);
+    p[i] = o.p; m[i] = o.m; v[i] = o.v;
   }
 }
+
+static int make_segs(AdamSegs& sg, int64_t n, int nseg, const int64_t* seg_end, const float* lr, const float* clip_norm, const float* floor_) {
+  if (n <= 0 || nseg <= 0 || nseg > 8 || !seg_end || seg_end[nseg - 1] != n) return -1;
+  sg.nseg = nseg;
+  for (int s = 0; s < 8; s++) {
+    int q = s < nseg ? s : nseg - 1;
+    sg.end[s] = seg_end[q]; sg.lr[s] = lr ? lr[q] : 0.f; sg.clip[s] = clip_norm ? clip_norm[q] : 0.f; sg.floor_[s] = floor_ ? floor_[q] : -INFINITY;
+  }
+  return 0;
+}
+static int flat_blocks(int64_t n) { int blocks = (int)((n + 1023)/1024); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1; return blocks; }   // a float4 per thread
 
 extern "C" int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, float* norms, int64_t n, int nseg,
                         const int64_t* seg_end, const float* lr, const float* clip_norm, const float* floor_, float beta1, float beta2, float eps,
-                        void* stream) {
+                        int norms_ready, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step || !norms || !seg_end || !lr || !clip_norm || !floor_) return lfail("fbl_adam: null argument");
-  if (n <= 0 || nseg <= 0 || nseg > 8 || seg_end[nseg - 1] != n) return lfail("fbl_adam: bad segments");
-  AdamSegs sg; sg.nseg = nseg;
-  for (int s = 0; s < 8; s++) {
-    int q = s < nseg ? s : nseg - 1;
-    sg.end[s] = seg_end[q]; sg.lr[s] = lr[q]; sg.clip[s] = clip_norm[q]; sg.floor_[s] = floor_[q];
-  }
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return lfail("fbl_adam: the flat buffers must be 16-byte aligned");
+  AdamSegs sg;
+  if (make_segs(sg, n, nseg, seg_end, lr, clip_norm, floor_)) return lfail("fbl_adam: bad segments");
   hipStream_t st = (hipStream_t)stream;
-  LCHK(hipMemsetAsync(norms, 0, sizeof(float)*nseg, st));
-  int blocks = (int)((n + 256*8 - 1)/(256*8)); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, st, grad, (long long)n, sg, norms, step);
+  const int blocks = flat_blocks(n);
+  if (!norms_ready) hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, st, grad, (long long)n, sg, norms, step);
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step, norms, (long long)n, sg, beta1, beta2, eps);
   LCHK(hipGetLastError());
   return 0;
 }
 
+// ------------------------------------------------------------------ gradient tensors -> the flat gradient buffer (+ squared norms)
+// The autograd engine returns one tensor per parameter; this is the ONE launch that lays them out in the flat buffer the
+// all-reduce and Adam work on.  A workgroup owns FLAT_CHUNK consecutive flat elements; almost every chunk lies inside one tensor
+// (straight coalesced copy, one Adam segment), the few that straddle small tensors walk the tensor table held in LDS.
+#define FLAT_MAXT 96
+#define FLAT_CHUNK 1024
+struct FlatSrc { int n; const float* src[FLAT_MAXT]; long long end[FLAT_MAXT]; };
+
+__global__ void __launch_bounds__(256) k_gather_flat(FlatSrc f, float* __restrict__ flat, long long total, AdamSegs sg, float* __restrict__ norms,
+                                                     float* __restrict__ step) {
+  __shared__ const float* s_src[FLAT_MAXT];
+  __shared__ long long s_end[FLAT_MAXT];
+  if (threadIdx.x < FLAT_MAXT) { s_src[threadIdx.x] = f.src[threadIdx.x < f.n ? threadIdx.x : 0]; s_end[threadIdx.x] = threadIdx.x < f.n ? f.end[threadIdx.x] : total; }
+  __syncthreads();
+  float acc[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) acc[s] = 0.f;
+  const long long base = (long long)blockIdx.x*FLAT_CHUNK;
+  long long lim = base + FLAT_CHUNK; if (lim > total) lim = total;
+  int t = 0;
+  { int lo = 0, hi = f.n - 1;                                    // first tensor whose end is beyond this chunk's first element
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (s_end[mid] > base) hi = mid; else lo = mid + 1; }
+    t = lo; }
+  if (s_end[t] >= lim) {                                         // the whole chunk is inside tensor t
+    const long long start = t ? s_end[t - 1] : 0;
+    const float* sp = s_src[t];
+    const int seg = seg_of(sg, base);
+    float a = 0.f;
+    if (sp) {
+      sp += base - start;
+      float v[FLAT_CHUNK/256];
+#pragma unroll
+      for (int j = 0; j < FLAT_CHUNK/256; j++) { const long long i = base + threadIdx.x + j*256; v[j] = i < lim ? sp[i - base] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < FLAT_CHUNK/256; j++) { const long long i = base + threadIdx.x + j*256; if (i < lim) flat[i] = v[j]; a += v[j]*v[j]; }
+    } else {
+      for (long long i = base + threadIdx.x; i < lim; i += 256) flat[i] = 0.f;                   // a parameter without gradient
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q == seg) acc[q] = a;
+  } else {
+    for (long long i = base + threadIdx.x; i < lim; i += 256) {
+      while (i >= s_end[t]) t++;
+      const long long start = t ? s_end[t - 1] : 0;
+      const float* sp = s_src[t];
+      float v = sp ? sp[i - start] : 0.f;
+      flat[i] = v;
+      int s = seg_of(sg, i);
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q == s) acc[q] += v*v;
+    }
+  }
+  if (norms) norm_commit(acc, sg.nseg, norms, step);
+}
+
+extern "C" int fbl_gather_flat(const float* const* src, const int64_t* end, int ntensor, float* flat, int nseg, const int64_t* seg_end,
+                               float* norms, float* step, void* stream) {
+  if (!src || !end || !flat || ntensor <= 0 || ntensor > FLAT_MAXT) return lfail("fbl_gather_flat: need 0 < ntensor <= 96");
+  if (norms && !step) return lfail("fbl_gather_flat: the norm pass needs the optimizer's step counters");
+  FlatSrc f; f.n = ntensor;
+  long long prev = 0;
+  for (int k = 0; k < FLAT_MAXT; k++) {
+    int q = k < ntensor ? k : ntensor - 1;
+    f.src[k] = src[q]; f.end[k] = end[q];
+    if (k < ntensor) { if (end[k] <= prev) return lfail("fbl_gather_flat: tensor ends must be increasing"); prev = end[k]; }
+  }
+  const long long total = end[ntensor - 1];
+  AdamSegs sg; sg.nseg = 1;
+  for (int q = 0; q < 8; q++) sg.end[q] = total;
+  if (norms && make_segs(sg, total, nseg, seg_end, nullptr, nullptr, nullptr)) return lfail("fbl_gather_flat: bad segments");
+  const int blocks = (int)((total + FLAT_CHUNK - 1)/FLAT_CHUNK);
+  hipLaunchKernelGGL(k_gather_flat, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f, flat, total, sg, norms, step);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ small element-wise pieces of the step
+// Gaussian head (MultivariateNormalDiagHead): mean = zm + bm, stddev = softplus(zs + bs) * mul + min_scale
+__global__ void __launch_bounds__(256) k_gauss_head(const float* __restrict__ zm, const float* __restrict__ zs, const float* __restrict__ bm,
+                                                    const float* __restrict__ bs, float mul, float min_scale, long long n, int D,
+                                                    float* __restrict__ mean, float* __restrict__ std_) {
+  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
+    const int c = (int)(i % D);
+    mean[i] = zm[i] + bm[c];
+    std_[i] = softplus_f(zs[i] + bs[c])*mul + min_scale;
+  }
+}
+// backward: d zs = d std * sigmoid(zs + bs) * mul (d zm = d mean needs no kernel); column sums of d mean and d zs by atomics.
+// A workgroup owns GH_ROWS rows; thread == column (D <= 256).
+#define GH_ROWS 4
+__global__ void __launch_bounds__(256) k_gauss_head_bwd(const float* __restrict__ dmean, const float* __restrict__ dstd, const float* __restrict__ zs,
+                                                        const float* __restrict__ bs, float mul, int M, int D, float* __restrict__ dzs,
+                                                        float* __restrict__ dbm, float* __restrict__ dbs) {
+  const int c = threadIdx.x;
+  if (c >= D) return;
+  const float b = bs[c];
+  float am = 0.f, as = 0.f;
+  const int r0 = blockIdx.x*GH_ROWS;
+  float ds[GH_ROWS], z[GH_ROWS], dm[GH_ROWS];
+#pragma unroll
+  for (int j = 0; j < GH_ROWS; j++) {
+    const size_t i = (size_t)(r0 + j)*D + c; const bool ok = r0 + j < M;
+    ds[j] = ok ? dstd[i] : 0.f; z[j] = ok ? zs[i] : 0.f; dm[j] = ok ? dmean[i] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < GH_ROWS; j++) {
+    float g = ds[j]*sigmoid_f(z[j] + b)*mul;
+    if (r0 + j < M) dzs[(size_t)(r0 + j)*D + c] = g;
+    as += g; am += dm[j];
+  }
+  atomicAdd(dbm + c, am); atomicAdd(dbs + c, as);
+}
+
+extern "C" int fbl_gauss_head(const float* zm, const float* zs, const float* bm, const float* bs, float mul, float min_scale, int M, int D,
+                              float* mean, float* std_, void* stream) {
+  if (!zm || !zs || !bm || !bs || !mean || !std_ || M <= 0 || D <= 0) return lfail("fbl_gauss_head: bad argument");
+  long long n = (long long)M*D; int blocks = (int)((n + 255)/256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_gauss_head, dim3(blocks), dim3(256), 0, (hipStream_t)stream, zm, zs, bm, bs, mul, min_scale, n, D, mean, std_);
+  LCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int fbl_gauss_head_bwd(const float* dmean, const float* dstd, const float* zs, const float* bs, float mul, int M, int D, float* dzs,
+                                  float* dbm, float* dbs, void* stream) {
+  if (!dmean || !dstd || !zs || !bs || !dzs || !dbm || !dbs || M <= 0 || D <= 0 || D > 256) return lfail("fbl_gauss_head_bwd: bad argument (D <= 256)");
+  hipLaunchKernelGGL(k_gauss_head_bwd, dim3((M + GH_ROWS - 1)/GH_ROWS), dim3(256), 0, (hipStream_t)stream, dmean, dstd, zs, bs, mul, M, D, dzs, dbm, dbs);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+// sampled[n][b][d] = mean[b][d] + std[b][d] * noise[n][b][d]; clamped = clip(sampled, -1, 1) (the critic's ClipToSpec input)
+__global__ void __launch_bounds__(256) k_sample_actions(const float* __restrict__ mean, const float* __restrict__ std_, const float* __restrict__ noise,
+                                                        long long n, long long bd, float* __restrict__ sampled, float* __restrict__ clamped) {
+  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
+    const long long j = i % bd;
+    float a = mean[j] + std_[j]*noise[i];
+    sampled[i] = a; clamped[i] = fminf(fmaxf(a, -1.f), 1.f);
+  }
+}
+extern "C" int fbl_sample_actions(const float* mean, const float* std_, const float* noise, int N, int B, int D, float* sampled, float* clamped, void* stream) {
+  if (!mean || !std_ || !noise || !sampled || !clamped || N <= 0 || B <= 0 || D <= 0) return lfail("fbl_sample_actions: bad argument");
+  long long bd = (long long)B*D, n = bd*N; int blocks = (int)((n + 255)/256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_sample_actions, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mean, std_, noise, n, bd, sampled, clamped);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+// out[b] = [obs[b] | clip(act[b], -1, 1)]   (critic input, network_factory.py: ClipToSpec + concat)
+__global__ void __launch_bounds__(256) k_concat_clamp(const float* __restrict__ obs, const float* __restrict__ act, int O, int A, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < O + A; c += blockDim.x)
+    out[(size_t)b*(O + A) + c] = c < O ? obs[(size_t)b*O + c] : fminf(fmaxf(act[(size_t)b*A + c - O], -1.f), 1.f);
+}
+extern "C" int fbl_concat_clamp(const float* obs, const float* act, int B, int O, int A, float* out, void* stream) {
+  if (!obs || !act || !out || B <= 0 || O <= 0 || A <= 0) return lfail("fbl_concat_clamp: bad argument");
+  hipLaunchKernelGGL(k_concat_clamp, dim3(B), dim3(256), 0, (hipStream_t)stream, obs, act, O, A, out);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ bias + LayerNorm + activation, bias + ELU (rows of width W)
-// One wavefront per row; a lane owns W/64 consecutive-strided columns (c = lane, lane + 64, ...).
+// One wavefront per row; a lane owns the columns c = lane, lane + 64, ...  The kernels are instantiated for the network widths
+// (NQ = W / 64 = 4, 8; EXACT: no column guards, so all of a row's loads are issued back to back) and once generically (W <= 1024).
 #define MAXW 1024
+template <int NQ, bool EXACT>
 __global__ void __launch_bounds__(WAVE) k_bias_ln_act(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps, int act, int W, float* __restrict__ y,
-                                                      float* __restrict__ xhat, float* __restrict__ rstd_out) {
+                                                      const float* __restrict__ beta, const float* __restrict__ rowadd, int period, float eps,
+                                                      int act, int W, float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd_out) {
   const int r = blockIdx.x, lane = threadIdx.x;
-  float v[MAXW/WAVE];
+  const float* xr = x + (size_t)r*W;
+  const float* ra = rowadd ? rowadd + (size_t)(r % period)*W : nullptr;      // x[r] + rowadd[r mod period]: [N][B][W] + [B][W]
+  float v[NQ], g[NQ], be[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int c = lane + q*WAVE; const bool ok = EXACT || c < W;
+    v[q] = ok ? xr[c] + bias[c] : 0.f; g[q] = ok ? gamma[c] : 0.f; be[q] = ok ? beta[c] : 0.f;
+  }
+  if (ra) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const int c = lane + q*WAVE; if (EXACT || c < W) v[q] += ra[c]; }
+  }
   float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) { int c = lane + q*WAVE; v[q] = c < W ? x[(size_t)r*W + c] + bias[c] : 0.f; s += v[q]; }
+  for (int q = 0; q < NQ; q++) s += v[q];
   const float mean = wsum(s)/(float)W;
   float s2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) { int c = lane + q*WAVE; float dlt = c < W ? v[q] - mean : 0.f; s2 += dlt*dlt; }
+  for (int q = 0; q < NQ; q++) { const int c = lane + q*WAVE; float dlt = (EXACT || c < W) ? v[q] - mean : 0.f; s2 += dlt*dlt; }
   const float rstd = rsqrtf(wsum(s2)/(float)W + eps);
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) {
-    int c = lane + q*WAVE;
-    if (c < W) {
-      float xh = (v[q] - mean)*rstd, u = xh*gamma[c] + beta[c];
+  for (int q = 0; q < NQ; q++) {
+    const int c = lane + q*WAVE;
+    if (EXACT || c < W) {
+      float xh = (v[q] - mean)*rstd, u = xh*g[q] + be[q];
       y[(size_t)r*W + c] = act == 1 ? tanhf(u) : u;
       if (xhat) xhat[(size_t)r*W + c] = xh;
     }
@@ -339,97 +618,116 @@ __global__ void __launch_bounds__(WAVE) k_bias_ln_act(const float* __restrict__ 
   if (rstd_out && lane == 0) rstd_out[r] = rstd;
 }
 
-// backward: a workgroup of 4 waves owns a tile of rows; every lane accumulates the column sums of its columns in registers,
+// backward: a workgroup of 4 waves owns LN_ROWS rows; every lane accumulates the column sums of its columns in registers,
 // the four waves are combined through LDS and ONE atomic per column and workgroup goes to the (zero-initialised) outputs
-#define LN_ROWS 8
+#define LN_ROWS 4
+template <int NQ, bool EXACT>
 __global__ void __launch_bounds__(256) k_bias_ln_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ xhat,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma, int act, int M, int W,
                                                          float* __restrict__ dx, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[3][4][MAXW/WAVE][WAVE];
+  __shared__ float red[3][4][NQ][WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float ab[MAXW/WAVE], ag[MAXW/WAVE], ae[MAXW/WAVE];
+  float ab[NQ], ag[NQ], ae[NQ], gam[NQ];
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) { ab[q] = 0.f; ag[q] = 0.f; ae[q] = 0.f; }
+  for (int q = 0; q < NQ; q++) { ab[q] = 0.f; ag[q] = 0.f; ae[q] = 0.f; const int c = lane + q*WAVE; gam[q] = (EXACT || c < W) ? gamma[c] : 0.f; }
   const int r0 = blockIdx.x*LN_ROWS;
   for (int r = r0 + wv; r < r0 + LN_ROWS && r < M; r += 4) {
-    float du[MAXW/WAVE], xh[MAXW/WAVE];
+    float du[NQ], xh[NQ], gy[NQ], yy[NQ];
+    const size_t ro = (size_t)r*W;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int c = lane + q*WAVE; const bool ok = EXACT || c < W;
+      gy[q] = ok ? dy[ro + c] : 0.f; yy[q] = (ok && act == 1) ? y[ro + c] : 0.f; xh[q] = ok ? xhat[ro + c] : 0.f;
+    }
+    const float rs = rstd[r];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < MAXW/WAVE; q++) {
-      int c = lane + q*WAVE;
-      if (c < W) {
-        float g = dy[(size_t)r*W + c];
-        if (act == 1) { float yy = y[(size_t)r*W + c]; g *= 1.f - yy*yy; }
-        xh[q] = xhat[(size_t)r*W + c];
-        ag[q] += g*xh[q]; ae[q] += g;
-        du[q] = g*gamma[c];
-        s1 += du[q]; s2 += du[q]*xh[q];
-      } else { du[q] = 0.f; xh[q] = 0.f; }
+    for (int q = 0; q < NQ; q++) {
+      float g = gy[q]*(1.f - yy[q]*yy[q]);                       // (act == 0: yy == 0)
+      ag[q] += g*xh[q]; ae[q] += g;
+      du[q] = g*gam[q];
+      s1 += du[q]; s2 += du[q]*xh[q];
     }
     s1 = wsum(s1)/(float)W; s2 = wsum(s2)/(float)W;
-    const float rs = rstd[r];
 #pragma unroll
-    for (int q = 0; q < MAXW/WAVE; q++) {
-      int c = lane + q*WAVE;
-      if (c < W) { float d = rs*(du[q] - s1 - xh[q]*s2); dx[(size_t)r*W + c] = d; ab[q] += d; }
+    for (int q = 0; q < NQ; q++) {
+      const int c = lane + q*WAVE;
+      if (EXACT || c < W) { float d = rs*(du[q] - s1 - xh[q]*s2); dx[ro + c] = d; ab[q] += d; }
     }
   }
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) { red[0][wv][q][lane] = ab[q]; red[1][wv][q][lane] = ag[q]; red[2][wv][q][lane] = ae[q]; }
+  for (int q = 0; q < NQ; q++) { red[0][wv][q][lane] = ab[q]; red[1][wv][q][lane] = ag[q]; red[2][wv][q][lane] = ae[q]; }
   __syncthreads();
-  if (wv == 0) {
-#pragma unroll
-    for (int q = 0; q < MAXW/WAVE; q++) {
-      int c = lane + q*WAVE;
-      if (c < W) {
-        atomicAdd(dbias + c, red[0][0][q][lane] + red[0][1][q][lane] + red[0][2][q][lane] + red[0][3][q][lane]);
-        atomicAdd(dgamma + c, red[1][0][q][lane] + red[1][1][q][lane] + red[1][2][q][lane] + red[1][3][q][lane]);
-        atomicAdd(dbeta + c, red[2][0][q][lane] + red[2][1][q][lane] + red[2][2][q][lane] + red[2][3][q][lane]);
-      }
+  // the 3 * NQ column blocks are spread over the four waves
+  for (int j = wv; j < 3*NQ; j += 4) {
+    const int a = j / NQ, q = j % NQ, c = lane + q*WAVE;
+    if (EXACT || c < W) {
+      float t = red[a][0][q][lane] + red[a][1][q][lane] + red[a][2][q][lane] + red[a][3][q][lane];
+      atomicAdd((a == 0 ? dbias : a == 1 ? dgamma : dbeta) + c, t);
     }
   }
 }
 
-__global__ void __launch_bounds__(256) k_bias_elu(const float* __restrict__ x, const float* __restrict__ bias, long long n, int W, float* __restrict__ y) {
-  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
-    float v = x[i] + bias[i % W];
-    y[i] = v > 0.f ? v : expm1f(v);
-  }
+template <int NQ, bool EXACT>
+__global__ void __launch_bounds__(WAVE) k_bias_elu(const float* __restrict__ x, const float* __restrict__ bias, int W, float* __restrict__ y) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const size_t ro = (size_t)r*W;
+  float v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) { const int c = lane + q*WAVE; v[q] = (EXACT || c < W) ? x[ro + c] + bias[c] : 0.f; }
+#pragma unroll
+  for (int q = 0; q < NQ; q++) { const int c = lane + q*WAVE; if (EXACT || c < W) y[ro + c] = v[q] > 0.f ? v[q] : expm1f(v[q]); }
 }
 
+template <int NQ, bool EXACT>
 __global__ void __launch_bounds__(256) k_bias_elu_bwd(const float* __restrict__ dy, const float* __restrict__ y, int M, int W, float* __restrict__ dx,
                                                       float* __restrict__ dbias) {
-  __shared__ float red[4][MAXW/WAVE][WAVE];
+  __shared__ float red[4][NQ][WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float ab[MAXW/WAVE];
+  float ab[NQ];
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) ab[q] = 0.f;
+  for (int q = 0; q < NQ; q++) ab[q] = 0.f;
   const int r0 = blockIdx.x*LN_ROWS;
   for (int r = r0 + wv; r < r0 + LN_ROWS && r < M; r += 4) {
+    const size_t ro = (size_t)r*W;
+    float gy[NQ], yy[NQ];
 #pragma unroll
-    for (int q = 0; q < MAXW/WAVE; q++) {
-      int c = lane + q*WAVE;
-      if (c < W) {
-        float yy = y[(size_t)r*W + c];
-        float d = dy[(size_t)r*W + c]*(yy > 0.f ? 1.f : yy + 1.f);          // ELU'(v) = 1 (v > 0) / exp(v) = y + 1
-        dx[(size_t)r*W + c] = d; ab[q] += d;
+    for (int q = 0; q < NQ; q++) { const int c = lane + q*WAVE; const bool ok = EXACT || c < W; gy[q] = ok ? dy[ro + c] : 0.f; yy[q] = ok ? y[ro + c] : 0.f; }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int c = lane + q*WAVE;
+      if (EXACT || c < W) {
+        float d = gy[q]*(yy[q] > 0.f ? 1.f : yy[q] + 1.f);       // ELU'(v) = 1 (v > 0) / exp(v) = y + 1
+        dx[ro + c] = d; ab[q] += d;
       }
     }
   }
 #pragma unroll
-  for (int q = 0; q < MAXW/WAVE; q++) red[wv][q][lane] = ab[q];
+  for (int q = 0; q < NQ; q++) red[wv][q][lane] = ab[q];
   __syncthreads();
-  if (wv == 0) {
-#pragma unroll
-    for (int q = 0; q < MAXW/WAVE; q++) { int c = lane + q*WAVE; if (c < W) atomicAdd(dbias + c, red[0][q][lane] + red[1][q][lane] + red[2][q][lane] + red[3][q][lane]); }
+  for (int q = wv; q < NQ; q += 4) {
+    const int c = lane + q*WAVE;
+    if (EXACT || c < W) atomicAdd(dbias + c, red[0][q][lane] + red[1][q][lane] + red[2][q][lane] + red[3][q][lane]);
   }
 }
 
-extern "C" int fbl_bias_ln_act(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, int M, int W,
-                               float* y, float* xhat, float* rstd, void* stream) {
+// width dispatch: the instantiation for W == 256 / 512, else the guarded generic one
+#define BY_WIDTH(W, LAUNCH)                                   \
+  do {                                                        \
+    if ((W) == 256) { LAUNCH(4, true); }                      \
+    else if ((W) == 512) { LAUNCH(8, true); }                 \
+    else { LAUNCH(MAXW/WAVE, false); }                        \
+  } while (0)
+
+extern "C" int fbl_bias_ln_act(const float* x, const float* bias, const float* gamma, const float* beta, const float* rowadd, int period, float eps,
+                               int act, int M, int W, float* y, float* xhat, float* rstd, void* stream) {
   if (!x || !bias || !gamma || !beta || !y) return lfail("fbl_bias_ln_act: null argument");
   if (M <= 0 || W <= 0 || W > MAXW) return lfail("fbl_bias_ln_act: need M > 0 and 0 < W <= 1024");
-  hipLaunchKernelGGL(k_bias_ln_act, dim3(M), dim3(WAVE), 0, (hipStream_t)stream, x, bias, gamma, beta, eps, act, W, y, xhat, rstd);
+  if (rowadd && (period <= 0 || M % period)) return lfail("fbl_bias_ln_act: the row count must be a multiple of the broadcast period");
+  const int per = period > 0 ? period : 1;
+#define L_(NQ, EX) hipLaunchKernelGGL((k_bias_ln_act<NQ, EX>), dim3(M), dim3(WAVE), 0, (hipStream_t)stream, x, bias, gamma, beta, rowadd, per, eps, act, W, y, xhat, rstd)
+  BY_WIDTH(W, L_);
+#undef L_
   LCHK(hipGetLastError());
   return 0;
 }
@@ -437,20 +735,25 @@ extern "C" int fbl_bias_ln_act_bwd(const float* dy, const float* y, const float*
                                    float* dx, float* dbias, float* dgamma, float* dbeta, void* stream) {
   if (!dy || !y || !xhat || !rstd || !gamma || !dx || !dbias || !dgamma || !dbeta) return lfail("fbl_bias_ln_act_bwd: null argument");
   if (M <= 0 || W <= 0 || W > MAXW) return lfail("fbl_bias_ln_act_bwd: need M > 0 and 0 < W <= 1024");
-  hipLaunchKernelGGL(k_bias_ln_act_bwd, dim3((M + LN_ROWS - 1)/LN_ROWS), dim3(256), 0, (hipStream_t)stream, dy, y, xhat, rstd, gamma, act, M, W, dx, dbias, dgamma, dbeta);
+#define L_(NQ, EX) hipLaunchKernelGGL((k_bias_ln_act_bwd<NQ, EX>), dim3((M + LN_ROWS - 1)/LN_ROWS), dim3(256), 0, (hipStream_t)stream, dy, y, xhat, rstd, gamma, act, M, W, dx, dbias, dgamma, dbeta)
+  BY_WIDTH(W, L_);
+#undef L_
   LCHK(hipGetLastError());
   return 0;
 }
 extern "C" int fbl_bias_elu(const float* x, const float* bias, int M, int W, float* y, void* stream) {
-  if (!x || !bias || !y || M <= 0 || W <= 0) return lfail("fbl_bias_elu: bad argument");
-  long long n = (long long)M*W; int blocks = (int)((n + 1023)/1024); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_bias_elu, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, bias, n, W, y);
+  if (!x || !bias || !y || M <= 0 || W <= 0 || W > MAXW) return lfail("fbl_bias_elu: bad argument (W <= 1024)");
+#define L_(NQ, EX) hipLaunchKernelGGL((k_bias_elu<NQ, EX>), dim3(M), dim3(WAVE), 0, (hipStream_t)stream, x, bias, W, y)
+  BY_WIDTH(W, L_);
+#undef L_
   LCHK(hipGetLastError());
   return 0;
 }
 extern "C" int fbl_bias_elu_bwd(const float* dy, const float* y, int M, int W, float* dx, float* dbias, void* stream) {
   if (!dy || !y || !dx || !dbias || M <= 0 || W <= 0 || W > MAXW) return lfail("fbl_bias_elu_bwd: bad argument");
-  hipLaunchKernelGGL(k_bias_elu_bwd, dim3((M + LN_ROWS - 1)/LN_ROWS), dim3(256), 0, (hipStream_t)stream, dy, y, M, W, dx, dbias);
+#define L_(NQ, EX) hipLaunchKernelGGL((k_bias_elu_bwd<NQ, EX>), dim3((M + LN_ROWS - 1)/LN_ROWS), dim3(256), 0, (hipStream_t)stream, dy, y, M, W, dx, dbias)
+  BY_WIDTH(W, L_);
+#undef L_
   LCHK(hipGetLastError());
   return 0;
 }

@@ -43,11 +43,16 @@ def lib():
             raise LearnerLibError(f'{LIB} not found: build it with `python -c "import __graft_entry__ as g; g.build()"`')
         L = C.CDLL(LIB)
         L.fbl_last_error.restype = C.c_char_p; L.fbl_version.restype = C.c_char_p
-        L.fbl_td_loss.argtypes = [C.c_void_p]*5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p]*4
+        L.fbl_td_loss.argtypes = [C.c_void_p]*7 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p]*6
         L.fbl_mpo_loss.argtypes = [C.c_void_p, C.c_void_p]
         L.fbl_mpo_workspace_floats.argtypes = [C.c_int, C.c_int]; L.fbl_mpo_workspace_floats.restype = C.c_size_t
-        L.fbl_adam.argtypes = [C.c_void_p]*6 + [C.c_int64, C.c_int] + [C.c_void_p]*4 + [C.c_float, C.c_float, C.c_float, C.c_void_p]
-        L.fbl_bias_ln_act.argtypes = [C.c_void_p]*4 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p]*4
+        L.fbl_adam.argtypes = [C.c_void_p]*6 + [C.c_int64, C.c_int] + [C.c_void_p]*4 + [C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.fbl_gather_flat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbl_bias_ln_act.argtypes = [C.c_void_p]*5 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p]*4
+        L.fbl_gauss_head.argtypes = [C.c_void_p]*4 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*3
+        L.fbl_gauss_head_bwd.argtypes = [C.c_void_p]*4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
+        L.fbl_sample_actions.argtypes = [C.c_void_p]*3 + [C.c_int]*3 + [C.c_void_p]*3
+        L.fbl_concat_clamp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_ln_act_bwd.argtypes = [C.c_void_p]*5 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p]*5
         L.fbl_bias_elu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_elu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -74,18 +79,66 @@ def available() -> bool:
     return os.path.exists(LIB)
 
 
+# ------------------------------------------------------------------ zero-initialised scratch for the atomically accumulated outputs
+class _ZeroPool:
+    """Column sums (bias / LayerNorm gradients), the TD loss mean ... are accumulated with atomics, so their buffers must start
+    at zero.  Instead of one fill kernel per buffer the learner zeroes ONE pool per step (`begin_step`) and the kernels' outputs
+    are carved from it; outside a step (or when the pool is too small: it grows at the next `begin_step`) `take` falls back
+    to torch.zeros."""
+
+    def __init__(self):
+        self.buf = None; self.off = 0; self.want = 0; self.active = False
+
+    def begin_step(self, device):
+        need = max(self.want, 1 << 14)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.zeros(need, device=device)
+        else:
+            self.buf.zero_()
+        self.off = 0; self.active = True
+
+    def end_step(self):
+        self.want = max(self.want, self.off); self.active = False
+
+    def take(self, *shape, device):
+        n = 1
+        for k in shape:
+            n *= int(k)
+        n_al = (n + 63) & ~63
+        if not self.active or self.buf.device != device:
+            return torch.zeros(*shape, device=device)
+        lo = self.off; self.off += n_al
+        if self.off > self.buf.numel():
+            return torch.zeros(*shape, device=device)
+        return self.buf[lo:lo + n].view(*shape)
+
+
+zero_pool = _ZeroPool()
+
+
 # ------------------------------------------------------------------ categorical TD loss
+def td_loss_grad(q_tm1_raw, bias_tm1, q_t_raw, bias_t, values, reward, discount, gamma):
+    """Loss AND gradient in one launch (GPU): returns (mean loss [scalar], sampled_q [N, B], d_logits [B, K], d_bias [K]).
+    q_*_raw are the logits GEMMs' outputs WITHOUT bias; the biases are added in the kernel.  Nothing here is recorded by autograd:
+    the learner seeds the backward pass of the networks with d_logits (learner.py)."""
+    N, B, K = q_t_raw.shape
+    qt = _f32c(q_t_raw.detach()); q1 = _f32c(q_tm1_raw.detach()); dev = qt.device
+    sampled_q = torch.empty(N, B, device=dev); dlog = torch.empty(B, K, device=dev); rows = torch.empty(B, device=dev)
+    acc = zero_pool.take(K + 1, device=dev)
+    _check(lib().fbl_td_loss(qt.data_ptr(), bias_t.data_ptr() if bias_t is not None else None, q1.data_ptr(),
+                             bias_tm1.data_ptr() if bias_tm1 is not None else None, _f32c(values).data_ptr(), _f32c(reward).data_ptr(),
+                             _f32c(discount).data_ptr(), float(gamma), N, B, K, sampled_q.data_ptr(), dlog.data_ptr(), acc.data_ptr(),
+                             rows.data_ptr(), acc[K:].data_ptr(), _stream()))
+    return acc[K], sampled_q, dlog, acc[:K]
+
+
 class _TDLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_tm1_logits, q_t_logits, values, reward, discount, gamma):
-        N, B, K = q_t_logits.shape
-        qt = _f32c(q_t_logits); q1 = _f32c(q_tm1_logits)
-        sampled_q = torch.empty(N, B, device=qt.device); dlog = torch.empty(B, K, device=qt.device); loss = torch.empty(B, device=qt.device)
-        _check(lib().fbl_td_loss(qt.data_ptr(), q1.data_ptr(), _f32c(values).data_ptr(), _f32c(reward).data_ptr(), _f32c(discount).data_ptr(),
-                                 float(gamma), N, B, K, sampled_q.data_ptr(), dlog.data_ptr(), loss.data_ptr(), _stream()))
+        loss, sampled_q, dlog, _ = td_loss_grad(q_tm1_logits, None, q_t_logits, None, values, reward, discount, gamma)
         ctx.save_for_backward(dlog)
         ctx.mark_non_differentiable(sampled_q)
-        return loss.mean(), sampled_q
+        return loss.clone(), sampled_q
 
     @staticmethod
     def backward(ctx, g_loss, g_q):
@@ -108,28 +161,52 @@ def td_loss(q_tm1_logits, q_t_logits, values, reward, discount, gamma):
 
 # ------------------------------------------------------------------ MPO loss
 _STAT_NAMES = ['loss_policy', 'loss_policy_mean', 'loss_policy_std', 'loss_kl_mean', 'loss_kl_std', 'loss_alpha', 'loss_temperature', 'kl_q_rel',
-               'penalty_kl_q_rel', 'kl_mean_rel', 'kl_stddev_rel', 'q_min', 'q_max', 'pi_stddev_min', 'pi_stddev_max', 'dual_temperature']
+               'penalty_kl_q_rel', 'kl_mean_rel', 'kl_stddev_rel', 'q_min', 'q_max', 'pi_stddev_min', 'pi_stddev_max', 'dual_temperature',
+               'dual_alpha_mean', 'dual_alpha_stddev']
+_mpo_ws = {}
+
+
+def mpo_loss_grad(mod, om, os_, tm, ts, actions, q):
+    """MPO loss value, statistics AND every gradient in ONE launch: returns (stats [20] device tensor (slot 0 = the loss),
+    d online_mean [B, D], d online_std [B, D], {dual parameter: gradient})."""
+    if mod.penalization_cost is not None and not hasattr(mod.penalization_cost, 'scale'):
+        raise LearnerLibError('the fused MPO loss supports PenalizationCostRealActions (or none) as the penalization cost')
+    N, B, D = actions.shape
+    dev = om.device
+    om_c, os_c, tm_c, ts_c, a_c, q_c = (_f32c(t.detach()) for t in (om, os_, tm, ts, actions, q))
+    g_om = torch.empty(B, D, device=dev); g_os = torch.empty(B, D, device=dev)
+    gd = torch.empty(2*D + 2, device=dev)                       # dual gradients: temperature | alpha_mean | alpha_stddev | penalty temperature
+    g_lt, g_am, g_as, g_pt = gd[0:1], gd[1:1 + D], gd[1 + D:1 + 2*D], gd[1 + 2*D:2 + 2*D]
+    stats = torch.empty(20, device=dev)
+    key = (dev, D)
+    if key not in _mpo_ws:                                      # persistent, self-cleaning accumulator block (zero between launches)
+        _mpo_ws[key] = torch.zeros(lib().fbl_mpo_workspace_floats(B, D), device=dev)
+    ws = _mpo_ws[key]
+    pc = mod.penalization_cost
+    a = _MpoArgs(N, B, D, om_c.data_ptr(), os_c.data_ptr(), tm_c.data_ptr(), ts_c.data_ptr(), a_c.data_ptr(), q_c.data_ptr(),
+                 pc.scale.data_ptr() if pc is not None else None, pc.offset.data_ptr() if pc is not None else None,
+                 mod.log_temperature.data_ptr(), mod.log_alpha_mean.data_ptr(), mod.log_alpha_stddev.data_ptr(), mod.log_penalty_temperature.data_ptr(),
+                 mod.epsilon, mod.epsilon_penalty, mod.epsilon_mean, mod.epsilon_stddev, int(bool(mod.action_penalization)),
+                 g_om.data_ptr(), g_os.data_ptr(), g_lt.data_ptr(), g_am.data_ptr(), g_as.data_ptr(), g_pt.data_ptr(),
+                 stats.data_ptr(), ws.data_ptr())
+    _check(lib().fbl_mpo_loss(C.byref(a), _stream()))
+    duals = {mod.log_temperature: g_lt, mod.log_alpha_mean: g_am, mod.log_alpha_stddev: g_as, mod.log_penalty_temperature: g_pt}
+    return stats, g_om, g_os, duals
+
+
+def mpo_stats_dict(mod, st):
+    stats = {k: st[i] for i, k in enumerate(_STAT_NAMES)}
+    if not mod.action_penalization:
+        stats.pop('penalty_kl_q_rel')
+    return stats
 
 
 class _MPOLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, om, os_, log_t, log_am, log_as, log_pt, tm, ts, actions, q, mod):
-        N, B, D = actions.shape
-        dev = om.device
-        om_c, os_c, tm_c, ts_c, a_c, q_c = (_f32c(t.detach()) for t in (om, os_, tm, ts, actions, q))
-        g_om = torch.empty(B, D, device=dev); g_os = torch.empty(B, D, device=dev)
-        g_lt = torch.empty(1, device=dev); g_am = torch.empty(D, device=dev); g_as = torch.empty(D, device=dev); g_pt = torch.zeros(1, device=dev)
-        stats = torch.empty(16, device=dev)
-        ws = torch.empty(lib().fbl_mpo_workspace_floats(B, D), device=dev)
-        pc = mod.penalization_cost
-        a = _MpoArgs(N, B, D, om_c.data_ptr(), os_c.data_ptr(), tm_c.data_ptr(), ts_c.data_ptr(), a_c.data_ptr(), q_c.data_ptr(),
-                     pc.scale.data_ptr() if pc is not None else None, pc.offset.data_ptr() if pc is not None else None,
-                     log_t.data_ptr(), log_am.data_ptr(), log_as.data_ptr(), log_pt.data_ptr(),
-                     mod.epsilon, mod.epsilon_penalty, mod.epsilon_mean, mod.epsilon_stddev, int(bool(mod.action_penalization)),
-                     g_om.data_ptr(), g_os.data_ptr(), g_lt.data_ptr(), g_am.data_ptr(), g_as.data_ptr(), g_pt.data_ptr(),
-                     stats.data_ptr(), ws.data_ptr())
-        _check(lib().fbl_mpo_loss(C.byref(a), _stream()))
-        ctx.save_for_backward(g_om, g_os, g_lt, g_am, g_as, g_pt)
+        stats, g_om, g_os, duals = mpo_loss_grad(mod, om, os_, tm, ts, actions, q)
+        ctx.save_for_backward(g_om, g_os, duals[mod.log_temperature], duals[mod.log_alpha_mean], duals[mod.log_alpha_stddev],
+                              duals[mod.log_penalty_temperature])
         ctx.pen = bool(mod.action_penalization)
         ctx.mark_non_differentiable(stats)
         return stats[0].clone(), stats
@@ -141,29 +218,25 @@ class _MPOLoss(torch.autograd.Function):
 
 
 def mpo_loss(mod, online_mean, online_std, target_mean, target_std, actions, q_values):
-    """MPOLoss.forward through the fused kernels (GPU) -- same return convention: (loss, stats dict)."""
-    if mod.penalization_cost is not None and not hasattr(mod.penalization_cost, 'scale'):
-        raise LearnerLibError('the fused MPO loss supports PenalizationCostRealActions (or none) as the penalization cost')
+    """MPOLoss.forward through the fused kernel (GPU), recorded by autograd -- same return convention: (loss, stats dict)."""
     loss, st = _MPOLoss.apply(online_mean, online_std, mod.log_temperature, mod.log_alpha_mean, mod.log_alpha_stddev,
                               mod.log_penalty_temperature, target_mean, target_std, actions, q_values, mod)
-    stats = {k: st[i] for i, k in enumerate(_STAT_NAMES)}
-    with torch.no_grad():
-        stats['dual_alpha_mean'] = (F.softplus(mod.log_alpha_mean) + 1e-8).mean()
-        stats['dual_alpha_stddev'] = (F.softplus(mod.log_alpha_stddev) + 1e-8).mean()
-    if not mod.action_penalization:
-        stats.pop('penalty_kl_q_rel')
-    return loss, stats
+    return loss, mpo_stats_dict(mod, st)
 
 
 # ------------------------------------------------------------------ bias + LayerNorm + tanh, bias + ELU
 class _BiasLnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, gamma, beta, eps, act):
+    def forward(ctx, x, bias, gamma, beta, eps, act, rowadd=None, need=True):
         x = _f32c(x); M, W = x.shape
-        need = x.requires_grad or bias.requires_grad or gamma.requires_grad
+        if rowadd is not None:
+            assert not need and not rowadd.requires_grad, 'the row-broadcast addend is a forward-only (target network) path'
+            rowadd = _f32c(rowadd)
         y = torch.empty_like(x)
         xhat = torch.empty_like(x) if need else None; rstd = torch.empty(M, device=x.device) if need else None
-        _check(lib().fbl_bias_ln_act(x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), int(act), M, W, y.data_ptr(),
+        _check(lib().fbl_bias_ln_act(x.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     rowadd.data_ptr() if rowadd is not None else None, rowadd.shape[0] if rowadd is not None else 1,
+                                     float(eps), int(act), M, W, y.data_ptr(),
                                      xhat.data_ptr() if need else None, rstd.data_ptr() if need else None, _stream()))
         if need:
             ctx.save_for_backward(y, xhat, rstd, gamma)
@@ -174,10 +247,10 @@ class _BiasLnAct(torch.autograd.Function):
     def backward(ctx, dy):
         y, xhat, rstd, gamma = ctx.saved_tensors
         dy = _f32c(dy); M, W = dy.shape
-        dx = torch.empty_like(dy); cols = torch.zeros(3, W, device=dy.device)
+        dx = torch.empty_like(dy); cols = zero_pool.take(3, W, device=dy.device)
         _check(lib().fbl_bias_ln_act_bwd(dy.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), ctx.act, M, W,
                                          dx.data_ptr(), cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), _stream()))
-        return dx, cols[0], cols[1], cols[2], None, None
+        return dx, cols[0], cols[1], cols[2], None, None, None, None
 
 
 class _BiasElu(torch.autograd.Function):
@@ -193,16 +266,23 @@ class _BiasElu(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         dy = _f32c(dy); M, W = dy.shape
-        dx = torch.empty_like(dy); db = torch.zeros(W, device=dy.device)
+        dx = torch.empty_like(dy); db = zero_pool.take(W, device=dy.device)
         _check(lib().fbl_bias_elu_bwd(dy.data_ptr(), y.data_ptr(), M, W, dx.data_ptr(), db.data_ptr(), _stream()))
         return dx, db
 
 
-def bias_ln_tanh(x, bias, norm: torch.nn.LayerNorm):
-    """tanh(LayerNorm(x + bias)) for a 2-D (or [N, B, W]) GEMM output."""
-    if x.is_cuda:
+def bias_ln_tanh(x, bias, norm: torch.nn.LayerNorm, rowadd=None):
+    """tanh(LayerNorm(x + bias [+ rowadd])) for a 2-D (or [N, B, W]) GEMM output; rowadd [B, W] is broadcast over the leading
+    dimension of an [N, B, W] input (forward-only: the target critic's shared observation half)."""
+    # (grad mode is only visible here, not inside Function.forward: without it the target networks save nothing for a backward)
+    need = torch.is_grad_enabled() and any(t.requires_grad for t in (x, bias, norm.weight, norm.bias) + ((rowadd,) if rowadd is not None else ()))
+    if x.is_cuda and (rowadd is None or not need):
         shp = x.shape
-        return _BiasLnAct.apply(x.reshape(-1, shp[-1]), bias, norm.weight, norm.bias, norm.eps, 1).view(shp)
+        return _BiasLnAct.apply(x.reshape(-1, shp[-1]), bias, norm.weight, norm.bias, norm.eps, 1, rowadd, need).view(shp)
+    if rowadd is not None:
+        x = x + rowadd
+    if x.is_cuda:
+        return bias_ln_tanh(x, bias, norm)
     return torch.tanh(norm(x + bias))
 
 
@@ -211,6 +291,57 @@ def bias_elu(x, bias):
         shp = x.shape
         return _BiasElu.apply(x.reshape(-1, shp[-1]), bias).view(shp)
     return F.elu(x + bias)
+
+
+class _GaussHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, zm, zs, bm, bs, mul, min_scale):
+        zm = _f32c(zm); zs = _f32c(zs); M, D = zm.shape
+        mean = torch.empty_like(zm); std = torch.empty_like(zs)
+        _check(lib().fbl_gauss_head(zm.data_ptr(), zs.data_ptr(), bm.data_ptr(), bs.data_ptr(), float(mul), float(min_scale), M, D,
+                                    mean.data_ptr(), std.data_ptr(), _stream()))
+        ctx.save_for_backward(zs, bs); ctx.mul = float(mul)
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, dmean, dstd):
+        zs, bs = ctx.saved_tensors
+        dmean = _f32c(dmean); dstd = _f32c(dstd); M, D = zs.shape
+        dzs = torch.empty_like(zs); db = zero_pool.take(2, D, device=zs.device)
+        _check(lib().fbl_gauss_head_bwd(dmean.data_ptr(), dstd.data_ptr(), zs.data_ptr(), bs.data_ptr(), ctx.mul, M, D, dzs.data_ptr(),
+                                        db[0].data_ptr(), db[1].data_ptr(), _stream()))
+        return dmean, dzs, db[0], db[1], None, None
+
+
+def gauss_head(zm, zs, bm, bs, mul, min_scale):
+    """(mean, stddev) = (zm + bm, softplus(zs + bs) * mul + min_scale) -- one launch forward, one backward."""
+    if zm.is_cuda and zm.dim() == 2:
+        return _GaussHead.apply(zm, zs, bm, bs, mul, min_scale)
+    return zm + bm, F.softplus(zs + bs)*mul + min_scale
+
+
+@torch.no_grad()
+def sample_actions(mean, std, noise):
+    """(mean + std * noise, the same clipped to [-1, 1]) for noise [N, B, D] -- one launch on the GPU."""
+    if mean.is_cuda:
+        N, B, D = noise.shape
+        sampled = torch.empty_like(noise); clamped = torch.empty_like(noise)
+        _check(lib().fbl_sample_actions(_f32c(mean).data_ptr(), _f32c(std).data_ptr(), _f32c(noise).data_ptr(), N, B, D, sampled.data_ptr(),
+                                        clamped.data_ptr(), _stream()))
+        return sampled, clamped
+    sampled = mean[None] + std[None]*noise
+    return sampled, sampled.clamp(-1.0, 1.0)
+
+
+@torch.no_grad()
+def concat_clamp(obs, act):
+    """[obs | clip(act, -1, 1)] (the critic's input) -- one launch on the GPU."""
+    if obs.is_cuda and obs.dim() == 2:
+        B, O = obs.shape; A = act.shape[-1]
+        out = torch.empty(B, O + A, device=obs.device)
+        _check(lib().fbl_concat_clamp(_f32c(obs).data_ptr(), _f32c(act).data_ptr(), B, O, A, out.data_ptr(), _stream()))
+        return out
+    return torch.cat([obs, act.clamp(-1.0, 1.0)], dim=-1)
 
 
 def replay_gather(u, size, capacity, fields):
@@ -231,7 +362,7 @@ class FlatAdam:
     def __init__(self, flat_param, flat_grad, seg_sizes, lrs, clips, floors=None, betas=(0.9, 0.999), eps=1e-8):
         self.p, self.g = flat_param, flat_grad
         self.m = torch.zeros_like(flat_param); self.v = torch.zeros_like(flat_param)
-        self.step_t = torch.zeros(1, device=flat_param.device)
+        self.step_t = torch.zeros(2, device=flat_param.device)          # {completed updates, update in flight} (include/flybody_learner.h: fbl_adam)
         ends, acc = [], 0
         for n in seg_sizes:
             acc += n; ends.append(acc)
@@ -239,7 +370,8 @@ class FlatAdam:
         self.ends = ends; self.lrs = list(lrs); self.clips = [c if c else 0.0 for c in clips]
         self.floors = [(-math.inf if f is None else f) for f in (floors or [None]*len(ends))]
         self.b1, self.b2 = betas; self.eps = eps
-        self._norms = torch.zeros(len(ends), device=flat_param.device)
+        self._norms = torch.zeros(512, device=flat_param.device)        # partial squared group norms: 2 parities x 32 slots x 8 segments
+        self._norms_ready = False
         self._c = dict(seg_end=(C.c_int64*len(ends))(*ends), lr=(C.c_float*len(ends))(*self.lrs),
                        clip=(C.c_float*len(ends))(*self.clips), floor=(C.c_float*len(ends))(*self.floors))
 
@@ -247,14 +379,50 @@ class FlatAdam:
         self.lrs = list(lrs); self._c['lr'] = (C.c_float*len(self.ends))(*self.lrs)
 
     @torch.no_grad()
+    def set_grads(self, grads, with_norms: bool):
+        """Lay the per-parameter gradient tensors (flat order; None = zeros) out in the flat gradient buffer -- ONE launch on the
+        GPU.  with_norms: also accumulate the squared group norms, so that `step` is a single launch (only valid when the flat
+        gradient is not modified -- all-reduced -- between this call and `step`)."""
+        ends, acc = [], 0
+        for g, n in zip(grads, self._sizes(grads)):
+            acc += n; ends.append(acc)
+        assert acc == self.p.numel(), 'gradient list does not cover the flat buffer'
+        if self.p.is_cuda:
+            n = len(grads)
+            src = (C.c_void_p*n)(*[(_f32c(g).data_ptr() if g is not None else None) for g in grads])
+            if self._norms_ready:                                  # a norm pass without its update (an interrupted step): start clean
+                self._norms.zero_()
+            _check(lib().fbl_gather_flat(src, (C.c_int64*n)(*ends), n, self.g.data_ptr(), len(self.ends), self._c['seg_end'],
+                                         self._norms.data_ptr() if with_norms else None, self.step_t.data_ptr(), _stream()))
+            self._norms_ready = bool(with_norms)
+            return
+        lo = 0
+        for g, hi in zip(grads, ends):
+            if g is None:
+                self.g[lo:hi].zero_()
+            else:
+                self.g[lo:hi].copy_(g.reshape(-1))
+            lo = hi
+
+    def _sizes(self, grads):
+        if getattr(self, '_grad_sizes', None) is None or len(self._grad_sizes) != len(grads):
+            assert all(g is not None for g in grads), 'the first gradient list must be complete (it defines the layout)'
+            self._grad_sizes = [g.numel() for g in grads]
+        return self._grad_sizes
+
+    def set_layout(self, sizes):
+        self._grad_sizes = [int(n) for n in sizes]
+
+    @torch.no_grad()
     def step(self):
         if self.p.is_cuda:
             _check(lib().fbl_adam(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.step_t.data_ptr(),
-                                  self._norms.data_ptr(), self.p.numel(), len(self.ends), self._c['seg_end'], self._c['lr'], self._c['clip'],
-                                  self._c['floor'], self.b1, self.b2, self.eps, _stream()))
+                                  self._norms.data_ptr(), self.p.numel(), len(self.ends), self._c['seg_end'],
+                                  self._c['lr'], self._c['clip'], self._c['floor'], self.b1, self.b2, self.eps, int(self._norms_ready), _stream()))
+            self._norms_ready = False
             return
         self.step_t += 1
-        t = float(self.step_t)
+        t = float(self.step_t[0])
         bc1 = 1 - self.b1**t; bc2s = math.sqrt(1 - self.b2**t)
         lo = 0
         for hi, lr, clip, fl in zip(self.ends, self.lrs, self.clips, self.floors):
@@ -270,10 +438,11 @@ class FlatAdam:
             lo = hi
 
     def state_tensors(self):
-        return [self.m, self.v, self.step_t]
+        """Everything `step` writes besides the parameters (the norm scratch is part of it: its parity follows the update count)."""
+        return [self.m, self.v, self.step_t, self._norms]
 
     def state_dict(self):
-        return dict(exp_avg=self.m.clone(), exp_avg_sq=self.v.clone(), step=self.step_t.clone())
+        return dict(exp_avg=self.m.clone(), exp_avg_sq=self.v.clone(), step=self.step_t[:1].clone())
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['exp_avg']); self.v.copy_(sd['exp_avg_sq']); self.step_t.copy_(sd['step'])
+        self.m.copy_(sd['exp_avg']); self.v.copy_(sd['exp_avg_sq']); self.step_t.copy_(sd['step'].reshape(-1)[:1].expand(2)); self._norms.zero_(); self._norms_ready = False

@@ -68,7 +68,10 @@ class DMPOLearner:
                                   [sum(p.numel() for p in g) for g in (self.policy_params, self.critic_params, self.dual_params)],
                                   lrs=[config.policy_lr, config.critic_lr, config.dual_lr], clips=[clip, clip, 0.0],
                                   floors=[None, None, -18.0])      # the duals are projected to >= -18 (losses_mpo.py: _MIN_LOG_TEMPERATURE)
+        self.opt.set_layout([p.numel() for p in allp])
         self.fused = self.device.type == 'cuda'       # GPU: fused loss kernels (they fail loudly if the library is missing)
+        # parameters whose gradient comes from the networks' backward pass (the logits bias and the duals get theirs from the loss kernels)
+        self._net_params = [p for p in self.policy_params + self.critic_params if p is not self.online.critic.logits.bias]
         if self.fused:
             fused.lib()
             # The learner's GEMMs are plain (no bias epilogue) [256 | 5120] x K x [51 .. 512] products.  hipBLASLt's heuristics pick
@@ -158,6 +161,12 @@ class DMPOLearner:
         return stats
 
     def _forward_backward(self, batch) -> Dict[str, torch.Tensor]:
+        if self.fused:
+            fused.zero_pool.begin_step(self.device)
+            try:
+                return self._forward_backward_fused(batch)
+            finally:
+                fused.zero_pool.end_step()
         cfg = self.cfg
         o_tm1, a_tm1, r_t, d_t, o_t = batch
         N, B = cfg.num_samples, o_t.shape[0]
@@ -169,26 +178,45 @@ class DMPOLearner:
             q_t_logits = self.target.critic.forward_samples(o_t, sampled)               # [N, B, atoms]
         o_mean, o_std = self.online.policy(o_t)
         q_tm1_logits = self.online.critic(o_tm1, a_tm1)
-        # categorical TD loss (+ the mean Q of every sampled action, the E-step input) and the MPO loss: fused kernels on the GPU
         critic_loss, sampled_q = fused.td_loss(q_tm1_logits, q_t_logits, self.online.critic.values, r_t, d_t, cfg.discount)
-        if self.fused:
-            policy_loss, stats = fused.mpo_loss(self.loss, o_mean, o_std, t_mean, t_std, sampled, sampled_q)
-        else:
-            policy_loss, stats = self.loss(o_mean, o_std, t_mean, t_std, sampled, sampled_q)
-        # critic loss trains the critic only; policy loss trains policy + duals (independent graphs).  The gradients come back
-        # as fresh tensors and land in the flat buffer with ONE multi-tensor copy (backward() into the pre-existing .grad views
-        # would cost an accumulate kernel per parameter tensor plus the zero-fill)
+        policy_loss, stats = self.loss(o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        # critic loss trains the critic only; policy loss trains policy + duals (independent graphs)
         allp = self.policy_params + self.critic_params + self.dual_params
         grads = torch.autograd.grad(critic_loss + policy_loss, allp, allow_unused=True)
-        views = [p.grad for p in allp]
-        if any(g is None for g in grads):                 # (the penalty temperature without action penalization)
-            for v, g in zip(views, grads):
-                if g is None:
-                    v.zero_()
-            views, grads = zip(*[(v, g) for v, g in zip(views, grads) if g is not None])
-        torch._foreach_copy_(list(views), list(grads))
+        self.opt.set_grads(list(grads), with_norms=False)        # (None -- the penalty temperature without action penalization -- = zeros)
         stats = dict(stats); stats['critic_loss'] = critic_loss.detach(); stats['policy_loss'] = policy_loss.detach()
         return stats
+
+    def _forward_backward_fused(self, batch) -> Dict[str, torch.Tensor]:
+        """The GPU step.  Everything that is not a GEMM is a hand-written kernel (dmpo/fused.py), and the two loss kernels return
+        the loss gradients wrt the network OUTPUTS directly (d logits, d mean, d stddev, d duals, d logits-bias): autograd only
+        runs the networks' own backward, seeded with those -- no loss graph, no unit-cotangent multiplies, no per-tensor fills."""
+        cfg = self.cfg
+        o_tm1, a_tm1, r_t, d_t, o_t = batch
+        N, B = cfg.num_samples, o_t.shape[0]
+        oc, tc = self.online.critic, self.target.critic
+        with torch.no_grad():
+            t_mean, t_std = self.target.policy(o_t)
+            noise = torch.randn(N, B, t_mean.shape[-1], device=self.device)
+            sampled, clipped = fused.sample_actions(t_mean, t_std, noise)
+            q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True)       # [N, B, atoms], logits bias not added yet
+        o_mean, o_std = self.online.policy(o_t)
+        q_tm1_raw = oc.forward_raw(o_tm1, a_tm1)
+        critic_loss, sampled_q, d_logits, d_logits_bias = fused.td_loss_grad(q_tm1_raw, oc.logits.bias, q_t_raw, tc.logits.bias, oc.values,
+                                                                             r_t, d_t, cfg.discount)
+        st, g_mean, g_std, g_duals = fused.mpo_loss_grad(self.loss, o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        net_grads = torch.autograd.grad([q_tm1_raw, o_mean, o_std], self._net_params, [d_logits, g_mean, g_std])
+        by_param = dict(zip(self._net_params, net_grads)); by_param[oc.logits.bias] = d_logits_bias; by_param.update(g_duals)
+        allp = self.policy_params + self.critic_params + self.dual_params
+        # ONE launch lays the gradients out in the flat buffer (and, on a single rank, accumulates the clipping norms)
+        self.opt.set_grads([by_param[p] for p in allp], with_norms=not self._distributed())
+        stats = fused.mpo_stats_dict(self.loss, st)
+        stats['critic_loss'] = critic_loss; stats['policy_loss'] = st[0]
+        return stats
+
+    @staticmethod
+    def _distributed():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     @torch.no_grad()
     def act(self, obs, deterministic: bool = False):

@@ -38,11 +38,11 @@ class LayerNormMLP(nn.Module):
     def forward(self, x):
         return self.tail(F.linear(x, self.first.weight))
 
-    def tail(self, z):
-        """Everything after the first GEMM.  The GEMMs run WITHOUT a bias epilogue (measured on MI355X: hipBLASLt's bias kernels
+    def tail(self, z, rowadd=None):
+        """Everything after the first GEMM (z + rowadd when a row-broadcast addend is given, fused.bias_ln_tanh).  The GEMMs run WITHOUT a bias epilogue (measured on MI355X: hipBLASLt's bias kernels
         take 63-170 us for the [256 x K] x [K x 256] shapes of this network against 5 us for the plain GEMM,
         profiles/r2/learner_gemm_probe.txt); bias + LayerNorm + tanh and bias + ELU are one fused kernel each (dmpo/fused.py)."""
-        h = fused.bias_ln_tanh(z, self.first.bias, self.norm)
+        h = fused.bias_ln_tanh(z, self.first.bias, self.norm, rowadd)
         for i, lin in enumerate(self.rest):
             z = F.linear(h, lin.weight)
             h = fused.bias_elu(z, lin.bias) if (self.activate_final or i < len(self.rest) - 1) else z + lin.bias
@@ -61,9 +61,9 @@ class GaussianHead(nn.Module):
         self.init_scale = init_scale; self.min_scale = min_scale
 
     def forward(self, h):
-        mean = F.linear(h, self.mean.weight) + self.mean.bias
-        std = F.softplus(F.linear(h, self.scale.weight) + self.scale.bias) * (self.init_scale / math.log(2.0)) + self.min_scale
-        return mean, std
+        # two plain GEMMs + ONE fused epilogue (bias, softplus, scale) -- fused.gauss_head; same arithmetic on the CPU
+        return fused.gauss_head(F.linear(h, self.mean.weight), F.linear(h, self.scale.weight), self.mean.bias, self.scale.bias,
+                                self.init_scale / math.log(2.0), self.min_scale)
 
 
 class Policy(nn.Module):
@@ -85,19 +85,30 @@ class Critic(nn.Module):
         self.register_buffer('values', torch.linspace(vmin, vmax, num_atoms))
 
     def forward(self, obs, action):
-        # ClipToSpec on canonical actions ([-1, 1] after CanonicalSpecWrapper, train_dmpo_ray.py:89)
-        x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
-        return F.linear(self.torso(x), self.logits.weight) + self.logits.bias
+        return self.forward_raw(obs, action) + self.logits.bias
 
-    def forward_samples(self, obs, actions):
+    def forward_raw(self, obs, action):
+        """The logits WITHOUT the last layer's bias (the fused TD-loss kernel adds it, fused.td_loss_grad)."""
+        # ClipToSpec on canonical actions ([-1, 1] after CanonicalSpecWrapper, train_dmpo_ray.py:89)
+        if torch.is_grad_enabled() and (obs.requires_grad or action.requires_grad):
+            x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
+        else:
+            x = fused.concat_clamp(obs, action)
+        return F.linear(self.torso(x), self.logits.weight)
+
+    def forward_samples(self, obs, actions, clipped=None, raw=False):
         """Logits [N, B, atoms] for N actions per observation (obs [B, O], actions [N, B, A]).  Same function as
         `forward` on the tiled inputs; the first layer is split into its observation and action halves so that the
-        observation half (741 of the 800 input columns) is multiplied once per observation instead of once per pair."""
+        observation half (741 of the 800 input columns) is multiplied once per observation instead of once per pair.
+        clipped: clip(actions, -1, 1) when the caller has it already; raw: leave the logits bias out (see forward_raw)."""
         t = self.torso
         no = obs.shape[-1]
+        if clipped is None:
+            clipped = actions.clamp(-1.0, 1.0)
         h_o = F.linear(obs, t.first.weight[:, :no])                                      # [B, H]
-        h_a = F.linear(actions.clamp(-1.0, 1.0), t.first.weight[:, no:])                 # [N, B, H]
-        return F.linear(t.tail(h_o[None] + h_a), self.logits.weight) + self.logits.bias
+        h_a = F.linear(clipped, t.first.weight[:, no:])                                  # [N, B, H]
+        z = F.linear(t.tail(h_a, rowadd=h_o), self.logits.weight)
+        return z if raw else z + self.logits.bias
 
     def mean_q(self, logits):
         return (F.softmax(logits, dim=-1) * self.values).sum(-1)

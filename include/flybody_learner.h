@@ -10,7 +10,10 @@
  *   fbl_mpo_loss     MPO.__call__ (agents/losses_mpo.py:175-368) with the action-penalisation branch: E-step weights,
  *                    temperature duals, decoupled mean / stddev cross-entropies, per-dimension KL penalties and alpha duals --
  *                    value, statistics AND every gradient (d online mean, d online stddev, d duals) in two launches.
+ *                    Wavefront sums run on the DPP datapath (row butterflies + row_bcast), not through LDS.
+ *   fbl_gather_flat  the autograd gradients -> the ONE flat buffer the all-reduce and the optimizer work on (+ squared group norms).
  *   fbl_adam         global-norm clipping (per parameter group, acme `clipping=True`: 40) + Adam on ONE flat parameter buffer.
+ *   fbl_bias_ln_act / fbl_bias_elu / fbl_gauss_head / fbl_sample_actions / fbl_concat_clamp: the layer epilogues and glue.
  * All pointers are DEVICE pointers to float32; `stream` is a hipStream_t (NULL = default).  Functions return 0 / -1 with the
  * message in fbl_last_error().  Everything is asynchronous and capturable into a HIP graph (no host synchronisation).
  */
@@ -26,14 +29,17 @@ extern "C" {
 const char* fbl_last_error(void);
 const char* fbl_version(void);
 
-/* q_t_logits [N][B][K] target-critic logits of the N sampled actions, q_tm1_logits [B][K] online logits, values [K] support
- * (ascending), reward [B], discount [B] (environment discount; multiplied by `gamma` here).  Outputs: sampled_q [N][B],
- * d_logits [B][K] = d mean_b(loss_b) / d q_tm1_logits, loss [B] per-row loss.  K <= 64. */
-int fbl_td_loss(const float* q_t_logits, const float* q_tm1_logits, const float* values, const float* reward, const float* discount,
-                float gamma, int N, int B, int K, float* sampled_q, float* d_logits, float* loss, void* stream);
+/* q_t_logits [N][B][K] target-critic logits of the N sampled actions, q_tm1_logits [B][K] online logits -- both as the GEMMs
+ * leave them; bias_t / bias_tm1 [K] (NULL: none) are the logits layers' biases, added here.  values [K] support (ascending),
+ * reward [B], discount [B] (environment discount; multiplied by `gamma` here).  Outputs: sampled_q [N][B], d_logits [B][K] =
+ * d mean_b(loss_b) / d q_tm1_logits, loss [B] per-row loss; d_bias [K] (column sums of d_logits) and loss_mean [1] are ACCUMULATED
+ * with atomics (NULL: skipped) -- the caller provides zeros.  K <= 64. */
+int fbl_td_loss(const float* q_t_logits, const float* bias_t, const float* q_tm1_logits, const float* bias_tm1, const float* values,
+                const float* reward, const float* discount, float gamma, int N, int B, int K, float* sampled_q, float* d_logits,
+                float* d_bias, float* loss, float* loss_mean, void* stream);
 
 typedef struct fbl_mpo_args {
-  int32_t N, B, D;                       /* samples per state, batch, action dimension (D <= 64) */
+  int32_t N, B, D;                       /* samples per state (<= 32), batch, action dimension (D <= 64) */
   const float *online_mean, *online_std, *target_mean, *target_std;     /* [B][D] */
   const float* actions;                  /* [N][B][D] sampled from the target policy */
   const float* q;                        /* [N][B] */
@@ -43,30 +49,56 @@ typedef struct fbl_mpo_args {
   int32_t action_penalization;
   float *d_online_mean, *d_online_std;   /* [B][D] gradients of the loss */
   float *d_log_temperature, *d_log_alpha_mean, *d_log_alpha_stddev, *d_log_penalty_temperature;   /* dual gradients (written, not accumulated) */
-  float* stats;                          /* [16]: loss, loss_policy_mean, loss_policy_std, loss_kl_mean, loss_kl_std, loss_alpha, loss_temperature,
-                                            kl_q_rel, penalty_kl_q_rel, kl_mean_rel, kl_stddev_rel, q_min, q_max, pi_stddev_min, pi_stddev_max, temperature */
-  float* workspace;                      /* [B][2 D + 16] scratch */
+  float* stats;                          /* [20]: loss, loss_policy_mean, loss_policy_std, loss_kl_mean, loss_kl_std, loss_alpha, loss_temperature,
+                                            kl_q_rel, penalty_kl_q_rel, kl_mean_rel, kl_stddev_rel, q_min, q_max, pi_stddev_min, pi_stddev_max, temperature,
+                                            mean alpha_mean, mean alpha_stddev, (2 spare) */
+  float* workspace;                      /* [fbl_mpo_workspace_floats] batch-sum accumulators: ZERO before the first call, left zero by
+                                            every call (two launches: rows -> sums; one wavefront -> duals, loss, statistics, clean-up) */
 } fbl_mpo_args;
 int fbl_mpo_loss(const fbl_mpo_args* a, void* stream);
 size_t fbl_mpo_workspace_floats(int B, int D);
 
 /* Adam on a flat buffer made of `nseg` consecutive segments (seg_end[s] = one past the last element of segment s).  Per segment:
  * learning rate lr[s], clip_norm[s] (<= 0: no clipping; otherwise grad *= min(1, clip / (||grad_seg|| + 1e-6)) like
- * torch.nn.utils.clip_grad_norm_), floor[s] (parameters are clamped to >= floor after the update; -inf: none).  `step` is a
- * device float holding the update count; it is incremented here.  norms: device scratch [nseg].  nseg <= 8. */
+ * torch.nn.utils.clip_grad_norm_), floor[s] (parameters are clamped to >= floor after the update; -inf: none).  `step` is TWO
+ * device floats {completed updates, update in flight}, both 0 at the start (a checkpoint restores both to the update count).
+ * norms [512]: partial squared gradient norms (2 parities x 32 slots x 8 segments), double-buffered on the parity of the update count; ZERO before the first call, kept
+ * consistent by the kernels (no memset, no atomics on the counters).  norms_ready != 0: the norms of this update were already
+ * accumulated by fbl_gather_flat (one launch here); 0: they are computed here first (two launches).  nseg <= 8. */
 int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, float* norms, int64_t n, int nseg,
              const int64_t* seg_end, const float* lr, const float* clip_norm, const float* floor_, float beta1, float beta2, float eps,
-             void* stream);
+             int norms_ready, void* stream);
 
-/* y = act(LayerNorm(x + bias))  (act: 0 none, 1 tanh) / y = ELU(x + bias), rows of width W <= 1024; x may alias y.  Backward
- * kernels return dx (= gradient wrt the GEMM output) and accumulate the column sums (d bias, d gamma, d beta) with atomics
- * into zero-initialised buffers. */
-int fbl_bias_ln_act(const float* x, const float* bias, const float* gamma, const float* beta, float eps, int act, int M, int W,
-                    float* y, float* xhat, float* rstd, void* stream);
+/* Lay `ntensor` gradient tensors (src[k], device pointers in HOST arrays; NULL = zeros) out in the flat buffer: tensor k occupies
+ * flat[end[k-1] .. end[k]).  norms != NULL: also accumulate the squared norm of every Adam segment (seg_end as in fbl_adam; segment
+ * boundaries must be tensor boundaries) into the optimizer's `norms` / `step` pair, exactly as fbl_adam's own norm pass would --
+ * call it ONCE per update, then fbl_adam with norms_ready = 1.  ntensor <= 96.  One launch. */
+int fbl_gather_flat(const float* const* src, const int64_t* end, int ntensor, float* flat, int nseg, const int64_t* seg_end,
+                    float* norms, float* step, void* stream);
+
+/* y = act(LayerNorm(x + bias [+ rowadd[r mod period]]))  (act: 0 none, 1 tanh) / y = ELU(x + bias), rows of width W <= 1024; x may
+ * alias y.  rowadd [period][W] (NULL: none) is a row-broadcast addend: the observation half of the critic's first layer, shared
+ * by the N sampled actions of a state.  Backward kernels return dx (= gradient wrt the GEMM output) and accumulate the column
+ * sums (d bias, d gamma, d beta) with atomics into zero-initialised buffers. */
+int fbl_bias_ln_act(const float* x, const float* bias, const float* gamma, const float* beta, const float* rowadd, int period, float eps,
+                    int act, int M, int W, float* y, float* xhat, float* rstd, void* stream);
 int fbl_bias_ln_act_bwd(const float* dy, const float* y, const float* xhat, const float* rstd, const float* gamma, int act, int M, int W,
                         float* dx, float* dbias, float* dgamma, float* dbeta, void* stream);
 int fbl_bias_elu(const float* x, const float* bias, int M, int W, float* y, void* stream);
 int fbl_bias_elu_bwd(const float* dy, const float* y, int M, int W, float* dx, float* dbias, void* stream);
+
+/* Gaussian policy head (acme MultivariateNormalDiagHead, network_factory.py:81-86): mean = zm + bm, stddev = softplus(zs + bs) mul
+ * + min_scale for the two [M][D] GEMM outputs zm, zs.  Backward: dzs = dstd sigmoid(zs + bs) mul (d zm == d mean), and the bias
+ * gradients dbm, dbs [D] accumulated with atomics into zero-initialised buffers.  D <= 256 for the backward. */
+int fbl_gauss_head(const float* zm, const float* zs, const float* bm, const float* bs, float mul, float min_scale, int M, int D,
+                   float* mean, float* std_, void* stream);
+int fbl_gauss_head_bwd(const float* dmean, const float* dstd, const float* zs, const float* bs, float mul, int M, int D, float* dzs,
+                       float* dbm, float* dbs, void* stream);
+
+/* sampled[n][b][d] = mean[b][d] + std[b][d] noise[n][b][d] and its clip to [-1, 1] (learning_dmpo.py:213-222 + ClipToSpec). */
+int fbl_sample_actions(const float* mean, const float* std_, const float* noise, int N, int B, int D, float* sampled, float* clamped, void* stream);
+/* out [B][O + A] = [obs | clip(act, -1, 1)]: the critic's input (network_factory.py:96-99). */
+int fbl_concat_clamp(const float* obs, const float* act, int B, int O, int A, float* out, void* stream);
 
 /* Uniform replay sampling (reverb selectors.Uniform): row index = floor(u[b] * min(size, capacity)) from B uniform numbers and the
  * DEVICE fill level, then the gather of `narr` row-major fields (observation, action, reward, discount, next observation) in

@@ -84,7 +84,7 @@ def test_flat_adam_kernel():
         g = torch.randn(n)*(0.2 if k % 2 else 0.01)
         a.g.copy_(g.cuda()); b.g.copy_(g); a.step(); b.step()
     _close(a.p, b.p, rtol=1e-5, atol=2e-6); _close(a.m, b.m, rtol=1e-4, atol=1e-6); _close(a.v, b.v, rtol=1e-4, atol=1e-9)
-    assert float(a.step_t) == 4.0
+    assert float(a.step_t[0]) == 4.0
 
 
 @pytest.mark.parametrize('M,W', [(256, 256), (5120, 512), (37, 200)])
@@ -172,3 +172,110 @@ def test_replay_gather_kernel():
     idx = torch.tensor([store[int(k)] for k in key.cpu()])
     assert torch.equal(rep.next_obs[idx.to(dev)], no) and torch.equal(rep.reward[idx.to(dev)], r)
     assert idx.max() < n and len(set(idx.tolist())) > 0.9*n
+
+
+def test_td_loss_bias_and_bias_gradient():
+    """fbl_td_loss adds the logits layers' biases itself and returns d loss / d bias and the batch-mean loss (atomics)."""
+    from flybody_amd.dmpo import fused
+    from flybody_amd.dmpo.losses import categorical_td_loss
+    torch.manual_seed(7)
+    for N, B, K in [(20, 256, 51), (3, 37, 8), (1, 5, 64)]:
+        dev = 'cuda'
+        values = torch.linspace(-150, 150, K, device=dev)
+        qt = torch.randn(N, B, K, device=dev)*2; q1 = torch.randn(B, K, device=dev)*2
+        bt = torch.randn(K, device=dev); b1 = torch.randn(K, device=dev, requires_grad=True)
+        r = torch.randn(B, device=dev)*30; d = (torch.rand(B, device=dev) > 0.1).float()
+        loss, sq, dlog, dbias = fused.td_loss_grad(q1, b1, qt, bt, values, r, d, 0.99)
+        q1r = q1.clone().requires_grad_(True)
+        avg = torch.logsumexp(torch.log_softmax(qt + bt, -1), 0)
+        ref = categorical_td_loss(q1r + b1, values, r, 0.99*d, avg).mean(); ref.backward()
+        _close(loss, ref); _close(dlog, q1r.grad, rtol=1e-3, atol=1e-8); _close(dbias, b1.grad, rtol=1e-3, atol=1e-7)
+        _close(sq, (torch.softmax(qt + bt, -1)*values).sum(-1), rtol=1e-4, atol=1e-3)
+
+
+def test_mpo_loss_workspace_is_self_cleaning():
+    """The single-launch MPO kernel leaves its accumulator block at zero: repeated calls give identical results."""
+    from flybody_amd.dmpo import MPOLoss, fused
+    torch.manual_seed(8)
+    N, B, D = 20, 256, 59
+    dev = 'cuda'
+    m = MPOLoss(D, epsilon=0.1, epsilon_mean=0.0025, epsilon_stddev=1e-7, action_penalization=True, epsilon_penalty=0.1).to(dev)
+    tm = torch.randn(B, D, device=dev)*0.3; ts = torch.rand(B, D, device=dev)*0.5 + 0.2
+    om = tm + 0.05*torch.randn(B, D, device=dev); os_ = ts*1.1
+    acts = tm[None] + ts[None]*torch.randn(N, B, D, device=dev); q = torch.randn(N, B, device=dev)*3
+    outs = []
+    for _ in range(3):
+        st, g_om, g_os, duals = fused.mpo_loss_grad(m, om, os_, tm, ts, acts, q)
+        outs.append((st[:18].clone(), g_om.clone(), duals[m.log_alpha_mean].clone(), duals[m.log_temperature].clone()))
+    torch.cuda.synchronize()
+    ws = fused._mpo_ws[(torch.device('cuda', torch.cuda.current_device()), D)] if (torch.device('cuda', torch.cuda.current_device()), D) in fused._mpo_ws \
+        else list(fused._mpo_ws.values())[0]
+    assert float(ws.abs().max()) == 0.0
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            _close(x, y, rtol=1e-5, atol=1e-6)                   # (atomic summation order may differ in the last bits)
+    _close(outs[0][0][16], (F.softplus(m.log_alpha_mean) + 1e-8).mean(), rtol=1e-5); _close(outs[0][0][17], (F.softplus(m.log_alpha_stddev) + 1e-8).mean(), rtol=1e-5)
+
+
+def test_gather_flat_and_single_launch_adam():
+    """fbl_gather_flat lays ragged gradient tensors (one missing) out in the flat buffer and accumulates the group norms; Adam with
+    those norms (one launch) equals Adam computing them itself (two launches)."""
+    from flybody_amd.dmpo.fused import FlatAdam
+    torch.manual_seed(9)
+    shapes = [(256, 741), (256,), (256,), (256,), (256, 256), (59, 256), (59,), (512, 800), (51,), (1,), (59,), (59,), (1,)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    groups = [sum(sizes[:7]), sum(sizes[7:9]), sum(sizes[9:])]; n = sum(sizes)
+    p0 = torch.randn(n, device='cuda')
+    mk = lambda: FlatAdam(p0.clone(), torch.full((n,), 7.0, device='cuda'), groups, lrs=[1e-4, 1e-4, 1e-3], clips=[40.0, 40.0, 0.0], floors=[None, None, -18.0])
+    a, b = mk(), mk()
+    a.set_layout(sizes); b.set_layout(sizes)
+    for k in range(3):
+        grads = [torch.randn(*s, device='cuda')*(3.0 if k == 1 else 0.01) for s in shapes]
+        grads[12] = None                                         # (the penalty temperature without action penalization)
+        a.set_grads(grads, with_norms=True); b.set_grads(grads, with_norms=False)
+        want = torch.cat([(g if g is not None else torch.zeros(s, device='cuda')).reshape(-1) for g, s in zip(grads, shapes)])
+        assert torch.equal(a.g, want) and torch.equal(b.g, want)
+        a.step(); b.step()
+        torch.cuda.synchronize()
+        assert float(a.step_t[0]) == k + 1 and float(b.step_t[1]) == k + 1
+    _close(a.p, b.p, rtol=1e-6, atol=1e-7); _close(a.m, b.m, rtol=1e-5, atol=1e-8)
+    assert float(a.step_t[0]) == 3.0 and float(b.step_t[0]) == 3.0
+
+
+def test_glue_kernels():
+    """Gaussian head (forward + backward), action sampling + clip, critic-input concat, LayerNorm with the row-broadcast addend."""
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(10)
+    dev = 'cuda'
+    M, D = 256, 59
+    zm = torch.randn(M, D, device=dev, requires_grad=True); zs = (torch.randn(M, D, device=dev)*3).requires_grad_(True)
+    bm = torch.randn(D, device=dev, requires_grad=True); bs = torch.randn(D, device=dev, requires_grad=True)
+    mul, mn = 0.7/math.log(2.0), 1e-6
+    mean, std = fused.gauss_head(zm, zs, bm, bs, mul, mn)
+    u1, u2 = torch.randn(M, D, device=dev), torch.randn(M, D, device=dev)
+    (mean*u1 + std*u2).sum().backward()
+    got = [t.grad.clone() for t in (zm, zs, bm, bs)]
+    for t in (zm, zs, bm, bs):
+        t.grad = None
+    mr, sr = zm + bm, F.softplus(zs + bs)*mul + mn
+    (mr*u1 + sr*u2).sum().backward()
+    _close(mean, mr, rtol=1e-6, atol=1e-6); _close(std, sr, rtol=1e-5, atol=1e-6)
+    for g, t in zip(got, (zm, zs, bm, bs)):
+        _close(g, t.grad, rtol=1e-4, atol=1e-4)
+    N, B = 20, 256
+    noise = torch.randn(N, B, D, device=dev)*2
+    s, c = fused.sample_actions(mean.detach(), std.detach(), noise)
+    ref = mr.detach()[None] + sr.detach()[None]*noise
+    _close(s, ref, rtol=1e-5, atol=1e-6); _close(c, ref.clamp(-1, 1), rtol=1e-5, atol=1e-6)
+    obs = torch.randn(B, 741, device=dev); act = torch.randn(B, D, device=dev)*2
+    assert torch.equal(fused.concat_clamp(obs, act), torch.cat([obs, act.clamp(-1, 1)], -1))
+    W = 512
+    ln = torch.nn.LayerNorm(W).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_()
+        x = torch.randn(N, B, W, device=dev); ra = torch.randn(B, W, device=dev); b = torch.randn(W, device=dev)
+        _close(fused.bias_ln_tanh(x, b, ln, rowadd=ra), torch.tanh(ln(x + ra[None] + b)), rtol=1e-4, atol=1e-5)
+    # with gradients enabled the broadcast addend falls back to an explicit add (and stays differentiable)
+    ra.requires_grad_(True)
+    y = fused.bias_ln_tanh(x, b, ln, rowadd=ra); y.sum().backward()
+    assert ra.grad is not None and torch.isfinite(ra.grad).all()

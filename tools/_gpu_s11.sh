@@ -1,4 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/s11; mkdir -p $O; cd $R
-timeout 200 python tools/phase_profile.py build_variants/libfb_v5bt.so 64 4096 > $O/phase64_bt.log 2>&1
-timeout 200 python tools/phase_profile.py build_variants/libfb_v5bt.so 32 4096 > $O/phase32_bt.log 2>&1
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_learner.py -x -q > $O/pytest_learner.log 2>&1; echo "rc $?" >> $O/pytest_learner.log
+timeout 200 python tools/learner_bench.py --steps 300 > $O/learner_graphs.log 2>&1
+timeout 200 python tools/learner_bench.py --steps 100 --no-graphs > $O/learner_nographs.log 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/learner_trace -o lb -- python $R/tools/learner_bench.py --steps 100 --no-graphs > $O/learner_rocprof.log 2>&1
