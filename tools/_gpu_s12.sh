@@ -1,8 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/s12; mkdir -p $O; cd $R
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
-timeout 600 python tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
-timeout 1200 bash tools/collect_profiles.sh r2 > $O/collect.log 2>&1
-cp -r $R/gpurun_out/profiles_r2 $O/ 2>/dev/null
-timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for n in 32 64 128 256 512 1024 2048 4096; do
+  timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 $n 20 >> $O/scale64.log 2>&1
+done
+for n in 64 256 1024 4096; do
+  timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 32 $n 20 >> $O/scale32.log 2>&1
+done
