@@ -758,6 +758,100 @@ extern "C" int fbl_bias_elu_bwd(const float* dy, const float* y, int M, int W, f
   return 0;
 }
 
+// ------------------------------------------------------------------ small f32 GEMM on the matrix cores (M <= a few hundred rows)
+// The learner's B = 256 layers are [256 x K] x [K x 256] products: 33-100 MFLOP each.  A library GEMM spends 6-8 us on them (tens
+// of workgroups, a K loop behind LDS staging and barriers); here a workgroup owns ONE 32 x 32 tile of C and its wavefronts
+// split K, each running v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain) on operands it loads straight from global
+// memory -- lane l feeds A[i = l & 31][k] and B[k][j = l & 31], so a lane's four consecutive k are one 16-byte load when the
+// operand is k-contiguous.  Up to 64 k per wave are in flight before the first MFMA issues; the four partial tiles meet in LDS
+// and leave through the epilogue (bias / bias + ELU).  C = A B with A(i, k) = a[i sai + k sak], B(k, j) = b[k sbk + j sbj]:
+// every transpose combination of the forward and backward passes is a choice of strides.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GB 8                                  // k-steps (of 8) prefetched per block: 64 k per wave in flight
+
+template <bool AV, bool BV>                   // operand is k-contiguous (stride 1 along k): 16-byte loads
+#define GW 4                                  // wavefronts per workgroup (K is split GW ways)
+__global__ void __launch_bounds__(64*GW) k_sgemm(const float* __restrict__ a, long long sai, long long sak, const float* __restrict__ b, long long sbk,
+                                               long long sbj, float* __restrict__ c, long long ldc, int M, int N, int K, int epi,
+                                               const float* __restrict__ bias) {
+  __shared__ float red[GW][16][WAVE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.y*32, j0 = blockIdx.x*32;
+  const int kc = ((K + 8*GW - 1)/(8*GW))*8;                            // k per wave, a multiple of 8
+  const int kb = wv*kc, ke = min(K, kb + kc);
+  const int ia = min(i0 + r, M - 1), jb = min(j0 + r, N - 1);           // (rows / columns past the edge read a valid one; their results are not stored)
+  const float* pa = a + (long long)ia*sai;
+  const float* pb = b + (long long)jb*sbj;
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kb; k0 < ke; k0 += 8*GB) {
+    float av[GB][4], bv[GB][4];
+#pragma unroll
+    for (int s = 0; s < GB; s++) {
+      const int k = k0 + 8*s + 4*h;                                     // this lane's four k of step s
+      if (k0 + 8*s >= ke) {                                             // (wave-uniform: nothing left for this step)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { av[s][q] = 0.f; bv[s][q] = 0.f; }
+      } else if (k + 3 < ke) {
+        if (AV) { const float4 t = *reinterpret_cast<const float4*>(pa + k); av[s][0] = t.x; av[s][1] = t.y; av[s][2] = t.z; av[s][3] = t.w; }
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) av[s][q] = pa[(long long)(k + q)*sak];
+        }
+        if (BV) { const float4 t = *reinterpret_cast<const float4*>(pb + k); bv[s][0] = t.x; bv[s][1] = t.y; bv[s][2] = t.z; bv[s][3] = t.w; }
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) bv[s][q] = pb[(long long)(k + q)*sbk];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bool ok = k + q < ke; const int kk = ok ? k + q : kb;
+          const float x = pa[(long long)kk*sak], y = pb[(long long)kk*sbk];
+          av[s][q] = ok ? x : 0.f; bv[s][q] = ok ? y : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < GB; s++) {
+      if (k0 + 8*s < ke) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][q], bv[s][q], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; v++) red[wv][v][lane] = acc[v];
+  __syncthreads();
+  // C/D map of the 32x32 MFMA: register v of lane l is C[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31]
+#pragma unroll
+  for (int q = 0; q < 16/GW; q++) {
+    const int v = wv + GW*q;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < GW; w++) t += red[w][v][lane];
+    const int i = i0 + (v & 3) + 8*(v >> 2) + 4*h, j = j0 + r;
+    if (i < M && j < N) {
+      float y = t;
+      if (epi >= 1) y += bias[j];
+      if (epi == 2) y = y > 0.f ? y : expm1f(y);
+      c[(long long)i*ldc + j] = y;
+    }
+  }
+}
+
+extern "C" int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
+                         int epilogue, const float* bias, void* stream) {
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 2 || (epilogue && !bias)) return lfail("fbl_sgemm: bad argument");
+  const dim3 grid((N + 31)/32, (M + 31)/32);
+  const bool av = sak == 1 && K >= 4, bv = sbk == 1 && K >= 4;
+  hipStream_t st = (hipStream_t)stream;
+#define L_(AV_, BV_) hipLaunchKernelGGL((k_sgemm<AV_, BV_>), grid, dim3(64*GW), 0, st, a, (long long)sai, (long long)sak, b, (long long)sbk, (long long)sbj, c, (long long)ldc, M, N, K, epilogue, bias)
+  if (av && bv) L_(true, true); else if (av) L_(true, false); else if (bv) L_(false, true); else L_(false, false);
+#undef L_
+  LCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ replay sampling: uniform row index + gather of all fields
 struct GatherArgs { int narr; const float* src[8]; float* dst[8]; int width[8]; };
 __global__ void __launch_bounds__(256) k_replay_gather(const float* __restrict__ u, const long long* __restrict__ size, long long capacity, GatherArgs g) {

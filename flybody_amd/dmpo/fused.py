@@ -53,6 +53,8 @@ def lib():
         L.fbl_gauss_head_bwd.argtypes = [C.c_void_p]*4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
         L.fbl_sample_actions.argtypes = [C.c_void_p]*3 + [C.c_int]*3 + [C.c_void_p]*3
         L.fbl_concat_clamp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fbl_sgemm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_ln_act_bwd.argtypes = [C.c_void_p]*5 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p]*5
         L.fbl_bias_elu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_elu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -291,6 +293,58 @@ def bias_elu(x, bias):
         shp = x.shape
         return _BiasElu.apply(x.reshape(-1, shp[-1]), bias).view(shp)
     return F.elu(x + bias)
+
+
+# ------------------------------------------------------------------ the B = 256 layers: small MFMA GEMM (+ bias + ELU epilogue)
+SMALL_GEMM_ROWS = 1024          # layers with more rows than this (the [5120 x 512] target-critic products) go to the BLAS library
+SMALL_GEMM_K = 512              # ... and so do longer reductions (741 / 800 input columns): measured 14.8 us here against 7.6 us there
+_USE_SGEMM = os.environ.get('FB_LEARNER_GEMM', 'mfma') != 'blas'
+
+
+def _sgemm(a, sai, sak, b, sbk, sbj, M, N, K, epilogue=0, bias=None):
+    c = torch.empty(M, N, device=a.device)
+    _check(lib().fbl_sgemm(a.data_ptr(), sai, sak, b.data_ptr(), sbk, sbj, c.data_ptr(), N, M, N, K, int(epilogue),
+                           bias.data_ptr() if bias is not None else None, _stream()))
+    return c
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T (act None) or ELU(x W^T + bias) (act 'elu') through fbl_sgemm; backward d x = d z W, d W = d z^T x on the same kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, elu):
+        x = _f32c(x); w = _f32c(w); M, K = x.shape; N = w.shape[0]
+        y = _sgemm(x, K, 1, w, 1, K, M, N, K, 2 if elu else 0, bias if elu else None)
+        ctx.save_for_backward(x, w, y if elu else None); ctx.elu = bool(elu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _f32c(dy); M, K = x.shape; N = w.shape[0]
+        db = None
+        if ctx.elu:                                               # d z = d y ELU'(.), d bias = column sums of d z: one launch
+            dz = torch.empty_like(dy); db = zero_pool.take(N, device=dy.device)
+            _check(lib().fbl_bias_elu_bwd(dy.data_ptr(), y.data_ptr(), M, N, dz.data_ptr(), db.data_ptr(), _stream()))
+        else:
+            dz = dy
+        dx = _sgemm(dz, N, 1, w, K, 1, M, K, N) if ctx.needs_input_grad[0] else None          # [M, K] = d z [M, N] W [N, K]
+        dw = _sgemm(dz, 1, N, x, K, 1, N, K, M) if ctx.needs_input_grad[1] else None          # [N, K] = d z^T [N, M] x [M, K]
+        return dx, dw, db, None
+
+
+def linear(x, w, bias=None, elu=False):
+    """x W^T (bias None) or ELU(x W^T + bias).  2-D GPU inputs of up to SMALL_GEMM_ROWS rows run on the hand-written MFMA kernel
+    (fbl_sgemm) with the epilogue fused; anything else is the BLAS GEMM + the fused epilogue kernel (bias_elu)."""
+    assert bias is None or elu, 'bias without activation is not used by the networks (the loss kernels add the output biases)'
+    if _USE_SGEMM and x.is_cuda and x.dim() == 2 and x.shape[0] <= SMALL_GEMM_ROWS and x.shape[1] <= SMALL_GEMM_K and x.dtype == torch.float32:
+        if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad))):
+            # forward only (target networks, actors): nothing is saved, and W may be a column slice of a wider matrix (row stride)
+            if x.stride(1) == 1 and w.stride(1) == 1:
+                return _sgemm(x, x.stride(0), 1, w, 1, w.stride(0), x.shape[0], w.shape[0], x.shape[1], 2 if elu else 0, bias if elu else None)
+        return _Linear.apply(x, w, bias, elu)
+    z = F.linear(x, w)
+    return bias_elu(z, bias) if elu else z
 
 
 class _GaussHead(torch.autograd.Function):

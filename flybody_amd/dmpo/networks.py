@@ -36,7 +36,7 @@ class LayerNormMLP(nn.Module):
             _uniform_fan_out_(lin.weight); nn.init.zeros_(lin.bias)
 
     def forward(self, x):
-        return self.tail(F.linear(x, self.first.weight))
+        return self.tail(fused.linear(x, self.first.weight))
 
     def tail(self, z, rowadd=None):
         """Everything after the first GEMM (z + rowadd when a row-broadcast addend is given, fused.bias_ln_tanh).  The GEMMs run WITHOUT a bias epilogue (measured on MI355X: hipBLASLt's bias kernels
@@ -44,8 +44,10 @@ class LayerNormMLP(nn.Module):
         profiles/r2/learner_gemm_probe.txt); bias + LayerNorm + tanh and bias + ELU are one fused kernel each (dmpo/fused.py)."""
         h = fused.bias_ln_tanh(z, self.first.bias, self.norm, rowadd)
         for i, lin in enumerate(self.rest):
-            z = F.linear(h, lin.weight)
-            h = fused.bias_elu(z, lin.bias) if (self.activate_final or i < len(self.rest) - 1) else z + lin.bias
+            if self.activate_final or i < len(self.rest) - 1:
+                h = fused.linear(h, lin.weight, lin.bias, elu=True)        # GEMM + bias + ELU (one launch for the B = 256 layers)
+            else:
+                h = fused.linear(h, lin.weight) + lin.bias
         return h
 
 
@@ -62,7 +64,7 @@ class GaussianHead(nn.Module):
 
     def forward(self, h):
         # two plain GEMMs + ONE fused epilogue (bias, softplus, scale) -- fused.gauss_head; same arithmetic on the CPU
-        return fused.gauss_head(F.linear(h, self.mean.weight), F.linear(h, self.scale.weight), self.mean.bias, self.scale.bias,
+        return fused.gauss_head(fused.linear(h, self.mean.weight), fused.linear(h, self.scale.weight), self.mean.bias, self.scale.bias,
                                 self.init_scale / math.log(2.0), self.min_scale)
 
 
@@ -94,7 +96,7 @@ class Critic(nn.Module):
             x = torch.cat([obs, action.clamp(-1.0, 1.0)], dim=-1)
         else:
             x = fused.concat_clamp(obs, action)
-        return F.linear(self.torso(x), self.logits.weight)
+        return fused.linear(self.torso(x), self.logits.weight)
 
     def forward_samples(self, obs, actions, clipped=None, raw=False):
         """Logits [N, B, atoms] for N actions per observation (obs [B, O], actions [N, B, A]).  Same function as
@@ -105,7 +107,7 @@ class Critic(nn.Module):
         no = obs.shape[-1]
         if clipped is None:
             clipped = actions.clamp(-1.0, 1.0)
-        h_o = F.linear(obs, t.first.weight[:, :no])                                      # [B, H]
+        h_o = fused.linear(obs, t.first.weight[:, :no])                                  # [B, H]
         h_a = F.linear(clipped, t.first.weight[:, no:])                                  # [N, B, H]
         z = F.linear(t.tail(h_a, rowadd=h_o), self.logits.weight)
         return z if raw else z + self.logits.bias

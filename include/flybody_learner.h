@@ -100,6 +100,15 @@ int fbl_sample_actions(const float* mean, const float* std_, const float* noise,
 /* out [B][O + A] = [obs | clip(act, -1, 1)]: the critic's input (network_factory.py:96-99). */
 int fbl_concat_clamp(const float* obs, const float* act, int B, int O, int A, float* out, void* stream);
 
+/* Small f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32) for the B = 256 layers of the networks and their backward
+ * passes: C[M][N] = sum_k A(i, k) B(k, j) with A(i, k) = a[i sai + k sak], B(k, j) = b[k sbk + j sbj], C row-major with leading
+ * dimension ldc -- every transpose combination is a choice of strides (forward x W^T: sak = 1, sbk = 1; d x = d y W: sak = 1,
+ * sbj = 1; d W = d y^T x: sai = 1, sbj = 1).  epilogue 0: none, 1: + bias[j], 2: ELU(. + bias[j]).  One 32 x 32 tile per workgroup,
+ * K split over its four wavefronts: meant for M, N, K up to a few hundred -- its time is launch + one memory round trip + K / 4 of MFMA
+ * chain, which beats a library GEMM only while that chain is short (the learner routes K <= 512, M <= 1024 here). */
+int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
+              int epilogue, const float* bias, void* stream);
+
 /* Uniform replay sampling (reverb selectors.Uniform): row index = floor(u[b] * min(size, capacity)) from B uniform numbers and the
  * DEVICE fill level, then the gather of `narr` row-major fields (observation, action, reward, discount, next observation) in
  * one launch.  dst[k] is [B][width[k]]. */

@@ -279,3 +279,29 @@ def test_glue_kernels():
     ra.requires_grad_(True)
     y = fused.bias_ln_tanh(x, b, ln, rowadd=ra); y.sum().backward()
     assert ra.grad is not None and torch.isfinite(ra.grad).all()
+
+
+@pytest.mark.parametrize('M,K,N', [(256, 741, 256), (256, 256, 256), (256, 800, 512), (256, 512, 512), (256, 256, 59), (256, 256, 51), (37, 203, 45), (64, 5, 33)])
+def test_small_mfma_gemm(M, K, N):
+    """fbl_sgemm (v_mfma_f32_32x32x2_f32, one 32 x 32 tile per workgroup, K split over four waves) against torch.matmul in FP64 --
+    forward with both epilogues, and the two backward products -- at the network's shapes and at ragged ones."""
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(11)
+    dev = 'cuda'
+    x = torch.randn(M, K, device=dev, requires_grad=True); w = (torch.randn(N, K, device=dev)/math.sqrt(K)).requires_grad_(True)
+    b = torch.randn(N, device=dev, requires_grad=True); up = torch.randn(M, N, device=dev)
+    ref = lambda t: t.detach().double()
+    tol = dict(rtol=2e-5, atol=2e-5)
+    y = fused.linear(x, w)
+    _close(y, ref(x) @ ref(w).T, **tol)
+    y.backward(up)
+    _close(x.grad, ref(up) @ ref(w), **tol); _close(w.grad, ref(up).T @ ref(x), rtol=2e-5, atol=2e-4)
+    x.grad = w.grad = None
+    y = fused.linear(x, w, b, elu=True); y.backward(up)
+    z = ref(x) @ ref(w).T + ref(b); dz = ref(up)*torch.where(z > 0, torch.ones_like(z), z.exp())
+    _close(y, F.elu(z), **tol)
+    _close(x.grad, dz @ ref(w), rtol=2e-5, atol=5e-5); _close(w.grad, dz.T @ ref(x), rtol=2e-5, atol=2e-4); _close(b.grad, dz.sum(0), rtol=2e-5, atol=2e-4)
+    # forward-only path on a column slice of a wider weight matrix (the target critic's observation half)
+    with torch.no_grad():
+        wide = torch.randn(N, K + 59, device=dev)
+        _close(fused.linear(x, wide[:, :K]), ref(x) @ ref(wide[:, :K]).T, rtol=2e-5, atol=2e-4)
