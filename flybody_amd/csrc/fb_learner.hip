@@ -317,6 +317,7 @@ __device__ __forceinline__ int seg_of(const AdamSegs& sg, long long i) {
 }
 
 // block-level sum of the per-thread per-segment squares -> one atomic per segment and workgroup
+template <bool ATOMIC>
 __device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __restrict__ norms, float* __restrict__ step) {
   __shared__ float red[8][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -324,21 +325,39 @@ __device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __
 #pragma unroll
   for (int s = 0; s < 8; s++) { float t = wsum(acc[s]); if (lane == 0) red[s][wv] = t; }
   __syncthreads();
-  if (threadIdx.x < 8 && threadIdx.x < nseg)
-    atomicAdd(norms + (par*NORM_SLOTS + (blockIdx.x & (NORM_SLOTS - 1)))*8 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x < 8 && threadIdx.x < nseg) {
+    const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    float* slot = norms + (par*NORM_SLOTS + (blockIdx.x & (NORM_SLOTS - 1)))*8 + threadIdx.x;
+    if (ATOMIC) atomicAdd(slot, t); else *slot = t;              // (!ATOMIC: exactly NORM_SLOTS workgroups, one slot each)
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) step[1] = step[0] + 1.f;
 }
 
+// The optimizer's own norm pass runs AFTER the gradient all-reduce of a data-parallel step: it is launched with exactly NORM_SLOTS
+// workgroups, each storing (not adding) its slot, so the result -- and with it the clipping factor and every replica's update --
+// is bit-reproducible.  (fbl_gather_flat's fused norm pass, single-rank only, uses atomics: reproducible to rounding.)
 __global__ void __launch_bounds__(256) k_sqnorm(const float* __restrict__ g, long long n, AdamSegs sg, float* __restrict__ norms, float* __restrict__ step) {
   float acc[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) acc[s] = 0.f;
-  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
-    float v = g[i]; int s = seg_of(sg, i);
+  const long long n4 = n >> 2;                                  // (fbl_adam checks the 16-byte alignment of the flat buffers)
+#pragma unroll 4
+  for (long long j = (long long)blockIdx.x*blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x*blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[j];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int s = seg_of(sg, 4*j + c);
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q == s) acc[q] += e[c]*e[c];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x; const float v = g[i]; const int s = seg_of(sg, i);
 #pragma unroll
     for (int q = 0; q < 8; q++) if (q == s) acc[q] += v*v;
   }
-  norm_commit(acc, sg.nseg, norms, step);
+  norm_commit<false>(acc, sg.nseg, norms, step);
 }
 
 struct AdamOut { float p, m, v; };
@@ -412,7 +431,7 @@ extern "C" int fbl_adam(float* param, const float* grad, float* exp_avg, float* 
   if (make_segs(sg, n, nseg, seg_end, lr, clip_norm, floor_)) return lfail("fbl_adam: bad segments");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = flat_blocks(n);
-  if (!norms_ready) hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, st, grad, (long long)n, sg, norms, step);
+  if (!norms_ready) hipLaunchKernelGGL(k_sqnorm, dim3(NORM_SLOTS), dim3(256), 0, st, grad, (long long)n, sg, norms, step);
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, step, norms, (long long)n, sg, beta1, beta2, eps);
   LCHK(hipGetLastError());
   return 0;
@@ -470,7 +489,7 @@ __global__ void __launch_bounds__(256) k_gather_flat(FlatSrc f, float* __restric
       for (int q = 0; q < 8; q++) if (q == s) acc[q] += v*v;
     }
   }
-  if (norms) norm_commit(acc, sg.nseg, norms, step);
+  if (norms) norm_commit<true>(acc, sg.nseg, norms, step);
 }
 
 extern "C" int fbl_gather_flat(const float* const* src, const int64_t* end, int ntensor, float* flat, int nseg, const int64_t* seg_end,

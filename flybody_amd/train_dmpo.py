@@ -37,11 +37,17 @@ class Trainer:
                  config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None,
                  directory=None, checkpoint_to_load=None, time_delta_minutes=30.0, checkpoint_max_to_keep=1):
         self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
-        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        # one process per GPU over RCCL; FB_BENCH_DEVICE / FB_BENCH_BACKEND (as in bench.py) pin every rank to one device over gloo,
+        # which is how the N > 1 path is exercised on a one-GPU box (tests/test_gpu_fly_envs.py)
+        self.local_rank = int(os.environ.get('FB_BENCH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device('cuda', self.local_rank)
         if self.world > 1 and not dist.is_initialized():
-            dist.init_process_group('nccl', device_id=self.device)
+            backend = os.environ.get('FB_BENCH_BACKEND', 'nccl')
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=self.device)
+            else:
+                dist.init_process_group(backend)
         # ref_path: reference walking dataset -> training-mode (DeepMimic) reward; None -> inference mode (reward == 1).
         # Environment ids are global (rank * n_env + local id) so that snippet selection does not depend on the GPU count.
         self.env = walk_imitation(ref_path=ref_path, traj_indices=traj_indices, terminal_com_dist=terminal_com_dist, n_env=n_env,

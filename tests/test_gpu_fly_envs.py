@@ -238,3 +238,19 @@ def test_flight_dataset_on_gpu(tmp_path):
     for e, od in enumerate(ods):
         assert np.abs(Q[e] - od.field('qpos')).max() < 1e-7*max(1.0, np.abs(od.field('qpos')).max()), e
     assert np.allclose(v['reward'].cpu().numpy(), [od.scalar('reward') for od in ods], atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graphs', ['1', '0'])
+def test_dmpo_two_ranks_stay_identical(graphs):
+    """BASELINE configs[4] plumbing on ONE GPU: two ranks (gloo, both on cuda:0), per-rank environment shard + replay, one flat
+    gradient all-reduce per learner step between the forward/backward graph and the optimizer graph; replicas stay identical."""
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', FB_LEARNER_GRAPHS=graphs)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', '_dmpo_two_ranks.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'TWO_RANKS_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
