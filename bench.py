@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--precision', type=int, default=int(os.environ.get('FB_PRECISION', '64')), choices=[32, 64])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary FP32-build measurement')
+    ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary two-half-batches-on-two-streams measurement')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -189,7 +190,44 @@ def main():
         del batch
         return dt, kernel_ms, nlaunch, finite
 
+    def run_split_leg(precision, parts=2):
+        """The same environments as `parts` independent half-batches, each with its own fb_batch handle and HIP stream: every
+        environment still advances K control steps, but the halves are not in lock-step with each other, so the tail of one
+        launch (its last long environments) overlaps the head of the other half's next launch.  Secondary number, never `value`."""
+        sub = n_env // parts
+        streams = [torch.cuda.Stream() for _ in range(parts)]
+        batches, actions, gens = [], [], []
+        for p in range(parts):
+            b = engine.Batch(model, sub, device=local_rank, precision=precision)
+            b.set_reference(qp, qv, terminal_com_dist=float('inf')); b.reset(stream=stream)
+            batches.append(b); actions.append(torch.empty(sub, nu, device='cuda', dtype=torch.float32))
+            g = torch.Generator(device='cuda'); g.manual_seed(1234 + rank*parts + p); gens.append(g)
+        torch.cuda.synchronize()
+
+        def one_step():
+            for p in range(parts):
+                with torch.cuda.stream(streams[p]):
+                    actions[p].normal_(generator=gens[p]).clamp_(-1.0, 1.0)
+                    batches[p].step_ptr(actions[p].data_ptr(), streams[p].cuda_stream)
+
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        finite = all(bool(np.isfinite(b.get('QPOS')).all()) for b in batches)
+        del batches
+        return dt, finite, sub*parts
+
     dt, kernel_ms, nlaunch, finite = run_leg(args.precision)
+    split = None if args.no_split_leg else run_split_leg(args.precision)
     f32 = None
     if args.precision == 64 and not args.no_f32_leg:
         f32 = run_leg(32)
@@ -237,6 +275,12 @@ def main():
                                'kernel_ms_avg': f32[1] / max(f32[2], 1), 'state_finite': f32[3],
                                'note': 'same workload on the FP32 build of the kernel (FP64 residual accumulation in the solver); '
                                        'statistical parity only, see DESIGN.md 6 -- not the headline'}
+        if split is not None:
+            out['two_stream_mode'] = {'value': split[2] * world * args.steps / split[0], 'unit': 'env steps/sec', 'ms_per_step': split[0] / args.steps * 1e3,
+                                      'state_finite': split[1],
+                                      'note': 'same environments stepped as 2 independent half-batches (2 fb_batch handles, 2 HIP streams): each half '
+                                              'is in lock-step, the halves are not, so one launch\'s tail overlaps the other\'s head; an actor-side '
+                                              'scheduling option (tools/split_bench.py), not the headline'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

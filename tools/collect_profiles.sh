@@ -2,7 +2,8 @@
 # Run on the GPU box (via gpurun): kernel-trace stats of the default bench command plus the PMC passes the MI355X guide
 # prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass; counters never together with API traces).  The default
 # bench launches both builds of the step kernel -- k_fly<double> (headline leg) and k_fly<float> (f32_mode leg) -- and
-# every summary below is kept per kernel.
+# every summary below is kept per kernel.  (--no-split-leg: the secondary two-stream leg overlaps launches of the same kernel, which
+# would blur the per-launch averages these summaries are about.)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r2}
@@ -10,11 +11,11 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-split-leg > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
 import csv, json, sys, os, collections
 out, tag = sys.argv[1], sys.argv[2]
