@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-end evidence refresh (one gpurun call): GPU test suite, default bench line, rocprofv3 kernel stats + PMC passes, phase
+# profile, batch-size / two-stream sweeps, secondary configs, learner bench + per-kernel breakdown.  Outputs -> gpurun_out/final/.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/final; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+python -c "import flybody_amd.engine as e; print(e.version())" > $O/version.txt 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests_full.txt 2>&1; tail -5 $O/gpu_tests_full.txt > $O/gpu_tests.txt
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 1500 bash tools/collect_profiles.sh final > $O/collect.log 2>&1
+timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 64 4096 > $O/phase64.txt 2>&1
+timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 32 4096 > $O/phase32.txt 2>&1
+for n in 32 256 1024 2048 4096; do timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 $n 20 >> $O/batch_sweep.txt 2>&1; done
+for P in 1 2 4; do timeout 120 python tools/split_bench.py 64 4096 $P 20 >> $O/split.txt 2>&1; done
+for P in 1 2; do timeout 120 python tools/split_bench.py 32 4096 $P 20 >> $O/split.txt 2>&1; done
+timeout 200 python tools/learner_bench.py --steps 300 > $O/learner_graphs.log 2>&1
+timeout 200 python tools/learner_bench.py --steps 100 --no-graphs > $O/learner_nographs.log 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/learner_trace -o lb -- python $R/tools/learner_bench.py --steps 100 --no-graphs > $O/learner_rocprof.log 2>&1
+cd $R
+python tools/learner_step_kernels.py $O/learner_trace/lb_kernel_trace.csv > $O/learner_step_kernels.txt 2>&1
+timeout 900 python tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err

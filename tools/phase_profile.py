@@ -23,8 +23,10 @@ for _ in range(K):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize(); dt = time.time() - t0
 p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
+# (sub-buckets 16-27 are parts of factor / pgs / kin / coll / acc and overlap their parents; 'cfin' spans the whole constraint stage)
 names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'fA_small', 'fA_wide', 'fB_write', 'sol_fwd', 'sol_bwd', 'f_chain', 'f_gen_diag', 'small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated']
-tot = p.sum(1).mean()
-print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step; mean cycles per env-step {tot/K:.0f}; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
+tot = p[:, names.index('TOTAL_clock64')].mean()          # denominator: the wave's own clock64 lifetime (col 28 holds a start tick, not a duration)
+print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step (profiling build); wave lifetime {tot/K:.0f} cycles per env-step; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
 for i, nm in enumerate(names):
+    if nm == 'env_post': continue
     print(f'  {nm:8s} {p[:, i].mean()/K:12.0f} cycles/env-step  {100*p[:, i].mean()/tot:5.1f}%')
