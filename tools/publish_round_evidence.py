@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Copy what tools/collect_round_evidence.sh left under gpurun_out/ (scratch) into profiles/<round>/ (tracked):
+    python tools/publish_round_evidence.py r2
+Per-launch PMC tables are reduced to the step kernel's rows; `pmc_traffic_f{64,32}.json` (read by bench.py) go to profiles/."""
+import csv, json, os, shutil, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+src, fin, dst = (os.path.join(ROOT, p) for p in ('gpurun_out/profiles_final', 'gpurun_out/final', f'profiles/{tag}'))
+os.makedirs(dst, exist_ok=True)
+clean = lambda p: '\n'.join(l for l in open(p).read().splitlines() if 'amdgpu.ids' not in l) + '\n'
+shutil.copy(f'{src}/trace/bench_kernel_stats.csv', f'{dst}/kernel_stats.csv')
+shutil.copy(f'{src}/bench_under_rocprof.json', f'{dst}/bench_under_rocprof.json')
+s = json.load(open(f'{src}/summary.json')); s['tag'] = tag; json.dump(s, open(f'{dst}/summary.json', 'w'), indent=1)
+for k in ('f64', 'f32'):
+    d = json.load(open(f'{src}/pmc_traffic_{k}.json')); d['source'] = d['source'].replace('profiles/final/', f'profiles/{tag}/')
+    json.dump(d, open(os.path.join(ROOT, 'profiles', f'pmc_traffic_{k}.json'), 'w'), indent=1)
+
+
+def per_launch(path, out):
+    rows = [r for r in csv.DictReader(open(path)) if 'k_fly' in r['Kernel_Name']]
+    with open(out, 'w') as f:
+        f.write('dispatch_id,kernel,counter,value\n')
+        for r in rows:
+            f.write(f"{r['Dispatch_Id']},{'k_fly<double>' if 'double' in r['Kernel_Name'] else 'k_fly<float>'},{r['Counter_Name']},{float(r['Counter_Value']):.6f}\n")
+
+
+for sub, pre, name in (('pmc_fetch', 'f', 'fetch'), ('pmc_write', 'w', 'write'), ('pmc_sq1', 's', 'sq1'), ('pmc_sq2', 's', 'sq2')):
+    per_launch(f'{src}/{sub}/{pre}_counter_collection.csv', f'{dst}/pmc_{name}_per_launch.csv')
+shutil.copy(f'{fin}/bench_default.json', f'{dst}/bench_default.json')
+shutil.copy(f'{fin}/gpu_tests.txt', f'{dst}/gpu_tests.txt')
+open(f'{dst}/other_configs.jsonl', 'w').write(clean(f'{fin}/other_configs.jsonl'))
+open(f'{dst}/phase_cycles.txt', 'w').write(
+    '# tools/phase_profile.py on the -DFB_PROFILE build (flybody_amd/libflybody_hip_prof.so), current kernel; percentages of the wave lifetime.\n'
+    '# Sub-buckets (f_*, fA_*, fB_*, sol_*, small_loops; kin_fk / kin_geoms also hold the collision mid+box / narrow phase) overlap their parent stages;\n'
+    '# cfin spans the whole constraint stage (csetup + pgs + noslip + row references + J^T f).\n' + clean(f'{fin}/phase64.txt') + clean(f'{fin}/phase32.txt'))
+open(f'{dst}/batch_size_and_streams.txt', 'w').write(
+    '# tools/quick_bench.py: ONE launch per control step, batch size sweep (FP64): the step time of a batch that fits the 2048 resident slots\n'
+    '# is its slowest environment; even 32 environments alone on the GPU need ~7 ms -- the per-environment chain, not contention, is the cost\n'
+    + clean(f'{fin}/batch_sweep.txt') + '# tools/split_bench.py: the same 4096 environments as P independent sub-batches on P HIP streams (bench.py: two_stream_mode)\n' + clean(f'{fin}/split.txt'))
+open(f'{dst}/learner_bench.txt', 'w').write('# tools/learner_bench.py (B = 256, N = 20, walk dims 741 / 59): HIP graphs, then eager\n' + clean(f'{fin}/learner_graphs.log') + clean(f'{fin}/learner_nographs.log'))
+shutil.copy(f'{fin}/learner_trace/lb_kernel_stats.csv', f'{dst}/learner_kernel_stats.csv')
+open(f'{dst}/learner_step_kernels.txt', 'w').write(
+    '# tools/learner_step_kernels.py on the rocprofv3 --kernel-trace of `tools/learner_bench.py --steps 100 --no-graphs`: the kernels of ONE learner step in launch order\n'
+    + open(f'{fin}/learner_step_kernels.txt').read())
+b = json.load(open(f'{dst}/bench_default.json'))
+print('published to', dst, '| value %.0f ms %.2f | two_stream %.0f | f32 %.0f | cpu %.0f' % (b['value'], b['ms_per_step'], b['two_stream_mode']['value'], b['f32_mode']['value'], b['cpu_baseline']['value']))
