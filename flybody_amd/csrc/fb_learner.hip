@@ -788,16 +788,24 @@ extern "C" int fbl_bias_elu_bwd(const float* dy, const float* y, int M, int W, f
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GB 8                                  // k-steps (of 8) prefetched per block: 64 k per wave in flight
 
+// Two operand sets per launch: mode 0 = one product; mode 1 = two independent products of the same shape (blockIdx.z picks the set:
+// the two heads of the Gaussian policy, their two weight gradients); mode 2 = ONE output that is the sum of two products
+// C = A0 B0 + A1 B1 (waves 0-1 take set 0, waves 2-3 set 1: the gradient wrt the torso output that feeds both heads).
+struct GemmOp { const float* a; const float* b; float* c; const float* bias; long long sai, sak, sbk, sbj; int epi; float p0, p1; };
+
 template <bool AV, bool BV>                   // operand is k-contiguous (stride 1 along k): 16-byte loads
 #define GW 4                                  // wavefronts per workgroup (K is split GW ways)
-__global__ void __launch_bounds__(64*GW) k_sgemm(const float* __restrict__ a, long long sai, long long sak, const float* __restrict__ b, long long sbk,
-                                               long long sbj, float* __restrict__ c, long long ldc, int M, int N, int K, int epi,
-                                               const float* __restrict__ bias) {
+__global__ void __launch_bounds__(64*GW) k_sgemm(GemmOp o0, GemmOp o1, int mode, long long ldc, int M, int N, int K) {
   __shared__ float red[GW][16][WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.y*32, j0 = blockIdx.x*32;
-  const int kc = ((K + 8*GW - 1)/(8*GW))*8;                            // k per wave, a multiple of 8
-  const int kb = wv*kc, ke = min(K, kb + kc);
+  const bool in1 = (mode == 1 && blockIdx.z == 1) || (mode == 2 && wv >= 2);          // which operand set this wave reads
+  const bool out1 = mode == 1 && blockIdx.z == 1;                                     // which set describes the output
+  const float* a = in1 ? o1.a : o0.a; const float* b = in1 ? o1.b : o0.b;
+  const long long sai = in1 ? o1.sai : o0.sai, sak = in1 ? o1.sak : o0.sak, sbk = in1 ? o1.sbk : o0.sbk, sbj = in1 ? o1.sbj : o0.sbj;
+  const int nsplit = mode == 2 ? GW/2 : GW, wl = mode == 2 ? (wv & 1) : wv;
+  const int kc = ((K + 8*nsplit - 1)/(8*nsplit))*8;                    // k per wave, a multiple of 8
+  const int kb = wl*kc, ke = min(K, kb + kc);
   const int ia = min(i0 + r, M - 1), jb = min(j0 + r, N - 1);           // (rows / columns past the edge read a valid one; their results are not stored)
   const float* pa = a + (long long)ia*sai;
   const float* pb = b + (long long)jb*sbj;
@@ -841,6 +849,8 @@ __global__ void __launch_bounds__(64*GW) k_sgemm(const float* __restrict__ a, lo
 #pragma unroll
   for (int v = 0; v < 16; v++) red[wv][v][lane] = acc[v];
   __syncthreads();
+  float* c = out1 ? o1.c : o0.c; const float* bias = out1 ? o1.bias : o0.bias;
+  const int epi = out1 ? o1.epi : o0.epi; const float p0 = out1 ? o1.p0 : o0.p0, p1 = out1 ? o1.p1 : o0.p1;
   // C/D map of the 32x32 MFMA: register v of lane l is C[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31]
 #pragma unroll
   for (int q = 0; q < 16/GW; q++) {
@@ -853,20 +863,69 @@ __global__ void __launch_bounds__(64*GW) k_sgemm(const float* __restrict__ a, lo
       float y = t;
       if (epi >= 1) y += bias[j];
       if (epi == 2) y = y > 0.f ? y : expm1f(y);
+      if (epi == 3) y = softplus_f(y)*p0 + p1;
       c[(long long)i*ldc + j] = y;
     }
   }
 }
 
-extern "C" int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
-                         int epilogue, const float* bias, void* stream) {
-  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 2 || (epilogue && !bias)) return lfail("fbl_sgemm: bad argument");
-  const dim3 grid((N + 31)/32, (M + 31)/32);
-  const bool av = sak == 1 && K >= 4, bv = sbk == 1 && K >= 4;
+static int gemm_launch(const fbl_gemm_op* q0, const fbl_gemm_op* q1, int mode, int64_t ldc, int M, int N, int K, void* stream) {
+  GemmOp o[2];
+  const fbl_gemm_op* q[2] = {q0, (mode ? q1 : q0)};
+  for (int z = 0; z < 2; z++) {
+    if (!q[z] || !q[z]->a || !q[z]->b) return lfail("fbl_sgemm: null operand");
+    if (q[z]->epilogue < 0 || q[z]->epilogue > 3 || (q[z]->epilogue && !q[z]->bias)) return lfail("fbl_sgemm: bad epilogue");
+    o[z].a = q[z]->a; o[z].b = q[z]->b; o[z].c = q[z]->c; o[z].bias = q[z]->bias; o[z].sai = q[z]->sai; o[z].sak = q[z]->sak; o[z].sbk = q[z]->sbk; o[z].sbj = q[z]->sbj;
+    o[z].epi = q[z]->epilogue; o[z].p0 = q[z]->p0; o[z].p1 = q[z]->p1;
+  }
+  if (!o[0].c || (mode == 1 && !o[1].c) || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return lfail("fbl_sgemm: bad argument");
+  const dim3 grid((N + 31)/32, (M + 31)/32, mode == 1 ? 2 : 1);
+  const bool av = o[0].sak == 1 && o[1].sak == 1 && K >= 4, bv = o[0].sbk == 1 && o[1].sbk == 1 && K >= 4;
   hipStream_t st = (hipStream_t)stream;
-#define L_(AV_, BV_) hipLaunchKernelGGL((k_sgemm<AV_, BV_>), grid, dim3(64*GW), 0, st, a, (long long)sai, (long long)sak, b, (long long)sbk, (long long)sbj, c, (long long)ldc, M, N, K, epilogue, bias)
+#define L_(AV_, BV_) hipLaunchKernelGGL((k_sgemm<AV_, BV_>), grid, dim3(64*GW), 0, st, o[0], o[1], mode, (long long)ldc, M, N, K)
   if (av && bv) L_(true, true); else if (av) L_(true, false); else if (bv) L_(false, true); else L_(false, false);
 #undef L_
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
+                         int epilogue, const float* bias, void* stream) {
+  if (epilogue > 2) return lfail("fbl_sgemm: bad argument");
+  fbl_gemm_op o = {a, b, c, bias, sai, sak, sbk, sbj, epilogue, 0.f, 0.f};
+  return gemm_launch(&o, nullptr, 0, ldc, M, N, K, stream);
+}
+extern "C" int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream) {
+  return gemm_launch(op0, op1, sum ? 2 : 1, ldc, M, N, K, stream);
+}
+
+// Gaussian head backward when the head ran through fbl_sgemm_pair (its pre-activation was never stored): sigmoid(z) = 1 - exp(-softplus(z)),
+// softplus(z) = (std - min_scale) / mul.  dzs = dstd sigmoid mul; column sums of dmean and dzs by atomics (zero-initialised outputs).
+__global__ void __launch_bounds__(256) k_gauss_head_bwd_std(const float* __restrict__ dmean, const float* __restrict__ dstd, const float* __restrict__ std_,
+                                                            float mul, float min_scale, int M, int D, float* __restrict__ dzs, float* __restrict__ dbm,
+                                                            float* __restrict__ dbs) {
+  const int c = threadIdx.x;
+  if (c >= D) return;
+  float am = 0.f, as = 0.f;
+  const int r0 = blockIdx.x*GH_ROWS;
+  float ds[GH_ROWS], sd[GH_ROWS], dm[GH_ROWS];
+#pragma unroll
+  for (int j = 0; j < GH_ROWS; j++) {
+    const size_t i = (size_t)(r0 + j)*D + c; const bool ok = r0 + j < M;
+    ds[j] = ok ? dstd[i] : 0.f; sd[j] = ok ? std_[i] : min_scale; dm[j] = ok ? dmean[i] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < GH_ROWS; j++) {
+    float g = ds[j]*(1.f - expf(-(sd[j] - min_scale)/mul))*mul;
+    if (r0 + j < M) dzs[(size_t)(r0 + j)*D + c] = g;
+    as += g; am += dm[j];
+  }
+  atomicAdd(dbm + c, am); atomicAdd(dbs + c, as);
+}
+extern "C" int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, const float* std_, float mul, float min_scale, int M, int D, float* dzs,
+                                      float* dbm, float* dbs, void* stream) {
+  if (!dmean || !dstd || !std_ || !dzs || !dbm || !dbs || M <= 0 || D <= 0 || D > 256 || mul <= 0.f) return lfail("fbl_gauss_head_bwd_std: bad argument (D <= 256)");
+  hipLaunchKernelGGL(k_gauss_head_bwd_std, dim3((M + GH_ROWS - 1)/GH_ROWS), dim3(256), 0, (hipStream_t)stream, dmean, dstd, std_, mul, min_scale, M, D, dzs, dbm, dbs);
   LCHK(hipGetLastError());
   return 0;
 }

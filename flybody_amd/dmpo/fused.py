@@ -23,6 +23,11 @@ class LearnerLibError(RuntimeError):
     pass
 
 
+class _GemmOp(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('bias', C.c_void_p), ('sai', C.c_int64), ('sak', C.c_int64),
+                ('sbk', C.c_int64), ('sbj', C.c_int64), ('epilogue', C.c_int32), ('p0', C.c_float), ('p1', C.c_float)]
+
+
 class _MpoArgs(C.Structure):
     _fields_ = [('N', C.c_int32), ('B', C.c_int32), ('D', C.c_int32),
                 ('online_mean', C.c_void_p), ('online_std', C.c_void_p), ('target_mean', C.c_void_p), ('target_std', C.c_void_p),
@@ -59,6 +64,8 @@ def lib():
         L.fbl_bias_elu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_elu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fbl_replay_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbl_sgemm_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.fbl_gauss_head_bwd_std.argtypes = [C.c_void_p]*3 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
         _lib = L
     return _lib
 
@@ -365,6 +372,50 @@ class _GaussHead(torch.autograd.Function):
         _check(lib().fbl_gauss_head_bwd(dmean.data_ptr(), dstd.data_ptr(), zs.data_ptr(), bs.data_ptr(), ctx.mul, M, D, dzs.data_ptr(),
                                         db[0].data_ptr(), db[1].data_ptr(), _stream()))
         return dmean, dzs, db[0], db[1], None, None
+
+
+def _op(a, sai, sak, b, sbk, sbj, c=None, bias=None, epilogue=0, p0=0.0, p1=0.0):
+    return _GemmOp(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None, bias.data_ptr() if bias is not None else None,
+                   sai, sak, sbk, sbj, epilogue, p0, p1)
+
+
+class _GaussHeadLinear(torch.autograd.Function):
+    """Both heads of the Gaussian policy in ONE launch (fbl_sgemm_pair: mean = h Wm^T + bm | stddev = softplus(h Ws^T + bs) mul + min);
+    backward: one element-wise launch (d zs + the two bias gradients), the two weight gradients in one launch, and d h = d mean Wm +
+    d zs Ws in one launch (K split between the two products)."""
+
+    @staticmethod
+    def forward(ctx, h, wm, bm, ws, bs, mul, min_scale):
+        h = _f32c(h); wm = _f32c(wm); ws = _f32c(ws); M, K = h.shape; D = wm.shape[0]
+        mean = torch.empty(M, D, device=h.device); std = torch.empty(M, D, device=h.device)
+        o0 = _op(h, K, 1, wm, 1, K, mean, bm, 1); o1 = _op(h, K, 1, ws, 1, K, std, bs, 3, float(mul), float(min_scale))
+        _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, D, M, D, K, _stream()))
+        ctx.save_for_backward(h, wm, ws, std); ctx.mul = float(mul); ctx.min_scale = float(min_scale)
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, dmean, dstd):
+        h, wm, ws, std = ctx.saved_tensors
+        dmean = _f32c(dmean); dstd = _f32c(dstd); M, K = h.shape; D = wm.shape[0]; dev = h.device
+        dzs = torch.empty_like(std); db = zero_pool.take(2, D, device=dev)
+        _check(lib().fbl_gauss_head_bwd_std(dmean.data_ptr(), dstd.data_ptr(), std.data_ptr(), ctx.mul, ctx.min_scale, M, D, dzs.data_ptr(),
+                                            db[0].data_ptr(), db[1].data_ptr(), _stream()))
+        dwm = torch.empty(D, K, device=dev); dws = torch.empty(D, K, device=dev)
+        o0 = _op(dmean, 1, D, h, K, 1, dwm); o1 = _op(dzs, 1, D, h, K, 1, dws)                 # d W = d z^T h  ([D, K], reduction over M)
+        _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, K, D, K, M, _stream()))
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(M, K, device=dev)
+            o0 = _op(dmean, D, 1, wm, K, 1, dh); o1 = _op(dzs, D, 1, ws, K, 1)                 # d h = d mean Wm + d zs Ws  ([M, K], reduction over D, twice)
+            _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 1, K, M, K, D, _stream()))
+        return dh, dwm, db[0], dws, db[1], None, None
+
+
+def gauss_head_linear(h, wm, bm, ws, bs, mul, min_scale):
+    """(mean, stddev) of the Gaussian policy head from the torso output h."""
+    if _USE_SGEMM and h.is_cuda and h.dim() == 2 and h.shape[0] <= SMALL_GEMM_ROWS and h.shape[1] <= SMALL_GEMM_K:
+        return _GaussHeadLinear.apply(h, wm, bm, ws, bs, mul, min_scale)
+    return gauss_head(linear(h, wm), linear(h, ws), bm, bs, mul, min_scale)
 
 
 def gauss_head(zm, zs, bm, bs, mul, min_scale):

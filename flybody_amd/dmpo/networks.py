@@ -63,9 +63,9 @@ class GaussianHead(nn.Module):
         self.init_scale = init_scale; self.min_scale = min_scale
 
     def forward(self, h):
-        # two plain GEMMs + ONE fused epilogue (bias, softplus, scale) -- fused.gauss_head; same arithmetic on the CPU
-        return fused.gauss_head(fused.linear(h, self.mean.weight), fused.linear(h, self.scale.weight), self.mean.bias, self.scale.bias,
-                                self.init_scale / math.log(2.0), self.min_scale)
+        # both GEMMs and their epilogues (bias | bias, softplus, scale) in ONE launch on the GPU (fused.gauss_head_linear); same arithmetic on the CPU
+        return fused.gauss_head_linear(h, self.mean.weight, self.mean.bias, self.scale.weight, self.scale.bias,
+                                       self.init_scale / math.log(2.0), self.min_scale)
 
 
 class Policy(nn.Module):

@@ -108,6 +108,15 @@ int fbl_concat_clamp(const float* obs, const float* act, int B, int O, int A, fl
  * chain, which beats a library GEMM only while that chain is short (the learner routes K <= 512, M <= 1024 here). */
 int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
               int epilogue, const float* bias, void* stream);
+/* Two operand sets of the same shape in ONE launch.  sum == 0: two independent products c0 = A0 B0, c1 = A1 B1, each with its own
+ * epilogue (0 none, 1 + bias, 2 ELU(. + bias), 3 softplus(. + bias) p0 + p1) -- the two heads of the Gaussian policy and their two
+ * weight gradients.  sum != 0: op0->c = A0 B0 + A1 B1 (op1->c unused; op0's epilogue) -- the gradient wrt the torso output feeding both
+ * heads.  Both sets must have the same k-contiguity (sak == 1 / sbk == 1). */
+typedef struct fbl_gemm_op { const float* a; const float* b; float* c; const float* bias; int64_t sai, sak, sbk, sbj; int32_t epilogue; float p0, p1; } fbl_gemm_op;
+int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream);
+/* fbl_gauss_head_bwd for a head evaluated through fbl_sgemm_pair (epilogue 3): the pre-activation is recovered from the stddev. */
+int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, const float* std_, float mul, float min_scale, int M, int D, float* dzs,
+                           float* dbm, float* dbs, void* stream);
 
 /* Uniform replay sampling (reverb selectors.Uniform): row index = floor(u[b] * min(size, capacity)) from B uniform numbers and the
  * DEVICE fill level, then the gather of `narr` row-major fields (observation, action, reward, discount, next observation) in

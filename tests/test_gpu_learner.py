@@ -305,3 +305,28 @@ def test_small_mfma_gemm(M, K, N):
     with torch.no_grad():
         wide = torch.randn(N, K + 59, device=dev)
         _close(fused.linear(x, wide[:, :K]), ref(x) @ ref(wide[:, :K]).T, rtol=2e-5, atol=2e-4)
+
+
+def test_gaussian_head_pair_launch():
+    """fbl_sgemm_pair: both policy heads in one launch (independent products with their own epilogues), their weight gradients in one
+    launch, and the summed input gradient d h = d mean Wm + d zs Ws in one launch -- against the plain PyTorch head."""
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(12)
+    dev = 'cuda'
+    M, K, D = 256, 256, 59
+    mul, mn = 0.7/math.log(2.0), 1e-6
+    h = torch.randn(M, K, device=dev, requires_grad=True)
+    wm = (torch.randn(D, K, device=dev)/16).requires_grad_(True); ws = (torch.randn(D, K, device=dev)/16).requires_grad_(True)
+    bm = torch.randn(D, device=dev, requires_grad=True); bs = torch.randn(D, device=dev, requires_grad=True)
+    u1, u2 = torch.randn(M, D, device=dev), torch.randn(M, D, device=dev)
+    mean, std = fused.gauss_head_linear(h, wm, bm, ws, bs, mul, mn)
+    (mean*u1 + std*u2).sum().backward()
+    got = [t.grad.clone() for t in (h, wm, bm, ws, bs)]
+    for t in (h, wm, bm, ws, bs):
+        t.grad = None
+    d = lambda t: t.double()
+    mr = d(h) @ d(wm).T + d(bm); sr = F.softplus(d(h) @ d(ws).T + d(bs))*mul + mn
+    (mr*d(u1) + sr*d(u2)).sum().backward()
+    _close(mean, mr, rtol=2e-5, atol=2e-5); _close(std, sr, rtol=2e-5, atol=2e-5)
+    for g, t, at in zip(got, (h, wm, bm, ws, bs), (5e-5, 3e-4, 3e-4, 3e-4, 3e-4)):
+        _close(g, t.grad, rtol=1e-4, atol=at)
