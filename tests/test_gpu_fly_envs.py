@@ -254,3 +254,31 @@ def test_dmpo_two_ranks_stay_identical(graphs):
            '--master-port', str(port), os.path.join(ROOT, 'tests', '_dmpo_two_ranks.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'TWO_RANKS_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_two_half_batches_on_two_streams_equal_one_batch():
+    """bench.py's two_stream_mode / tools/split_bench.py: the same environments stepped as two fb_batch handles on two HIP streams
+    (their launches overlap) give bit-identical observations to one batch in lock-step -- environments are independent."""
+    import torch
+    from flybody_amd.fly_envs import walk_imitation
+    n = 512
+    one = walk_imitation(n_env=n, precision=64, terminal_com_dist=float('inf'))
+    halves = [walk_imitation(n_env=n//2, precision=64, terminal_com_dist=float('inf'), env_id_base=k*n//2) for k in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    one.reset_all()
+    for h in halves:
+        h.reset_all()
+    torch.cuda.synchronize()
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    for step in range(12):
+        a = torch.empty(n, 59, device='cuda').normal_(generator=g).clamp_(-1, 1)
+        v1 = one.step_tensor(a)
+        torch.cuda.synchronize()
+        outs = []
+        for k, h in enumerate(halves):
+            with torch.cuda.stream(streams[k]):
+                outs.append(h.step_tensor(a[k*n//2:(k + 1)*n//2].contiguous()))
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([o['obs'] for o in outs]), v1['obs']), step
+        assert torch.equal(torch.cat([o['reward'].view(-1) for o in outs]), v1['reward'].view(-1))
