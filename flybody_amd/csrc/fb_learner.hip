@@ -381,16 +381,17 @@ __device__ __forceinline__ AdamOut adam_one(float p, float g, float m, float v, 
 // One float4 of p, g, m, v per thread and iteration: the 28 bytes per parameter stream with all of a thread's loads in flight.
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                               float* __restrict__ step, float* __restrict__ norms, long long n, AdamSegs sg, float b1, float b2, float eps) {
-  __shared__ float sN[NORM_SLOTS*8], nrm[8];
+  __shared__ float sN[NORM_SLOTS*8], nrm[8], sbc[2];
   const float t = step[1];
   const int par = ((int)t - 1) & 1;
-  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
   sN[threadIdx.x] = norms[par*NORM_SLOTS*8 + threadIdx.x];                                  // (blockDim.x == NORM_SLOTS * 8)
   if (blockIdx.x == 0) norms[(1 - par)*NORM_SLOTS*8 + threadIdx.x] = 0.f;
   if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = t;
+  if (threadIdx.x == 64) { sbc[0] = 1.f - powf(b1, t); sbc[1] = sqrtf(1.f - powf(b2, t)); }  // bias corrections: once per workgroup (two powf are ~400 instructions)
   __syncthreads();
   if (threadIdx.x < 8) { float a = 0.f; for (int q = 0; q < NORM_SLOTS; q++) a += sN[q*8 + threadIdx.x]; nrm[threadIdx.x] = a; }
   __syncthreads();
+  const float bc1 = sbc[0], bc2s = sbc[1];
   const long long n4 = n >> 2;
   for (long long j = (long long)blockIdx.x*blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x*blockDim.x) {
     const float4 P = reinterpret_cast<float4*>(p)[j], M = reinterpret_cast<float4*>(m)[j], V = reinterpret_cast<float4*>(v)[j];
