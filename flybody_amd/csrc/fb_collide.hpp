@@ -339,9 +339,14 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p
   int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   real margin = M.pair_margin[p];
-  const real *p1 = w.gxpos() + 3*g1, *p2 = w.gxpos() + 3*g2;
-  const real *m1 = w.gxmat() + 9*g1, *m2 = w.gxmat() + 9*g2;
-  const real *s1 = M.geom_size + 3*g1, *s2 = M.geom_size + 3*g2;
+  // Both geoms' pose and size into registers ONCE, through the typed (global address space) accessors.  Handing the routines
+  // below generic pointers into the workspace made every use a flat_load that the compiler could not hoist out of the MPR loops
+  // (a flat access may alias the scratch-resident contact list): ~30 reloads per support-function pair, 96 flat loads in all.
+  real p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { p1[k] = w.gxpos()[3*g1 + k]; p2[k] = w.gxpos()[3*g2 + k]; s1[k] = M.geom_size[3*g1 + k]; s2[k] = M.geom_size[3*g2 + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m1[k] = w.gxmat()[9*g1 + k]; m2[k] = w.gxmat()[9*g2 + k]; }
   if (t1 == GEOM_PLANE) {
     real n[3] = {m1[2], m1[5], m1[8]};
     if (t2 == GEOM_SPHERE) c_plane_sphere(lc, p1, n, p2, s2[0], margin);
