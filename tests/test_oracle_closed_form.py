@@ -210,3 +210,161 @@ def test_standing_fly_is_carried_by_its_weight(oracle_model, walk_arrays, refere
     v = np.abs(od.field('qvel')[:6]).max()
     assert v < 0.5, v                                           # settled
     assert abs(total[2] - weight)/weight < 0.05, (total, weight)
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1*w2 - x1*x2 - y1*y2 - z1*z2, w1*x2 + x1*w2 + y1*z2 - z1*y2, w1*y2 - x1*z2 + y1*w2 + z1*x2, w1*z2 + x1*y2 - y1*x2 + z1*w2])
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_semi_implicit_euler_with_implicit_damping_against_dense_algebra(oracle_model, walk_arrays, seed):
+    """The integration stage (mj_Euler with the implicit joint-damping term, MuJoCo's default `eulerdamp`) against a dense numpy
+    restatement of the documented update -- no sparse factor, no quaternion helper of the oracle:
+        v' = v + h (M + h D)^-1 (qfrc_smooth + qfrc_constraint),   act' = act + h (ctrl - act) / tau   (dyntype filter),
+        hinge / slide: q' = q + h v',   free joint: x' = x + h v', quat' = quat * exp(h w' / 2) with w' in the body frame."""
+    from oracle import fbo
+    A = walk_arrays
+    od = fbo.OracleData(oracle_model)
+    rng = np.random.default_rng(seed)
+    q, v = random_state(A, rng, z=0.125)
+    od.field('qpos')[:] = q; od.field('qvel')[:] = v*0.5
+    od.field('act')[:len(A['actuator_actadr'])] = rng.uniform(-0.2, 0.2, len(A['actuator_actadr']))
+    ctrl = rng.uniform(-1, 1, 59)*np.abs(A['actuator_ctrlrange']).max(1)*1.5        # some outside the control range: clamped
+    od.field('ctrl')[:] = ctrl
+    od.call('forward')
+    assert od.scalar('nefc') > 0
+    nv = len(v); h = float(A['opt_timestep'])
+    M = _dense_M(od, nv); D = np.asarray(A['dof_damping'], float)
+    f = od.field('qfrc_smooth') + od.field('qfrc_constraint')
+    assert np.allclose(M @ od.field('qacc'), f, rtol=1e-9, atol=1e-9*np.abs(f).max())
+    q0, v0, a0 = od.field('qpos').copy(), od.field('qvel').copy(), od.field('act').copy()
+    od.call('euler')
+    v1 = v0 + h*np.linalg.solve(M + h*np.diag(D), f)
+    assert np.allclose(od.field('qvel'), v1, rtol=1e-9, atol=1e-11*np.abs(v1).max())
+    # the implicit term matters at this time step (otherwise the check above would not distinguish it from explicit Euler)
+    assert np.abs(v1 - (v0 + h*np.linalg.solve(M, f))).max() > 1e-6*np.abs(v1).max()
+    # first-order activation filter on the CLAMPED control
+    lo, hi = A['actuator_ctrlrange'][:, 0], A['actuator_ctrlrange'][:, 1]
+    tau = np.asarray(A['actuator_dynprm'], float).reshape(59, -1)[:, 0]
+    aa = np.asarray(A['actuator_actadr'])
+    want_act = a0.copy()
+    want_act[aa] = a0[aa] + h*(np.clip(ctrl, lo, hi) - a0[aa])/tau
+    assert np.allclose(od.field('act')[:59], want_act[:59], rtol=1e-12, atol=1e-15)
+    # positions: the free joint's quaternion by the exponential map, everything else linearly, all with the NEW velocity
+    want_q = q0.copy()
+    for j, (jt, qa, da) in enumerate(zip(A['jnt_type'], A['jnt_qposadr'], A['jnt_dofadr'])):
+        if jt == 0:
+            want_q[qa:qa + 3] = q0[qa:qa + 3] + h*v1[da:da + 3]
+            w = v1[da + 3:da + 6]; ang = np.linalg.norm(w)*h
+            dq = np.r_[np.cos(ang/2), np.sin(ang/2)*w/np.linalg.norm(w)]
+            qq = _quat_mul(q0[qa + 3:qa + 7], dq); want_q[qa + 3:qa + 7] = qq/np.linalg.norm(qq)
+        else:
+            want_q[qa] = q0[qa] + h*v1[da]
+    assert np.allclose(od.field('qpos'), want_q, rtol=1e-12, atol=1e-14)
+
+
+def test_position_actuators_against_the_documented_force_law(oracle_model, walk_arrays):
+    """Joint- and tendon-transmission actuators (53 of the walker's 59; the 6 adhesion actuators act through contacts and are
+    held at zero here): force = gain * act + bias0 + bias1 * length + bias2 * velocity, clamped to the force range, mapped to
+    generalized forces by the transmission's moment arm (unit gear on the joint / the fixed tendon's coefficients) --
+    MuJoCo's documented actuation model (affine bias, filter dynamics: the force uses the ACTIVATION, not the control)."""
+    from oracle import fbo
+    A = walk_arrays
+    od = fbo.OracleData(oracle_model)
+    rng = np.random.default_rng(5)
+    q, v = random_state(A, rng, z=0.2)                                  # above the floor: adhesion has nothing to act on anyway
+    od.field('qpos')[:] = q; od.field('qvel')[:] = v*0.5
+    trn = np.asarray(A['actuator_trntype']); tid = np.asarray(A['actuator_trnid']).reshape(59, -1)[:, 0]
+    act = rng.uniform(-1, 1, 59)*np.abs(A['actuator_ctrlrange']).max(1)*2.0     # large enough for some force clamping
+    act[trn == 5] = 0.0
+    od.field('act')[:59] = act; od.field('ctrl')[:] = 0.0
+    od.call('forward')
+    qpos, qvel = od.field('qpos'), od.field('qvel')
+    gain = np.asarray(A['actuator_gainprm'], float).reshape(59, -1); bias = np.asarray(A['actuator_biasprm'], float).reshape(59, -1)
+    want = np.zeros(len(qvel)); nclamped = 0
+    for i in range(59):
+        if trn[i] == 5:
+            continue
+        if trn[i] == 0:
+            j = int(tid[i]); dofs = [int(A['jnt_dofadr'][j])]; qs = [int(A['jnt_qposadr'][j])]; coef = [1.0]
+        else:
+            t = int(tid[i]); lo = int(A['tendon_adr'][t]); n = int(A['tendon_num'][t])
+            dofs = [int(d) for d in A['wrap_dofid'][lo:lo + n]]; coef = [float(c) for c in A['wrap_coef'][lo:lo + n]]
+            jof = {int(A['jnt_dofadr'][j]): int(A['jnt_qposadr'][j]) for j in range(len(A['jnt_type']))}
+            qs = [jof[d] for d in dofs]
+        length = sum(c*qpos[a] for c, a in zip(coef, qs)); velocity = sum(c*qvel[d] for c, d in zip(coef, dofs))
+        f = gain[i, 0]*act[i] + bias[i, 0] + bias[i, 1]*length + bias[i, 2]*velocity
+        if A['actuator_forcelimited'][i]:
+            fc = float(np.clip(f, *A['actuator_forcerange'][i])); nclamped += fc != f; f = fc
+        for c, d in zip(coef, dofs):
+            want[d] += c*f
+    assert nclamped >= 1                                                  # (only the head actuators are force-limited)
+    got = od.field('qfrc_actuator')
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-12*np.abs(want).max()), np.abs(got - want).max()
+
+
+def _state_at(A, q, v, a, eps):
+    """Configuration reached after time eps under constant generalized acceleration (second order; odd error terms cancel in the
+    symmetric differences below): free joint = world-frame translation + body-frame rotation by the exponential map."""
+    out = q.copy()
+    for jt, qa, da in zip(A['jnt_type'], A['jnt_qposadr'], A['jnt_dofadr']):
+        if jt == 0:
+            out[qa:qa + 3] = q[qa:qa + 3] + eps*v[da:da + 3] + 0.5*eps*eps*a[da:da + 3]
+            rot = eps*v[da + 3:da + 6] + 0.5*eps*eps*a[da + 3:da + 6]; ang = np.linalg.norm(rot)
+            dq = np.r_[np.cos(ang/2), np.sin(ang/2)*rot/ang] if ang > 0 else np.array([1.0, 0, 0, 0])
+            qq = _quat_mul(q[qa + 3:qa + 7], dq); out[qa + 3:qa + 7] = qq/np.linalg.norm(qq)
+        else:
+            out[qa] = q[qa] + eps*v[da] + 0.5*eps*eps*a[da]
+    return out
+
+
+def test_inertial_sensors_against_finite_differences_of_the_kinematics(oracle_model, walk_arrays):
+    """Accelerometer, gyro, velocimeter and the six leg force sensors of a fly in free flight (no contacts) against quantities that do
+    not pass through the oracle's rnePostConstraint: the thorax site's acceleration and every body's centre-of-mass acceleration
+    are SECOND DIFFERENCES of forward kinematics along the motion  q(t +- eps)  generated by the solved qacc, so
+        accelerometer = R_site^T (a_site - g),   force sensor k = R_site^T sum_{i in subtree(body_k)} m_i (a_com,i - g),
+        gyro = R_site^T w_body,  velocimeter = R_site^T v_site  (from the Jacobians)."""
+    from oracle import fbo
+    A = walk_arrays
+    od = fbo.OracleData(oracle_model)
+    rng = np.random.default_rng(9)
+    q, v = random_state(A, rng, spread=0.05, z=0.3)                    # (small joint offsets: no self-contact)
+    od.field('qpos')[:] = q; od.field('qvel')[:] = v*0.2
+    od.field('act')[:59] = rng.uniform(-0.1, 0.1, 59); od.field('ctrl')[:] = rng.uniform(-0.3, 0.3, 59)
+    od.call('forward')
+    assert od.scalar('ncon') == 0
+    q0, v0, a0 = od.field('qpos').copy(), od.field('qvel').copy(), od.field('qacc').copy()
+    sens = od.field('sensordata').copy()
+    nb = len(A['body_parent']); g = np.asarray(A['opt_gravity'], float)
+    s_th = int(A['sensor_site_thorax'])
+
+    def kin(eps):
+        o2 = fbo.OracleData(oracle_model); o2._keep = oracle_model
+        o2.field('qpos')[:] = _state_at(A, q0, v0, a0, eps)
+        o2.call('kinematics')
+        return o2.field('xipos').reshape(nb, 3).copy(), o2.field('site_xpos').reshape(-1, 3).copy()
+    eps = 5e-6                                                           # (truncation error ~ eps^2: 5e-6 relative here, 7e-5 at 2e-5)
+    (cp, sp), (c0, s0), (cm, sm) = kin(eps), kin(0.0), kin(-eps)
+    acom = (cp + cm - 2*c0)/eps**2; asite = (sp + sm - 2*s0)/eps**2
+    R = od.field('site_xmat').reshape(-1, 3, 3)
+    scale = np.abs(asite[s_th] - g).max()
+    assert np.allclose(sens[0:3], R[s_th].T @ (asite[s_th] - g), rtol=0, atol=2e-5*scale)
+    b_th = int(A['site_bodyid'][s_th])
+    jp, jr = od.jac(od.field('site_xpos').reshape(-1, 3)[s_th], b_th)
+    assert np.allclose(sens[3:6], R[s_th].T @ (jr @ v0), rtol=1e-10, atol=1e-12)
+    assert np.allclose(sens[6:9], R[s_th].T @ (jp @ v0), rtol=1e-10, atol=1e-12)
+    parent = np.asarray(A['body_parent']); mass = np.asarray(A['body_mass'], float)
+    for k, s in enumerate(np.asarray(A['sensor_force_sites']).astype(int)):
+        b = int(A['site_bodyid'][s])
+        sub = [i for i in range(nb) if any(j == b for j in _ancestors(parent, i))]
+        F = sum(mass[i]*(acom[i] - g) for i in sub)
+        want = R[s].T @ F
+        assert np.allclose(sens[9 + 3*k:12 + 3*k], want, rtol=0, atol=3e-5*np.abs(want).max() + 1e-12), (k, sens[9 + 3*k:12 + 3*k], want)
+
+
+def _ancestors(parent, i):
+    out = []
+    while i > 0:
+        out.append(i); i = int(parent[i])
+    return out
