@@ -368,3 +368,31 @@ def _ancestors(parent, i):
     while i > 0:
         out.append(i); i = int(parent[i])
     return out
+
+
+@pytest.mark.parametrize('seed,z', [(0, 0.125), (4, 0.12)])
+def test_contact_jacobian_rows_against_point_jacobians(oracle_model, walk_arrays, seed, z):
+    """Every elliptic contact's three constraint rows against the difference of the two bodies' point Jacobians at the contact
+    position (the Jacobians themselves are pinned by finite differences in test_oracle.py): the normal row is n^T (Jp2 - Jp1)
+    and the block is F^T (Jp2 - Jp1) for an orthonormal frame F whose first axis is the contact normal."""
+    od = _forward(oracle_model, walk_arrays, seed, z)
+    A = walk_arrays
+    nv = len(A['dof_bodyid']); nefc = int(od.scalar('nefc'))
+    J = od.field('efc_J')[:nefc*nv].reshape(nefc, nv)
+    checked = 0
+    for c in od.contacts():
+        adr, dim = int(c[10]), int(c[9])
+        if adr < 0 or dim != 3:
+            continue
+        b1, b2 = int(A['geom_bodyid'][int(c[7])]), int(A['geom_bodyid'][int(c[8])])
+        jp1, _ = od.jac(c[1:4], b1); jp2, _ = od.jac(c[1:4], b2)
+        dJ = jp2 - jp1
+        n = c[4:7]
+        scale = np.abs(dJ).max()
+        assert np.allclose(J[adr], n @ dJ, rtol=0, atol=1e-10*scale)
+        F, *_ = np.linalg.lstsq(dJ.T, J[adr:adr + 3].T, rcond=None)          # dJ^T F = J_block^T
+        F = F.T
+        assert np.allclose(F @ dJ, J[adr:adr + 3], rtol=0, atol=1e-9*scale)
+        assert np.allclose(F @ F.T, np.eye(3), atol=1e-8) and np.allclose(F[0], n, atol=1e-8)
+        checked += 1
+    assert checked >= 3
