@@ -83,3 +83,36 @@ def test_observation_layout_matches_reference(walk_arrays):
     nobs = 3 + 59 + 3*len(a['appendage_sites']) + 3*len(a['sensor_force_sites']) + 3 + 2*len(a['observable_joints']) + 65*7 + len(a['sensor_touch_sites']) + 3 + 3
     assert nobs == PINS['hot_path_dims']['walk']['nobs']
     assert len(a['observable_joints']) == 85
+
+
+def test_ellipsoid_added_mass_against_lamb():
+    """The wing ellipsoids' virtual mass / inertia (MuJoCo compiles them into the model; the reference cannot derive them)
+    against what does not depend on this repository's quadrature: (1) the identity alpha0 + beta0 + gamma0 = 2 of the three
+    depolarisation-type integrals, (2) adaptive quadrature (scipy) of their definition, (3) the closed form for a prolate spheroid,
+    (4) Lamb's published table of inertia coefficients k1, k2, k' (Hydrodynamics, Art. 115), and (5) the fruit fly's wing semi-axes
+    run through all of the above."""
+    import math
+    from scipy.integrate import quad
+    from flybody_amd.mjcf_compile import _rj_integrals, ellipsoid_virtual_inertia
+    for a, b, c in [(0.0005, 0.0551, 0.114), (1.0, 0.7, 0.2), (3.0, 1.0, 1.0), (0.3, 0.3, 1.0)]:
+        al, be, ga = _rj_integrals(a, b, c)
+        assert abs(al + be + ga - 2.0) < 1e-6
+        for d, val in zip((a, b, c), (al, be, ga)):
+            f = lambda u: a*b*c/((d*d + u)*math.sqrt((a*a + u)*(b*b + u)*(c*c + u)))
+            s = (a*b*c)**(2/3)
+            ref = quad(f, 0, s, epsabs=0, epsrel=1e-12)[0] + quad(lambda t: f(1/t)/t**2, 0, 1/s, epsabs=0, epsrel=1e-12)[0]
+            assert abs(val - ref) < 2e-6*max(ref, 1e-3), (a, b, c, d, val, ref)
+    # prolate spheroid a > b = c: alpha0 in closed form (Lamb Art. 114), and Lamb's table (a/b: k1, k2, k')
+    table = {1.5: (0.305, 0.621, 0.094), 2.0: (0.209, 0.702, 0.240), 3.99: (0.082, 0.860, 0.608), 6.01: (0.045, 0.918, 0.764), 9.97: (0.021, 0.960, 0.883)}
+    for ratio, (k1, k2, kr) in table.items():
+        a, b = ratio, 1.0
+        e = math.sqrt(1 - b*b/(a*a))
+        alpha_closed = 2*(1 - e*e)/e**3*(0.5*math.log((1 + e)/(1 - e)) - e)
+        al, be, ga = _rj_integrals(a, b, b)
+        assert abs(al - alpha_closed) < 1e-6 and abs(be - ga) < 1e-9
+        vm, vi = ellipsoid_virtual_inertia([a, b, b])
+        vol = 4/3*math.pi*a*b*b
+        # (the 1932 table is printed to three decimals and is off by up to 0.002 against its own closed form)
+        assert abs(vm[0]/vol - k1) < 3e-3 and abs(vm[1]/vol - k2) < 3e-3
+        assert abs(vm[0]/vol - alpha_closed/(2 - alpha_closed)) < 1e-6
+        assert abs(vi[1]/(vol/5*(a*a + b*b)) - kr) < 3e-3 and abs(vi[0]) < 1e-12          # no added inertia about the symmetry axis
