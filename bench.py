@@ -190,15 +190,23 @@ def main():
         del batch
         return dt, kernel_ms, nlaunch, finite
 
-    def run_split_leg(precision, parts=2):
+    stream_pool = []
+
+    def run_split_leg(precision, parts=2, dense=False):
         """The same environments as `parts` independent half-batches, each with its own fb_batch handle and HIP stream: every
         environment still advances K control steps, but the halves are not in lock-step with each other, so the tail of one
         launch (its last long environments) overlaps the head of the other half's next launch.  Secondary number, never `value`."""
-        sub = n_env // parts
-        streams = [torch.cuda.Stream() for _ in range(parts)]
+        sizes = [n_env // parts + (1 if p < n_env % parts else 0) for p in range(parts)]
+        mdl = engine.Model.from_asset('walk_imitation', dense=True) if dense else model
+        # (the same stream objects for every pipelined leg: HIP multiplexes streams onto a few hardware queues, and two sub-batches
+        # that land on one queue serialise -- measured 22.9 ms instead of 14.2 ms for the three-stream leg)
+        while len(stream_pool) < parts:
+            stream_pool.append(torch.cuda.Stream())
+        streams = stream_pool[:parts]
         batches, actions, gens = [], [], []
         for p in range(parts):
-            b = engine.Batch(model, sub, device=local_rank, precision=precision)
+            sub = sizes[p]
+            b = engine.Batch(mdl, sub, device=local_rank, precision=precision)
             b.set_reference(qp, qv, terminal_com_dist=float('inf')); b.reset(stream=stream)
             batches.append(b); actions.append(torch.empty(sub, nu, device='cuda', dtype=torch.float32))
             g = torch.Generator(device='cuda'); g.manual_seed(1234 + rank*parts + p); gens.append(g)
@@ -224,10 +232,15 @@ def main():
             dt = float(t.item())
         finite = all(bool(np.isfinite(b.get('QPOS')).all()) for b in batches)
         del batches
-        return dt, finite, sub*parts
+        return dt, finite, sum(sizes)
 
     dt, kernel_ms, nlaunch, finite = run_leg(args.precision)
     split = None if args.no_split_leg else run_split_leg(args.precision)
+    # ... and on the 12-environments-per-CU build of the same kernel (engine.HIP_LIB_DENSE) as three sub-batches: slower than the
+    # default build in lock-step, faster pipelined (more resident environments)
+    split_dense = None
+    if not args.no_split_leg and args.precision == 64 and os.path.exists(engine.HIP_LIB_DENSE):
+        split_dense = run_split_leg(64, parts=3, dense=True)
     f32 = None
     if args.precision == 64 and not args.no_f32_leg:
         f32 = run_leg(32)
@@ -281,6 +294,11 @@ def main():
                                       'note': 'same environments stepped as 2 independent half-batches (2 fb_batch handles, 2 HIP streams): each half '
                                               'is in lock-step, the halves are not, so one launch\'s tail overlaps the other\'s head; an actor-side '
                                               'scheduling option (tools/split_bench.py), not the headline'}
+        if split_dense is not None:
+            out['pipelined_dense_mode'] = {'value': split_dense[2] * world * args.steps / split_dense[0], 'unit': 'env steps/sec',
+                                           'ms_per_step': split_dense[0] / args.steps * 1e3, 'state_finite': split_dense[1],
+                                           'note': '3 independent sub-batches on 3 HIP streams, FB_F64_DENSE build (12 instead of 8 FP64 environments per CU); '
+                                                   'secondary like two_stream_mode: the headline is the lock-step batch on the default build'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

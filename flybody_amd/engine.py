@@ -17,6 +17,10 @@ from .model_blob import load_npz, pack_model
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, 'libflybody_hip.so')
+# Same sources built with -DFB_F64_DENSE=1: 12 instead of 8 FP64 environments per CU (smaller LDS Delassus matrix, 168-VGPR
+# stages; +24 % per-environment time).  Slower for a 4096-batch in lock-step (1.33 rounds), faster for batches that are
+# multiples of 3072 and for sub-batches pipelined on several streams.  Opt-in: Model(..., dense=True).
+HIP_LIB_DENSE = os.path.join(_HERE, 'libflybody_hip_dense.so')
 ASSETS = os.path.join(_HERE, 'assets')
 
 # field ids (include/flybody_engine.h)
@@ -42,7 +46,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(path):
         raise EngineError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
-    if lib_path is None:
+    if lib_path is None or lib_path == HIP_LIB_DENSE:
         # torch bundles its own libamdhip64; it must be the first HIP runtime loaded into the
         # process, otherwise torch.cuda later fails with "No HIP GPUs are available".
         try:
@@ -102,7 +106,9 @@ def _check(L, rc):
 class Model:
     """Compiled model handle (fb_model)."""
 
-    def __init__(self, arrays: Dict[str, np.ndarray], lib_path: Optional[str] = None):
+    def __init__(self, arrays: Dict[str, np.ndarray], lib_path: Optional[str] = None, dense: bool = False):
+        if dense and lib_path is None:
+            lib_path = HIP_LIB_DENSE
         self.L = load_library(lib_path)
         self.arrays = arrays
         self.blob = pack_model(arrays)
@@ -111,8 +117,8 @@ class Model:
         self.h = h
 
     @classmethod
-    def from_asset(cls, name: str = 'walk_imitation', lib_path: Optional[str] = None) -> 'Model':
-        return cls(load_npz(os.path.join(ASSETS, name + '.npz')), lib_path)
+    def from_asset(cls, name: str = 'walk_imitation', lib_path: Optional[str] = None, dense: bool = False) -> 'Model':
+        return cls(load_npz(os.path.join(ASSETS, name + '.npz')), lib_path, dense)
 
     def dim(self, name: str) -> int:
         return self.L.fb_model_dim(self.h, name.encode())

@@ -15,9 +15,11 @@ def _declared_symbols():
     return sorted(set(re.findall(r'\b(fb_[a-z_0-9]+)\s*\(', hdr)))
 
 
-def test_library_exports_header_symbols():
+@pytest.mark.parametrize('which', ['default', 'dense'])
+def test_library_exports_header_symbols(which):
+    """Both builds of the engine (default; FB_F64_DENSE = 12 FP64 environments per CU, engine.HIP_LIB_DENSE) export the whole header."""
     import __graft_entry__ as g
-    lib = C.CDLL(g.build_hip())
+    lib = C.CDLL(g.build_hip() if which == 'default' else g.build_hip_dense())
     syms = _declared_symbols()
     assert len(syms) >= 17 and "fb_batch_step" in syms
     for s in syms:

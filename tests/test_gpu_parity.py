@@ -395,3 +395,34 @@ def test_solver_paths_by_system_size_gpu(gpu_model, oracle_model, walk_arrays, p
         assert _rel(B.get('QACC')[e], od.field('qacc')) < (1e-6 if precision == 64 else 3e-2), (e, n)
         if precision == 64:
             assert _rel(B.get('EFC_FORCE')[e][:n], od.field('efc_force')[:n]) < 1e-6, (e, n)
+
+
+@pytest.mark.gpu
+def test_dense_residency_build_matches_the_oracle(oracle_model, reference_traj):
+    """The FB_F64_DENSE build of the same sources (12 FP64 environments per CU: 23-row LDS Delassus matrix, LDS overlay for wider
+    systems, 168-VGPR stage budget -- engine.HIP_LIB_DENSE, used by bench.py's pipelined_dense_mode) against the FP64 oracle:
+    1e-6 on qpos / qvel of every one of 32 environments after 40 control steps of N(0, 1) actions."""
+    import torch
+    from oracle import fbo
+    from flybody_amd import engine
+    n, steps = 128, 40
+    M = engine.Model.from_asset('walk_imitation', dense=True)
+    assert 'flybody_engine' in M.L.fb_version().decode()
+    B = engine.Batch(M, n, precision=64)
+    qp, qv = reference_traj
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    ods = _oracle_envs(oracle_model, n, qp, qv, terminal_com_dist=float('inf'))
+    rng = np.random.default_rng(17)
+    st = torch.cuda.current_stream().cuda_stream
+    widest = 0
+    for k in range(steps):
+        a = np.clip(rng.normal(size=(n, 59)), -1, 1).astype(np.float32)
+        act = torch.from_numpy(a).cuda()
+        B.step_ptr(act.data_ptr(), st)
+        fbo.step_batch(ods, a.astype(np.float64))
+        torch.cuda.synchronize()
+        widest = max(widest, int(B.get('NEFC').max()))
+    Q, V = B.get('QPOS'), B.get('QVEL')
+    for e in range(n):
+        assert _rel(Q[e], ods[e].field('qpos')) <= 1e-6 and _rel(V[e], ods[e].field('qvel')) <= 1e-6, e
+    assert widest > 23                                             # (some systems did not fit the 23-row matrix: the overlay path ran)

@@ -12,6 +12,9 @@ timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 32 
 for n in 32 256 1024 2048 4096; do timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 $n 20 >> $O/batch_sweep.txt 2>&1; done
 for P in 1 2 4; do timeout 120 python tools/split_bench.py 64 4096 $P 20 >> $O/split.txt 2>&1; done
 for P in 1 2; do timeout 120 python tools/split_bench.py 32 4096 $P 20 >> $O/split.txt 2>&1; done
+echo '# FB_LIB=flybody_amd/libflybody_hip_dense.so (FB_F64_DENSE build): 4096 as 1 / 2 / 3 sub-batches, 6144 as 2' > $O/split_dense.txt
+for P in 1 2 3; do FB_LIB=$R/flybody_amd/libflybody_hip_dense.so timeout 120 python tools/split_bench.py 64 4096 $P 20 >> $O/split_dense.txt 2>&1; done
+FB_LIB=$R/flybody_amd/libflybody_hip_dense.so timeout 120 python tools/split_bench.py 64 6144 2 20 >> $O/split_dense.txt 2>&1
 timeout 200 python tools/learner_bench.py --steps 300 > $O/learner_graphs.log 2>&1
 timeout 200 python tools/learner_bench.py --steps 100 --no-graphs > $O/learner_nographs.log 2>&1
 cd /tmp

@@ -8,7 +8,7 @@ import torch
 from flybody_amd import engine
 from flybody_amd.reference import default_walking_reference
 prec = int(sys.argv[1]); n = int(sys.argv[2]); P = int(sys.argv[3]); K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-M = engine.Model.from_asset('walk_imitation')
+M = engine.Model.from_asset('walk_imitation', lib_path=os.environ.get('FB_LIB'))          # FB_LIB: an A/B build (tools/build_variant.sh)
 qp, qv = default_walking_reference()
 Bs, streams, acts, gens = [], [], [], []
 for p in range(P):
