@@ -396,3 +396,23 @@ def test_contact_jacobian_rows_against_point_jacobians(oracle_model, walk_arrays
         assert np.allclose(F @ F.T, np.eye(3), atol=1e-8) and np.allclose(F[0], n, atol=1e-8)
         checked += 1
     assert checked >= 3
+
+
+def test_passive_joint_forces_closed_form(oracle_model, walk_arrays):
+    """Joint springs and dampers (the only passive forces next to the fluid model): -k (q - q_spring) on sprung hinges, -d v on
+    every dof; the walker's inertia-box fluid forces are what is left of qfrc_passive and stay small in still air at these speeds."""
+    from oracle import fbo
+    A = walk_arrays
+    od = fbo.OracleData(oracle_model)
+    q, v = random_state(A, np.random.default_rng(21), z=0.3)
+    od.field('qpos')[:] = q; od.field('qvel')[:] = v
+    od.call('forward')
+    spring = np.zeros(len(v))
+    for jt, qa, da, k in zip(A['jnt_type'], A['jnt_qposadr'], A['jnt_dofadr'], A['jnt_stiffness']):
+        if jt == 3 and k != 0:
+            spring[da] = -k*(q[qa] - A['qpos_spring'][qa])
+    assert (np.asarray(A['jnt_stiffness']) != 0).sum() >= 10
+    assert np.allclose(od.field('qfrc_spring'), spring, rtol=1e-12, atol=1e-15)
+    assert np.allclose(od.field('qfrc_damper'), -np.asarray(A['dof_damping'])*v, rtol=1e-12, atol=1e-15)
+    fluid = od.field('qfrc_passive') - spring + np.asarray(A['dof_damping'])*v
+    assert np.allclose(fluid, od.field('qfrc_fluid'), rtol=1e-9, atol=1e-12)
