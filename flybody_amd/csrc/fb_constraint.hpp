@@ -10,6 +10,7 @@
 #include "fb_types.hpp"
 #include "fb_math.hpp"
 #include "fb_smooth.hpp"
+#include "fb_newton.hpp"
 
 #define JIDX(side, s, r) (((side)*FB_MAXCH + (s))*FB_MAXEFC_ + (r))
 #define MINIMP ((real)0.0001)
@@ -435,8 +436,9 @@ template <bool S, typename real, typename ARP> FBD void res_axpy3(R3<double>& re
 // k+128); a row update reads its residual with v_readlane and, if the force changed by delta, adds
 // delta * AR[row,:] to every lane's residuals -- one LDS row read and one FMA per lane, no reduction on the
 // critical path.  Mathematically identical to recomputing each row's dot product.
+// `sweeps` false: the forces in efc_force are final (the Newton solver produced them) and only the noslip passes run.
 template <typename real, typename ARP, bool S>
-FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane) {
+FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane, bool sweeps = true) {
   int nv = M.nv;
   PROF_BEGIN();
   R3<real> f, rb, rR, rfr0, rfr1, rla, rdiag;
@@ -466,7 +468,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     real fk = r3_get<S>(f, k);
     if (fk != 0) res_axpy<S>(res, AR, k, nefc, fk, lane);
   }
-  {
+  if (sweeps) {
     // dual cost of the warm start 0.5 f'ARf + f'b; fall back to zero force if it is worse than zero
     real c = (real)0.5*(f.v0*((real)res.v0 + rb.v0) + f.v1*((real)res.v1 + rb.v1) + f.v2*((real)res.v2 + rb.v2));
     c = wave_sum(c);
@@ -477,7 +479,10 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // (A block, scaled friction-plane matrix and its inverse at multiplier 0, reciprocals): every sweep fetches them
   // with v_readlane instead of re-reading and re-deriving them
   R3<real> cA00, cA01, cA02, cA11, cA12, cA22, cEc, cEs, cE1, cE2, cR1, cR2, cI00;
-  {
+#define FB_C3Z(name) name.v0 = 0; name.v1 = 0; name.v2 = 0;
+  FB_C3Z(cA00) FB_C3Z(cA01) FB_C3Z(cA02) FB_C3Z(cA11) FB_C3Z(cA12) FB_C3Z(cA22) FB_C3Z(cEc) FB_C3Z(cEs) FB_C3Z(cE1) FB_C3Z(cE2) FB_C3Z(cR1) FB_C3Z(cR2) FB_C3Z(cI00)
+#undef FB_C3Z
+  if (sweeps) {
     real t[13][3];
     for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
@@ -520,7 +525,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // ---- projected Gauss-Seidel over rows; elliptic contacts are updated as 3-row blocks
   real scale = (real)1 / (M.meaninertia * (real)(nv > 1 ? nv : 1));
   // solver options into registers: a read of the model inside the sweep loop would sit on the critical path of every sweep
-  const int max_it = M.iterations, max_noslip = M.noslip_iterations;
+  const int max_it = sweeps ? M.iterations : 0, max_noslip = M.noslip_iterations;
   const real tol_scaled = M.tolerance, noslip_tol = M.noslip_tolerance;
   int niter = 0;
 #ifndef FB_PGS_BRANCHY
@@ -865,27 +870,52 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   }
   SYNC();
   int niter;
+  // Solver: the model's choice (opt_solver; the reference XML sets none = Newton) for systems of up to one row per lane, PGS otherwise.
+  const bool newton = uniform_int(M.solver) == FB_SOLVER_NEWTON && nefc <= FB_NEWTON_MAXROWS;
+  const int tri = nefc*(nefc + 1)/2;
   if (nefc <= LdsCfg<real>::WIDE_ROWS) {
     // Delassus matrix in LDS.  A system that does not fit the matrix slot alone borrows the factor row in front of it (the
-    // pool is contiguous): the factor is parked in the environment's global row during the sweeps -- two coalesced passes
+    // pool is contiguous): the factor is parked in the environment's global row during the solve -- two coalesced passes
     // instead of a global-memory round trip on the critical path of every row update of a system that is slow already.
+    // The Newton solver needs a second triangle of the same size (its work matrix K): behind AR in the matrix slot when both
+    // fit, in the (parked) factor row otherwise, in the environment's global row as the last resort.
     const bool wide = nefc > LdsCfg<real>::AR_ROWS;
-    if (wide) {
+    const bool k_in_slot = newton && !wide && 2*tri <= LdsCfg<real>::AR_ELEMS;
+    const bool park = wide || (newton && !k_in_slot);
+    if (park) {
       for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
       SYNC();
+    }
+    if (wide) {
       const real* src = w.AR();
-      for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lLD[i] = src[i];
+      for (int i = lane; i < tri; i += FB_WAVE) w.lLD[i] = src[i];
       SYNC();
     }
     const FB_LDS real* arp = wide ? (const FB_LDS real*)w.lLD : (const FB_LDS real*)w.lAR;
-    niter = d_pgs<real, const FB_LDS real*, true>(M, w, arp, nefc, lane);
-    if (wide) {
+    if (newton) {
+      const WS<real> wc = w;               // (the callee is not inlined: hand it a copy, the caller's descriptor stays in registers)
+      if (k_in_slot) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lAR + tri, nefc, lane);
+      else if (!wide) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lLD, nefc, lane);
+      else if (2*tri <= FB_LDS_SCRATCH + LdsCfg<real>::AR_ELEMS) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lLD + tri, nefc, lane);
+      else niter = d_newton<real, const FB_LDS real*, real*>(M, wc, arp, w.AR() + tri, nefc, lane);
+      SYNC();
+    }
+    // PGS sweeps (when PGS is the solver) and the noslip passes (after either solver)
+    if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const FB_LDS real*, true>(M, w, arp, nefc, lane, !newton); if (!newton) niter = it2; }
+    if (park) {
       SYNC();
       for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD()[i];
       SYNC();
     }
   }
-  else if (nefc <= 64) niter = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane);
+  else if (nefc <= 64) {
+    if (newton) {
+      const WS<real> wc = w;
+      niter = d_newton<real, const real*, real*>(M, wc, (const real*)w.AR(), w.AR() + tri, nefc, lane);
+      SYNC();
+    }
+    if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane, !newton); if (!newton) niter = it2; }
+  }
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
   if (lane == 0) w.istate()[IS_NITER] = niter;
   SYNC();

@@ -553,6 +553,8 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   M.nobsjnt = m->nobsjnt; M.napp = m->napp; M.nforce = m->nforce; M.ntouch = m->ntouch;
   M.site_thorax = m->i("sensor_site_thorax")[0]; M.nadh = (int)m->adh_act.size();
   M.iterations = m->i("opt_iterations")[0]; M.noslip_iterations = m->i("opt_noslip_iterations")[0];
+  // opt_solver is optional: a blob without it gets MuJoCo's default, Newton -- what the reference XML selects (fruitfly.xml:4)
+  M.solver = (m->has("opt_solver", 1) && m->i("opt_solver")[0] == FB_SOLVER_PGS) ? FB_SOLVER_PGS : FB_SOLVER_NEWTON;
   M.timestep = (real)m->d("opt_timestep")[0]; M.control_timestep = (real)m->d("opt_control_timestep")[0];
   for (int k = 0; k < 3; k++) M.grav[k] = (real)m->d("opt_gravity")[k];
   M.density = (real)m->d("opt_density")[0]; M.viscosity = (real)m->d("opt_viscosity")[0];

@@ -100,7 +100,7 @@ template <typename real>
 struct DevModel {
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep;
   int nobsjnt, napp, nforce, ntouch, site_thorax, nadh;
-  int iterations, noslip_iterations;
+  int iterations, noslip_iterations, solver;      // solver: mjtSolver numbering (0 PGS, 2 Newton)
   real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
   // topology
   GP<const int> body_parent, body_dofadr, body_nsub, body_depth;

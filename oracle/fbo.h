@@ -32,7 +32,7 @@ enum { FBO_GEOM_PLANE = 0, FBO_GEOM_SPHERE = 2, FBO_GEOM_CAPSULE = 3, FBO_GEOM_E
 enum { FBO_TRN_JOINT = 0, FBO_TRN_TENDON = 3, FBO_TRN_BODY = 5 };
 enum { FBO_DYN_NONE = 0, FBO_DYN_FILTER = 2, FBO_DYN_FILTEREXACT = 3 };
 enum { FBO_CNSTR_LIMIT = 0, FBO_CNSTR_CONTACT_FRICTIONLESS = 1, FBO_CNSTR_CONTACT_ELLIPTIC = 2 };
-enum { FBO_SOLVER_PGS = 0, FBO_SOLVER_NEWTON = 1 };
+enum { FBO_SOLVER_PGS = 0, FBO_SOLVER_CG = 1, FBO_SOLVER_NEWTON = 2 };   /* mjtSolver numbering */
 
 typedef struct {
   void* blob;   /* private copy of the compiled-model blob */

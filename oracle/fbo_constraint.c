@@ -362,6 +362,150 @@ static void solve_noslip(fbo_data* d) {
   }
 }
 
+
+/* ------------------------------------------------------------------ Newton (the reference model's solver: fruitfly.xml:4 sets no
+ * `solver`, i.e. MuJoCo's default, Newton)
+ *
+ * MuJoCo's Newton solver minimises the PRIMAL cost  P(a) = 1/2 (a - a_s)' M (a - a_s) + sum_i s_i(J a - aref)  over the
+ * acceleration a; s is the convex constraint cost whose negative gradient is the constraint force (constraint_update above: zero /
+ * quadratic rows, and the three zones of an elliptic cone).  PGS solves the dual of the same problem, so both have one solution.
+ * Restated here in constraint space: every Newton iterate has the form a = a_s + M^-1 J' lam, so the state is lam (nefc numbers,
+ * equal to the force at the solution), jar = b + A lam with A = J M^-1 J' (the Delassus matrix WITHOUT the regulariser R), and
+ *     P(lam) = 1/2 lam' A lam + s(jar),   gradient (wrt a) = J'(lam - f(jar)),   Hessian = M + J' H J,  H = d2s/djar2 (block diagonal).
+ * The Newton direction in lam-coordinates solves (I + H A) dlam = f - lam.  With H = F F' (F: one column per active scalar row / three
+ * per contact in the bottom zone / the two rank-one factors of the cone Hessian in the middle zone) the Woodbury identity gives
+ *     dlam = r - F (I + F' A F)^-1 F' A r,   r = f - lam,
+ * i.e. one Cholesky factorisation of the SPD matrix K = I + F'AF (pivots >= 1) per iteration; then an exact (to ls_tolerance) line
+ * search on the 1-D convex function P(lam + alpha dlam) by safeguarded Newton steps on its derivative.  Terminates when the bound
+ * 1/2 r'Ar on the attainable improvement, scaled like MuJoCo's `improvement` (1/(meaninertia nv)), drops below opt.tolerance. */
+#define NEWTON_LS_TOL 0.01
+#define NEWTON_LS_MAX 20
+#define NEWTON_MAXROWS 64      /* the kernel's Newton keeps one row per lane of a wavefront; larger systems fall back to PGS there, hence here too */
+
+typedef struct { double f, cost; int base; double frow[3], fcol[3]; } nrow;
+
+/* force, cost and Hessian factor of every row at `jar`; rows of one contact get identical block data */
+static double newton_update(const fbo_data* d, const double* jar, nrow* q) {
+  int n = d->nefc; double cost = 0;
+  for (int i = 0; i < n;) {
+    if (d->efc_type[i] != FBO_CNSTR_CONTACT_ELLIPTIC) {
+      nrow* r = q + i; r->base = i; r->f = 0; r->frow[0] = r->frow[1] = r->frow[2] = 0; r->fcol[0] = r->fcol[1] = r->fcol[2] = 0;
+      if (jar[i] < 0) { r->f = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; r->frow[0] = r->fcol[0] = sqrt(d->efc_D[i]); }
+      i++; continue;
+    }
+    const fbo_contact* con = d->contact + d->efc_id[i];
+    double mu = con->mu, s[3] = {mu, con->friction[0], con->friction[1]};
+    double U0 = jar[i]*s[0], U1 = jar[i+1]*s[1], U2 = jar[i+2]*s[2];
+    double N = U0, T = sqrt(U1*U1 + U2*U2);
+    for (int k = 0; k < 3; k++) { nrow* r = q + i + k; r->base = i; r->f = 0; for (int c = 0; c < 3; c++) r->frow[c] = r->fcol[c] = 0; }
+    if (N >= mu*T || (T <= 0 && N >= 0)) { /* top zone: no force */ }
+    else if (mu*N + T <= 0 || (T <= 0 && N < 0)) {
+      for (int k = 0; k < 3; k++) { double D = d->efc_D[i+k]; q[i+k].f = -D*jar[i+k]; cost += 0.5*D*jar[i+k]*jar[i+k]; q[i+k].frow[k] = q[i+k].fcol[k] = sqrt(D); }
+    } else {
+      double Dm = d->efc_D[i] / fmax(FBO_MINVAL, mu*mu*(1 + mu*mu));
+      double NT = N - mu*T, t1 = U1/T, t2 = U2/T;
+      cost += 0.5*Dm*NT*NT;
+      double f0 = -Dm*NT*mu;
+      q[i].f = f0; q[i+1].f = -f0*t1*s[1]; q[i+2].f = -f0*t2*s[2];
+      /* cone Hessian in U-space: Dm (e_n - mu t)(e_n - mu t)' + Dm mu (mu - N/T) t_perp t_perp' ; jar-space: scale rows by s */
+      double g1 = sqrt(Dm), g2 = sqrt(Dm*mu*(mu - N/T));
+      double c1[3] = {g1*s[0], -g1*mu*t1*s[1], -g1*mu*t2*s[2]};       /* column 0 of the block factor */
+      double c2[3] = {0, -g2*t2*s[1], g2*t1*s[2]};                      /* column 1; column 2 is zero */
+      for (int k = 0; k < 3; k++) { q[i+k].frow[0] = c1[k]; q[i+k].frow[1] = c2[k]; q[i+k].frow[2] = 0; }
+      for (int k = 0; k < 3; k++) { q[i].fcol[k] = c1[k]; q[i+1].fcol[k] = c2[k]; q[i+2].fcol[k] = 0; }
+    }
+    i += 3;
+  }
+  return cost;
+}
+
+static void solve_newton(fbo_data* d) {
+  const fbo_model* m = d->m;
+  const int n = d->nefc;
+  const double* AR = d->efc_AR; const double* b = d->efc_b;
+  double scale = 1.0 / (m->meaninertia * (m->nv > 1 ? m->nv : 1));
+  double* W = (double*)malloc(sizeof(double)*((size_t)n*n + 12*(size_t)n));
+  double *K = W, *lam = W + (size_t)n*n, *jar = lam + n, *r = jar + n, *qv = r + n, *p = qv + n, *z = p + n, *dl = z + n, *Adl = dl + n, *tj = Adl + n;
+  nrow* rw = (nrow*)malloc(sizeof(nrow)*(size_t)n);
+#define AMUL(out, x) for (int i_ = 0; i_ < n; i_++) { double s_ = 0; for (int k_ = 0; k_ < n; k_++) s_ += AR[(size_t)i_*n + k_]*(x)[k_]; (out)[i_] = s_ - d->efc_R[i_]*(x)[i_]; }
+  /* warm start: the force implied by the previous acceleration, unless the zero force is cheaper */
+  memcpy(lam, d->efc_force, sizeof(double)*n);
+  AMUL(jar, lam);
+  double lAl = 0; for (int i = 0; i < n; i++) { lAl += lam[i]*jar[i]; jar[i] += b[i]; }
+  double c_ws = 0.5*lAl + newton_update(d, jar, rw), c_0 = newton_update(d, b, rw);
+  if (c_ws > c_0) { memset(lam, 0, sizeof(double)*n); memcpy(jar, b, sizeof(double)*n); }
+  d->solver_niter = 0;
+  for (int it = 0; it < m->iterations; it++) {
+    newton_update(d, jar, rw);
+    for (int i = 0; i < n; i++) r[i] = rw[i].f - lam[i];
+    AMUL(qv, r);
+    double dec = 0; for (int i = 0; i < n; i++) dec += r[i]*qv[i];
+    if (0.5*dec*scale < m->tolerance) break;
+    /* K = I + F'AF (lower triangle), p = F'q */
+    for (int j = 0; j < n; j++) {
+      int bj = rw[j].base, nj = (d->efc_type[j] == FBO_CNSTR_CONTACT_ELLIPTIC) ? 3 : 1;
+      double pj = 0; for (int a = 0; a < nj; a++) pj += rw[j].fcol[a]*qv[bj + a];
+      p[j] = pj;
+      for (int k = 0; k <= j; k++) {
+        int bk = rw[k].base, nk = (d->efc_type[k] == FBO_CNSTR_CONTACT_ELLIPTIC) ? 3 : 1;
+        double s = 0;
+        for (int a = 0; a < nj; a++) {
+          double wa = 0;
+          for (int c = 0; c < nk; c++) { int ra = bj + a, rc = bk + c; wa += (AR[(size_t)ra*n + rc] - (ra == rc ? d->efc_R[ra] : 0.0))*rw[k].fcol[c]; }
+          s += rw[j].fcol[a]*wa;
+        }
+        K[(size_t)j*n + k] = s + (j == k ? 1.0 : 0.0);
+      }
+    }
+    /* Cholesky K = L L' (right-looking), forward substitution folded in; then back substitution */
+    for (int j = 0; j < n; j++) {
+      double inv = 1.0/sqrt(K[(size_t)j*n + j]);
+      K[(size_t)j*n + j] = inv;                      /* the diagonal slot keeps 1/L_jj */
+      double yj = p[j]*inv; p[j] = yj;
+      for (int i = j + 1; i < n; i++) { double l = K[(size_t)i*n + j]*inv; K[(size_t)i*n + j] = l; p[i] -= l*yj; }
+      for (int i = j + 1; i < n; i++) { double l = K[(size_t)i*n + j]; for (int k = j + 1; k <= i; k++) K[(size_t)i*n + k] -= l*K[(size_t)k*n + j]; }
+    }
+    for (int j = n - 1; j >= 0; j--) {
+      double zj = p[j]*K[(size_t)j*n + j]; z[j] = zj;
+      for (int i = 0; i < j; i++) p[i] -= K[(size_t)j*n + i]*zj;
+    }
+    for (int i = 0; i < n; i++) {
+      int bi = rw[i].base, ni = (d->efc_type[i] == FBO_CNSTR_CONTACT_ELLIPTIC) ? 3 : 1;
+      double s = 0; for (int c = 0; c < ni; c++) s += rw[i].frow[c]*z[bi + c];
+      dl[i] = r[i] - s;
+    }
+    AMUL(Adl, dl);
+    double lAd = 0, dAd = 0;
+    for (int i = 0; i < n; i++) { lAd += (jar[i] - b[i])*dl[i]; dAd += dl[i]*Adl[i]; }
+    /* line search on phi(alpha) = P(lam + alpha dl):  phi' = lAd + alpha dAd - f(jar + alpha Adl).Adl,  phi'' = dAd + |F' Adl|^2 */
+    double alpha = 0, g0 = 0, lo = 0, hi = -1;
+    for (int k = 0; k <= NEWTON_LS_MAX; k++) {
+      for (int i = 0; i < n; i++) tj[i] = jar[i] + alpha*Adl[i];
+      newton_update(d, tj, rw);
+      double g = lAd + alpha*dAd, h = dAd;
+      for (int i = 0; i < n; i++) {
+        g -= rw[i].f*Adl[i];
+        int bi = rw[i].base, ni = (d->efc_type[i] == FBO_CNSTR_CONTACT_ELLIPTIC) ? 3 : 1;
+        double wv = 0; for (int a = 0; a < ni; a++) wv += rw[i].fcol[a]*Adl[bi + a];
+        h += wv*wv;
+      }
+      if (k == 0) { g0 = g; if (!(g0 < 0) || !(h > FBO_MINVAL)) break; alpha = -g0/h; continue; }
+      if (fabs(g) <= NEWTON_LS_TOL*fabs(g0) || k == NEWTON_LS_MAX) break;
+      if (g < 0) lo = alpha; else hi = alpha;
+      double an = (h > FBO_MINVAL) ? alpha - g/h : -1;
+      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = (hi < 0) ? 2*alpha : 0.5*(lo + hi);
+      alpha = an;
+    }
+    if (!(alpha > 0)) break;
+    for (int i = 0; i < n; i++) { lam[i] += alpha*dl[i]; jar[i] += alpha*Adl[i]; }
+    d->solver_niter = it + 1;
+  }
+  newton_update(d, jar, rw);
+  for (int i = 0; i < n; i++) d->efc_force[i] = rw[i].f;
+#undef AMUL
+  free(W); free(rw);
+}
+
 void fbo_fwd_constraint(fbo_data* d) {
   const fbo_model* m = d->m;
   int nv = m->nv, n = d->nefc;
@@ -391,9 +535,10 @@ void fbo_fwd_constraint(fbo_data* d) {
       jar[i] = s - d->efc_aref[i];
     }
     constraint_update(d, jar);
-    if (dual_cost(d, d->efc_force) > 0) memset(d->efc_force, 0, sizeof(double)*n);
+    if (!(m->solver == FBO_SOLVER_NEWTON && n <= NEWTON_MAXROWS) && dual_cost(d, d->efc_force) > 0) memset(d->efc_force, 0, sizeof(double)*n);
   }
-  solve_pgs(d);
+  if (m->solver == FBO_SOLVER_NEWTON && n <= NEWTON_MAXROWS) solve_newton(d);
+  else solve_pgs(d);
   if (m->noslip_iterations > 0) solve_noslip(d);
   /* qfrc_constraint = J^T f ; qacc = qacc_smooth + M^-1 qfrc_constraint */
   memset(d->qfrc_constraint, 0, sizeof(double)*nv);

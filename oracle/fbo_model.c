@@ -90,7 +90,9 @@ int fbo_model_load(const void* blob_in, size_t n, fbo_model** out) {
   m->noslip_iterations = geti(b, "opt_noslip_iterations", NULL)[0];
   m->iterations = geti(b, "opt_iterations", NULL)[0];
   m->cone_elliptic = geti(b, "opt_cone_elliptic", NULL)[0];
-  m->solver = FBO_SOLVER_PGS;
+  /* opt_solver (optional array, mjtSolver numbering): absent = MuJoCo's default, Newton -- what fruitfly.xml:4 selects */
+  { const blob_entry* e = find(b, "opt_solver"); m->solver = FBO_SOLVER_NEWTON;
+    if (e && e->dtype == 1 && e->nbytes >= 4 && ((const int*)((const char*)b + e->offset))[0] == FBO_SOLVER_PGS) m->solver = FBO_SOLVER_PGS; }
   m->nsubstep = (int)floor(m->control_timestep / m->timestep + 0.5);
   m->na = 0;
   for (int i = 0; i < m->nu; i++) if (m->actuator_actadr[i] >= 0) m->na++;
