@@ -27,6 +27,12 @@
 
 #define FB_NEWTON_LS_MAX 20
 #define FB_NEWTON_MAXROWS 64
+#ifndef FB_NEWTON_NR
+#define FB_NEWTON_NR 16     // active columns of the work matrix up to which the Cholesky factorisation runs in registers
+#endif
+#ifndef FB_NEWTON_F32_FLOOR
+#define FB_NEWTON_F32_FLOOR 1e-10
+#endif
 enum { FB_SOLVER_PGS = 0, FB_SOLVER_CG = 1, FB_SOLVER_NEWTON = 2 };      // mjtSolver numbering
 
 #ifndef FB_NEWTON_INLINE
@@ -83,6 +89,14 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   const int n = nefc;
   const bool on = lane < n;
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long nwp_[7] = {0, 0, 0, 0, 0, 0, 0}, nwt_ = clock64(), nwc_[2] = {0, 0};
+#define NW_PROF(k) do { long long n_ = clock64(); nwp_[k] += n_ - nwt_; nwt_ = clock64(); } while (0)
+#define NW_COUNT(k) nwc_[k]++
+#else
+#define NW_PROF(k) do {} while (0)
+#define NW_COUNT(k) do {} while (0)
+#endif
   // ---- per-row constants
   const int type = on ? w.efc_type()[lane] : CN_LIMIT;
   NwConst<real> c;
@@ -138,12 +152,21 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     if (c_ws > c_0) { lam = 0; jb0 = bb0; jb1 = bb1; jb2 = bb2; }
   }
   int niter = 0;
+  NW_PROF(0);
   for (int it = 0; it < max_it; it++) {
     nw_update(c, jb0, jb1, jb2, o);
     const real r = o.f - lam;
     const real q = amul(r);
     const real dec = wave_sum(r*q);
+    NW_PROF(1);
     if ((real)0.5*dec*scale < tol) break;           // bound on the attainable improvement (MuJoCo's `improvement` scaling)
+    if (sizeof(real) == 4) {
+      // single precision cannot resolve the absolute tolerance: r = f - lam carries a rounding error of ~1e-7 |f|, so the
+      // decrement bottoms out at ~1e-14 |lam|_A^2 times the conditioning.  Stop at that floor (the FP64 build never gets here).
+      const real jo_ = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
+      const real lAl = wave_sum(lam*(jo_ - b));
+      if (dec <= (real)FB_NEWTON_F32_FLOOR*(lAl + dec)) break;
+    }
     const unsigned long long m_act = __ballot(o.fc0 != 0 || o.fc1 != 0 || o.fc2 != 0);     // non-zero columns of F
     // ---- p = F'q and K = I + F'AF (lane == row of K, lower triangle)
     real y;
@@ -151,13 +174,14 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       const real q0 = nw_lane(q, base), q1 = nw_lane(q, base + 1), q2 = nw_lane(q, base + 2);
       y = o.fc0*q0 + o.fc1*q1 + o.fc2*q2;
     }
+    // Only the non-zero columns of F take part: K is the identity in the others.  Row `lane` keeps its entries of the
+    // active columns left of it, compacted (entry p = the p-th active column), at K[tri_l + p].
+    const int n_act = __popcll(m_act);
+    const int my_ci = __popcll(m_act & ((1ull << lane) - 1ull));          // compact index of this lane's own column
     real dg = 1;                                    // running diagonal K[lane][lane]: stays in the owner's registers
     for (int bk = 0; bk < n;) {
       const int nk = ((m_first >> bk) & 1ull) ? 3 : 1;
-      if (!((m_act >> bk) & (nk == 3 ? 7ull : 1ull))) {       // identity columns
-        for (int cc = 0; cc < nk; cc++) { const int col = bk + cc; if (on && col < lane) K[tri_l + col] = 0; }
-        bk += nk; continue;
-      }
+      if (!((m_act >> bk) & (nk == 3 ? 7ull : 1ull))) { bk += nk; continue; }      // identity columns
       // v_cc = sum_a F[block row a][lane] A[block row a][bk + cc]
       real v0 = 0, v1 = 0, v2 = 0;
 #pragma unroll
@@ -170,45 +194,93 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
           if (cc == 0) v0 = vv; else if (cc == 1) v1 = vv; else v2 = vv;
         }
       }
+      int ci = __popcll(m_act & ((1ull << bk) - 1ull));
 #pragma unroll
       for (int cc = 0; cc < 3; cc++) {
         if (cc < nk) {
           const int col = bk + cc;
-          real kv = v0*rdlane(o.fc0, col);
-          if (nk == 3) kv += v1*rdlane(o.fc1, col) + v2*rdlane(o.fc2, col);
-          if (on && col < lane) K[tri_l + col] = kv;
-          if (col == lane) dg = kv + 1;
+          if ((m_act >> col) & 1ull) {
+            real kv = v0*rdlane(o.fc0, col);
+            if (nk == 3) kv += v1*rdlane(o.fc1, col) + v2*rdlane(o.fc2, col);
+            if (on && col < lane) K[tri_l + ci] = kv;
+            if (col == lane) dg = kv + 1;
+            ci++;
+          }
         }
       }
       bk += nk;
     }
-    // ---- Cholesky K = L L' (right-looking; column by v_readlane, rows updated in place), forward substitution folded in
+    NW_PROF(2);
+    // ---- Cholesky K = L L' (right-looking), forward substitution folded in.  The column of a pivot travels by v_readlane,
+    // every lane updates its own row.  Up to FB_NEWTON_NR active columns the rows live in registers (the loops over the
+    // compact column index are unrolled, so the register index is static; they leave at the first exhausted bit mask);
+    // larger systems update their rows in LDS.
     real invd = 1;
-    for (int j = 0; j < n; j++) {
-      if (!((m_act >> j) & 1ull)) continue;
-      const real inv = fb_rsqrt(rdlane(dg, j));
-      real lcol = 0;
-      if (on && lane > j) { lcol = K[tri_l + j]*inv; K[tri_l + j] = lcol; }
-      if (lane == j) invd = inv;
-      const real yj = rdlane(y, j)*inv;
-      y = (lane == j) ? yj : y - lcol*yj;
-      for (int kk = j + 1; kk < n; kk++) {
-        if (!((m_act >> kk) & 1ull)) continue;
-        const real lk = rdlane(lcol, kk);
-        if (lane == kk) dg -= lcol*lk;
-        else if (on && lane > kk) K[tri_l + kk] -= lcol*lk;
+    if (n_act <= FB_NEWTON_NR) {
+      real Kr[FB_NEWTON_NR];
+#pragma unroll
+      for (int pp = 0; pp < FB_NEWTON_NR; pp++) Kr[pp] = (pp < n_act) ? K[tri_l + pp] : (real)0;
+      unsigned long long mrem = m_act;
+#pragma unroll
+      for (int pp = 0; pp < FB_NEWTON_NR; pp++) {
+        if (mrem) {
+          const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
+          const real inv = fb_rsqrt(rdlane(dg, j));
+          const real lcol = (on && lane > j) ? Kr[pp]*inv : (real)0;
+          Kr[pp] = lcol;
+          if (lane == j) invd = inv;
+          const real yj = rdlane(y, j)*inv;
+          y = (lane == j) ? yj : y - lcol*yj;
+          unsigned long long m2 = mrem;
+#pragma unroll
+          for (int p2 = pp + 1; p2 < FB_NEWTON_NR; p2++) {
+            if (m2) {
+              const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
+              const real lk = rdlane(lcol, kk);
+              Kr[p2] -= lcol*lk;                    // (lanes <= kk update an entry they never use)
+              dg -= (lane == kk) ? lcol*lk : (real)0;
+            }
+          }
+        }
+      }
+      // L goes back to LDS: the back substitution reads row j across lanes
+#pragma unroll
+      for (int pp = 0; pp < FB_NEWTON_NR; pp++) if (pp < n_act && on && pp < my_ci) K[tri_l + pp] = Kr[pp];
+    } else {
+      unsigned long long mrem = m_act;
+      for (int pp = 0; mrem; pp++) {
+        const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
+        const real inv = fb_rsqrt(rdlane(dg, j));
+        real lcol = 0;
+        if (on && lane > j) { lcol = K[tri_l + pp]*inv; K[tri_l + pp] = lcol; }
+        if (lane == j) invd = inv;
+        const real yj = rdlane(y, j)*inv;
+        y = (lane == j) ? yj : y - lcol*yj;
+        unsigned long long m2 = mrem;
+        for (int p2 = pp + 1; m2; p2++) {
+          const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
+          const real lk = rdlane(lcol, kk);
+          if (lane == kk) dg -= lcol*lk;
+          else if (on && lane > kk) K[tri_l + p2] -= lcol*lk;
+        }
       }
     }
     SYNC();                                         // the rows of L are read across lanes below
-    // ---- back substitution L' z = y
+    NW_PROF(3);
+    // ---- back substitution L' z = y over the active columns, last first
     real z = 0;
-    for (int j = n - 1; j >= 0; j--) {
-      if (!((m_act >> j) & 1ull)) continue;
-      const real zj = rdlane(y, j)*rdlane(invd, j);
-      if (lane == j) z = zj;
-      if (lane < j) y -= K[j*(j + 1)/2 + lane]*zj;
+    {
+      unsigned long long mrem = m_act;
+      const bool mine = on && ((m_act >> lane) & 1ull);
+      while (mrem) {
+        const int j = 63 - __clzll((long long)mrem); mrem &= ~(1ull << j);
+        const real zj = rdlane(y, j)*rdlane(invd, j);
+        if (lane == j) z = zj;
+        if (mine && lane < j) y -= K[j*(j + 1)/2 + my_ci]*zj;
+      }
     }
     SYNC();                                         // (K is rewritten by the next iteration)
+    NW_PROF(4);
     real dl;
     {
       const real z0 = nw_lane(z, base), z1 = nw_lane(z, base + 1), z2 = nw_lane(z, base + 2);
@@ -218,10 +290,12 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     const real Ab0 = nw_lane(Adl, base), Ab1 = nw_lane(Adl, base + 1), Ab2 = nw_lane(Adl, base + 2);
     const real jo = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
     const real lAd = wave_sum((jo - b)*dl), dAd = wave_sum(dl*Adl);
+    NW_PROF(5);
     // ---- line search: phi'(alpha) = lAd + alpha dAd - f(jar + alpha Adl).Adl,  phi'' = dAd + |F'Adl|^2
     real alpha = 0, g0 = 0, lo = 0, hi = -1;
     NwRow<real> o2 = o;
     for (int kls = 0; kls <= FB_NEWTON_LS_MAX; kls++) {
+      NW_COUNT(1);
       if (kls > 0) nw_update(c, jb0 + alpha*Ab0, jb1 + alpha*Ab1, jb2 + alpha*Ab2, o2);
       const real wv = o2.fc0*Ab0 + o2.fc1*Ab1 + o2.fc2*Ab2;
       const real g = lAd + alpha*dAd - wave_sum(o2.f*Adl);
@@ -233,11 +307,15 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = (hi < 0) ? 2*alpha : (real)0.5*(lo + hi);
       alpha = an;
     }
+    NW_PROF(6); NW_COUNT(0);
     if (!(alpha > 0)) break;
     lam += alpha*dl; jb0 += alpha*Ab0; jb1 += alpha*Ab1; jb2 += alpha*Ab2;
     niter = it + 1;
   }
   nw_update(c, jb0, jb1, jb2, o);
   if (on) w.efc_force()[lane] = o.f;
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 7; k_++) pp_[32 + k_] += nwp_[k_]; pp_[39] += nwc_[0]; pp_[40] += nwc_[1]; pp_[41] += 1; }
+#endif
   return niter;
 }
