@@ -24,6 +24,9 @@ ALGO_BYTES_PER_ENV_STEP = {32: 5420.0, 64: 2*276*8.0 + (59 + 741 + 3)*4.0}
 # multiplies, divisions and square roots of one walk_imitation control step, mean over 200 steps in contact under the
 # bench's action distribution; replaces SURVEY.md 8(d)'s provisional 9 MFLOP
 ALGO_FLOP_PER_ENV_STEP = 3.44e6
+# flight_imitation (configs[3]): SURVEY.md 8(d) -- 1 156 B and ~0.53 MFLOP per env control step (4 substeps of 5e-5 s, nv 42, no floor)
+FLIGHT_BYTES_PER_ENV_STEP = {32: 1156.0, 64: 2*(43 + 42)*8.0 + (12 + 104 + 3)*4.0}
+FLIGHT_FLOP_PER_ENV_STEP = 0.53e6
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}
 
@@ -107,6 +110,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary FP32-build measurement')
     ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary two-half-batches-on-two-streams measurement')
+    ap.add_argument('--no-secondary-configs', action='store_true', help='skip the flight_imitation (configs[3]) and DMPO (configs[2]) legs')
+    ap.add_argument('--no-parity-sample', action='store_true', help='skip the post-run replay of sampled environments on the CPU oracle')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -159,12 +164,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(precision):
-        """W untimed + K timed control steps of the whole batch; returns (seconds, kernel ms total, launches, finite)."""
+    sample_ids = np.unique(np.concatenate([[0, 1, n_env - 2, n_env - 1, n_env//2 - 1, n_env//2], np.linspace(0, n_env - 1, 12).astype(int)]))[:16]
+    seed0 = 1234 + rank
+
+    def run_leg(precision, extras=None):
+        """W untimed + K timed control steps of the whole batch; returns (seconds, kernel ms total, launches, finite).
+        extras (dict): filled with the end state of the sampled environments and the FB_WARN population."""
         batch = engine.Batch(model, n_env, device=local_rank, precision=precision)
         batch.set_reference(qp, qv, terminal_com_dist=float('inf'))
         batch.reset(stream=stream)
-        gen = torch.Generator(device='cuda'); gen.manual_seed(1234 + rank)
+        gen = torch.Generator(device='cuda'); gen.manual_seed(seed0)
         action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
 
         def one_step():
@@ -187,8 +196,95 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         finite = bool(np.isfinite(batch.get('QPOS')).all())
+        if extras is not None:
+            wv = batch.get('WARN_EVER').ravel()
+            extras['warn'] = {name: int(((wv & bit) != 0).sum()) for name, bit in engine.WARN_BITS.items()}
+            extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
+            extras['solver_iterations_mean'] = float(batch.get('SOLVER_NITER').mean())
         del batch
         return dt, kernel_ms, nlaunch, finite
+
+    def parity_sample(extras):
+        """OUTSIDE the clock: the recorded action streams of the sampled environments (the generator is re-run from its seed) are
+        replayed on the CPU oracle from the same reset state; the FP64 end states are compared."""
+        from flybody_amd.model_blob import pack_model
+        from oracle import fbo
+        gen = torch.Generator(device='cuda'); gen.manual_seed(seed0)
+        action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
+        ids_dev = torch.as_tensor(sample_ids, device='cuda')
+        rec = []
+        for _ in range(args.warmup + args.steps):
+            action.normal_(generator=gen).clamp_(-1.0, 1.0)
+            rec.append(action[ids_dev].cpu().numpy())
+        acts = np.ascontiguousarray(np.stack(rec, axis=1).astype(np.float64))            # [n_sample][steps][nu]
+        om = fbo.OracleModel(pack_model(model.arrays)); envs = []
+        for _ in sample_ids:
+            d = fbo.OracleData(om); d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset(); envs.append(d)
+        fbo.rollout_batch(envs, acts)
+        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+        eq = max(rel(extras['qpos'][i], envs[i].field('qpos')) for i in range(len(envs)))
+        ev = max(rel(extras['qvel'][i], envs[i].field('qvel')) for i in range(len(envs)))
+        return {'n': len(envs), 'control_steps': args.warmup + args.steps, 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
+                'tolerance': 1e-6, 'ok': bool(eq < 1e-6 and ev < 1e-6),
+                'note': 'FP64 kernel end state of sampled environments (both residency rounds) vs the FP64 CPU oracle replaying the same '
+                        'action streams from the same reset; oracle vs CPU MuJoCo stays unpinned'}
+
+    def run_flight_leg(precision, steps, warmup):
+        """BASELINE configs[3]: 8192 flight_imitation environments (WBPG + ellipsoid wing fluid forces, 4 substeps of 5e-5 s),
+        U(-1, 1)^12 actions, per-environment initial wing-beat phase, auto-reset included."""
+        from flybody_amd.fly_envs import flight_imitation
+        n_f = 8192
+        env = flight_imitation(n_env=n_f, device=local_rank, precision=precision, env_id_base=rank*n_f)
+        b = env.batch
+        gen = torch.Generator(device='cuda'); gen.manual_seed(4321 + rank)
+        a = torch.empty(n_f, b.model.dim('nact'), device='cuda', dtype=torch.float32)
+        env.reset_all()
+
+        def one_step():
+            a.uniform_(-1.0, 1.0, generator=gen)
+            b.step_ptr(a.data_ptr(), stream)
+        for _ in range(warmup):
+            one_step()
+        barrier()
+        b.timing_begin(stream); t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        kms, nl = b.timing_end(stream)
+        barrier()
+        dtf = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dtf], device='cuda' if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX); dtf = float(t.item())
+        per = (kms/1e3)/max(nl, 1)
+        tfl = FLIGHT_FLOP_PER_ENV_STEP*n_f/per/1e12
+        out = {'value': n_f*world*steps/dtf, 'unit': 'env steps/sec', 'envs_per_gpu': n_f, 'ms_per_step': dtf/steps*1e3, 'kernel_ms_avg': per*1e3,
+               'state_finite': bool(np.isfinite(b.get('QPOS')).all()),
+               'roofline': {'bound': 'valu', 'achieved': tfl, 'peak': VALU_PEAK_TFLOPS[precision], 'unit': 'TFLOP/s', 'frac': tfl/VALU_PEAK_TFLOPS[precision],
+                            'algorithmic_flop_per_env_step': FLIGHT_FLOP_PER_ENV_STEP,
+                            'hbm': {'achieved': FLIGHT_BYTES_PER_ENV_STEP[precision]*n_f/per/1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                    'algorithmic_bytes_per_env_step': FLIGHT_BYTES_PER_ENV_STEP[precision]}}}
+        del env
+        return out
+
+    def run_dmpo_leg():
+        """BASELINE configs[2]: DMPO training, 4096 environments on this GPU, the reference's rate limiter (15 samples per insert =
+        240 learner steps per control step).  Own process (it owns the torch RNG and the HIP graphs); FP32 physics as in training."""
+        import subprocess
+        cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', '4096', '--iters', '12', '--warmup', '4', '--min-replay', '8192', '--precision', '32']
+        t0 = time.perf_counter()
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        except subprocess.TimeoutExpired:
+            return {'error': 'timeout'}
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            return {'error': r.stderr[-400:]}
+        o = json.loads(line[-1])
+        return {'env_steps_per_sec': o['env_steps_per_sec'], 'learner_steps_per_sec': o['learner_steps_per_sec'], 'envs_per_gpu': o['envs_per_gpu'],
+                'learner_steps_per_env_step': o['learner_steps_per_env_step'], 'batch_size': o['batch_size'], 'samples_per_insert': o['samples_per_insert'],
+                'dtype': o['dtype'], 'reward': o['reward'], 'wall_s_incl_startup': time.perf_counter() - t0,
+                'note': 'one GPU, physics and learner on the same device; 12 timed control steps after 4 warm-up steps'}
 
     stream_pool = []
 
@@ -234,7 +330,8 @@ def main():
         del batches
         return dt, finite, sum(sizes)
 
-    dt, kernel_ms, nlaunch, finite = run_leg(args.precision)
+    extras = {}
+    dt, kernel_ms, nlaunch, finite = run_leg(args.precision, extras)
     split = None if args.no_split_leg else run_split_leg(args.precision)
     # ... and on the 12-environments-per-CU build of the same kernel (engine.HIP_LIB_DENSE) as three sub-batches: slower than the
     # default build in lock-step, faster pipelined (more resident environments)
@@ -244,6 +341,14 @@ def main():
     f32 = None
     if args.precision == 64 and not args.no_f32_leg:
         f32 = run_leg(32)
+    flight = dmpo = None
+    if not args.no_secondary_configs:
+        flight = {f'f{p}': run_flight_leg(p, max(10, args.steps), max(5, args.warmup)) for p in ((64, 32) if args.precision == 64 else (32,))}
+        if rank == 0 and world == 1:
+            dmpo = run_dmpo_leg()
+    parity = None
+    if rank == 0 and args.precision == 64 and not args.no_parity_sample:
+        parity = parity_sample(extras)
     traffic = None
     tr_path = os.path.join(ROOT, 'profiles', f'pmc_traffic_f{args.precision}.json')
     if os.path.exists(tr_path):
@@ -264,7 +369,9 @@ def main():
             'config': {'workload': 'configs[1]: 4096 batched walk_imitation envs per GPU, random-action rollout, '
                                    'physics kernels + obs/reward/termination epilogue, no learner',
                        'envs_per_gpu': n_env, 'global_envs': n_env * world, 'substeps_per_step': model.dim('nsubstep'),
-                       'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite},
+                       'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite,
+                       'solver': 'Newton (the reference XML sets no solver = MuJoCo default), constraint-space restatement; noslip 3',
+                       'solver_iterations_mean': extras.get('solver_iterations_mean')},
             # the binding roofline of this path is the vector ALU (neither HBM nor MFMA bounds it), so the primary
             # achieved/peak/frac are algorithmic FLOP/s against the vector peak of the arithmetic type; the HBM view the
             # contract also asks for (algorithmic bytes / launch time against 8 TB/s, and the PMC traffic) sits in `hbm`
@@ -276,10 +383,16 @@ def main():
                          'algorithmic_flop_per_env_step': ALGO_FLOP_PER_ENV_STEP,
                          'algorithmic_bytes_per_env_step': algo_bytes,
                          'hbm': {'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved_gbs / HBM_PEAK_GBS},
-                         'note': 'vector-ALU / dependent-latency bound (one environment per wavefront); flops are the '
-                                 'instrumented 3.44 MFLOP/env-step of the FP64 CPU oracle (tools/flopcount)',
+                         'note': 'vector-ALU / dependent-latency bound (one environment per wavefront, ONE ROW PER ENVIRONMENT in HBM rather than SoA across '
+                                 'environments: every derived array of a substep round-trips through the row, which is where `traffic` comes from -- DESIGN.md 3); '
+                                 'flops are the instrumented 3.44 MFLOP/env-step of the FP64 CPU oracle with its PGS solver (tools/flopcount)',
                          'valu_achieved_tflops': valu_tflops, 'valu_peak_tflops': VALU_PEAK_TFLOPS[args.precision],
                          'valu_frac': valu_tflops / VALU_PEAK_TFLOPS[args.precision]},
+            'parity_sample': parity,
+            'warn': {'envs_with_flag_since_reset': extras.get('warn'), 'note': 'FB_WARN_EVER population over the batch: contact cap (64), constraint-row cap (192), '
+                     'solver at opt.iterations, MPR at its iteration limit -- MuJoCo reports the first two as nconmax / njmax warnings (fruitfly.xml:6)'},
+            'rccl': ('exercised: init_process_group(nccl) + all_reduce(MAX) + barrier over %d ranks' % world) if (world > 1 and backend == 'nccl') else
+                    ('unexercised (gloo substitute)' if world > 1 else 'unexercised (single rank: no collective on the data path)'),
             'parity': 'FP64 kernel vs in-repo FP64 C oracle (1e-6 over 100 control steps, tests/test_gpu_parity.py); '
                       'parity vs CPU MuJoCo is UNPINNED (no MuJoCo here; tools/dump_mujoco_golden.py + tests/test_mujoco_golden.py)',
         }
@@ -299,6 +412,10 @@ def main():
                                            'ms_per_step': split_dense[0] / args.steps * 1e3, 'state_finite': split_dense[1],
                                            'note': '3 independent sub-batches on 3 HIP streams, FB_F64_DENSE build (12 instead of 8 FP64 environments per CU); '
                                                    'secondary like two_stream_mode: the headline is the lock-step batch on the default build'}
+        if flight is not None:
+            out['flight_mode'] = {'config': 'configs[3]: flight_imitation, 8192 envs per GPU, U(-1,1)^12 actions, WBPG + ellipsoid wing fluid forces', **flight}
+        if dmpo is not None:
+            out['dmpo_mode'] = {'config': 'configs[2]: walk_imitation DMPO training, 4096 envs, on-GPU rollout + learner + replay, SPI 15', **dmpo}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -118,7 +118,7 @@ FBD void find_pos(const MprPt<real>* p, real* pos) {
 
 // Minkowski portal refinement on the margin-inflated shapes; returns penetration depth >= 0
 template <typename real>
-__device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos) {
+__device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos, int* hit_cap) {
   MprPt<real> p[4], v4;
   real d[3], va[3], vb[3];
   copy3(p[0].v1, a.pos); copy3(p[0].v2, b.pos); sub3(p[0].v, a.pos, b.pos);
@@ -140,7 +140,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
   cross3(d, va, vb); normalize3(d);
   if (dot3(d, p[0].v) > 0) { MprPt<real> t = p[1]; p[1] = p[2]; p[2] = t; scl3(d, d, (real)-1); }
   for (int it = 0;; it++) {
-    if (it > 4*MPR_ITER) return false;
+    if (it > 4*MPR_ITER) { *hit_cap = 1; return false; }
     md_support(a, b, d, p[3]);
     if (dot3(p[3].v, d) < 0) return false;
     bool cont = false;
@@ -158,6 +158,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
     portal_dir(p, d);
     if (dot3(d, p[1].v) >= 0) break;
     md_support(a, b, d, v4);
+    if (it > MPR_ITER) *hit_cap = 1;
     if (dot3(v4.v, d) < 0 || reach_tol(p, v4, d) || it > MPR_ITER) return false;
     expand_portal(p, v4);
   }
@@ -165,6 +166,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
     portal_dir(p, d);
     md_support(a, b, d, v4);
     if (reach_tol(p, v4, d) || it > MPR_ITER) {
+      if (it > MPR_ITER && !reach_tol(p, v4, d)) *hit_cap = 1;
       real wit[3];
       real d2 = origin_tri_dist2(p[1].v, p[2].v, p[3].v, wit);
       *depth = sqrt(d2);
@@ -178,7 +180,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
 
 // ---- per-lane narrow phase: up to 4 contacts (dist, pos, normal) for one pair
 template <typename real>
-struct LaneContacts { real dist[4], pos[12], nrm[12]; int n; };
+struct LaneContacts { real dist[4], pos[12], nrm[12]; int n, ccd_cap; };
 
 template <typename real>
 FBD void lc_add(LaneContacts<real>& lc, real dist, const real* pos, const real* n) {
@@ -379,7 +381,7 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p
   else {
     CGeom<real> A = {p1, m1, s1, t1, margin}, B = {p2, m2, s2, t2, margin};
     real depth, dir[3], pos[3];
-    if (mpr_penetration(A, B, &depth, dir, pos)) lc_add(lc, margin - depth, pos, dir);
+    if (mpr_penetration(A, B, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
   }
 }
 
@@ -434,6 +436,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
       ncand += __popcll(bal);
     }
   }
+  int warn = (ncand > maxcand) ? WARN_CONTACT_CAP : 0;
   if (ncand > maxcand) ncand = maxcand;
   SYNC();
   const WS<real> wc = w;
@@ -456,7 +459,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   // ---- narrow phase (not inlined: it gets a copy of the descriptor, the caller's stays in registers)
   int ncon = 0;
   for (int base = 0; base < ncand; base += FB_WAVE) {
-    LaneContacts<real> lc; lc.n = 0;
+    LaneContacts<real> lc; lc.n = 0; lc.ccd_cap = 0;
     int c = base + lane, p = -1;
     if (c < ncand) { p = w.cand()[c]; narrow_phase(M, wc, p, lc); }
     int off = ncon + wave_excl_scan(lc.n, lane);
@@ -472,9 +475,10 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
       w.con_pair()[ci] = p;
     }
     ncon += wave_sum_i(lc.n);
+    if (__ballot(lc.ccd_cap != 0)) warn |= WARN_CCD_MAXITER;
   }
-  if (ncon > FB_MAXCON_) ncon = FB_MAXCON_;
-  if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; }
+  if (ncon > FB_MAXCON_) { ncon = FB_MAXCON_; warn |= WARN_CONTACT_CAP; }
+  if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; if (warn) { w.istate()[IS_WARN] |= warn; w.istate()[IS_WARN_EVER] |= warn; } }
   SYNC();
   PROF(26);
 }

@@ -149,7 +149,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       }
     }
   }
-  if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; }
+  if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
   SYNC();
   for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D()[r] = (real)1 / w.efc_R()[r];
 }
@@ -917,7 +917,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane, !newton); if (!newton) niter = it2; }
   }
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
-  if (lane == 0) w.istate()[IS_NITER] = niter;
+  if (lane == 0) { w.istate()[IS_NITER] = niter; if (niter >= M.iterations) { w.istate()[IS_WARN] |= WARN_SOLVER_MAXITER; w.istate()[IS_WARN_EVER] |= WARN_SOLVER_MAXITER; } }
   SYNC();
   if (nefc <= FB_WAVE) {
     // ---- qfrc_constraint = J^T f, one lane per dof: lane == row keeps (force, last dof of each chain) in registers and

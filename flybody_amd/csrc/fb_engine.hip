@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
 #else
   long long life0_ = wall_clock64();
 #endif
-  if (lane == 0) w.istate()[IS_PRIO] = 0;
+  if (lane == 0) { w.istate()[IS_PRIO] = 0; if (mode == MODE_STEP || mode == MODE_RESET) w.istate()[IS_WARN] = 0; }
   d_run(M, w, env, mode, nsub, nslot, B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; pp_[28] = r0_; /* start tick (replaces the env_post phase counter) */ }
@@ -938,6 +938,8 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_REWARD: *f = {2, 0, 1, b->reward}; break;
     case FB_DISCOUNT: *f = {2, 0, 1, b->discount}; break;
     case FB_STEP_TYPE: *f = {3, 0, 1, b->step_type}; break;
+    case FB_WARN: *f = {1, o.istate + IS_WARN, 1, nullptr}; break;
+    case FB_WARN_EVER: *f = {1, o.istate + IS_WARN_EVER, 1, nullptr}; break;
     case FB_STEP_TICKS: *f = {3, 0, 1, b->cost}; break;
     case FB_LAUNCH_ORDER: *f = {3, 0, 1, b->order}; break;
     default: return fail("unknown field");

@@ -301,7 +301,7 @@ extern "C" int fbl_mpo_loss(const fbl_mpo_args* a, void* stream) {
 
 // ------------------------------------------------------------------ clipped Adam on a flat buffer
 #define NORM_SLOTS 32
-// Step bookkeeping without fences or memsets.  step[0] = completed updates (written by k_adam), step[1] = the update in
+// Step bookkeeping without fences or memsets (int32 counters).  step[0] = completed updates (written by k_adam), step[1] = the update in
 // flight (written by the norm pass: k_gather_flat or k_sqnorm).  The squared group norms are double-buffered on the parity of
 // step[0]: the norm pass of update t accumulates into norms[(t-1) & 1], k_adam(t) reads that half and clears the OTHER one, which
 // is where update t+1 will accumulate.  Within a kernel nobody reads what the same kernel writes.  Each half holds NORM_SLOTS
@@ -318,10 +318,10 @@ __device__ __forceinline__ int seg_of(const AdamSegs& sg, long long i) {
 
 // block-level sum of the per-thread per-segment squares -> one atomic per segment and workgroup
 template <bool ATOMIC>
-__device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __restrict__ norms, float* __restrict__ step) {
+__device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __restrict__ norms, int* __restrict__ step) {
   __shared__ float red[8][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int par = ((int)step[0]) & 1;
+  const int par = step[0] & 1;
 #pragma unroll
   for (int s = 0; s < 8; s++) { float t = wsum(acc[s]); if (lane == 0) red[s][wv] = t; }
   __syncthreads();
@@ -330,13 +330,13 @@ __device__ __forceinline__ void norm_commit(float (&acc)[8], int nseg, float* __
     float* slot = norms + (par*NORM_SLOTS + (blockIdx.x & (NORM_SLOTS - 1)))*8 + threadIdx.x;
     if (ATOMIC) atomicAdd(slot, t); else *slot = t;              // (!ATOMIC: exactly NORM_SLOTS workgroups, one slot each)
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) step[1] = step[0] + 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) step[1] = step[0] + 1;
 }
 
 // The optimizer's own norm pass runs AFTER the gradient all-reduce of a data-parallel step: it is launched with exactly NORM_SLOTS
 // workgroups, each storing (not adding) its slot, so the result -- and with it the clipping factor and every replica's update --
 // is bit-reproducible.  (fbl_gather_flat's fused norm pass, single-rank only, uses atomics: reproducible to rounding.)
-__global__ void __launch_bounds__(256) k_sqnorm(const float* __restrict__ g, long long n, AdamSegs sg, float* __restrict__ norms, float* __restrict__ step) {
+__global__ void __launch_bounds__(256) k_sqnorm(const float* __restrict__ g, long long n, AdamSegs sg, float* __restrict__ norms, int* __restrict__ step) {
   float acc[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) acc[s] = 0.f;
@@ -380,13 +380,14 @@ __device__ __forceinline__ AdamOut adam_one(float p, float g, float m, float v, 
 
 // One float4 of p, g, m, v per thread and iteration: the 28 bytes per parameter stream with all of a thread's loads in flight.
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                              float* __restrict__ step, float* __restrict__ norms, long long n, AdamSegs sg, float b1, float b2, float eps) {
+                                              int* __restrict__ step, float* __restrict__ norms, long long n, AdamSegs sg, float b1, float b2, float eps) {
   __shared__ float sN[NORM_SLOTS*8], nrm[8], sbc[2];
-  const float t = step[1];
-  const int par = ((int)t - 1) & 1;
+  const int ti = step[1];                      // integer update count: a float counter stops counting at 2^24 updates (~1.7 h of training)
+  const float t = (float)ti;                   // (only the bias corrections use it as a real number; they saturate long before 2^24)
+  const int par = (ti - 1) & 1;
   sN[threadIdx.x] = norms[par*NORM_SLOTS*8 + threadIdx.x];                                  // (blockDim.x == NORM_SLOTS * 8)
   if (blockIdx.x == 0) norms[(1 - par)*NORM_SLOTS*8 + threadIdx.x] = 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = t;
+  if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = ti;
   if (threadIdx.x == 64) { sbc[0] = 1.f - powf(b1, t); sbc[1] = sqrtf(1.f - powf(b2, t)); }  // bias corrections: once per workgroup (two powf are ~400 instructions)
   __syncthreads();
   if (threadIdx.x < 8) { float a = 0.f; for (int q = 0; q < NORM_SLOTS; q++) a += sN[q*8 + threadIdx.x]; nrm[threadIdx.x] = a; }
@@ -423,7 +424,7 @@ static int make_segs(AdamSegs& sg, int64_t n, int nseg, const int64_t* seg_end, 
 }
 static int flat_blocks(int64_t n) { int blocks = (int)((n + 1023)/1024); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1; return blocks; }   // a float4 per thread
 
-extern "C" int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, float* norms, int64_t n, int nseg,
+extern "C" int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step, float* norms, int64_t n, int nseg,
                         const int64_t* seg_end, const float* lr, const float* clip_norm, const float* floor_, float beta1, float beta2, float eps,
                         int norms_ready, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !step || !norms || !seg_end || !lr || !clip_norm || !floor_) return lfail("fbl_adam: null argument");
@@ -447,7 +448,7 @@ extern "C" int fbl_adam(float* param, const float* grad, float* exp_avg, float* 
 struct FlatSrc { int n; const float* src[FLAT_MAXT]; long long end[FLAT_MAXT]; };
 
 __global__ void __launch_bounds__(256) k_gather_flat(FlatSrc f, float* __restrict__ flat, long long total, AdamSegs sg, float* __restrict__ norms,
-                                                     float* __restrict__ step) {
+                                                     int* __restrict__ step) {
   __shared__ const float* s_src[FLAT_MAXT];
   __shared__ long long s_end[FLAT_MAXT];
   if (threadIdx.x < FLAT_MAXT) { s_src[threadIdx.x] = f.src[threadIdx.x < f.n ? threadIdx.x : 0]; s_end[threadIdx.x] = threadIdx.x < f.n ? f.end[threadIdx.x] : total; }
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(256) k_gather_flat(FlatSrc f, float* __restric
 }
 
 extern "C" int fbl_gather_flat(const float* const* src, const int64_t* end, int ntensor, float* flat, int nseg, const int64_t* seg_end,
-                               float* norms, float* step, void* stream) {
+                               float* norms, int32_t* step, void* stream) {
   if (!src || !end || !flat || ntensor <= 0 || ntensor > FLAT_MAXT) return lfail("fbl_gather_flat: need 0 < ntensor <= 96");
   if (norms && !step) return lfail("fbl_gather_flat: the norm pass needs the optimizer's step counters");
   FlatSrc f; f.n = ntensor;

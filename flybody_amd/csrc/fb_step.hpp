@@ -685,6 +685,7 @@ template <typename real> FB_STAGE_C bool s_constraint_a(const DevModel<real>& M_
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_); return d_constraint_a(M, w, lane); }
 template <typename real> FB_STAGE_C void s_init(const DevModel<real>& M_, const WS<real>& w_, int env, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  if (lane == 0) w.istate()[IS_WARN_EVER] = 0;
   if (M.task == 1) d_flight_init(M, w, env, lane); else if (M.task == 2) d_ball_init(M, w, lane); else d_walk_init(M, w, env, lane); }
 template <typename real> FB_STAGE_C void s_pre(const DevModel<real>& M_, const WS<real>& w_, const float* action, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);

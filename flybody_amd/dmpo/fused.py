@@ -467,7 +467,7 @@ class FlatAdam:
     def __init__(self, flat_param, flat_grad, seg_sizes, lrs, clips, floors=None, betas=(0.9, 0.999), eps=1e-8):
         self.p, self.g = flat_param, flat_grad
         self.m = torch.zeros_like(flat_param); self.v = torch.zeros_like(flat_param)
-        self.step_t = torch.zeros(2, device=flat_param.device)          # {completed updates, update in flight} (include/flybody_learner.h: fbl_adam)
+        self.step_t = torch.zeros(2, dtype=torch.int32, device=flat_param.device)   # int32 {completed updates, update in flight} (include/flybody_learner.h: fbl_adam)
         ends, acc = [], 0
         for n in seg_sizes:
             acc += n; ends.append(acc)
@@ -527,7 +527,7 @@ class FlatAdam:
             self._norms_ready = False
             return
         self.step_t += 1
-        t = float(self.step_t[0])
+        t = int(self.step_t[0])
         bc1 = 1 - self.b1**t; bc2s = math.sqrt(1 - self.b2**t)
         lo = 0
         for hi, lr, clip, fl in zip(self.ends, self.lrs, self.clips, self.floors):
@@ -550,4 +550,4 @@ class FlatAdam:
         return dict(exp_avg=self.m.clone(), exp_avg_sq=self.v.clone(), step=self.step_t[:1].clone())
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['exp_avg']); self.v.copy_(sd['exp_avg_sq']); self.step_t.copy_(sd['step'].reshape(-1)[:1].expand(2)); self._norms.zero_(); self._norms_ready = False
+        self.m.copy_(sd['exp_avg']); self.v.copy_(sd['exp_avg_sq']); self.step_t.copy_(sd['step'].reshape(-1)[:1].to(torch.float64).round().to(torch.int32).expand(2)); self._norms.zero_(); self._norms_ready = False

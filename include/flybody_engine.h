@@ -61,11 +61,18 @@ enum {
   FB_LAUNCH_ORDER = 31, /* [n_env] int32: environment ids in the order the next full-batch step launches them
                            (longest last step first; scheduling only, results do not depend on it) */
   FB_REWARD_FACTORS = 26, /* [n_env][5] training-mode reward factors (com, qvel, root2site, joint_quat, wings) */
-  FB_PROF = 25,       /* [n_env][48] int32 pairs = 24 int64 per-phase cycle counters (profiling builds) */
+  FB_PROF = 25,       /* [n_env][96] int32 = 48 int64 per-phase cycle counters (profiling builds) */
+  FB_WARN = 32,       /* [n_env] int32: FB_WARN_* bits raised during the last launch (cleared when a control step / reset starts).
+                         Mirrors MuJoCo's nconmax / njmax warnings (fruitfly.xml:6) and adds the iteration limits. */
+  FB_WARN_EVER = 33,  /* [n_env] int32: the same bits accumulated since the environment's last reset */
   FB_NFIELD
 };
 
 enum { FB_MAXCON = 64, FB_MAXEFC = 192, FB_NSENSOR = 33 };
+/* FB_WARN bits: more than FB_MAXCON contacts (the rest were dropped); more than FB_MAXEFC constraint rows (contacts beyond
+ * the cap were dropped); the constraint solver stopped at opt.iterations; a convex-pair penetration query (MPR) hit its
+ * iteration limit */
+enum { FB_WARN_CONTACT_CAP = 1, FB_WARN_EFC_CAP = 2, FB_WARN_SOLVER_MAXITER = 4, FB_WARN_CCD_MAXITER = 8 };
 
 /* model dimensions by name: "nq","nv","nu","na","nbody","nobs","nsubstep", ... ; -1 if unknown */
 int fb_model_dim(const fb_model* m, const char* name);

@@ -65,7 +65,7 @@ size_t fbl_mpo_workspace_floats(int B, int D);
  * norms [512]: partial squared gradient norms (2 parities x 32 slots x 8 segments), double-buffered on the parity of the update count; ZERO before the first call, kept
  * consistent by the kernels (no memset, no atomics on the counters).  norms_ready != 0: the norms of this update were already
  * accumulated by fbl_gather_flat (one launch here); 0: they are computed here first (two launches).  nseg <= 8. */
-int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, float* norms, int64_t n, int nseg,
+int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step, float* norms, int64_t n, int nseg,
              const int64_t* seg_end, const float* lr, const float* clip_norm, const float* floor_, float beta1, float beta2, float eps,
              int norms_ready, void* stream);
 
@@ -74,7 +74,7 @@ int fbl_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
  * boundaries must be tensor boundaries) into the optimizer's `norms` / `step` pair, exactly as fbl_adam's own norm pass would --
  * call it ONCE per update, then fbl_adam with norms_ready = 1.  ntensor <= 96.  One launch. */
 int fbl_gather_flat(const float* const* src, const int64_t* end, int ntensor, float* flat, int nseg, const int64_t* seg_end,
-                    float* norms, float* step, void* stream);
+                    float* norms, int32_t* step, void* stream);
 
 /* y = act(LayerNorm(x + bias [+ rowadd[r mod period]]))  (act: 0 none, 1 tanh) / y = ELU(x + bias), rows of width W <= 1024; x may
  * alias y.  rowadd [period][W] (NULL: none) is a row-broadcast addend: the observation half of the critic's first layer, shared

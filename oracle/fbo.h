@@ -170,6 +170,7 @@ void fbo_env_set_wbpg(fbo_data* d, const double* traj, const double* phase, cons
                       double base_freq, double rel_range, double rate, unsigned seed);
 double fbo_hash_uniform(unsigned seed, unsigned env, unsigned episode);
 void fbo_env_step(fbo_data* d, const double* action);
+void fbo_env_set_id(fbo_data* d, unsigned env_id);          /* global environment id: keys the per-episode random draws (wing-beat phase, snippet) */
 void fbo_env_set_flight_dataset(fbo_data* d, int n_traj, const int* traj_offset, const double* root_qpos, const double* qvel, const int* select,
                                 int n_select, int future_steps, double terminal_com_dist, double time_limit, int randomize_start_step,
                                 unsigned seed, unsigned env_id);

@@ -159,6 +159,10 @@ class OracleData:
         L.fbo_env_set_flight_dataset(self.h, n_traj, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, len(sel),
                                      future_steps, float(terminal_com_dist), float(time_limit), int(bool(randomize_start_step)), seed, env_id)
 
+    def set_env_id(self, env_id: int):
+        lib().fbo_env_set_id.argtypes = [C.c_void_p, C.c_uint]
+        lib().fbo_env_set_id(self.h, int(env_id))
+
     def env_reset(self):
         lib().fbo_env_reset(self.h)
 

@@ -535,7 +535,7 @@ void fbo_env_step_batch(fbo_data** ds, int n, const double* actions, int nthread
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 1)
 #endif
-  for (int e = 0; e < n; e++) fbo_env_step(ds[e], actions + (size_t)e*ds[e]->m->nu);
+  for (int e = 0; e < n; e++) fbo_env_step(ds[e], actions + (size_t)e*(ds[e]->m->nu + (ds[e]->m->user_action_idx >= 0 ? 1 : 0)));     /* action = ctrl + user action */
 }
 
 /* Throughput driver of the CPU baseline: every environment runs `nsteps` control steps with its own action sequence
@@ -548,8 +548,10 @@ void fbo_env_rollout_batch(fbo_data** ds, int n, const double* actions, int nste
 #pragma omp parallel for schedule(dynamic, 1)
 #endif
   for (int e = 0; e < n; e++) {
-    const int nu = ds[e]->m->nu;
+    const int nu = ds[e]->m->nu + (ds[e]->m->user_action_idx >= 0 ? 1 : 0);
     for (int k = 0; k < nsteps; k++) fbo_env_step(ds[e], actions + ((size_t)e*nsteps + k)*nu);
   }
 }
 
+
+void fbo_env_set_id(fbo_data* d, unsigned env_id) { d->env_id = env_id; }

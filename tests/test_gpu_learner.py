@@ -84,7 +84,29 @@ def test_flat_adam_kernel():
         g = torch.randn(n)*(0.2 if k % 2 else 0.01)
         a.g.copy_(g.cuda()); b.g.copy_(g); a.step(); b.step()
     _close(a.p, b.p, rtol=1e-5, atol=2e-6); _close(a.m, b.m, rtol=1e-4, atol=1e-6); _close(a.v, b.v, rtol=1e-4, atol=1e-9)
-    assert float(a.step_t[0]) == 4.0
+    assert int(a.step_t[0]) == 4 and a.step_t.dtype == torch.int32
+
+
+def test_flat_adam_counts_past_2_pow_24():
+    """The update counter is an integer: a float32 counter stops at 16 777 216 updates (t + 1 == t), after which the parity of the
+    double-buffered clipping norms and the bias correction freeze -- ~1.7 h of training at the measured learner rate.  Seeded just
+    below 2^24, six updates must keep counting, keep clipping with the CURRENT gradient norm, and match the CPU arithmetic."""
+    from flybody_amd.dmpo.fused import FlatAdam
+    torch.manual_seed(4)
+    sizes = [4096, 2048]; n = sum(sizes)
+    p0 = torch.randn(n)
+    mk = lambda dev: FlatAdam(p0.clone().to(dev), torch.zeros(n, device=dev), sizes, lrs=[1e-3, 1e-3], clips=[1.0, 0.5])
+    a, b = mk('cuda'), mk('cpu')
+    t0 = (1 << 24) - 3
+    for o in (a, b):
+        o.load_state_dict(dict(exp_avg=torch.zeros(n), exp_avg_sq=torch.zeros(n), step=torch.tensor([t0])))
+    for k in range(6):
+        g = torch.randn(n)*(10.0 if k % 2 else 0.01)              # alternating norms: a stale norm half would clip wrongly
+        a.g.copy_(g.cuda()); b.g.copy_(g); a.step(); b.step()
+        assert int(a.step_t[0]) == t0 + k + 1
+        _close(a.p, b.p, rtol=1e-5, atol=2e-6)
+    assert int(a.step_t[0]) == (1 << 24) + 3
+    sd = a.state_dict(); assert sd['step'].dtype == torch.int32 and int(sd['step'][0]) == (1 << 24) + 3
 
 
 @pytest.mark.parametrize('M,W', [(256, 256), (5120, 512), (37, 200)])

@@ -311,11 +311,11 @@ def test_rollout_tolerance_fp32(gpu_model, oracle_model, reference_traj):
                 assert np.median(eq) < 5e-3 and np.median(ev) < 1e-1 and eq.max() < 5e-2, (eq, ev)
 
 
-def test_flight_rollout_parity_fp64(oracle_model):
-    """flight_imitation on the GPU against the oracle: 20 control steps with the wing-beat generator,
-    ellipsoid wing fluid forces, flight reward."""
+def flight_rollout_vs_oracle(lib_path, n, steps, checkpoints, on_gpu=True):
+    """n flight_imitation environments with their own U(-1, 1)^12 action streams and initial wing-beat phases against n oracle
+    environments: step type, discount and reward at every step, state and observation at the checkpoints {step: tolerance}.
+    Returns the [steps][n] matrix of step types.  (Also run on the kernel-source emulation by tests/test_kernel_emulation.py.)"""
     import os
-    import torch
     from conftest import ROOT
     from flybody_amd import engine
     from flybody_amd.mjcf_compile import qrot
@@ -324,27 +324,60 @@ def test_flight_rollout_parity_fp64(oracle_model):
     from flybody_amd.wbpg import build_tables
     from oracle import fbo
     arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
-    M = engine.Model(arr); B = engine.Batch(M, 8, precision=64)
-    od = fbo.OracleData(fbo.OracleModel(pack_model(arr)))
-    tabs = build_tables(); od.set_wbpg(tabs, seed=5); B.set_wbpg(tabs, seed=5)
+    M = engine.Model(arr, lib_path=lib_path); B = engine.Batch(M, n, precision=64)
+    om = fbo.OracleModel(pack_model(arr))
+    tabs = build_tables(); B.set_wbpg(tabs, seed=5)
     cq, cv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
     root = cq.copy()
     for i in range(len(root)):
         root[i, :3] = cq[i, :3] + qrot(cq[i, 3:], -arr['com_offset'])
-    od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
     B.set_reference(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
-    od.env_reset(); B.reset()
+    ods = []
+    for e in range(n):
+        od = fbo.OracleData(om); od.set_wbpg(tabs, seed=5); od.set_env_id(e)
+        od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6); od.env_reset(); ods.append(od)
+    B.reset()
+    q0 = B.get('QPOS')
+    assert len({tuple(np.round(q, 12)) for q in q0}) > n // 2                   # the environments start at different wing-beat phases
+    for e in range(n):
+        assert _rel(q0[e], ods[e].field('qpos')) < 1e-12, e
     rng = np.random.default_rng(1)
-    for k in range(20):
-        a = rng.uniform(-1, 1, 12).astype(np.float32)
-        act = torch.from_numpy(np.tile(a, (8, 1))).cuda()
-        B.step_ptr(act.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        od.env_step(a.astype(np.float64))
-        assert abs(float(B.get('REWARD')[0, 0]) - od.scalar('reward')) < 1e-5
-    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-8
-    assert _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-8
-    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-2)
+    types = []
+    for k in range(1, steps + 1):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        if on_gpu:
+            import torch
+            act = torch.from_numpy(a).cuda()
+            B.step_ptr(act.data_ptr(), torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        else:
+            B.step_ptr(a.ctypes.data)
+        fbo.step_batch(ods, a.astype(np.float64))
+        stg = B.get('STEP_TYPE').ravel().tolist()
+        assert stg == [int(od.scalar('step_type')) for od in ods], k
+        assert np.array_equal(B.get('DISCOUNT').ravel(), np.array([od.scalar('discount') for od in ods], np.float32)), k
+        assert np.abs(B.get('REWARD').ravel() - np.array([od.scalar('reward') for od in ods])).max() < 1e-5, k
+        types.append(stg)
+        if k in checkpoints:
+            tol = checkpoints[k]
+            Q, V, obs = B.get('QPOS'), B.get('QVEL'), B.get('OBS')
+            for e in range(n):
+                assert _rel(Q[e], ods[e].field('qpos')) < tol and _rel(V[e], ods[e].field('qvel')) < tol, (k, e)
+                assert np.allclose(obs[e], ods[e].field('obs'), rtol=max(1e-5, 10*tol), atol=max(1e-5, 10*tol)), (k, e)
+    assert (B.get('WARN_EVER') == 0).all()
+    return np.array(types)
+
+
+def test_flight_rollout_parity_fp64():
+    """flight_imitation (BASELINE configs[3]) on the GPU against the oracle: 32 environments with their own U(-1, 1)^12 action
+    streams and their own initial wing-beat phases (flight_imitation.py:128-129), through the full episode
+    of 194 control steps, LAST -> FIRST (auto-reset) and into the second episode -- every environment compared: wing-beat
+    generator, ellipsoid wing fluid forces, reward / step type / discount at every step; qpos / qvel at 1e-6 (step 50) and 1e-4
+    (steps 150 and 200: up to 776 physics steps of wing-beat dynamics since the last reset), observations likewise."""
+    t = flight_rollout_vs_oracle(None, 32, 200, {50: 1e-6, 150: 1e-4, 200: 1e-4})
+    assert (t == 2).sum() >= 32                                   # every environment ended an episode (trajectory end or a crash) ...
+    for e in range(t.shape[1]):
+        last = np.where(t[:-1, e] == 2)[0]
+        assert len(last) >= 1 and (t[last + 1, e] == 0).all(), e   # ... and restarted with FIRST on the next step
 
 
 def test_launch_order_on_gpu(gpu_model, reference_traj):
@@ -426,3 +459,83 @@ def test_dense_residency_build_matches_the_oracle(oracle_model, reference_traj):
     for e in range(n):
         assert _rel(Q[e], ods[e].field('qpos')) <= 1e-6 and _rel(V[e], ods[e].field('qvel')) <= 1e-6, e
     assert widest > 23                                             # (some systems did not fit the 23-row matrix: the overlay path ran)
+
+
+# ------------------------------------------------------------------ the headline configuration itself
+def _headline_run(models, sizes, steps, oracle_model, reference_traj, seed, streams):
+    """`len(sizes)` sub-batches (own fb_batch handle, own HIP stream) stepping `steps` control steps of the bench's clipped
+    N(0, 1) actions; 64 sampled environments spread over every sub-batch (first / last ids, ids around the residency boundary
+    of 2048 resident FP64 environments, random ones) are replayed on the CPU oracle.  Returns the worst relative errors and the
+    launch-order positions the sampled environments had."""
+    import torch
+    from oracle import fbo
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    rng = np.random.default_rng(seed)
+    batches, samples, ods, positions = [], [], [], []
+    per = 64 // len(sizes)
+    for p, n in enumerate(sizes):
+        B = engine.Batch(models[p], n, precision=64)
+        B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+        batches.append(B)
+        fixed = [0, 1, n - 2, n - 1] + ([2047, 2048, 2049, 3071, 3072] if n > 3072 else [n // 2 - 1, n // 2])
+        ids = sorted(set(fixed) | set(rng.choice(n, per - len(fixed), replace=False).tolist()))
+        samples.append(np.array(ids)); ods.append(_oracle_envs(oracle_model, len(ids), qp, qv, terminal_com_dist=float('inf')))
+        positions.append([])
+    torch.cuda.synchronize()
+    for k in range(steps):
+        acts = [np.clip(rng.normal(size=(n, 59)), -1, 1).astype(np.float32) for n in sizes]
+        devs = []
+        for p, B in enumerate(batches):
+            with torch.cuda.stream(streams[p]):
+                d = torch.from_numpy(acts[p]).cuda(non_blocking=False); devs.append(d)
+                B.step_ptr(d.data_ptr(), streams[p].cuda_stream)
+        for p in range(len(sizes)):
+            fbo.step_batch(ods[p], acts[p][samples[p]].astype(np.float64))
+        torch.cuda.synchronize()
+        for p, B in enumerate(batches):
+            order = B.get('LAUNCH_ORDER').ravel()
+            if k > 0:
+                pos = np.empty(sizes[p], np.int64); pos[order] = np.arange(sizes[p]); positions[p].append(pos[samples[p]])
+    eq = ev = 0.0
+    for p, B in enumerate(batches):
+        Q, V = B.get('QPOS'), B.get('QVEL')
+        assert np.isfinite(Q).all()
+        assert (B.get('WARN_EVER') == 0).all(), np.unique(B.get('WARN_EVER'))          # no cap was hit, no solver ran out of iterations
+        for i, e in enumerate(samples[p]):
+            eq = max(eq, _rel(Q[e], ods[p][i].field('qpos'))); ev = max(ev, _rel(V[e], ods[p][i].field('qvel')))
+        obs = B.get('OBS')
+        for i, e in enumerate(samples[p]):
+            assert np.allclose(obs[e], ods[p][i].field('obs'), rtol=1e-5, atol=2e-6), (p, e)
+    return eq, ev, [np.array(x) for x in positions]
+
+
+@pytest.mark.parametrize('dense', [False, True])
+def test_headline_batch_parity_fp64(gpu_model, oracle_model, reference_traj, dense):
+    """BENCH configuration, checked against the oracle: FP64, 4096 environments in lock-step = two residency rounds of the 2048
+    resident FP64 environments (default build; the 12-per-CU build holds 3072), 30 control steps of the bench's clipped N(0, 1)
+    actions with the longest-first launch order active.  64 sampled environments -- including ids on both sides of the
+    residency boundary and environments that were launched in the SECOND round -- against the CPU oracle at 1e-6."""
+    import torch
+    from flybody_amd import engine
+    M = engine.Model.from_asset('walk_imitation', dense=True) if dense else gpu_model
+    eq, ev, pos = _headline_run([M], [4096], 30, oracle_model, reference_traj, seed=11, streams=[torch.cuda.current_stream()])
+    assert eq < 1e-6 and ev < 1e-6, (eq, ev)
+    resident = 3072 if dense else 2048
+    second_round = (pos[0] >= resident)
+    assert second_round.any(axis=0).sum() >= 16, second_round.any(axis=0).sum()        # sampled environments did run in the second round
+    assert (~second_round).any(axis=0).sum() >= 16
+
+
+@pytest.mark.parametrize('dense,parts', [(False, 2), (True, 3)])
+def test_pipelined_sub_batches_parity_fp64(gpu_model, oracle_model, reference_traj, dense, parts):
+    """bench.py's secondary legs (two_stream_mode: 2 x 2048 on two HIP streams, default build; pipelined_dense_mode: 3 sub-batches
+    on three streams, 12-per-CU build) against the ORACLE, not against each other: sub-batches that overlap on the GPU share CUs,
+    LDS and the L2 with launches of other handles -- 1e-6 on sampled environments of every sub-batch after 30 control steps."""
+    import torch
+    from flybody_amd import engine
+    M = engine.Model.from_asset('walk_imitation', dense=True) if dense else gpu_model
+    sizes = [4096 // parts + (1 if p < 4096 % parts else 0) for p in range(parts)]
+    streams = [torch.cuda.Stream() for _ in range(parts)]
+    eq, ev, _ = _headline_run([M]*parts, sizes, 30, oracle_model, reference_traj, seed=12, streams=streams)
+    assert eq < 1e-6 and ev < 1e-6, (eq, ev)

@@ -256,3 +256,11 @@ def test_numeric_guards_emulation(emu_model, oracle_model, reference_traj):
     B.step_ptr(a0.ctypes.data); ods[2].env_step(a0[2].astype(np.float64))
     assert B.get('STEP_TYPE').ravel().tolist() == [1, 1, 0] and np.isfinite(B.get('QPOS')).all()
     assert _rel(B.get('QPOS')[2], ods[2].field('qpos')) < 1e-12
+
+
+def test_flight_episode_matches_oracle(emu_lib):
+    """A full flight_imitation episode on the kernel source (tests/test_gpu_parity.py::test_flight_rollout_parity_fp64 is the GPU run):
+    4 environments with their own actions and wing-beat phases, 194 steps to LAST, FIRST, into the second episode."""
+    from test_gpu_parity import flight_rollout_vs_oracle
+    t = flight_rollout_vs_oracle(emu_lib, 4, 200, {50: 1e-6, 150: 1e-4, 200: 1e-4}, on_gpu=False)
+    assert ((t == 2).sum(axis=0) >= 1).all()

