@@ -534,7 +534,8 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // Measured on MI355X (tools/microbench/lat.hip, one wave): a dependent FP64 FMA costs ~6 cycles, but a wave-uniform branch
   // on a VALU result costs ~60-90 (v_cmp -> VCC -> s_cbranch) and a v_readlane feeding the VALU ~35.  The row-type dispatch
   // therefore runs on a scalar bit mask (SALU only), the ray update and the cone post-processing are selects, and the Newton
-  // iteration on the friction multiplier has ONE exit test per pass.  Same arithmetic, same order, same results.
+  // iteration on the friction multiplier has ONE exit test per pass.  Same arithmetic and order; FP64 results are identical, FP32 may
+  // differ in the last Newton pass of a non-converged multiplier (u is recomputed after the 19th update here).
   unsigned long long m_first;        // bit i: row i is the first row of an elliptic contact
   {
     bool fst = lane < nefc && w.efc_type()[lane] == CN_ELLIPTIC && w.con_efc()[w.efc_id()[lane]] == lane;
@@ -631,7 +632,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
         kk = onb ? kk : (real)1;
         u1 *= kk; u2 *= kk;
       }
-      if (sizeof(real) == 4) rla.v0 = (lane == i) ? la : rla.v0;
+      if (sizeof(real) == 4) rla.v0 = (lane == i && !(dead || sing)) ? la : rla.v0;      // (a dead / singular contact keeps its last multiplier, like the branchy path)
       real v1 = ec*u1 - es*u2, v2 = es*u1 + ec*u2;
       const bool nofr = dead || sing;
       f0 = dead ? (real)0 : f0;

@@ -6,8 +6,9 @@ flybody/agents/ray_distributed_dmpo.py:67-105) and Acme's NStepTransitionAdder(n
 crosses PCIe and -- unlike a host-driven adder -- nothing synchronises with the host: the number of transitions a control
 step produces depends on which environments started / ended an episode, so the write cursor, the fill level and the
 insert count are DEVICE scalars and every append has a static shape (rows that carry no transition are steered into a
-per-environment trash row behind the ring).  `add` and `sample` are therefore HIP-graph capturable and can be queued
-behind the physics kernel without stalling the launch thread.
+per-environment trash row behind the ring).  Neither call stalls the launch thread, so both queue behind the physics kernel.
+`sample` is HIP-graph capturable (the trainer captures it with the learner step).  `add` is NOT: the slot of the n-step ring
+(control step mod n) comes from the host counter `_t`, which a capture would bake in -- `add` asserts that no capture is active.
 """
 from __future__ import annotations
 
@@ -86,6 +87,8 @@ class NStepReplay:
         transition starts at the episode's first observation; at LAST the shorter tails are flushed.
         """
         n = self.n
+        if self.device.type == 'cuda':
+            assert not torch.cuda.is_current_stream_capturing(), 'NStepReplay.add is not graph-capturable (host-side ring cursor)'
         first = first.view(-1); last = last.view(-1)
         valid = ~first
         self._t += 1

@@ -57,8 +57,9 @@ def get_model(cfg: TaskConfig, allow_compile: bool = True) -> Dict[str, np.ndarr
     if key == cfg.name:
         return load_npz(os.path.join(ASSETS, cfg.name + '.npz'))
     path = os.path.join(VARIANTS, key + '.npz')
-    if os.path.exists(path):
-        return load_npz(path)
+    for cand in (path, os.path.join(os.path.expanduser(os.environ.get('FLYBODY_CACHE', '~/.cache/flybody_amd')), 'variants', key + '.npz')):
+        if os.path.exists(cand):
+            return load_npz(cand)
     xml = find_xml() if allow_compile else None
     if xml is None:
         raise FileNotFoundError(
@@ -66,9 +67,17 @@ def get_model(cfg: TaskConfig, allow_compile: bool = True) -> Dict[str, np.ndarr
             f"reference's flybody/fruitfly/assets/fruitfly.xml (or run `python tools/compile_models.py --variants` where the reference "
             f'checkout exists) -- the file goes to {path}')
     m = compile_model(xml, cfg)
-    os.makedirs(VARIANTS, exist_ok=True)
-    save_model(m, path)
-    return load_npz(path)
+    # several ranks of one launch may compile the same variant at the same time: every rank writes its own temporary file and
+    # renames it into place (atomic), so a reader never sees a partial .npz; a read-only package directory falls back to a user cache
+    for d in (VARIANTS, os.path.join(os.path.expanduser(os.environ.get('FLYBODY_CACHE', '~/.cache/flybody_amd')), 'variants')):
+        try:
+            os.makedirs(d, exist_ok=True)
+            final = os.path.join(d, key + '.npz'); tmp = os.path.join(d, f'.{key}.{os.getpid()}.tmp.npz')
+            save_model(m, tmp); os.replace(tmp, final)
+            return load_npz(final)
+        except OSError:
+            continue
+    return {k: np.asarray(v) for k, v in m.items()}
 
 
 def task_config(task: str, force_actuators: bool = False, use_wings: Optional[bool] = None, use_legs: Optional[bool] = None,

@@ -76,7 +76,7 @@ class Trainer:
         self.use_graphs = os.environ.get('FB_LEARNER_GRAPHS', '1') == '1'
         self.views = self.env.reset_all()
         self.obs = self.views['obs'].clone()
-        self.env_steps = 0; self.learner_steps = 0
+        self.env_steps = 0; self.learner_steps = 0; self._gate_checked = False
         # checkpoints / policy snapshots / metrics (rank 0 writes; every rank restores so that replicas stay identical)
         self.counter = Counter(); self.checkpointer = self.snapshotter = None; self.logger = MetricsLogger(None)
         self._ep_return = torch.zeros(n_env, device=self.device); self._ep_len = torch.zeros(n_env, device=self.device)
@@ -126,6 +126,17 @@ class Trainer:
         allowed = self.limiter.learner_steps_allowed(B) if learn else 0
         if self.lsteps_per is not None:
             allowed = self.lsteps_per if (learn and self.limiter.inserts >= self.limiter.min_size) else 0
+        if allowed > 0 and not self._gate_checked:
+            # The limiter counts control steps x environments on the host; the ring holds what the n-step adder actually emitted
+            # (FIRST rows insert nothing, episode ends flush up to n - 1 extra items).  When the gate opens for the first time the
+            # device fill level is read back ONCE (one sync in the whole run); an under-filled ring postpones learning.
+            fill = self.replay._size.clone()
+            if self.world > 1:
+                dist.all_reduce(fill, op=dist.ReduceOp.MIN)        # every rank takes the same decision (one collective in the whole run)
+            if int(fill) < min(self.limiter.min_size, self.cfg.batch_size):
+                allowed = 0
+            else:
+                self._gate_checked = True
         if allowed > 0:
             if self.use_graphs and self.learner._graph_fb is None:
                 self.learner.enable_graphs(self.replay.sample(B), sampler=lambda: self.replay.sample(B))

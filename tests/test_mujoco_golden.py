@@ -101,3 +101,33 @@ def test_engine_rollout_matches_mujoco(walk_arrays):
         a = torch.from_numpy(np.tile(act.astype(np.float32), (2, 1))).cuda()
         B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
         assert _rel(B.get('QPOS')[0], g['qpos'][k][:nq]) < TOL and _rel(B.get('QVEL')[0], g['qvel'][k][:nv]) < TOL, k
+
+
+def test_check_mode_reports_first_divergence(tmp_path, oracle_model, reference_traj):
+    """`tools/dump_mujoco_golden.py --check` (the report whoever records the goldens off-box gets back): exercised here on files
+    fabricated from the oracle itself -- clean files give no finding, a perturbed trajectory is located at its control step."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import dump_mujoco_golden as D
+    from oracle import fbo
+    qp, qv = reference_traj
+    od = fbo.OracleData(oracle_model); od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
+    rng = np.random.default_rng(0); rec = {k: [] for k in ('action', 'qpos', 'qvel', 'act', 'ctrl', 'qacc', 'ncon', 'nefc')}
+    out = {}
+    for k in range(10):
+        a = rng.uniform(-0.5, 0.5, 59).astype(np.float32).astype(np.float64)
+        od.env_step(a)
+        for key in ('qpos', 'qvel', 'act', 'ctrl', 'qacc'):
+            rec[key].append(od.field(key).copy())
+        rec['action'].append(a); rec['ncon'].append(od.scalar('ncon')); rec['nefc'].append(od.scalar('nefc'))
+        if k < 5:
+            oc = od.contacts(); c = np.zeros((len(oc), 16)); c[:, 0] = oc[:, 0]; c[:, 1:4] = oc[:, 1:4]; c[:, 4:7] = oc[:, 4:7]; c[:, 13:15] = oc[:, 7:9]
+            out[f'contact_{k}'] = c
+    out.update({k: np.array(v) for k, v in rec.items()})
+    np.savez(tmp_path / 'mujoco_walk_rollout.npz', mujoco_version=np.array('self-test'), **out)
+    lines = []
+    assert D.check(str(tmp_path), out=lines.append) == [] and any('free-running rollout' in l for l in lines)
+    out['qpos'][6:] += 1e-3
+    np.savez(tmp_path / 'mujoco_walk_rollout.npz', mujoco_version=np.array('self-test'), **out)
+    f = D.check(str(tmp_path), out=lambda s: None)
+    assert len(f) == 1 and f[0][0] == 'rollout' and 'first control step outside 0.0001: 7' in f[0][1]

@@ -5,6 +5,7 @@ parity statement of this repository says "MuJoCo parity unpinned").
 
     pip install mujoco dm_control  &&  pip install -e <reference checkout>
     python tools/dump_mujoco_golden.py [--out tests/golden] [--steps 100] [--flight]
+    python tools/dump_mujoco_golden.py --check [--out tests/golden]      # back in this repository: first-divergence report
 
 It drives exactly the workload the reference's env test drives (tests/test_walking_env.py:60-72: `walk_imitation(
 terminal_com_dist=inf)`, the default inference trajectory, 100 x `env.step(U(-0.5, 0.5)^59)`), with `np.random.seed(0)`,
@@ -112,11 +113,125 @@ def model_constants(physics):
     return out
 
 
+def _rel(a, b):
+    a = np.asarray(a, float).ravel(); b = np.asarray(b, float).ravel()
+    n = min(len(a), len(b))
+    return float(np.abs(a[:n] - b[:n]).max() / max(np.abs(b[:n]).max(), 1e-300)) if n else 0.0
+
+
+def check(gold_dir, tol=1e-4, out=print):
+    """--check: given the two golden files, say WHERE this repository's restatement of mj_step first leaves MuJoCo, stage by
+    stage -- compiled constants -> (teacher-forced from MuJoCo's recorded states) kinematics-dependent contact list -> constraint
+    forces -> accelerations -> the free-running rollout, control step by control step and substep by substep.  Needs only numpy
+    and the in-repo CPU oracle (no MuJoCo).  Returns the list of findings (empty = everything inside `tol`)."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    sys.path.insert(0, root)
+    from flybody_amd.model_blob import load_npz, pack_model
+    from flybody_amd.reference import default_walking_reference
+    from oracle import fbo
+    arrays = load_npz(os.path.join(root, 'flybody_amd', 'assets', 'walk_imitation.npz'))
+    findings = []
+    def flag(stage, msg):
+        findings.append((stage, msg)); out(f'  !! [{stage}] {msg}')
+    cpath, rpath = os.path.join(gold_dir, 'mujoco_model_constants.npz'), os.path.join(gold_dir, 'mujoco_walk_rollout.npz')
+    nq, nv = len(arrays['qpos0']), len(arrays['dof_bodyid'])
+    # ---- 1. compiled constants
+    if os.path.exists(cpath):
+        g = np.load(cpath)
+        out(f'[1] constants vs MuJoCo {g["mujoco_version"]}')
+        names = [str(x) for x in g['names_body']]; ours = [str(x) for x in arrays['names_body']]
+        idx = [names.index('walker/' + n) if ('walker/' + n) in names else (names.index(n) if n in names else -1) for n in ours[1:]]
+        if min(idx) < 0:
+            flag('constants', 'body names do not map: ' + ', '.join(n for n, i in zip(ours[1:], idx) if i < 0))
+        else:
+            for key, ours_v, theirs, t in (('body_mass', arrays['body_mass'][1:], g['body_mass'][idx], 1e-5),
+                                           ('body_inertia', arrays['body_inertia'][1:], g['body_inertia'][idx], 1e-4),
+                                           ('body_ipos', arrays['body_ipos'][1:], g['body_ipos'][idx], 1e-6),
+                                           ('dof_M0', arrays['dof_M0'], g['dof_M0'][:nv], 1e-5),
+                                           ('dof_invweight0', arrays['dof_invweight0'], g['dof_invweight0'][:nv], 1e-4),
+                                           ('body_invweight0', arrays['body_invweight0'][1:], g['body_invweight0'][idx], 1e-4)):
+                d = np.abs(np.asarray(ours_v, float) - np.asarray(theirs, float)); sc = np.abs(np.asarray(theirs, float)).max()
+                w = int(np.argmax(d.reshape(len(d), -1).max(axis=1)))
+                line = f'    {key:18s} max |diff| / max |value| = {d.max()/max(sc, 1e-300):.2e}'
+                if d.max() > t*sc:
+                    flag('constants', f'{key}: worst entry {w} ({ours[1 + w] if key.startswith("body") else "dof " + str(w)}): ours {np.asarray(ours_v)[w]} MuJoCo {np.asarray(theirs)[w]}')
+                else:
+                    out(line)
+            for key in ('opt_timestep', 'opt_impratio', 'opt_tolerance', 'opt_noslip_iterations', 'opt_iterations', 'opt_solver', 'opt_cone', 'opt_integrator'):
+                if key in g.files:
+                    out(f'    {key:22s} MuJoCo {g[key]}' + (f'   ours {arrays[key]}' if key in arrays else ''))
+    else:
+        out('[1] constants: ' + cpath + ' absent')
+    if not os.path.exists(rpath):
+        out('[2-4] rollout: ' + rpath + ' absent'); return findings
+    g = np.load(rpath)
+    om = fbo.OracleModel(pack_model(arrays)); qp, qv = default_walking_reference()
+    def fresh():
+        od = fbo.OracleData(om); od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset(); return od
+    # ---- 2. teacher-forced stages at MuJoCo's recorded states (first 5 control steps)
+    out('[2] teacher-forced stages (oracle evaluated AT MuJoCo\'s recorded state)')
+    for k in range(5):
+        if f'contact_{k}' not in g.files:
+            break
+        od = fresh()
+        od.field('qpos')[:] = g['qpos'][k][:nq]; od.field('qvel')[:] = g['qvel'][k][:nv]
+        if len(g['act'][k]): od.field('act')[:len(g['act'][k])] = g['act'][k]
+        od.field('ctrl')[:] = g['ctrl'][k][:len(od.field('ctrl'))]
+        od.call('forward')
+        mc = g[f'contact_{k}']; oc = od.contacts()
+        mine = {(int(c[7]), int(c[8])) for c in oc}; theirs_raw = [(int(c[13]), int(c[14])) for c in mc]
+        out(f'    step {k + 1}: contacts ours {len(oc)} / MuJoCo {len(mc)} (MuJoCo geom ids include the ghost and the floor offsets: compare counts, depths, normals)')
+        if len(oc) != len(mc):
+            flag('collision', f'step {k + 1}: contact count differs (ours {len(oc)}, MuJoCo {len(mc)}): check the pair filter / margins / MPR vs native CCD')
+        else:
+            dd = np.abs(np.sort(oc[:, 0]) - np.sort(mc[:, 0])).max()
+            if dd > 1e-6:
+                flag('collision', f'step {k + 1}: sorted contact distances differ by {dd:.2e} (narrow phase / geom poses)')
+        nef = int(od.scalar('nefc'))
+        if nef != int(g['nefc'][k]):
+            flag('constraint rows', f'step {k + 1}: nefc ours {nef} MuJoCo {int(g["nefc"][k])} (limits / margins / condim)')
+        # (efc_force / qacc of a recorded step belong to the LAST mj_step2, i.e. to the state one substep earlier: they are compared
+        #  through the free-running rollout below, not at the recorded state)
+    # ---- 3. substeps of the first control step
+    if 'substep_qpos' in g.files:
+        out('[3] first control step, substep by substep (free-running oracle)')
+        od = fresh(); a0 = g['action'][0].astype(np.float64)
+        od.field('ctrl')[:] = 0
+        import ctypes
+        # env_step runs all substeps; single substeps through step2 / step1 after the task pre-hook wrote ctrl
+        od2 = fresh(); od2.env_step(a0)                     # reference end state of the control step
+        od.field('ctrl')[:] = od2.field('ctrl')
+        for s_ in range(len(g['substep_qpos'])):
+            od.call('step')
+            eq, ev = _rel(od.field('qpos'), g['substep_qpos'][s_][:nq]), _rel(od.field('qvel'), g['substep_qvel'][s_][:nv])
+            out(f'    substep {s_ + 1}: qpos {eq:.2e} qvel {ev:.2e}')
+            if max(eq, ev) > tol:
+                flag('substep', f'first control step leaves the tolerance at substep {s_ + 1} (qpos {eq:.2e}, qvel {ev:.2e})'); break
+    # ---- 4. free-running rollout
+    out('[4] free-running rollout (north_star tolerance %g)' % tol)
+    od = fresh(); first = None
+    for k, act in enumerate(g['action']):
+        od.env_step(act.astype(np.float64))
+        eq, ev = _rel(od.field('qpos'), g['qpos'][k][:nq]), _rel(od.field('qvel'), g['qvel'][k][:nv])
+        extra = f' ncon {int(od.scalar("ncon"))}/{int(g["ncon"][k])} nefc {int(od.scalar("nefc"))}/{int(g["nefc"][k])}'
+        if k < 5 or k % 10 == 9:
+            out(f'    step {k + 1:3d}: qpos {eq:.2e} qvel {ev:.2e}{extra}')
+        if first is None and max(eq, ev) > tol:
+            first = k + 1; w = int(np.argmax(np.abs(od.field('qpos') - g['qpos'][k][:nq])))
+            flag('rollout', f'first control step outside {tol:g}: {first} (qpos {eq:.2e}, qvel {ev:.2e}; worst qpos index {w};{extra})')
+    if not findings:
+        out('all stages inside the tolerances')
+    return findings
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden'))
     ap.add_argument('--steps', type=int, default=100); ap.add_argument('--flight', action='store_true')
+    ap.add_argument('--check', action='store_true', help='no MuJoCo needed: compare the golden files in --out with the in-repo oracle, stage by stage')
     a = ap.parse_args()
+    if a.check:
+        sys.exit(1 if check(a.out) else 0)
     try:
         import mujoco, dm_control
         from flybody.fly_envs import walk_imitation, flight_imitation
