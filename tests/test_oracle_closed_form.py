@@ -23,12 +23,15 @@ def _dense_M(od, nv):
     return M
 
 
-def _forward(oracle_model, walk_arrays, seed, z, noslip=None):
+def _forward(oracle_model, walk_arrays, seed, z, noslip=None, solver=None):
     from flybody_amd.model_blob import pack_model
     from oracle import fbo
     om = oracle_model
-    if noslip is not None:
-        a = dict(walk_arrays); a['opt_noslip_iterations'] = np.array(noslip); om = fbo.OracleModel(pack_model(a))
+    if noslip is not None or solver is not None:
+        a = dict(walk_arrays)
+        if noslip is not None: a['opt_noslip_iterations'] = np.array(noslip)
+        if solver is not None: a['opt_solver'] = np.array(solver, np.int32)          # mjtSolver numbering: 0 PGS, 2 Newton (absent = Newton)
+        om = fbo.OracleModel(pack_model(a))
     od = fbo.OracleData(om)
     q, v = random_state(walk_arrays, np.random.default_rng(seed), z=z)
     od.field('qpos')[:] = q; od.field('qvel')[:] = v*0.3
@@ -165,8 +168,19 @@ def _compare_with_reference(od, walk_arrays, tol_err):
 @pytest.mark.parametrize('seed,z', [(0, 0.125), (1, 0.13), (4, 0.128)])
 def test_pgs_forces_against_an_independent_cone_solver(oracle_model, walk_arrays, seed, z):
     """Random poses pressed into the floor (40-70 rows): measured force error vs the independent solver ~1e-7."""
-    od = _forward(oracle_model, walk_arrays, seed, z, noslip=0)                      # PGS alone: noslip post-processes its result
+    od = _forward(oracle_model, walk_arrays, seed, z, noslip=0, solver=0)            # PGS alone: noslip post-processes its result
     _compare_with_reference(od, walk_arrays, 1e-4)
+
+
+@pytest.mark.parametrize('seed,z', [(0, 0.134), (1, 0.136), (4, 0.135), (6, 0.14), (7, 0.138)])
+def test_newton_forces_against_an_independent_cone_solver(oracle_model, walk_arrays, seed, z):
+    """The model's own solver (fruitfly.xml:4 sets none = MuJoCo's default, Newton), restated in constraint space
+    (oracle/fbo_constraint.c: solve_newton; kernel: csrc/fb_newton.hpp), on systems of up to 64 rows: KKT conditions, dual cost and
+    forces against scipy's SLSQP solution of the same cone problem -- an order of magnitude tighter than the PGS tolerance."""
+    od = _forward(oracle_model, walk_arrays, seed, z, noslip=0, solver=2)
+    n = int(od.scalar('nefc')); assert 6 <= n <= 64, n
+    assert int(od.scalar('solver_niter')) <= 20
+    _compare_with_reference(od, walk_arrays, 1e-5)
 
 
 def test_pgs_forces_in_a_rollout_state(walk_arrays, reference_traj):
@@ -174,7 +188,7 @@ def test_pgs_forces_in_a_rollout_state(walk_arrays, reference_traj):
     still lands on the solution of the convex problem -- the solution MuJoCo's Newton solver converges to."""
     from flybody_amd.model_blob import pack_model
     from oracle import fbo
-    a = dict(walk_arrays); a['opt_noslip_iterations'] = np.array(0)
+    a = dict(walk_arrays); a['opt_noslip_iterations'] = np.array(0); a['opt_solver'] = np.array(0, np.int32)
     od = fbo.OracleData(fbo.OracleModel(pack_model(a))); qp, qv = reference_traj
     od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
     rng = np.random.default_rng(0); worst = 0.0; checked = 0
@@ -416,3 +430,25 @@ def test_passive_joint_forces_closed_form(oracle_model, walk_arrays):
     assert np.allclose(od.field('qfrc_damper'), -np.asarray(A['dof_damping'])*v, rtol=1e-12, atol=1e-15)
     fluid = od.field('qfrc_passive') - spring + np.asarray(A['dof_damping'])*v
     assert np.allclose(fluid, od.field('qfrc_fluid'), rtol=1e-9, atol=1e-12)
+
+
+def test_newton_forces_in_rollout_states(walk_arrays, reference_traj):
+    """The workload's own states under the model's solver: every sampled state of a random-action rollout is a KKT point of the
+    cone problem to 1e-6 (block PGS stalls at up to 3e-2 on the same states, and gets stuck at the cone apex in ~1 % of them:
+    tools/solver_proto), in at most 12 Newton iterations."""
+    from flybody_amd.model_blob import pack_model
+    from oracle import fbo
+    a = dict(walk_arrays); a['opt_noslip_iterations'] = np.array(0)
+    od = fbo.OracleData(fbo.OracleModel(pack_model(a))); qp, qv = reference_traj
+    od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
+    rng = np.random.default_rng(1); worst = 0.0; checked = 0; iters = []
+    for k in range(60):
+        od.env_step(np.clip(rng.normal(size=59), -1, 1)); iters.append(int(od.scalar('solver_niter')))
+        if k % 6 == 5:
+            od.call('forward')
+            if int(od.scalar('nefc')) >= 6:
+                A, b, blocks, scalar = _cone_problem(od, walk_arrays)
+                f = od.field('efc_force')[:len(b)].copy()
+                worst = max(worst, _kkt_violation(A, b, f, blocks, scalar)); checked += 1
+    assert checked >= 6 and worst < 1e-6, worst
+    assert max(iters) <= 12 and np.mean(iters) < 7, (max(iters), np.mean(iters))
