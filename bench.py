@@ -22,11 +22,11 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_ENV_STEP = {32: 5420.0, 64: 2*276*8.0 + (59 + 741 + 3)*4.0}
 # instrumented count of the FP64 CPU oracle (tools/flopcount/count_flops.py, profiles/r1/oracle_flop_count.jsonl): adds,
 # multiplies, divisions and square roots of one walk_imitation control step, mean over 200 steps in contact under the
-# bench's action distribution; replaces SURVEY.md 8(d)'s provisional 9 MFLOP
-ALGO_FLOP_PER_ENV_STEP = 3.44e6
+# bench's action distribution; replaces SURVEY.md 8(d)'s provisional 9 MFLOP.  Counted on the algorithm the oracle runs NOW
+ALGO_FLOP_PER_ENV_STEP = 3.14e6                # round 3 (Newton solver): 3 138 048; rounds 1-2 (PGS): 3 443 346 (profiles/r3/oracle_flop_count.jsonl)
 # flight_imitation (configs[3]): SURVEY.md 8(d) -- 1 156 B and ~0.53 MFLOP per env control step (4 substeps of 5e-5 s, nv 42, no floor)
 FLIGHT_BYTES_PER_ENV_STEP = {32: 1156.0, 64: 2*(43 + 42)*8.0 + (12 + 104 + 3)*4.0}
-FLIGHT_FLOP_PER_ENV_STEP = 0.53e6
+FLIGHT_FLOP_PER_ENV_STEP = 0.534e6
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = {32: 157.3, 64: 78.6}
 
@@ -385,7 +385,7 @@ def main():
                          'hbm': {'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved_gbs / HBM_PEAK_GBS},
                          'note': 'vector-ALU / dependent-latency bound (one environment per wavefront, ONE ROW PER ENVIRONMENT in HBM rather than SoA across '
                                  'environments: every derived array of a substep round-trips through the row, which is where `traffic` comes from -- DESIGN.md 3); '
-                                 'flops are the instrumented 3.44 MFLOP/env-step of the FP64 CPU oracle with its PGS solver (tools/flopcount)',
+                                 'flops are the instrumented 3.14 MFLOP/env-step of the FP64 CPU oracle with the Newton solver (tools/flopcount; 3.44 with PGS)',
                          'valu_achieved_tflops': valu_tflops, 'valu_peak_tflops': VALU_PEAK_TFLOPS[args.precision],
                          'valu_frac': valu_tflops / VALU_PEAK_TFLOPS[args.precision]},
             'parity_sample': parity,

@@ -51,6 +51,7 @@ FBD void kbi(const DevModel<real>& M, const real* solref, const real* solimp, re
 template <typename real>
 __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
   // ---- joint limits (row order: joint order)
+  PROF_BEGIN();
   int nlimit = 0;
   for (int base = 0; base < M.njnt; base += FB_WAVE) {
     int j = base + lane;
@@ -77,6 +78,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     }
     nlimit += wave_sum_i(has);
   }
+  PROF(42);
   // ---- contacts: lane == contact
   int ncon = w.istate()[IS_NCON];
   int dim = 0, p = 0; real dist = 0, incl = 0;
@@ -96,12 +98,10 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     if (lane >= first) dim = 0;
   }
   if (lane < ncon) { w.con_efc()[lane] = dim ? adr : -1; w.con_dim()[lane] = dim; }
+  int b1 = 0, b2 = 0;
   if (dim) {
     int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-    int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-    const real* pos = w.con_pos() + 3*lane;
-    const real* frame = w.con_frame() + 9*lane;
-    real off[3]; sub3(off, pos, w.com());
+    b1 = M.geom_bodyid[g1]; b2 = M.geom_bodyid[g2];
     real K, B, imp;
     kbi(M, M.pair_solref + 2*p, M.pair_solimp + 5*p, dist, incl, false, K, B, imp);
     real tran = M.body_invweight0[2*b1] + M.body_invweight0[2*b2];
@@ -120,35 +120,43 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       w.efc_R()[r] = (k == 0) ? R0 : (k == 1 ? R1 : R2);
       w.efc_mu()[r] = mu;
     }
-    for (int side = 0; side < 2; side++) {
-      int body = side ? b2 : b1;
-      real sgn = side ? (real)1 : (real)-1;
-      int len = M.body_chlen[body];
-      int ch[FB_MAXCH];
-      load_chain(M, body, ch);
-      // motion axes of the chain in chunks of 5 slots: 30 independent gathers per chunk instead of 20 dependent round trips
+  }
+  PROF(43);
+  // ---- contact Jacobians, one lane per (contact, side, chain slot): 40 entries per contact, 64 per pass.  Every entry needs
+  // ONE dependent pair of gathers (chain slot -> dof, dof -> motion axis) and writes its <= 3 rows; with lane == contact the same
+  // work was 8 rounds of 30 gathers + 15 stores per lane, each round queued behind the stores of the previous one.
+  {
+    const int cb1 = b1, cb2 = b2;
+    const int nitem = ncon*(2*FB_MAXCH);
+    for (int t0 = 0; t0 < nitem; t0 += FB_WAVE) {
+      const int t = t0 + lane;
+      const int c = min(t/(2*FB_MAXCH), FB_WAVE - 1), rem = t - c*(2*FB_MAXCH), side = rem >= FB_MAXCH ? 1 : 0, sl = rem - side*FB_MAXCH;
+      const int cdim = __shfl(dim, c, 64), cadr = __shfl(adr, c, 64);
+      const int sb1 = __shfl(cb1, c, 64), sb2 = __shfl(cb2, c, 64);          // (both shuffles by every lane: they are wave collectives)
+      const int body = side ? sb2 : sb1;
+      if (t < nitem && cdim) {
+        const int len = M.body_chlen[body];
+        const int dof = M.body_chain[body*FB_MAXCH + sl];
+        real jp[3] = {0, 0, 0};
+        const real* pos = w.con_pos() + 3*c;
+        const real* frame = w.con_frame() + 9*c;
+        const real* cp = w.cdof() + 6*((sl < len) ? dof : 0);
+        real cd[6], off[3], fr[9];
 #pragma unroll
-      for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
-        real c[5][6];
+        for (int k = 0; k < 6; k++) cd[k] = cp[k];
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
-          const real* cp = w.cdof() + 6*((s0 + u < len) ? ch[s0 + u] : 0);
-#pragma unroll
-          for (int k = 0; k < 6; k++) c[u][k] = cp[k];
+        for (int k = 0; k < 9; k++) fr[k] = frame[k];
+        sub3(off, pos, w.com());
+        if (sl < len) {
+          real tt[3]; cross3(tt, cd, off);
+          jp[0] = cd[3] + tt[0]; jp[1] = cd[4] + tt[1]; jp[2] = cd[5] + tt[2];
         }
-#pragma unroll
-        for (int u = 0; u < 5; u++) {
-          int sl = s0 + u;
-          real jp[3] = {0, 0, 0};
-          if (sl < len) {
-            real t[3]; cross3(t, c[u], off);
-            jp[0] = c[u][3] + t[0]; jp[1] = c[u][4] + t[1]; jp[2] = c[u][5] + t[2];
-          }
-          for (int k = 0; k < dim; k++) w.efc_J()[JIDX(side, sl, adr + k)] = sgn*dot3(frame + 3*k, jp);
-        }
+        const real sgn = side ? (real)1 : (real)-1;
+        for (int k = 0; k < cdim; k++) w.efc_J()[JIDX(side, sl, cadr + k)] = sgn*dot3(fr + 3*k, jp);
       }
     }
   }
+  PROF(44);
   if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
   SYNC();
   for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D()[r] = (real)1 / w.efc_R()[r];

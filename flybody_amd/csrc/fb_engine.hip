@@ -40,7 +40,7 @@ struct fb_model {
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
-  std::vector<int> body_fluid_geom;
+  std::vector<int> body_fluid_geom, sens_body;
   double totalmass;
   // A missing or ill-typed array is an error of the caller's blob, never a reason to take the process down: the accessors
   // throw, every extern "C" entry point that reads the model catches and returns -1 with the message in fb_last_error().
@@ -377,6 +377,16 @@ static int model_load_impl(fb_model* m, size_t n) {
     m->body_box[3*b+1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass[b] * 6.0);
     m->body_box[3*b+2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass[b] * 6.0);
   }
+  // bodies whose acceleration / force the sensors need: the accelerometer's body and the subtrees below the force-sensor bodies
+  {
+    std::vector<char> need(nb, 0);
+    const int* sb = m->i("site_bodyid");
+    need[sb[m->i("sensor_site_thorax")[0]]] = 1;
+    size_t nf = 0; const int* fs = m->i("sensor_force_sites", &nf);
+    for (size_t k = 0; k < nf; k++) { int b = sb[fs[k]]; for (int d = 0; d < m->body_nsub[b]; d++) need[b + d] = 1; }
+    for (int b = 0; b < nb; b++) if (need[b]) m->sens_body.push_back(b);
+    if ((int)m->sens_body.size() > FB_WAVE) m->sens_body.clear();
+  }
   m->body_fluid_geom.assign(nb, -1);
   { const double* gfl = m->d("geom_fluid"); const int* gb = m->i("geom_bodyid");
     for (int g = 0; g < m->ngeom; g++) if (gfl[12*g] > 0) m->body_fluid_geom[gb[g]] = g; }
@@ -569,7 +579,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(body_nsub, body_nsub) UV(body_depth, body_depth) UV(body_chlen, body_chlen) UV(body_chain, body_chain) UV(body_common, body_common)
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
-  UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom)
+  UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }

@@ -217,35 +217,33 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     // larger systems update their rows in LDS.
     real invd = 1;
     if (n_act <= FB_NEWTON_NR) {
+      // Kr[q] = this row's entry of the q-th REMAINING active column: every elimination step shifts the row by one register
+      // (the shift rides on the update's FMA), so the pivot column is always Kr[0], the register indices are static, and the
+      // outer loop stays rolled -- one short loop body instead of NR^2/2 unrolled updates streaming through the instruction cache
       real Kr[FB_NEWTON_NR];
 #pragma unroll
-      for (int pp = 0; pp < FB_NEWTON_NR; pp++) Kr[pp] = (pp < n_act) ? K[tri_l + pp] : (real)0;
+      for (int q = 0; q < FB_NEWTON_NR; q++) Kr[q] = (q < n_act) ? K[tri_l + q] : (real)0;
       unsigned long long mrem = m_act;
+      for (int pp = 0; mrem; pp++) {
+        const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
+        const real inv = fb_rsqrt(rdlane(dg, j));
+        const bool below = on && lane > j;
+        const real lcol = below ? Kr[0]*inv : (real)0;
+        if (below) K[tri_l + pp] = lcol;            // L goes back to LDS: the back substitution reads row j across lanes
+        if (lane == j) invd = inv;
+        const real yj = rdlane(y, j)*inv;
+        y = (lane == j) ? yj : y - lcol*yj;
+        unsigned long long m2 = mrem;
 #pragma unroll
-      for (int pp = 0; pp < FB_NEWTON_NR; pp++) {
-        if (mrem) {
-          const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
-          const real inv = fb_rsqrt(rdlane(dg, j));
-          const real lcol = (on && lane > j) ? Kr[pp]*inv : (real)0;
-          Kr[pp] = lcol;
-          if (lane == j) invd = inv;
-          const real yj = rdlane(y, j)*inv;
-          y = (lane == j) ? yj : y - lcol*yj;
-          unsigned long long m2 = mrem;
-#pragma unroll
-          for (int p2 = pp + 1; p2 < FB_NEWTON_NR; p2++) {
-            if (m2) {
-              const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
-              const real lk = rdlane(lcol, kk);
-              Kr[p2] -= lcol*lk;                    // (lanes <= kk update an entry they never use)
-              dg -= (lane == kk) ? lcol*lk : (real)0;
-            }
+        for (int q = 1; q < FB_NEWTON_NR; q++) {
+          if (m2) {
+            const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
+            const real lk = rdlane(lcol, kk);
+            Kr[q - 1] = Kr[q] - lcol*lk;            // (lanes <= kk update an entry they never use)
+            dg -= (lane == kk) ? lcol*lk : (real)0;
           }
         }
       }
-      // L goes back to LDS: the back substitution reads row j across lanes
-#pragma unroll
-      for (int pp = 0; pp < FB_NEWTON_NR; pp++) if (pp < n_act && on && pp < my_ci) K[tri_l + pp] = Kr[pp];
     } else {
       unsigned long long mrem = m_act;
       for (int pp = 0; mrem; pp++) {

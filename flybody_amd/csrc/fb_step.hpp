@@ -57,6 +57,7 @@ FBD real ray_site(const real* pos, const real* mat, const real* size, int type, 
 // acceleration-stage sensors: accelerometer (thorax site), 6 force sensors, 6 touch sensors
 template <typename real>
 __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<real>& w, int lane) {
+  PROF_BEGIN();
   int ncon = w.istate()[IS_NCON];
   // wrench of each active contact about the tree CoM, in the lane that owns the contact (at most 64 contacts)
   int cb1 = -1, cb2 = -1;
@@ -75,9 +76,14 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
       cross3(cw, r, cw + 3);
     }
   }
+  // Only the bodies the sensors read are needed: the accelerometer's body and the subtrees below the force-sensor bodies
+  // (fruit fly: thorax + 6 x 5 tarsus segments = 31 of 68 bodies -> ONE pass of the wave instead of two, the second of which
+  // would run the whole chain walk for four bodies).  A model with more than 64 such bodies takes the all-bodies passes.
+  const int nsb = M.nsensbody;
+  const int npass = nsb > 0 ? 1 : (M.nbody + FB_WAVE - 1)/FB_WAVE;
   // external wrench per body: lane == body, the contacts are broadcast one at a time (in contact order)
-  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
-    int b = b0 + lane;
+  for (int ps = 0; ps < npass; ps++) {
+    const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
     real acc[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ncon; c++) {
       int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
@@ -89,11 +95,14 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
         for (int k = 0; k < 6; k++) acc[k] += sgn*wr[k];
       }
     }
-    if (b < M.nbody) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
+    if (b >= 0) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
   }
   SYNC();
+  PROF(45);
   // body accelerations (chain walk, now including qacc) and body forces
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+  for (int ps = 0; ps < npass; ps++) {
+    const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
+    if (b < 0) continue;
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
     real* out = w.cfrc() + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc()[k] = a[k]; } continue; }
@@ -108,6 +117,7 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k] - w.cfrc_ext()[6*b + k];
   }
   SYNC();
+  PROF(46);
   if (lane == 0) {
     int s = M.site_thorax, b = M.site_bodyid[s];
     const real* ca = w.cacc() + 6*b;

@@ -134,6 +134,7 @@ struct DevModel {
   GP<const int> pair_word;   // [npair] geom1 | geom2 << 10 | (slot of the plane normal in the LDS staging area, 0: no plane) << 20
   GP<const int> plane_geoms; int nplane;   // geoms of type plane (their normals are staged behind the bounding spheres)
   GP<const int> obs_jnt, app_sites, force_sites, touch_sites, wing_jnt;
+  GP<const int> sens_body; int nsensbody;     // bodies the acceleration-stage sensors read (0: more than 64, all bodies are processed)
   // constants
   GP<const real> body_mass, body_inertia, body_invweight0, body_box;
   GP<const real> body_rec;      // [nbody][FB_BODYREC] flattened kinematics record of a body (fb_engine.hip)

@@ -73,6 +73,6 @@ out = {'task': asset, 'control_steps_counted': nstep, 'per_control_step': dict(z
        'flop_per_control_step_add_mul_div_sqrt': float(c[:4].sum()), 'substeps_per_control_step': int(round(float(arr['opt_control_timestep'])/float(arr['opt_timestep']))),
        'flop_per_substep': float(c[:4].sum()/int(round(float(arr['opt_control_timestep'])/float(arr['opt_timestep'])))),
        'matches_plain_oracle_bitwise': bool(np.array_equal(q_counted, q_plain)),
-       'note': 'scalar FP64 oracle (PGS, sparse LDL); fused multiply-adds count as two operations; comparisons and '
+       'note': 'scalar FP64 oracle (constraint-space Newton for <= 64 rows else PGS, noslip, sparse LDL); fused multiply-adds count as two operations; comparisons and '
                'transcendental calls are listed separately and not included in the flop total'}
 print(json.dumps(out))
