@@ -169,44 +169,97 @@ template <typename real, typename ARP>
 FB_STAGE_B void d_build_AR(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane);
 
 // ------------------------------------------------------------------ Y = J L^-1 D^-1/2 and AR = Y Y^T + R
+// one row's half-solve along one chain: y <- J[side][.][r] L^-1 D^-1/2 (chain-compressed; sd = sqrt(1/D) per dof, staged in LDS)
+template <typename real>
+FBD void project_row(const DevModel<real>& M, const WS<real>& w, int side, int r, int body, int len, const FB_LDS real* sd, real* y) {
+  int chain[FB_MAXCH], rowadr[FB_MAXCH];
+  load_chain(M, body, chain);
+#pragma unroll
+  for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
+  // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
+#pragma unroll
+  for (int s = FB_MAXCH - 1; s >= 1; s--) {
+    if (s < len && y[s] != 0) {
+      const FB_LDS real* row = w.lLD + rowadr[s];
+#pragma unroll
+      for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? y[s]*sd[chain[s]] : (real)0;
+}
+
+// AR of a system of at most 64 rows from the rows' Y held in the registers of lane == row: the row loop broadcasts them with
+// v_readlane; the shared-prefix lengths of the NEXT row are fetched while the current row is accumulated
+template <typename real, typename ARP>
+FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane, const real* yA, const real* yB, int bA, int bB, int lA, int lB) {
+  const bool valid = lane < nefc;
+  const int c = lane;
+  const int* common = M.body_common; const int nb = M.nbody;
+  int rbA = rdlane(bA, 0), rbB = rdlane(bB, 0);
+  int cAA = common[rbA*nb + bA], cAB = common[rbA*nb + bB], cBA = common[rbB*nb + bA], cBB = common[rbB*nb + bB];
+  const real Rc = valid ? w.efc_R()[c] : (real)0;
+  for (int r = 0; r < nefc; r++) {
+    int rlA = rdlane(lA, r), rlB = rdlane(lB, r);
+    int cmAA = min(min(cAA, lA), rlA), cmAB = min(min(cAB, lB), rlA), cmBA = min(min(cBA, lA), rlB), cmBB = min(min(cBB, lB), rlB);
+    if (r + 1 < nefc) {
+      rbA = rdlane(bA, r + 1); rbB = rdlane(bB, r + 1);
+      cAA = common[rbA*nb + bA]; cAB = common[rbA*nb + bB]; cBA = common[rbB*nb + bA]; cBB = common[rbB*nb + bB];
+    }
+    real acc = 0;
+#pragma unroll
+    for (int s = 0; s < FB_MAXCH; s++) {
+      if (s < rlA) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < FB_MAXCH; s++) {
+      if (s < rlB) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
+    }
+    if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
+      if (c == r) acc += Rc;
+      AR[ARIDX(r, c)] = acc;
+    }
+  }
+  SYNC();
+}
+
 template <typename real>
 __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, const WS<real>& w, int lane) {
   int nefc = w.istate()[IS_NEFC];
   if (nefc == 0) return;
+  // sqrt(1/D) of every dof, once (two passes of the wave) instead of once per row and chain slot (40 square roots per lane).
+  // The solve vector is free between the Euler solve and the next acceleration stage.
+  FB_LDS real* sd = w.lx;
+  for (int i = lane; i < M.nv; i += FB_WAVE) sd[i] = sqrt(w.lLD[w.lmadr[i]]);          // 1/D of the dof: diagonal slot = start of its row
+  SYNC();
+  if (nefc <= FB_WAVE) {
+    // lane == row == column: the rows' Y never leave the registers (no efc_Y round trip through the environment's global row)
+    real yA[FB_MAXCH], yB[FB_MAXCH];
+    int bA = 0, bB = 0, lA = 0, lB = 0;
+    if (lane < nefc) { bA = w.efc_bA()[lane]; bB = w.efc_bB()[lane]; lA = w.efc_lA()[lane]; lB = w.efc_lB()[lane]; }
+    project_row(M, w, 0, lane < nefc ? lane : 0, bA, lA, sd, yA);
+    project_row(M, w, 1, lane < nefc ? lane : 0, bB, lB, sd, yB);
+    if (nefc <= LdsCfg<real>::AR_ROWS) ar_from_registers(M, w, w.lAR, nefc, lane, yA, yB, bA, bB, lA, lB);
+    else ar_from_registers(M, w, w.AR(), nefc, lane, yA, yB, bA, bB, lA, lB);
+    return;
+  }
   for (int base = 0; base < nefc; base += FB_WAVE) {
     int r = base + lane;
     if (r < nefc) {
       for (int side = 0; side < 2; side++) {
         int body = side ? w.efc_bB()[r] : w.efc_bA()[r];
         int len = side ? w.efc_lB()[r] : w.efc_lA()[r];
-        int chain[FB_MAXCH], rowadr[FB_MAXCH];
-        load_chain(M, body, chain);
         real y[FB_MAXCH];
+        project_row(M, w, side, r, body, len, sd, y);
 #pragma unroll
-        for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
-        // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
-#pragma unroll
-        for (int s = FB_MAXCH - 1; s >= 1; s--) {
-          if (s < len && y[s] != 0) {
-            const FB_LDS real* row = w.lLD + rowadr[s];
-#pragma unroll
-            for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < FB_MAXCH; s++) {
-          real v = 0;
-          if (s < len) v = y[s] * sqrt(w.lLD[rowadr[s] - s]);          // 1/D of the dof: diagonal slot of its row
-          w.efc_Y()[JIDX(side, s, r)] = v;
-        }
+        for (int s = 0; s < FB_MAXCH; s++) w.efc_Y()[JIDX(side, s, r)] = y[s];
       }
     }
   }
   SYNC();
   // AR lives in LDS when it fits, otherwise in the environment's global workspace
   const WS<real> wc = w;                 // the callee is not inlined: hand it a copy, the caller's descriptor stays in registers
-  if (nefc <= LdsCfg<real>::AR_ROWS) d_build_AR(M, wc, w.lAR, nefc, lane);
-  else d_build_AR(M, wc, w.AR(), nefc, lane);
+  d_build_AR(M, wc, w.AR(), nefc, lane);
 }
 
 template <typename real, typename ARP>
@@ -828,28 +881,37 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   }
   PROF_BEGIN();
   // ---- per-row reference: vel = J qvel, b = J qacc_smooth - aref, jar = J qacc_ws - aref
-  // (the chain and its four gathers per slot are issued in chunks of 5 slots; slots past the chain read dof 0 and are masked)
-  for (int r = lane; r < nefc; r += FB_WAVE) {
+  // Four lanes per row (16 rows per pass): each takes one half of one of the row's two chains -- 10 slots, 40 gathers in two
+  // rounds instead of 160 in eight -- and the quad adds its partial sums up on the DPP datapath.
+  for (int r0 = 0; r0 < nefc; r0 += FB_WAVE/4) {
+    const int r = r0 + (lane >> 2), part = lane & 3, side = part >> 1, sbase = (part & 1)*(FB_MAXCH/2);
+    const bool rv = r < nefc;
+    const int rr = rv ? r : 0;
     real vel = 0, ja = 0, jw = 0;
-    for (int side = 0; side < 2; side++) {
-      int body = side ? w.efc_bB()[r] : w.efc_bA()[r];
-      int len = side ? w.efc_lB()[r] : w.efc_lA()[r];
-      int ch[FB_MAXCH];
-      load_chain(M, body, ch);
+    {
+      int body = side ? w.efc_bB()[rr] : w.efc_bA()[rr];
+      int len = rv ? (side ? w.efc_lB()[rr] : w.efc_lA()[rr]) : 0;
+      const int* chp = M.body_chain + body*FB_MAXCH + sbase;
+      int ch[FB_MAXCH/2];
 #pragma unroll
-      for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
+      for (int u = 0; u < FB_MAXCH/2; u++) ch[u] = chp[u];
+#pragma unroll
+      for (int s0 = 0; s0 < FB_MAXCH/2; s0 += 5) {
         real jv[5], qv[5], qs[5], qw[5];
 #pragma unroll
         for (int u = 0; u < 5; u++) {
-          int sl = s0 + u; int dof = (sl < len) ? ch[sl] : 0;
-          jv[u] = w.efc_J()[JIDX(side, sl, r)]; qv[u] = w.qvel()[dof]; qs[u] = w.qacc_smooth()[dof]; qw[u] = w.qacc_ws()[dof];
+          int sl = sbase + s0 + u; int dof = (sl < len) ? ch[s0 + u] : 0;
+          jv[u] = w.efc_J()[JIDX(side, sl, rr)]; qv[u] = w.qvel()[dof]; qs[u] = w.qacc_smooth()[dof]; qw[u] = w.qacc_ws()[dof];
         }
 #pragma unroll
-        for (int u = 0; u < 5; u++) if (s0 + u < len) { vel += jv[u]*qv[u]; ja += jv[u]*qs[u]; jw += jv[u]*qw[u]; }
+        for (int u = 0; u < 5; u++) if (sbase + s0 + u < len) { vel += jv[u]*qv[u]; ja += jv[u]*qs[u]; jw += jv[u]*qw[u]; }
       }
     }
-    real aref = -w.efc_B()[r]*vel - w.efc_K()[r]*w.efc_imp()[r]*(w.efc_pos()[r] - w.efc_margin()[r]);
-    w.efc_vel()[r] = vel; w.efc_aref()[r] = aref; w.efc_b()[r] = ja - aref; w.efc_jar()[r] = jw - aref;
+    vel = quad_sum(vel); ja = quad_sum(ja); jw = quad_sum(jw);
+    if (rv && part == 0) {
+      real aref = -w.efc_B()[r]*vel - w.efc_K()[r]*w.efc_imp()[r]*(w.efc_pos()[r] - w.efc_margin()[r]);
+      w.efc_vel()[r] = vel; w.efc_aref()[r] = aref; w.efc_b()[r] = ja - aref; w.efc_jar()[r] = jw - aref;
+    }
   }
   SYNC();
   // ---- warm start: force implied by the previous acceleration (primal map)

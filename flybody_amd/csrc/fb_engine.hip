@@ -37,7 +37,7 @@ struct fb_model {
   std::vector<int> body_nsub, body_depth, body_chlen, body_chain, body_common, dof_depth, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, plane_geoms;
-  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w; int ngen = 0, ntrunk = 1;
+  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w, fac_band; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom, sens_body;
@@ -280,27 +280,50 @@ static int model_load_impl(fb_model* m, size_t n) {
   // descendant lists and may only sit in the first FB_FGEN slots.  One packed word per slot (fb_smooth.hpp).
   {
     struct Ent { int i, j, work; bool gen; };
-    std::vector<Ent> ents;
+    std::vector<Ent> gen_ents, chain_ents;
     for (int i = m->ntrunk; i < nv; i++)
-      for (int j = dofpar[i]; j >= 0; j = dofpar[j]) ents.push_back({i, j, m->dof_ndesc[i] + 1, m->dof_gen[i] >= 0});
-    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { if (a.gen != b.gen) return a.gen; return a.work > b.work; });
-    std::vector<int> load(FB_WAVE, 0), ngs(FB_WAVE, 0), ncs(FB_WAVE, 0);
-    for (int k = m->ntrunk; k < nv; k++) load[k & 63] += m->dof_ndesc[k] + 1;
+      for (int j = dofpar[i]; j >= 0; j = dofpar[j]) (m->dof_gen[i] >= 0 ? gen_ents : chain_ents).push_back({i, j, m->dof_ndesc[i] + 1, m->dof_gen[i] >= 0});
     m->fac_w.assign((size_t)FB_FSLOT*FB_WAVE, (31 << 13) | (int)(15u << 28));        // depth 31: empty slot
-    for (const Ent& e : ents) {
-      int best = -1;
-      for (int l = 0; l < FB_WAVE; l++) {
-        bool room = e.gen ? (ngs[l] < FB_FGEN) : (ncs[l] < FB_FSLOT - FB_FGEN || ngs[l] < FB_FGEN);
-        if (room && (best < 0 || load[l] < load[best])) best = l;
-      }
-      if (best < 0) { return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
-      int slot;
-      if (e.gen || ncs[best] >= FB_FSLOT - FB_FGEN) slot = ngs[best]++; else slot = FB_FGEN + ncs[best]++;
-      load[best] += e.work;
+    auto put = [&](const Ent& e, int lane_, int slot) -> bool {
       int dep = m->dof_depth[e.i], base = madr[e.i] - dep*(dep + 1)/2, ee = dep - m->dof_depth[e.j];
-      if (base < -4096 || base > 4095 || dep > 30) { return fail("fb_model_load: factor work list field overflow"); }
-      size_t o = (size_t)slot*FB_WAVE + best;
-      m->fac_w[o] = (base & 0x1fff) | (dep << 13) | (m->dof_cl[e.i] << 18) | (ee << 23) | (int)((unsigned)(e.gen ? m->dof_gen[e.i] : 15) << 28);
+      if (base < -4096 || base > 4095 || dep > 30) return false;
+      m->fac_w[(size_t)slot*FB_WAVE + lane_] = (base & 0x1fff) | (dep << 13) | (m->dof_cl[e.i] << 18) | (ee << 23) | (int)((unsigned)(e.gen ? m->dof_gen[e.i] : 15) << 28);
+      return true;
+    };
+    // Entries of branching dofs: the first FB_FGEN slots, spread over the lanes.
+    std::vector<int> ngs(FB_WAVE, 0);
+    if ((int)gen_ents.size() > FB_FGEN*FB_WAVE) { return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
+    for (size_t k = 0; k < gen_ents.size(); k++) { int l = (int)(k % FB_WAVE); if (!put(gen_ents[k], l, ngs[l]++)) return fail("fb_model_load: factor work list field overflow"); }
+    // Chain entries: sorted deepest dof first and DEALT to the lanes in turn, so slot s of every lane holds entries of (nearly) the
+    // same depth.  An entry publishes on level dep and pulls on levels dep+1 .. dep+cl; with this order the slots that do
+    // anything on a level form a narrow band that is the same for all lanes, and the level loop skips the rest (fac_band).
+    std::stable_sort(chain_ents.begin(), chain_ents.end(), [&](const Ent& a, const Ent& b) {
+      int da = m->dof_depth[a.i], db = m->dof_depth[b.i]; if (da != db) return da > db; return a.work > b.work; });
+    const int nchain_slots = FB_FSLOT - FB_FGEN;
+    size_t placed = 0;
+    for (; placed < chain_ents.size() && placed < (size_t)nchain_slots*FB_WAVE; placed++)
+      if (!put(chain_ents[placed], (int)(placed % FB_WAVE), FB_FGEN + (int)(placed / FB_WAVE))) return fail("fb_model_load: factor work list field overflow");
+    // what does not fit the chain slots (the shallowest entries) goes to free slots of the first FB_FGEN (never skipped)
+    for (; placed < chain_ents.size(); placed++) {
+      int best = -1;
+      for (int l = 0; l < FB_WAVE; l++) if (ngs[l] < FB_FGEN && (best < 0 || ngs[l] < ngs[best])) best = l;
+      if (best < 0) { return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
+      if (!put(chain_ents[placed], best, ngs[best]++)) return fail("fb_model_load: factor work list field overflow");
+    }
+    // per level: the band of chain slots that publish (dep == d) and the band that pulls (dep < d <= dep + cl), over all lanes
+    m->fac_band.assign(32, 0);
+    for (int d = 0; d < 32; d++) {
+      int plo = FB_FSLOT, phi = 0, qlo = FB_FSLOT, qhi = 0;
+      for (int s = FB_FGEN; s < FB_FSLOT; s++)
+        for (int l = 0; l < FB_WAVE; l++) {
+          int wd = m->fac_w[(size_t)s*FB_WAVE + l], dep = (wd >> 13) & 31, cl_ = (wd >> 18) & 31;
+          if (dep == 31) continue;
+          if (dep == d) { plo = std::min(plo, s); phi = std::max(phi, s + 1); }
+          if (dep < d && d <= dep + cl_) { qlo = std::min(qlo, s); qhi = std::max(qhi, s + 1); }
+        }
+      if (plo > phi) plo = phi = 0;
+      if (qlo > qhi) qlo = qhi = 0;
+      m->fac_band[d] = plo | (phi << 8) | (qlo << 16) | (qhi << 24);
     }
   }
   const int* trn = m->i("actuator_trntype");
@@ -580,7 +603,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
-  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) M.ntrunk = m->ntrunk;
+  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   UI(wing_act_idx, "wing_action_idx")

@@ -258,6 +258,12 @@ template <typename real> FBD real wave_sum(real v) {
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 #endif
+// sum over the four lanes of a quad (lanes 4k .. 4k+3), result in all four; every lane must call
+#ifdef FB_EMULATE
+template <typename real> FBD real quad_sum(real v) { v += shfl_xor_r(v, 1); v += shfl_xor_r(v, 2); return v; }
+#else
+template <typename real> FBD real quad_sum(real v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); return v; }
+#endif
 FBD double shfl_xor_any(double v, int m) { return __shfl_xor(v, m, 64); }
 FBD float shfl_xor_any(float v, int m) { return __shfl_xor(v, m, 64); }
 FBD int wave_sum_i(int v) {

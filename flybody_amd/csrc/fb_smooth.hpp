@@ -414,6 +414,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM);
   PROF_BEGIN();
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long fp_[6] = {0, 0, 0, 0, 0, 0}, ft_ = clock64();
+#define F_PROF(k) do { long long n_ = clock64(); fp_[k] += n_ - ft_; ft_ = n_; } while (0)
+#else
+#define F_PROF(k) do {} while (0)
+#endif
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
   // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
@@ -439,6 +445,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     accd[q] = v;
   }
   PROF(17);
+  F_PROF(0);
   for (int d = nlevel - 1; d >= nT; d--) {
     const int Td = d*(d + 1)/2;
     // (keep the packed words opaque: otherwise every field of every slot is hoisted into its own register)
@@ -449,18 +456,26 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     // publish the rows of level d (unnormalised) and 1/D
 #pragma unroll
     for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; }
+    // the chain slots are sorted by depth and dealt to the lanes (fb_engine.hip), so the slots that publish / pull on this level
+    // form one narrow band, the same for every lane: everything outside it is skipped by a wave-uniform test
+    const int band = uniform_int(M.fac_band[d]);
+    const int pub_lo = band & 255, pub_hi = (band >> 8) & 255, pull_lo = (band >> 16) & 255, pull_hi = (band >> 24) & 255;
 #pragma unroll
     for (int s = 0; s < FB_FSLOT; s++) {
-      // branch-free: a slot that is not on level d stores to a dummy word behind the factor
-      int adr = (FW_DEP(fw[s]) == d) ? FW_BASE(fw[s]) + Td + FW_E(fw[s]) : FB_LDS_SCRATCH - 1;
-      RM[adr] = acc[s];
+      if (s < FB_FGEN || (s >= pub_lo && s < pub_hi)) {
+        // branch-free inside the band: a slot that is not on level d stores to a dummy word behind the factor
+        int adr = (FW_DEP(fw[s]) == d) ? FW_BASE(fw[s]) + Td + FW_E(fw[s]) : FB_LDS_SCRATCH - 1;
+        RM[adr] = acc[s];
+      }
     }
+    F_PROF(1);
     SYNC();
-    PROF(16);
+    F_PROF(2);
     // pull the contribution of level d into every shallower entry.  The chain loads are unconditional (an LDS read
     // cannot fault) so that a group's reads are in flight together; inactive slots discard the product.
 #pragma unroll
     for (int s0 = 0; s0 < FB_FSLOT; s0 += FB_FGROUP) {
+      if (!(s0 < FB_FGEN || (s0 + FB_FGROUP > pull_lo && s0 < pull_hi))) continue;
       real la[FB_FGROUP], lb[FB_FGROUP], ld[FB_FGROUP];
 #pragma unroll
       for (int u = 0; u < FB_FGROUP; u++) {
@@ -476,7 +491,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         acc[s0 + u] -= (t < (unsigned)FW_CL(wd)) ? pr : (real)0;
       }
     }
-    PROF(22);
+    F_PROF(3);
 #pragma unroll
     for (int s = 0; s < FB_FGEN; s++) {
       int wd = fw[s], dep = FW_DEP(wd), g = (wd >> 28) & 15;
@@ -493,9 +508,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         else if (FW_E(wd) != 31) { int o = 2*(FW_E(wd)*FB_MAXCH + d); accd[q] -= gen_pull3(RM, gm[o], gm[o + 1], t + 1, t + 1, FW_BASE(wd) + (dep + 1)*(dep + 2)/2); }
       }
     }
-    PROF(23);
+    F_PROF(4);
   }
-  PROF(18);
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[17] += fp_[0]; pp_[16] += fp_[1]; pp_[18] += fp_[2]; pp_[22] += fp_[3]; pp_[23] += fp_[4]; }
+#endif
+  PROF_RESET();
   // the register accumulators are dead from here on (every entry was published, unnormalised, on its own level): the trunk
   // and the normalisation run as a function of their own, with their own register allocation
   d_factor_tail(M, w_, qM, diag_add, hscale, RM, lane);
