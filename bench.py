@@ -112,6 +112,8 @@ def main():
     ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary two-half-batches-on-two-streams measurement')
     ap.add_argument('--no-secondary-configs', action='store_true', help='skip the flight_imitation (configs[3]) and DMPO (configs[2]) legs')
     ap.add_argument('--no-parity-sample', action='store_true', help='skip the post-run replay of sampled environments on the CPU oracle')
+    ap.add_argument('--rccl-dry-run', action='store_true', help='with --gpus N > 1: use RCCL when N devices are visible; otherwise run the N ranks on the '
+                    'one visible device over gloo (same code path up to the backend) and say `rccl: unexercised` in the JSON')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -119,11 +121,14 @@ def main():
         import socket
         import subprocess
         import torch
+        dry_env = {}
         if 'FB_BENCH_DEVICE' not in os.environ and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible')
+            if not args.rccl_dry_run:
+                raise SystemExit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible (--rccl-dry-run: run the ranks on one device over gloo)')
+            dry_env = {'FB_BENCH_DEVICE': '0', 'FB_BENCH_BACKEND': 'gloo'}
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **dry_env)
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))

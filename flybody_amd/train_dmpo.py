@@ -77,6 +77,8 @@ class Trainer:
         self.views = self.env.reset_all()
         self.obs = self.views['obs'].clone()
         self.env_steps = 0; self.learner_steps = 0; self._gate_checked = False
+        self.overlap = os.environ.get('FB_TRAIN_OVERLAP', '1') == '1'
+        self._env_stream = torch.cuda.Stream(device=self.device); self._ev_act = torch.cuda.Event(); self._ev_phys = torch.cuda.Event()
         # checkpoints / policy snapshots / metrics (rank 0 writes; every rank restores so that replicas stay identical)
         self.counter = Counter(); self.checkpointer = self.snapshotter = None; self.logger = MetricsLogger(None)
         self._ep_return = torch.zeros(n_env, device=self.device); self._ep_len = torch.zeros(n_env, device=self.device)
@@ -94,10 +96,25 @@ class Trainer:
                 self.logger = MetricsLogger(directory, 'learner')
 
     def iterate(self, learn=True):
-        """One control step of every environment, replay insertion, and the scheduled learner steps."""
+        """One control step of every environment, replay insertion, and the scheduled learner steps.
+
+        overlap (default on): the physics kernel of this control step runs on its own HIP stream WHILE the learner steps run on
+        the main stream -- the actor's forward pass precedes both, and the replay append (the only thing that depends on both)
+        follows them on the main stream.  The learner therefore samples transitions up to the PREVIOUS control step, one step
+        of lag in a pipeline that is asynchronous in the reference anyway (Ray actors + Reverb).  FB_TRAIN_OVERLAP=0: serial."""
         canon = self.learner.act(self.obs)
         real = (self.a_min + 0.5 * (canon + 1.0) * self.a_scale).contiguous()       # CanonicalSpecWrapper inverse
-        v = self.env.step_tensor(real)
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            self._ev_act.record(main)
+            with torch.cuda.stream(self._env_stream):
+                self._env_stream.wait_event(self._ev_act)
+                v = self.env.step_tensor(real)
+                self._ev_phys.record(self._env_stream)
+            stats = self._learn(learn)                                             # concurrent with the physics kernel
+            main.wait_event(self._ev_phys)
+        else:
+            v = self.env.step_tensor(real)
         st = v['step_type']
         first, last = st == 0, st == 2
         nxt = v['obs'].clone()
@@ -121,6 +138,12 @@ class Trainer:
                 self._fin_n.zero_(); self._fin_ret.zero_(); self._fin_len.zero_()
         self.counter.increment(actor_steps=self.env.n_env*self.world)
         self.limiter.insert(self.env.n_env)
+        if not self.overlap:
+            stats = self._learn(learn)
+        return stats
+
+    def _learn(self, learn=True):
+        """The learner steps the rate limiter allows at this point (inserts counted so far)."""
         stats = None
         B = self.cfg.batch_size
         allowed = self.limiter.learner_steps_allowed(B) if learn else 0

@@ -20,7 +20,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-           '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline']
+           '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline', '--no-secondary-configs']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -37,7 +37,7 @@ def test_bench_bare_gpus_flag_spawns_the_ranks():
     args.gpus used to be ignored).  On this one-GPU box both ranks share cuda:0 over gloo, exactly like the test above."""
     env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--envs-per-gpu', '256', '--no-f32-leg',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--envs-per-gpu', '256', '--no-f32-leg', '--no-secondary-configs',
            '--no-cpu-baseline']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -49,3 +49,22 @@ def test_bench_bare_gpus_flag_spawns_the_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '1', '--warmup', '0'], cwd=ROOT,
                        env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and '--gpus 3' in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_rccl_dry_run_reports_unexercised_on_one_gpu():
+    """`python bench.py --gpus 2 --rccl-dry-run`: with two visible devices it is a plain RCCL run; on a one-GPU
+    box the two ranks share the device over gloo and the JSON line says that RCCL was not exercised."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FB_BENCH_DEVICE', 'FB_BENCH_BACKEND')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rccl-dry-run', '--steps', '3', '--warmup', '1', '--envs-per-gpu', '256',
+           '--no-f32-leg', '--no-split-leg', '--no-cpu-baseline', '--no-secondary-configs']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['config']['state_finite']
+    if torch.cuda.device_count() >= 2:
+        assert out['rccl'].startswith('exercised')
+    else:
+        assert out['rccl'].startswith('unexercised')
+    assert out['parity_sample']['ok'] and out['parity_sample']['max_rel_qpos'] < 1e-6        # rank 0's shard, replayed on the oracle
