@@ -7,6 +7,10 @@ python -c "import flybody_amd.engine as e; print(e.version())" > $O/version.txt 
 timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests_full.txt 2>&1; tail -5 $O/gpu_tests_full.txt > $O/gpu_tests.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 1500 bash tools/collect_profiles.sh final > $O/collect.log 2>&1
+timeout 600 bash tools/calibrate_traffic.sh final > $O/calibrate.log 2>&1
+timeout 900 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_1000_steps.json 2> $O/bench_1000_steps.err
+timeout 300 python tools/solver_bench.py 4096 30 64 > $O/solver_bench.txt 2>&1
+timeout 300 python tools/solver_bench.py 4096 30 32 >> $O/solver_bench.txt 2>&1
 timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 64 4096 > $O/phase64.txt 2>&1
 timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 32 4096 > $O/phase32.txt 2>&1
 for n in 32 256 1024 2048 4096; do timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 $n 20 >> $O/batch_sweep.txt 2>&1; done

@@ -4,7 +4,7 @@
 Per-launch PMC tables are reduced to the step kernel's rows; `pmc_traffic_f{64,32}.json` (read by bench.py) go to profiles/."""
 import csv, json, os, shutil, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 src, fin, dst = (os.path.join(ROOT, p) for p in ('gpurun_out/profiles_final', 'gpurun_out/final', f'profiles/{tag}'))
 os.makedirs(dst, exist_ok=True)
 clean = lambda p: '\n'.join(l for l in open(p).read().splitlines() if 'amdgpu.ids' not in l) + '\n'
@@ -13,6 +13,15 @@ shutil.copy(f'{src}/bench_under_rocprof.json', f'{dst}/bench_under_rocprof.json'
 s = json.load(open(f'{src}/summary.json')); s['tag'] = tag; json.dump(s, open(f'{dst}/summary.json', 'w'), indent=1)
 for k in ('f64', 'f32'):
     d = json.load(open(f'{src}/pmc_traffic_{k}.json')); d['source'] = d['source'].replace('profiles/final/', f'profiles/{tag}/')
+    cal = f'{src}/pmc_calibration.json'
+    if os.path.exists(cal):
+        # calibrated on this box (tools/calibrate_traffic.sh): FETCH_SIZE reports 1/2 of the bytes for the 8 B / 4 B per lane row segments this
+        # kernel reads, WRITE_SIZE reports them exactly -> bytes_per_launch = 2 * FETCH + WRITE
+        c = json.load(open(cal))['kernels']['k_rows_read']['fetch_reported_over_true']; cw = json.load(open(cal))['kernels']['k_rows_write']['write_reported_over_true']
+        d['fetch_calibration_reported_over_true'] = c; d['write_calibration_reported_over_true'] = cw
+        d['bytes_per_launch_uncalibrated'] = d['bytes_per_launch']
+        d['bytes_per_launch'] = (d['FETCH_SIZE_KB_per_launch']/c + d['WRITE_SIZE_KB_per_launch']/cw)*1024
+        d['source'] = d['source'].split('FETCH_SIZE is NOT doubled')[0] + f'calibrated with tools/microbench/traffic_cal.hip (profiles/{tag}/pmc_calibration.json): FETCH_SIZE / {c:.3f} + WRITE_SIZE / {cw:.3f}'
     json.dump(d, open(os.path.join(ROOT, 'profiles', f'pmc_traffic_{k}.json'), 'w'), indent=1)
 
 
@@ -24,8 +33,12 @@ def per_launch(path, out):
             f.write(f"{r['Dispatch_Id']},{'k_fly<double>' if 'double' in r['Kernel_Name'] else 'k_fly<float>'},{r['Counter_Name']},{float(r['Counter_Value']):.6f}\n")
 
 
-for sub, pre, name in (('pmc_fetch', 'f', 'fetch'), ('pmc_write', 'w', 'write'), ('pmc_sq1', 's', 'sq1'), ('pmc_sq2', 's', 'sq2')):
-    per_launch(f'{src}/{sub}/{pre}_counter_collection.csv', f'{dst}/pmc_{name}_per_launch.csv')
+for sub, pre, name in (('pmc_fetch', 'f', 'fetch'), ('pmc_write', 'w', 'write'), ('pmc_sq1', 's', 'sq1'), ('pmc_sq2', 's', 'sq2'), ('pmc_sq3', 's', 'sq3'), ('pmc_sq4', 's', 'sq4')):
+    if os.path.exists(f'{src}/{sub}/{pre}_counter_collection.csv'):
+        per_launch(f'{src}/{sub}/{pre}_counter_collection.csv', f'{dst}/pmc_{name}_per_launch.csv')
+for extra, name in ((f'{src}/pmc_calibration.json', 'pmc_calibration.json'), (f'{fin}/bench_1000_steps.json', 'bench_1000_steps.json'), (f'{fin}/solver_bench.txt', 'solver_newton_vs_pgs.txt')):
+    if os.path.exists(extra):
+        open(f'{dst}/{name}', 'w').write(clean(extra))
 shutil.copy(f'{fin}/bench_default.json', f'{dst}/bench_default.json')
 shutil.copy(f'{fin}/gpu_tests.txt', f'{dst}/gpu_tests.txt')
 open(f'{dst}/other_configs.jsonl', 'w').write(clean(f'{fin}/other_configs.jsonl'))
