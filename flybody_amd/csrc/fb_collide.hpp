@@ -389,6 +389,12 @@ template <typename real>
 __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   PROF_BEGIN();
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long cp_[5] = {0, 0, 0, 0, 0}, ct_ = clock64();
+#define C_PROF(k) do { long long n_ = clock64(); cp_[k] += n_ - ct_; ct_ = n_; } while (0)
+#else
+#define C_PROF(k) do {} while (0)
+#endif
   // ---- mid phase: bounding spheres.  The spheres {centre, radius} of all geoms and the normals of the planes are staged
   // in LDS first (slot of the Delassus matrix, not live yet), the pair list is a packed word per pair fetched four wave
   // passes at a time: ~10 global round trips per substep instead of two dependent ones for each of the 34 passes.
@@ -405,6 +411,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     o[0] = nx; o[1] = ny; o[2] = nz; o[3] = 0;
   }
   SYNC();
+  C_PROF(0);
   int ncand = 0;
   const int maxcand = 2*FB_MAXCON_ + 64;
   for (int base = 0; base < M.npair; base += 4*FB_WAVE) {
@@ -439,6 +446,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   int warn = (ncand > maxcand) ? WARN_CONTACT_CAP : 0;
   if (ncand > maxcand) ncand = maxcand;
   SYNC();
+  C_PROF(1);
   const WS<real> wc = w;
   // ---- oriented-box filter, compacting the candidate list in place (order preserved: contacts keep their pair order)
   {
@@ -455,6 +463,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     ncand = nkeep;
     SYNC();
   }
+  C_PROF(2);
   PROF(25);
   // ---- narrow phase (not inlined: it gets a copy of the descriptor, the caller's stays in registers)
   int ncon = 0;
@@ -462,6 +471,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     LaneContacts<real> lc; lc.n = 0; lc.ccd_cap = 0;
     int c = base + lane, p = -1;
     if (c < ncand) { p = w.cand()[c]; narrow_phase(M, wc, p, lc); }
+    C_PROF(3);
     int off = ncon + wave_excl_scan(lc.n, lane);
     for (int k = 0; k < lc.n; k++) {
       int ci = off + k;
@@ -477,8 +487,12 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     ncon += wave_sum_i(lc.n);
     if (__ballot(lc.ccd_cap != 0)) warn |= WARN_CCD_MAXITER;
   }
+  C_PROF(4);
   if (ncon > FB_MAXCON_) { ncon = FB_MAXCON_; warn |= WARN_CONTACT_CAP; }
   if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; if (warn) { w.istate()[IS_WARN] |= warn; w.istate()[IS_WARN_EVER] |= warn; } }
   SYNC();
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 5; k_++) pp_[42 + k_] += cp_[k_]; }
+#endif
   PROF(26);
 }

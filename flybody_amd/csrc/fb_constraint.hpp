@@ -78,7 +78,6 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     }
     nlimit += wave_sum_i(has);
   }
-  PROF(42);
   // ---- contacts: lane == contact
   int ncon = w.istate()[IS_NCON];
   int dim = 0, p = 0; real dist = 0, incl = 0;
@@ -121,7 +120,6 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       w.efc_mu()[r] = mu;
     }
   }
-  PROF(43);
   // ---- contact Jacobians, one lane per (contact, side, chain slot): 40 entries per contact, 64 per pass.  Every entry needs
   // ONE dependent pair of gathers (chain slot -> dof, dof -> motion axis) and writes its <= 3 rows; with lane == contact the same
   // work was 8 rounds of 30 gathers + 15 stores per lane, each round queued behind the stores of the previous one.
@@ -156,7 +154,6 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       }
     }
   }
-  PROF(44);
   if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
   SYNC();
   for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D()[r] = (real)1 / w.efc_R()[r];

@@ -98,7 +98,6 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     if (b >= 0) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
   }
   SYNC();
-  PROF(45);
   // body accelerations (chain walk, now including qacc) and body forces
   for (int ps = 0; ps < npass; ps++) {
     const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
@@ -117,7 +116,6 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k] - w.cfrc_ext()[6*b + k];
   }
   SYNC();
-  PROF(46);
   if (lane == 0) {
     int s = M.site_thorax, b = M.site_bodyid[s];
     const real* ca = w.cacc() + 6*b;

@@ -25,7 +25,7 @@ torch.cuda.synchronize(); dt = time.time() - t0
 p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
 # (sub-buckets 16-27 are parts of factor / pgs / kin / coll / acc and overlap their parents; 'cfin' spans the whole constraint stage)
 names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish(stores)', 'f_setup', 'f_sync', 'f_tail', 'sol_fwd', 'sol_bwd', 'f_pull', 'f_gen_diag', 'small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated',
-         'nw_setup', 'nw_residual', 'nw_kbuild', 'nw_chol', 'nw_backsub', 'nw_direction', 'nw_linesearch', 'nw_iterations(count)', 'nw_ls_evals(count)', 'nw_solves(count)', 'mk_limits', 'mk_rows', 'mk_jac', 'sa_cfrc_ext', 'sa_cacc_cfrc', '-']
+         'nw_setup', 'nw_residual', 'nw_kbuild', 'nw_chol', 'nw_backsub', 'nw_direction', 'nw_linesearch', 'nw_iterations(count)', 'nw_ls_evals(count)', 'nw_solves(count)', 'co_stage_spheres', 'co_mid_phase', 'co_box_filter', 'co_narrow', 'co_write', '-']
 tot = p[:, names.index('TOTAL_clock64')].mean()          # denominator: the wave's own clock64 lifetime (col 28 holds a start tick, not a duration)
 print(f'precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step (profiling build); wave lifetime {tot/K:.0f} cycles per env-step; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
 for i, nm in enumerate(names):
