@@ -264,3 +264,17 @@ def test_flight_episode_matches_oracle(emu_lib):
     from test_gpu_parity import flight_rollout_vs_oracle
     t = flight_rollout_vs_oracle(emu_lib, 4, 200, {50: 1e-6, 150: 1e-4, 200: 1e-4}, on_gpu=False)
     assert ((t == 2).sum(axis=0) >= 1).all()
+
+
+def test_warn_flags(emu_lib, walk_arrays):
+    """FB_WARN / FB_WARN_EVER (include/flybody_engine.h): zero in a normal forward pass; a model whose solver is cut off after one
+    iteration raises FB_WARN_SOLVER_MAXITER in the environments that have constraints; a reset clears the accumulated mask."""
+    from flybody_amd import engine
+    rng = np.random.default_rng(2)
+    q, v = random_state(walk_arrays, rng, z=0.128)
+    for iters, expect in ((100, 0), (1, engine.WARN_BITS['SOLVER_MAXITER'])):
+        a = dict(walk_arrays); a['opt_iterations'] = np.array(iters, np.int32)
+        B = engine.Batch(engine.Model(a, lib_path=emu_lib), 2, precision=64)
+        B.set('QPOS', q); B.set('QVEL', v); B.forward()
+        assert int(B.get('NEFC')[0, 0]) > 0
+        assert B.get('WARN').ravel().tolist() == [expect, expect] and B.get('WARN_EVER').ravel().tolist() == [expect, expect], iters
