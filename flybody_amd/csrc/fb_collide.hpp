@@ -25,11 +25,11 @@ FBD void support(const CGeom<real>& g, const real* dir, real* out) {
     real s[3] = {g.size[0]*l[0], g.size[1]*l[1], g.size[2]*l[2]};
     real n = norm3(s);
     if (n < FB_MINV) { p[0] = g.size[0]; p[1] = 0; p[2] = 0; }
-    else { p[0] = g.size[0]*s[0]/n; p[1] = g.size[1]*s[1]/n; p[2] = g.size[2]*s[2]/n; }
+    else { real ni = fb_inv(n); p[0] = g.size[0]*s[0]*ni; p[1] = g.size[1]*s[1]*ni; p[2] = g.size[2]*s[2]*ni; }
   } else if (g.type == GEOM_CYLINDER) {
-    real n = sqrt(l[0]*l[0] + l[1]*l[1]);
+    real n = fb_sqrt(l[0]*l[0] + l[1]*l[1]);
     if (n < FB_MINV) { p[0] = 0; p[1] = 0; }
-    else { p[0] = g.size[0]*l[0]/n; p[1] = g.size[0]*l[1]/n; }
+    else { real ni = fb_inv(n); p[0] = g.size[0]*l[0]*ni; p[1] = g.size[0]*l[1]*ni; }
     p[2] = (l[2] >= 0 ? g.size[1] : -g.size[1]);
   } else { p[0] = p[1] = p[2] = 0; }
   addscl3(p, l, (real)0.5*g.margin);
@@ -169,7 +169,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
       if (it > MPR_ITER && !reach_tol(p, v4, d)) *hit_cap = 1;
       real wit[3];
       real d2 = origin_tri_dist2(p[1].v, p[2].v, p[3].v, wit);
-      *depth = sqrt(d2);
+      *depth = fb_sqrt(d2);
       if (*depth < MPR_EPS) copy3(dir, d); else { copy3(dir, wit); normalize3(dir); }
       find_pos(p, pos);
       return true;

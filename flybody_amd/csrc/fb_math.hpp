@@ -41,6 +41,54 @@
 #endif
 #define FB_MINV ((real)1e-15)
 
+// division on solver hot paths: exact in FP64 (bit-faithful to the oracle), v_rcp_f32 (1 ulp) in FP32
+// FP64: IEEE division costs ~25 dependent instructions (v_div_scale x2, v_rcp_f64, 5 FMAs, v_div_fmas, v_div_fixup) in the
+// middle of the solver's serial chain.  Unless FB_EXACT_DIV64 is defined the quotient is v_rcp_f64 + two Newton steps + one residual
+// correction (<= 1 ulp for the normal-range operands the solver produces, no denormal / overflow handling).
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+FBD double fb_div(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  double q = a*r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+#else
+FBD double fb_div(double a, double b) { return a / b; }
+#endif
+#ifdef FB_EMULATE
+FBD float fb_div(float a, float b) { return a / b; }
+#else
+FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+FBD double fb_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
+  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
+  return y;
+}
+#else
+FBD double fb_rsqrt(double a) { return 1.0 / sqrt(a); }
+#endif
+#ifdef FB_EMULATE
+FBD float fb_rsqrt(float a) { return 1.0f / sqrtf(a); }
+#else
+FBD float fb_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
+#endif
+// sqrt / reciprocal on the same footing: v_rsq_f64 / v_rcp_f64 + Newton steps (<= 1 ulp) instead of the IEEE sequences (~30 dependent
+// instructions each) -- used by the vector normalisations and the iterative collision query, which sit on serial chains.
+// The host emulation and FB_EXACT_DIV64 builds keep the exact operations.
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+FBD double fb_sqrt(double a) { return a > 0 ? a*fb_rsqrt(a) : 0.0; }
+FBD float fb_sqrt(float a) { return a > 0 ? a*fb_rsqrt(a) : 0.0f; }
+#else
+FBD double fb_sqrt(double a) { return sqrt(a); }
+FBD float fb_sqrt(float a) { return sqrtf(a); }
+#endif
+FBD double fb_inv(double a) { return fb_div(1.0, a); }
+FBD float fb_inv(float a) { return fb_div(1.0f, a); }
+
 template <typename real> FBD real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 template <typename real> FBD void cross3(real* r, const real* a, const real* b) {
   real x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
@@ -51,11 +99,11 @@ template <typename real> FBD void sub3(real* r, const real* a, const real* b) { 
 template <typename real> FBD void add3(real* r, const real* a, const real* b) { r[0] = a[0]+b[0]; r[1] = a[1]+b[1]; r[2] = a[2]+b[2]; }
 template <typename real> FBD void scl3(real* r, const real* a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
 template <typename real> FBD void addscl3(real* r, const real* a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
-template <typename real> FBD real norm3(const real* a) { return sqrt(dot3(a, a)); }
+template <typename real> FBD real norm3(const real* a) { return fb_sqrt(dot3(a, a)); }
 template <typename real> FBD real normalize3(real* a) {
   real n = norm3(a);
   if (n < FB_MINV) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
-  real inv = (real)1 / n;
+  real inv = fb_inv(n);
   a[0] *= inv; a[1] *= inv; a[2] *= inv;
   return n;
 }
@@ -82,9 +130,9 @@ template <typename real> FBD void mulquat(real* r, const real* a, const real* b)
   r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
 template <typename real> FBD void normquat(real* q) {
-  real n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  real n = fb_sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
   if (n < FB_MINV) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
-  else { real inv = (real)1 / n; q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv; }
+  else { real inv = fb_inv(n); q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv; }
 }
 template <typename real> FBD void quat2mat(real* m, const real* q) {
   real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
@@ -136,41 +184,6 @@ template <typename real> FBD void makeframe(real* f) {
   normalize3(y);
   cross3(z, x, y);
 }
-// division on solver hot paths: exact in FP64 (bit-faithful to the oracle), v_rcp_f32 (1 ulp) in FP32
-// FP64: IEEE division costs ~25 dependent instructions (v_div_scale x2, v_rcp_f64, 5 FMAs, v_div_fmas, v_div_fixup) in the
-// middle of the solver's serial chain.  Unless FB_EXACT_DIV64 is defined the quotient is v_rcp_f64 + two Newton steps + one residual
-// correction (<= 1 ulp for the normal-range operands the solver produces, no denormal / overflow handling).
-#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
-FBD double fb_div(double a, double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  double q = a*r;
-  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
-}
-#else
-FBD double fb_div(double a, double b) { return a / b; }
-#endif
-#ifdef FB_EMULATE
-FBD float fb_div(float a, float b) { return a / b; }
-#else
-FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-#endif
-#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
-FBD double fb_rsqrt(double a) {
-  double y = __builtin_amdgcn_rsq(a);
-  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
-  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
-  return y;
-}
-#else
-FBD double fb_rsqrt(double a) { return 1.0 / sqrt(a); }
-#endif
-#ifdef FB_EMULATE
-FBD float fb_rsqrt(float a) { return 1.0f / sqrtf(a); }
-#else
-FBD float fb_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
-#endif
 template <typename real> FBD real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // hide a register value from loop-invariant code motion: values derived from it are recomputed where they are

@@ -52,7 +52,7 @@ template <typename real>
 FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<real>& o) {
   const real jo = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
   const real U0 = jb0*c.s0, U1 = jb1*c.s1, U2 = jb2*c.s2;
-  const real N = U0, T = sqrt(U1*U1 + U2*U2);
+  const real N = U0, T = fb_sqrt(U1*U1 + U2*U2);
   const bool top = (N >= c.mu*T) || (T <= 0 && N >= 0);
   const bool bot = !top && ((c.mu*N + T <= 0) || (T <= 0 && N < 0));
   const bool mid = c.ell && !top && !bot;
@@ -65,7 +65,7 @@ FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<r
   o.f = quad ? -c.D*jo : (mid ? fm : (real)0);
   o.cost = quad ? (real)0.5*c.D*jo*jo : ((mid && c.k == 0) ? (real)0.5*c.Dm*NT*NT : (real)0);
   // cone Hessian in the scaled coordinates: Dm (e_n - mu t)(e_n - mu t)' + Dm mu (mu - N/T) t_perp t_perp'
-  const real g2 = mid ? sqrt(c.Dm*c.mu*(c.mu - N*Ti)) : (real)0;
+  const real g2 = mid ? fb_sqrt(c.Dm*c.mu*(c.mu - N*Ti)) : (real)0;
   const real a0 = c.g1*c.s0, a1 = -c.g1*c.mu*t1*c.s1, a2 = -c.g1*c.mu*t2*c.s2;       // column 0 of the block factor
   const real b1 = -g2*t2*c.s1, b2 = g2*t1*c.s2;                                          // column 1 (its first entry is 0); column 2 is zero
   const real qd = quad ? c.sqD : (real)0;

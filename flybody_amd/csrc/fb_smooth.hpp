@@ -455,7 +455,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) FB_OPAQUE(fd[q]);
     // publish the rows of level d (unnormalised) and 1/D
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = (real)1/accd[q]; RM[FW_BASE(fd[q]) + Td] = di; }
+    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; }
     // the chain slots are sorted by depth and dealt to the lanes (fb_engine.hip), so the slots that publish / pull on this level
     // form one narrow band, the same for every lane: everything outside it is skipped by a wave-uniform test
     const int band = uniform_int(M.fac_band[d]);
@@ -583,7 +583,7 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
 #pragma unroll
   for (int k = FB_MAXTRUNK - 1; k >= 0; k--) {
     if (k < nT) {
-      real Dk = S[k*(k + 1)/2 + k], Di = (real)1/Dk;
+      real Dk = S[k*(k + 1)/2 + k], Di = fb_inv(Dk);
       if (lane == 0) RM[k*(k + 1)/2] = Di;
 #pragma unroll
       for (int a = 0; a < k; a++) {
