@@ -26,6 +26,7 @@ FBD real get_impedance(const real* si, real pos, real margin) {
   if (x <= 0) return s0;
   real y;
   if (s4 == 1) y = x;
+  else if (s4 == 2) y = (x <= s3) ? x*x/s3 : 1 - (1 - x)*(1 - x)/(1 - s3);      // MuJoCo's default power (the fruit fly's solimp): no pow() -- ~200 instructions per call
   else if (x <= s3) y = pow(x, s4) / pow(s3, s4 - 1);
   else y = 1 - pow(1 - x, s4) / pow(1 - s3, s4 - 1);
   return s0 + y*(s1 - s0);

@@ -90,6 +90,7 @@ static void get_impedance(const double* solimp_in, double pos, double margin, do
   if (x <= 0) { *imp = s[0]; return; }
   double y;
   if (s[4] == 1) y = x;
+  else if (s[4] == 2) y = (x <= s[3]) ? x*x/s[3] : 1 - (1 - x)*(1 - x)/(1 - s[3]);      /* default power: same value as pow(x, 2), spelled like the kernel */
   else if (x <= s[3]) y = pow(x, s[4]) / pow(s[3], s[4] - 1);
   else y = 1 - pow(1 - x, s[4]) / pow(1 - s[3], s[4] - 1);
   *imp = s[0] + y*(s[1] - s[0]);
