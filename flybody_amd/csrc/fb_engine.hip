@@ -40,7 +40,7 @@ struct fb_model {
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w, fac_band; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
-  std::vector<int> body_fluid_geom, sens_body;
+  std::vector<int> body_fluid_geom, sens_body, dof_jump, dof_vbef, body_veldof;
   double totalmass;
   // A missing or ill-typed array is an error of the caller's blob, never a reason to take the process down: the accessors
   // throw, every extern "C" entry point that reads the model catches and returns -1 with the message in fb_last_error().
@@ -400,6 +400,26 @@ static int model_load_impl(fb_model* m, size_t n) {
     m->body_box[3*b+1] = sqrt(fmax(1e-15, I[0] + I[2] - I[1]) / mass[b] * 6.0);
     m->body_box[3*b+2] = sqrt(fmax(1e-15, I[0] + I[1] - I[2]) / mass[b] * 6.0);
   }
+  // tree prefix sums over the dofs (body velocities, bias accelerations): ancestors at distance 2^k, the dof whose inclusive
+  // velocity prefix is the velocity "before" a dof (mj_comVel: the parent body's velocity plus the earlier dofs of the same body;
+  // a free joint's rotational axes see its three translations, a ball joint none of its own dofs), the last dof of a body's chain
+  {
+    if (FB_MAXCH > (1 << FB_NJUMP) || nv > 2*FB_WAVE) return fail("fb_model_load: dof tree too deep / too wide for the prefix tables");
+    m->dof_jump.assign((size_t)FB_NJUMP*nv, -1);
+    for (int i = 0; i < nv; i++) m->dof_jump[i] = dofpar[i];
+    for (int k = 1; k < FB_NJUMP; k++)
+      for (int i = 0; i < nv; i++) { int a = m->dof_jump[(size_t)(k - 1)*nv + i]; m->dof_jump[(size_t)k*nv + i] = a >= 0 ? m->dof_jump[(size_t)(k - 1)*nv + a] : -1; }
+    const int *djnt = m->i("dof_jntid"), *jt = m->i("jnt_type"), *jda = m->i("jnt_dofadr");
+    m->dof_vbef.assign(nv, -1);
+    for (int i = 0; i < nv; i++) {
+      int j = djnt[i];
+      if (jt[j] == JNT_FREE) m->dof_vbef[i] = (i - jda[j] < 3) ? -2 : jda[j] + 2;
+      else if (jt[j] == JNT_BALL) m->dof_vbef[i] = dofpar[jda[j]];
+      else m->dof_vbef[i] = dofpar[i];
+    }
+    m->body_veldof.assign(nb, -1);
+    for (int b = 1; b < nb; b++) if (m->body_chlen[b] > 0) m->body_veldof[b] = m->body_chain[(size_t)b*FB_MAXCH + m->body_chlen[b] - 1];
+  }
   // bodies whose acceleration / force the sensors need: the accelerometer's body and the subtrees below the force-sensor bodies
   {
     std::vector<char> need(nb, 0);
@@ -603,6 +623,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(jnt_type, "jnt_type") UI(jnt_qposadr, "jnt_qposadr") UI(jnt_dofadr, "jnt_dofadr") UI(jnt_bodyid, "jnt_bodyid") UI(jnt_limited, "jnt_limited")
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
+  UV(dof_jump, dof_jump) UV(dof_vbef, dof_vbef) UV(body_veldof, body_veldof)
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }

@@ -697,37 +697,77 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
 
 // ------------------------------------------------------------------ velocity stage
 // cvel per body and cdof_dot per dof by walking the owning chain (no tree-level barriers)
+// ---- tree prefix sums over the dofs, in registers
+// A body's spatial velocity is the sum of cdof_i qvel_i over the dofs of its root->body chain; the bias acceleration is the same
+// sum of cdof_dot_i qvel_i, the sensor stage's acceleration adds cdof_i qacc_i.  Rounds 1-2 walked every body's chain (one lane per
+// body: load the chain, 5 rounds of 28 gathers, for two passes of the wave) three times per substep.  Here lane l holds dofs l and
+// l + 64 and the inclusive prefix V_i = sum over ancestors-or-self is formed by POINTER JUMPING: in round k every dof adds the
+// value its 2^k-th ancestor held before the round (ds_bpermute from that dof's lane), 5 rounds for chains of up to 32 dofs -- no
+// memory traffic, no chain tables.  (The additions associate pairwise instead of root-to-leaf: rounding-level differences only.)
+template <typename real> struct DofPair { real a[6], b[6]; };         // a: dof `lane`, b: dof `lane + 64`
+
+// value of dof d (lane d & 63, slot d >> 6) for every lane's own d; d < 0 gives 0.  A wave collective: every lane calls it.
+template <typename real>
+FBD void dof_fetch6(const DofPair<real>& x, int d, real* out) {
+  const int src = d & 63;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const real va = __shfl(x.a[c], src, 64), vb = __shfl(x.b[c], src, 64);
+    out[c] = d < 0 ? (real)0 : ((d >> 6) ? vb : va);
+  }
+}
+template <typename real>
+FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
+  const int nv = M.nv;
+  int ja[FB_NJUMP], jb[FB_NJUMP];
+#pragma unroll
+  for (int k = 0; k < FB_NJUMP; k++) { ja[k] = lane < nv ? M.dof_jump[k*nv + lane] : -1; jb[k] = lane + FB_WAVE < nv ? M.dof_jump[k*nv + lane + FB_WAVE] : -1; }
+#pragma unroll
+  for (int k = 0; k < FB_NJUMP; k++) {
+    real ga[6], gb[6];
+    dof_fetch6(x, ja[k], ga); dof_fetch6(x, jb[k], gb);
+#pragma unroll
+    for (int c = 0; c < 6; c++) { x.a[c] += ga[c]; x.b[c] += gb[c]; }
+  }
+}
+
+// cvel, cdof_dot and the bias acceleration sum of every body (cabias, without gravity)
 template <typename real>
 __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real v[6] = {0, 0, 0, 0, 0, 0};
-    int n = M.body_chlen[b];
-    int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6<4>(ch, n, M.chmax, w.cdof(), w.qvel(), v);
-    for (int k = 0; k < 6; k++) w.cvel()[6*b + k] = v[k];
-  }
-  SYNC();
-  // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i: the parent body's velocity plus the earlier dofs of the
-  // same body (free joint: its rotational axes see the three translational dofs; ball joint: none of its own dofs)
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    int j = M.dof_jntid[i], b = M.dof_bodyid[i];
-    real* cd = w.cdof_dot() + 6*i;
-    int first = M.body_dofadr[b], nsame;
-    if (M.jnt_type[j] == JNT_FREE) {
-      int k = i - M.jnt_dofadr[j];
-      if (k < 3) { for (int q = 0; q < 6; q++) cd[q] = 0; continue; }
-      nsame = M.jnt_dofadr[j] + 3 - first;
-    } else if (M.jnt_type[j] == JNT_BALL) nsame = M.jnt_dofadr[j] - first;
-    else nsame = i - first;
+  const int nv = M.nv;
+  const int ia = lane, ib = lane + FB_WAVE;
+  const bool ha = ia < nv, hb = ib < nv;
+  real ca[6], cb[6];
+  const real qa = ha ? w.qvel()[ia] : (real)0, qb = hb ? w.qvel()[ib] : (real)0;
+  DofPair<real> V;
+#pragma unroll
+  for (int c = 0; c < 6; c++) { ca[c] = ha ? w.cdof()[6*ia + c] : (real)0; cb[c] = hb ? w.cdof()[6*ib + c] : (real)0; V.a[c] = ca[c]*qa; V.b[c] = cb[c]*qb; }
+  tree_prefix6(M, V, lane);
+  // body velocities: the prefix of the last dof on the body's chain
+  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
+    const int b = b0 + lane;
     real v[6];
-    const real* pv = w.cvel() + 6*M.body_parent[b];
-    for (int k = 0; k < 6; k++) v[k] = pv[k];
-    for (int s = 0; s < nsame; s++) {                 // at most 5 (free joint), usually 0..2
-      real qv = w.qvel()[first + s];
-      const real* c = w.cdof() + 6*(first + s);
-      for (int k = 0; k < 6; k++) v[k] += c[k]*qv;
-    }
-    crossmotion(cd, v, w.cdof() + 6*i);
+    dof_fetch6(V, b < M.nbody ? M.body_veldof[b] : -1, v);
+    if (b < M.nbody) for (int c = 0; c < 6; c++) w.cvel()[6*b + c] = v[c];
+  }
+  // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i (dof_vbef, fb_engine.hip)
+  DofPair<real> A;
+  {
+    const int va = ha ? M.dof_vbef[ia] : -1, vb = hb ? M.dof_vbef[ib] : -1;
+    real ua[6], ub[6], da[6], db[6];
+    dof_fetch6(V, va, ua); dof_fetch6(V, vb, ub);
+    crossmotion(da, ua, ca); crossmotion(db, ub, cb);
+#pragma unroll
+    for (int c = 0; c < 6; c++) { da[c] = (va == -2) ? (real)0 : da[c]; db[c] = (vb == -2) ? (real)0 : db[c]; A.a[c] = da[c]*qa; A.b[c] = db[c]*qb; }
+    if (ha) for (int c = 0; c < 6; c++) w.cdof_dot()[6*ia + c] = da[c];
+    if (hb) for (int c = 0; c < 6; c++) w.cdof_dot()[6*ib + c] = db[c];
+  }
+  tree_prefix6(M, A, lane);
+  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
+    const int b = b0 + lane;
+    real v[6];
+    dof_fetch6(A, b < M.nbody ? M.body_veldof[b] : -1, v);
+    if (b < M.nbody) for (int c = 0; c < 6; c++) w.cabias()[6*b + c] = v[c];
   }
   SYNC();
 }
@@ -862,9 +902,7 @@ __device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<rea
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
     real* out = w.cfrc() + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
-    int n = M.body_chlen[b];
-    int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6<4>(ch, n, M.chmax, w.cdof_dot(), w.qvel(), a);
+    for (int k = 0; k < 6; k++) a[k] += w.cabias()[6*b + k];            // sum of cdof_dot qvel along the body's chain (d_com_vel)
     real t[6], t1[6], t2[6];
     mulinertvec(t, w.cinert() + 10*b, a);
     mulinertvec(t1, w.cinert() + 10*b, w.cvel() + 6*b);

@@ -98,16 +98,26 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     if (b >= 0) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
   }
   SYNC();
-  // body accelerations (chain walk, now including qacc) and body forces
+  // body accelerations: -g + sum of cdof_dot qvel along the chain (cabias, from the velocity stage) + sum of cdof qacc (tree
+  // prefix over the dofs in registers, fb_smooth.hpp), and body forces
+  DofPair<real> Q;
+  {
+    const int ia = lane, ib = lane + FB_WAVE;
+    const bool ha = ia < M.nv, hb = ib < M.nv;
+    const real qa = ha ? w.qacc()[ia] : (real)0, qb = hb ? w.qacc()[ib] : (real)0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) { Q.a[c] = ha ? w.cdof()[6*ia + c]*qa : (real)0; Q.b[c] = hb ? w.cdof()[6*ib + c]*qb : (real)0; }
+    tree_prefix6(M, Q, lane);
+  }
   for (int ps = 0; ps < npass; ps++) {
     const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
+    real qsum[6];
+    dof_fetch6(Q, b >= 0 ? M.body_veldof[b] : -1, qsum);               // (wave collective: before any lane leaves the iteration)
     if (b < 0) continue;
     real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
     real* out = w.cfrc() + 6*b;
     if (b == 0) { for (int k = 0; k < 6; k++) { out[k] = 0; w.cacc()[k] = a[k]; } continue; }
-    int n = M.body_chlen[b];
-    int ch[FB_MAXCH]; load_chain(M, b, ch);
-    chain_axpy6x2<2>(ch, n, M.chmax, w.cdof_dot(), w.qvel(), w.cdof(), w.qacc(), a);
+    for (int k = 0; k < 6; k++) a[k] += w.cabias()[6*b + k] + qsum[k];
     for (int k = 0; k < 6; k++) w.cacc()[6*b + k] = a[k];
     real t[6], t1[6], t2[6];
     mulinertvec(t, w.cinert() + 10*b, a);

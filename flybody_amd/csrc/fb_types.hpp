@@ -30,6 +30,7 @@
 #define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)
 #define FB_MAXNV 112
+#define FB_NJUMP 5           // pointer-jumping rounds: 2^5 >= FB_MAXCH
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_HINGE = 3 };
 enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5 };
@@ -84,7 +85,7 @@ template <typename T> struct GP {
   X(efc_B, FB_MAXEFC_) X(efc_imp, FB_MAXEFC_) X(efc_aref, FB_MAXEFC_) X(efc_b, FB_MAXEFC_) X(efc_force, FB_MAXEFC_) \
   X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) \
   X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2) /* packed lower triangle, only written for systems that do not fit the LDS copy */ \
-  X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody)
+  X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody)
 
 #define FB_WS_INT(X) \
   X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
@@ -135,6 +136,9 @@ struct DevModel {
   GP<const int> pair_word;   // [npair] geom1 | geom2 << 10 | (slot of the plane normal in the LDS staging area, 0: no plane) << 20
   GP<const int> plane_geoms; int nplane;   // geoms of type plane (their normals are staged behind the bounding spheres)
   GP<const int> obs_jnt, app_sites, force_sites, touch_sites, wing_jnt;
+  GP<const int> dof_jump;       // [FB_NJUMP][nv] the 2^k-th ancestor of a dof (-1: none): tree prefix sums by pointer jumping (fb_smooth.hpp)
+  GP<const int> dof_vbef;       // [nv] dof whose inclusive velocity prefix is the velocity "before" this dof (-1: zero, -2: cdof_dot is zero)
+  GP<const int> body_veldof;    // [nbody] last dof on the body's chain (-1: none)
   GP<const int> sens_body; int nsensbody;     // bodies the acceleration-stage sensors read (0: more than 64, all bodies are processed)
   // constants
   GP<const real> body_mass, body_inertia, body_invweight0, body_box;
