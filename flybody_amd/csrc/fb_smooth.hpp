@@ -23,6 +23,15 @@
 #else
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+// LDS-only variant: orders this wave's LDS traffic (a wave's LDS instructions execute in order; the wait drains them) and stops the
+// compiler from moving memory operations across it, WITHOUT waiting for outstanding global stores.  For loops whose iterations
+// communicate through LDS only while they also stream results to the global row (the kinematics level loop): SYNC()'s fence waits
+// for the store acknowledgements of every level (~1-2 k cycles each).
+#ifdef FB_EMULATE
+#define SYNC_LDS() __syncthreads()
+#else
+#define SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 // optional per-phase cycle accounting (build with -DFB_PROFILE): lane 0 accumulates s_memtime deltas
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
 #define PROF_BEGIN() long long prof_t_ = clock64()
@@ -171,13 +180,19 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
       mulquat(qi, quat, R + 14);
       quat2mat(w.ximat() + 9*b, qi);
     }
-    SYNC();
+    SYNC_LDS();                      // the next level reads the frames from LDS; the global copies are read after the pass
   }
 }
 
 template <typename real>
 __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<real>& w, int lane) {
   PROF_BEGIN();
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  long long kp_[4] = {0, 0, 0, 0}, kt_ = clock64();
+#define K_PROF(k) do { long long n_ = clock64(); kp_[k] += n_ - kt_; kt_ = n_; } while (0)
+#else
+#define K_PROF(k) do {} while (0)
+#endif
   FB_LDS real* S = w.lLD;                       // body frames: 7*nbody
   FB_LDS real* JQ = w.lLD + 7*M.nbody;          // joint rotations: 4*njnt
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
@@ -195,10 +210,12 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
     for (int k = 0; k < 9; k++) { real v = (k % 4 == 0) ? (real)1 : (real)0; w.xmat()[k] = v; w.ximat()[k] = v; }
   }
   SYNC();
+  K_PROF(0);
   fk_pass(M, w, S, JQ, lane, 1, M.fk_dmax, lane);
   if (M.nbody > FB_WAVE) fk_pass(M, w, S, JQ, lane + FB_WAVE, M.fk2_dlo, M.fk_dmax, lane);
   PROF(25);
   SYNC();
+  K_PROF(1);
   // geoms and sites hang off their body frames
   for (int g = lane; g < M.ngeom; g += FB_WAVE) {
     int b = M.geom_bodyid[g];
@@ -217,12 +234,17 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
     quat2mat(w.sxmat() + 9*s, q);
   }
   PROF(26);
+  K_PROF(2);
   // centre of mass of the (single) kinematic tree
   real c[3] = {0, 0, 0};
   for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos() + 3*b, M.body_mass[b]);
   c[0] = wave_sum(c[0]); c[1] = wave_sum(c[1]); c[2] = wave_sum(c[2]);
   if (lane == 0) { real inv = (real)1 / M.totalmass; w.com()[0] = c[0]*inv; w.com()[1] = c[1]*inv; w.com()[2] = c[2]*inv; }
   SYNC();
+  K_PROF(3);
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 4; k_++) pp_[48 + k_] += kp_[k_]; }
+#endif
 }
 
 // ------------------------------------------------------------------ cinert, cdof, tendons

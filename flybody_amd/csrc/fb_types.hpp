@@ -25,7 +25,7 @@
 #define FB_MAXCON_ 64
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
-#define FB_NPROF 48
+#define FB_NPROF 56
 #define FB_NSCHED 64          // progress counters of one launch (one per substep)
 #define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
 #define FB_MAXNM 1280      // LDS capacity for the sparse mass-matrix factor (fruit fly: 1213)

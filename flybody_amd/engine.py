@@ -229,7 +229,7 @@ class Batch:
                     DISCOUNT=1, STEP_TYPE=1, NCON=1, NEFC=1, SOLVER_NITER=1, QFRC_BIAS=m.dim('nv'),
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
-                    SUBTREE_COM=3, PROF=96, REWARD_FACTORS=5, GEOM_XPOS=3*m.dim('ngeom'),
+                    SUBTREE_COM=3, PROF=112, REWARD_FACTORS=5, GEOM_XPOS=3*m.dim('ngeom'),
                     GEOM_XMAT=9*m.dim('ngeom'), CVEL=6*m.dim('nbody'), STEP_TICKS=1, LAUNCH_ORDER=1, WARN=1, WARN_EVER=1)[name]
 
     def get(self, name: str) -> np.ndarray:

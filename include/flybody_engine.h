@@ -61,7 +61,7 @@ enum {
   FB_LAUNCH_ORDER = 31, /* [n_env] int32: environment ids in the order the next full-batch step launches them
                            (longest last step first; scheduling only, results do not depend on it) */
   FB_REWARD_FACTORS = 26, /* [n_env][5] training-mode reward factors (com, qvel, root2site, joint_quat, wings) */
-  FB_PROF = 25,       /* [n_env][96] int32 = 48 int64 per-phase cycle counters (profiling builds) */
+  FB_PROF = 25,       /* [n_env][112] int32 = 56 int64 per-phase cycle counters (profiling builds) */
   FB_WARN = 32,       /* [n_env] int32: FB_WARN_* bits raised during the last launch (cleared when a control step / reset starts).
                          Mirrors MuJoCo's nconmax / njmax warnings (fruitfly.xml:6) and adds the iteration limits. */
   FB_WARN_EVER = 33,  /* [n_env] int32: the same bits accumulated since the environment's last reset */

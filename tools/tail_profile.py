@@ -24,7 +24,7 @@ def list_schedule(durations, order, slots):
 slots = 2048 if prec == 64 else 4096
 prev = None
 for rep in range(4):
-    B.set('PROF', np.zeros(96, np.int32))
+    B.set('PROF', np.zeros(112, np.int32))
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     p = B.get('PROF').view(np.int64).astype(np.float64)
