@@ -627,6 +627,19 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
+  {
+    // kinematics level loop: bodies beyond the wavefront width ride along on lanes whose own body sits on a
+    // different level, so one trip down the levels covers every body (fb_smooth.hpp fk_pass)
+    std::vector<int> second(FB_WAVE, -1);
+    bool ok = m->nbody > FB_WAVE && m->nbody <= 2*FB_WAVE;
+    for (int bq = FB_WAVE; ok && bq < m->nbody; bq++) {
+      int pick = -1;
+      for (int l = 0; l < FB_WAVE && pick < 0; l++) if (second[l] < 0 && (l == 0 || m->body_depth[l] != m->body_depth[bq])) pick = l;
+      if (pick < 0) ok = false; else second[pick] = bq;
+    }
+    M.fk_second = nullptr;
+    if (ok && upload_i(b, second.data(), second.size(), &M.fk_second)) return -1;
+  }
   UI(wing_act_idx, "wing_action_idx")
   // leg joints (optional array: models compiled before the flight-with-legs variant do not carry it)
   if (m->has("leg_joints", 1)) { UI(leg_jnt, "leg_joints") M.nlegjnt = (int)c; for (size_t k = 0; k < c; k++) if (m->i("leg_joints")[k] < 0 || m->i("leg_joints")[k] >= m->njnt) return fail("fb_batch_create: leg_joints out of range"); }

@@ -121,11 +121,15 @@ FBD void chain_axpy6x2(const int* ch, int n, int nmax, const real* X1, const rea
 // LDS, which takes the trigonometry off the serial level chain.  The scratch is the LDS row of the mass-matrix
 // factor, which is dead between the Euler solve and the next factorisation.
 template <typename real>
-FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, int b, int dlo, int dhi, int lane) {
-  bool has = b < M.nbody && b > 0;
-  int dep = has ? M.body_depth[has ? b : 0] : -1;
+FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, int b1, int b2, int dlo, int dhi, int lane) {
+  // a lane may own a second body (b2, on a different level than b1: fb_engine.hip pairs them) so that a model
+  // with a few bodies beyond the wavefront width still takes one trip down the levels
+  bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
+  int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
+  int dep2 = has2 ? M.body_depth[has2 ? b2 : 0] : -1;
   for (int d = dlo; d <= dhi; d++) {
-    if (dep == d) {
+    int b = (dep1 == d) ? b1 : b2;
+    if (dep1 == d || dep2 == d) {
       // one round of independent loads: the body's flattened record (fb_engine.hip) and the free-joint pose
       real R[37];
       const real* rec = M.body_rec + b*FB_BODYREC;
@@ -211,8 +215,11 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   }
   SYNC();
   K_PROF(0);
-  fk_pass(M, w, S, JQ, lane, 1, M.fk_dmax, lane);
-  if (M.nbody > FB_WAVE) fk_pass(M, w, S, JQ, lane + FB_WAVE, M.fk2_dlo, M.fk_dmax, lane);
+  if (M.fk_second) fk_pass(M, w, S, JQ, lane, M.fk_second[lane], 1, M.fk_dmax, lane);
+  else {
+    fk_pass(M, w, S, JQ, lane, -1, 1, M.fk_dmax, lane);
+    for (int b0 = FB_WAVE; b0 < M.nbody; b0 += FB_WAVE) fk_pass(M, w, S, JQ, lane + b0, -1, M.fk2_dlo, M.fk_dmax, lane);
+  }
   PROF(25);
   SYNC();
   K_PROF(1);

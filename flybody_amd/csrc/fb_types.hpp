@@ -124,6 +124,7 @@ struct DevModel {
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
   int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
+  const int* fk_second;      // [64] second body of each lane in the kinematics level loop (-1 = none); null = separate passes
   GP<const int> geom_type, geom_bodyid, site_bodyid, site_type;
   GP<const int> tendon_adr, tendon_num;
   GP<const int> act_trntype, act_trnid, act_dyntype, act_biastype, act_ctrllimited, act_forcelimited, act_actadr;
