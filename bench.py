@@ -102,6 +102,9 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
+    ap.add_argument('--preroll', type=int, default=220,
+                    help='untimed control steps before the warm-up: the episode is 235 steps (walk_imitation.py:104-105), so with the default the '
+                         'timed region crosses the auto-reset (LAST -> FIRST of every environment) even at --steps 20 --warmup 5')
     # The headline leg is the FP64 build: it reproduces the FP64 CPU oracle step for step (<= 2e-11 relative over 100 control
     # steps), i.e. it is inside north_star's 1e-4 tolerance for every environment.  The FP32 build (2.3x faster) drifts
     # chaotically like any single-precision MuJoCo (median environment inside 1e-4 after 100 physics steps, not every one);
@@ -186,8 +189,9 @@ def main():
             action.normal_(generator=gen).clamp_(-1.0, 1.0)
             batch.step_ptr(action.data_ptr(), stream)
 
-        for _ in range(args.warmup):
+        for _ in range(args.preroll + args.warmup):
             one_step()
+        sc0 = batch.get('STEP_COUNT').ravel().astype(np.int64)       # episode step of every environment entering the timed region
         barrier()
         batch.timing_begin(stream)
         t0 = time.perf_counter()
@@ -202,6 +206,9 @@ def main():
             dt = float(t.item())
         finite = bool(np.isfinite(batch.get('QPOS')).all())
         if extras is not None:
+            sc1 = batch.get('STEP_COUNT').ravel().astype(np.int64)
+            extras['auto_resets'] = {'envs_reset_inside_timed_region': int((sc1 < sc0 + args.steps).sum()),
+                                     'episode_step_entering': int(sc0[0]), 'episode_step_leaving': int(sc1[0])}
             wv = batch.get('WARN_EVER').ravel()
             extras['warn'] = {name: int(((wv & bit) != 0).sum()) for name, bit in engine.WARN_BITS.items()}
             extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
@@ -218,7 +225,7 @@ def main():
         action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
         ids_dev = torch.as_tensor(sample_ids, device='cuda')
         rec = []
-        for _ in range(args.warmup + args.steps):
+        for _ in range(args.preroll + args.warmup + args.steps):
             action.normal_(generator=gen).clamp_(-1.0, 1.0)
             rec.append(action[ids_dev].cpu().numpy())
         acts = np.ascontiguousarray(np.stack(rec, axis=1).astype(np.float64))            # [n_sample][steps][nu]
@@ -229,7 +236,7 @@ def main():
         rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
         eq = max(rel(extras['qpos'][i], envs[i].field('qpos')) for i in range(len(envs)))
         ev = max(rel(extras['qvel'][i], envs[i].field('qvel')) for i in range(len(envs)))
-        return {'n': len(envs), 'control_steps': args.warmup + args.steps, 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
+        return {'n': len(envs), 'control_steps': args.preroll + args.warmup + args.steps, 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
                 'tolerance': 1e-6, 'ok': bool(eq < 1e-6 and ev < 1e-6),
                 'note': 'FP64 kernel end state of sampled environments (both residency rounds) vs the FP64 CPU oracle replaying the same '
                         'action streams from the same reset; oracle vs CPU MuJoCo stays unpinned'}
@@ -368,7 +375,7 @@ def main():
         valu_tflops = ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12
         out = {
             'metric': 'env steps/sec (whole node), walk_imitation 4096-batch random-action rollout',
-            'value': value, 'unit': 'env steps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': value, 'unit': 'env steps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'preroll': args.preroll,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 32 else 'f64', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: 4096 batched walk_imitation envs per GPU, random-action rollout, '
@@ -376,7 +383,8 @@ def main():
                        'envs_per_gpu': n_env, 'global_envs': n_env * world, 'substeps_per_step': model.dim('nsubstep'),
                        'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite,
                        'solver': 'Newton (the reference XML sets no solver = MuJoCo default), constraint-space restatement; noslip 3',
-                       'solver_iterations_mean': extras.get('solver_iterations_mean')},
+                       'solver_iterations_mean': extras.get('solver_iterations_mean'),
+                       'auto_resets': extras.get('auto_resets')},
             # the binding roofline of this path is the vector ALU (neither HBM nor MFMA bounds it), so the primary
             # achieved/peak/frac are algorithmic FLOP/s against the vector peak of the arithmetic type; the HBM view the
             # contract also asks for (algorithmic bytes / launch time against 8 TB/s, and the PMC traffic) sits in `hbm`

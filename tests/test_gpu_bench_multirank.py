@@ -20,7 +20,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-           '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline', '--no-secondary-configs']
+           '--preroll', '231', '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline', '--no-secondary-configs']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -29,6 +29,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['dtype'] == 'f64'
     assert out['config']['global_envs'] == 512 and out['config']['state_finite']
     assert abs(out['value'] - 512*4/(out['ms_per_step']*4/1e3)) < 1e-6*out['value']       # whole-job aggregate over both ranks
+    # the untimed pre-roll put the auto-reset (episode = 235 control steps) INSIDE the 4 timed steps, and the replay of the sampled
+    # environments on the oracle crossed it too (the timed region used to end before the first reset)
+    ar = out['config']['auto_resets']
+    assert out['preroll'] == 231 and ar['envs_reset_inside_timed_region'] == 256 and ar['episode_step_entering'] == 233, ar
+    assert out['parity_sample']['ok'] and out['parity_sample']['control_steps'] == 237
 
 
 @pytest.mark.gpu
@@ -37,8 +42,8 @@ def test_bench_bare_gpus_flag_spawns_the_ranks():
     args.gpus used to be ignored).  On this one-GPU box both ranks share cuda:0 over gloo, exactly like the test above."""
     env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--envs-per-gpu', '256', '--no-f32-leg', '--no-secondary-configs',
-           '--no-cpu-baseline']
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--preroll', '0', '--envs-per-gpu', '256', '--no-f32-leg',
+           '--no-secondary-configs', '--no-cpu-baseline']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -57,7 +62,7 @@ def test_rccl_dry_run_reports_unexercised_on_one_gpu():
     box the two ranks share the device over gloo and the JSON line says that RCCL was not exercised."""
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FB_BENCH_DEVICE', 'FB_BENCH_BACKEND')}
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rccl-dry-run', '--steps', '3', '--warmup', '1', '--envs-per-gpu', '256',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rccl-dry-run', '--steps', '3', '--warmup', '1', '--preroll', '0', '--envs-per-gpu', '256',
            '--no-f32-leg', '--no-split-leg', '--no-cpu-baseline', '--no-secondary-configs']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
