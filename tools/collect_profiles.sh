@@ -12,14 +12,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
 # wait split: in-flight instruction levels per memory class -- LEVEL / count = mean latency of that class in
 # cycles; LEVEL / WAVE_CYCLES = mean number of outstanding instructions of the class per wave-cycle
-rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq3 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq4 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq3 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq4 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
 import csv, json, sys, os, collections
 out, tag = sys.argv[1], sys.argv[2]

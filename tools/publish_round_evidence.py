@@ -48,7 +48,7 @@ open(f'{dst}/phase_cycles.txt', 'w').write(
     '# cfin spans the whole constraint stage (csetup + pgs + noslip + row references + J^T f).\n' + clean(f'{fin}/phase64.txt') + clean(f'{fin}/phase32.txt'))
 open(f'{dst}/batch_size_and_streams.txt', 'w').write(
     '# tools/quick_bench.py: ONE launch per control step, batch size sweep (FP64): the step time of a batch that fits the 2048 resident slots\n'
-    '# is its slowest environment; even 32 environments alone on the GPU need ~7 ms -- the per-environment chain, not contention, is the cost\n'
+    '# is its slowest environment; even 32 environments alone on the GPU need ~4 ms -- the per-environment chain, not contention, is the cost\n'
     + clean(f'{fin}/batch_sweep.txt') + '# tools/split_bench.py: the same 4096 environments as P independent sub-batches on P HIP streams (bench.py: two_stream_mode)\n' + clean(f'{fin}/split.txt')
     + (clean(f'{fin}/split_dense.txt') if os.path.exists(f'{fin}/split_dense.txt') else ''))
 open(f'{dst}/learner_bench.txt', 'w').write('# tools/learner_bench.py (B = 256, N = 20, walk dims 741 / 59): HIP graphs, then eager\n' + clean(f'{fin}/learner_graphs.log') + clean(f'{fin}/learner_nographs.log'))
