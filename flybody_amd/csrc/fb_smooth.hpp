@@ -435,13 +435,18 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
 
 template <typename real>
 FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
-                              FB_LDS real* RM, int lane);
+                              FB_LDS real* RM, FB_LDS real* x, int lane);
 
+// The factorisation carries a right-hand side along: x (LDS, nv reals) leaves as L^-T x.  The leaf-to-root half of a solve visits
+// the levels in the order of the elimination and pulls through the same three LDS words as a diagonal entry (row entry, 1/D, and
+// the descendant's x), so it costs one more read and one more fma per level here against a level loop of its own (publish,
+// fence, pull: ~20 k cycles) in d_solve -- both factorisations of a substep are followed by a solve whose right-hand side is
+// known before they start (fb_step.hpp).  The products are formed in d_solve's order: the results are bit-identical.
 template <typename real>
 FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
-                         FB_LDS real* RM, int lane) {
+                         FB_LDS real* RM, FB_LDS real* x, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
-  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM);
+  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   long long fp_[6] = {0, 0, 0, 0, 0, 0}, ft_ = clock64();
@@ -451,6 +456,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
 #endif
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
+  const FB_LDS uint32_t* gk = w.lgk;
   // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
   int fw[FB_FSLOT];
   real acc[FB_FSLOT];
@@ -462,7 +468,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     acc[s] = (dep != 31) ? v : (real)0;
   }
   // diagonal entries of the two dofs this lane owns, same packed format (e field = general-dof index, 31 = none)
-  int fd[2]; real accd[2];
+  int fd[2]; real accd[2], xa[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     int j = lane + q*FB_WAVE;
@@ -472,6 +478,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     real v = 0;
     if (has) { v = qM[mj]; if (diag_add) v += hscale*diag_add[j]; }
     accd[q] = v;
+    xa[q] = has ? x[j] : (real)0;
   }
   PROF(17);
   F_PROF(0);
@@ -484,7 +491,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) FB_OPAQUE(fd[q]);
     // publish the rows of level d (unnormalised) and 1/D
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; }
+    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; x[lane + q*FB_WAVE] = xa[q]; }
     // the chain slots are sorted by depth and dealt to the lanes (fb_engine.hip), so the slots that publish / pull on this level
     // form one narrow band, the same for every lane: everything outside it is skipped by a wave-uniform test
     const int band = uniform_int(M.fac_band[d]);
@@ -533,8 +540,30 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) {
       int wd = fd[q], dep = FW_DEP(wd), t = d - dep - 1;
       if (t >= 0) {
-        if (t < FW_CL(wd)) { int aD = FW_BASE(wd) + Td; real l = RM[aD + t + 1]; accd[q] -= l*l*RM[aD]; }
-        else if (FW_E(wd) != 31) { int o = 2*(FW_E(wd)*FB_MAXCH + d); accd[q] -= gen_pull3(RM, gm[o], gm[o + 1], t + 1, t + 1, FW_BASE(wd) + (dep + 1)*(dep + 2)/2); }
+        const int j = lane + q*FB_WAVE;
+        if (t < FW_CL(wd)) {
+          int aD = FW_BASE(wd) + Td; real l = RM[aD + t + 1], di = RM[aD], xk = x[j + t + 1];
+          accd[q] -= l*l*di;
+          xa[q] -= (l*di)*xk;                                   // L[k,j] x[k], L rounded as the normalisation will round it
+        }
+        else if (FW_E(wd) != 31) {
+          // branching dof: <= 4 listed descendant rows on this level; the diagonal's and x's pulls share the row entry and 1/D
+          int o = 2*(FW_E(wd)*FB_MAXCH + d);
+          const int ms = FW_BASE(wd) + (dep + 1)*(dep + 2)/2;
+          const unsigned pk = gk[FW_E(wd)*FB_MAXCH + d], m01 = gm[o], m23 = gm[o + 1];
+          real pd[4], px[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            int mk = ((c < 2 ? m01 : m23) >> (16*(c & 1))) & 0xffff, k = (pk >> (8*c)) & 255;
+            bool ok = mk != 0xffff;
+            int mm = ok ? mk : ms, kk = ok ? k : j + 1;
+            real l = RM[mm + t + 1], di = RM[mm], xk = x[kk];
+            real vd = l*l*di, vx = (l*di)*xk;
+            pd[c] = ok ? vd : (real)0; px[c] = ok ? vx : (real)0;
+          }
+          accd[q] -= (pd[0] + pd[1]) + (pd[2] + pd[3]);
+          xa[q] -= (px[0] + px[1]) + (px[2] + px[3]);
+        }
       }
     }
     F_PROF(4);
@@ -545,7 +574,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   PROF_RESET();
   // the register accumulators are dead from here on (every entry was published, unnormalised, on its own level): the trunk
   // and the normalisation run as a function of their own, with their own register allocation
-  d_factor_tail(M, w_, qM, diag_add, hscale, RM, lane);
+  d_factor_tail(M, w_, qM, diag_add, hscale, RM, x, lane);
 }
 
 // Second half of the factorisation: the dense Schur complement of the trunk rows (the free joint), the normalisation of
@@ -553,9 +582,9 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
 // them are the packed work words (re-read from the model) and the trunk rows of M.
 template <typename real>
 FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
-                              FB_LDS real* RM, int lane) {
+                              FB_LDS real* RM, FB_LDS real* x, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
-  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM);
+  qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk);
   int fd[2];
@@ -567,25 +596,30 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
     fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13);
   }
   // trunk: S[a,b] = M[a,b] - sum_{k >= nT} M~[k,a] M~[k,b] / D[k], then dense LDL (every lane, uniform values)
-  real S[FB_NTT];
+  real S[FB_NTT], xt[FB_MAXTRUNK];
 #pragma unroll
   for (int e = 0; e < FB_NTT; e++) S[e] = 0;
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = 0;
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     int dep = FW_DEP(fd[q]);
     if (dep != 31) {
       int row = FW_BASE(fd[q]) + dep*(dep + 1)/2;
-      real dk = RM[row], col[FB_MAXTRUNK];
+      real dk = RM[row], col[FB_MAXTRUNK], xk = x[lane + q*FB_WAVE];      // (every non-trunk x was published on its own level)
 #pragma unroll
       for (int a = 0; a < FB_MAXTRUNK; a++) col[a] = (a < nT) ? RM[row + dep - a] : (real)0;
 #pragma unroll
       for (int a = 0; a < FB_MAXTRUNK; a++) {
         real ca = col[a]*dk;
+        xt[a] += ca*xk;                                         // the trunk's share of L^-T x: x[a] -= sum_k L[k,a] x[k]
 #pragma unroll
         for (int b2 = 0; b2 <= a; b2++) S[a*(a + 1)/2 + b2] += ca*col[b2];
       }
     }
   }
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] - wave_sum(xt[a]) : (real)0;
 #pragma unroll
   for (int a = 0; a < FB_MAXTRUNK; a++)
 #pragma unroll
@@ -609,6 +643,7 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
     }
   }
   // trunk rows: dof k sits at depth k, row start T(k)
+  real Lt[FB_NTT];
 #pragma unroll
   for (int k = FB_MAXTRUNK - 1; k >= 0; k--) {
     if (k < nT) {
@@ -617,19 +652,28 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
 #pragma unroll
       for (int a = 0; a < k; a++) {
         real Lka = S[k*(k + 1)/2 + a]*Di;
+        Lt[k*(k + 1)/2 + a] = Lka;
         if (lane == 0) RM[k*(k + 1)/2 + (k - a)] = Lka;
 #pragma unroll
         for (int b2 = 0; b2 <= a; b2++) S[a*(a + 1)/2 + b2] -= Lka*S[k*(k + 1)/2 + b2];
       }
     }
   }
+  // L^-T inside the trunk (d_solve's order), and the trunk entries of x go back to LDS
+#pragma unroll
+  for (int a = FB_MAXTRUNK - 1; a >= 0; a--)
+#pragma unroll
+    for (int k = a + 1; k < FB_MAXTRUNK; k++) if (k < nT) xt[a] -= Lt[k*(k + 1)/2 + a]*xt[k];
+#pragma unroll
+  for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT && lane == 0) x[a] = xt[a];
   SYNC();
   PROF(19);
 }
 
-// x <- M^-1 x using the factorisation (everything in LDS)
+// x <- M^-1 x using the factorisation (everything in LDS).  half = true: x already holds L^-T x (d_factor carried it along), only
+// D^-1 and L^-1 are applied.
 template <typename real>
-FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, FB_LDS real* x, int lane) {
+FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, FB_LDS real* x, bool half, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
@@ -647,8 +691,9 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
     base[q] = mj - dp*(dp + 1)/2; rowt[q] = mj + dp;
     a_[q] = has ? x[j] : (real)0;
   }
+  half = uniform_int(half ? 1 : 0) != 0;
   // ---- x <- L^-T x, deepest level first
-  for (int d = nlevel - 1; d >= nT; d--) {
+  for (int d = half ? nT - 1 : nlevel - 1; d >= nT; d--) {
     const int Td = d*(d + 1)/2;
 #pragma unroll
     for (int q = 0; q < 2; q++) if (dep[q] == d) x[jd[q]] = a_[q];
@@ -685,12 +730,18 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
       col[q][a] = (dep[q] != 31 && a < nT) ? RM[rowt[q] - a] : (real)0;
       xt[a] += col[q][a]*a_[q];
     }
+  if (half) {
 #pragma unroll
-  for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] - wave_sum(xt[a]) : (real)0;
+    for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] : (real)0;
+    SYNC_LDS();                  // every lane has read the trunk entries before lane 0 overwrites them below
+  } else {
 #pragma unroll
-  for (int a = FB_MAXTRUNK - 1; a >= 0; a--)
+    for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] - wave_sum(xt[a]) : (real)0;
 #pragma unroll
-    for (int k = a + 1; k < FB_MAXTRUNK; k++) if (k < nT) xt[a] -= RM[k*(k + 1)/2 + (k - a)]*xt[k];
+    for (int a = FB_MAXTRUNK - 1; a >= 0; a--)
+#pragma unroll
+      for (int k = a + 1; k < FB_MAXTRUNK; k++) if (k < nT) xt[a] -= RM[k*(k + 1)/2 + (k - a)]*xt[k];
+  }
   // ---- x <- D^-1 x
 #pragma unroll
   for (int a = 0; a < FB_MAXTRUNK; a++) if (a < nT) xt[a] *= RM[a*(a + 1)/2];         // 1/D sits in the diagonal slot of the row

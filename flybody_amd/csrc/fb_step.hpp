@@ -207,23 +207,6 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
   SYNC();
 }
 
-// LDS does not survive a kernel boundary: the factor of M, its inverse diagonal and the Delassus
-// matrix produced by the position stage are parked in the environment's global row at the end of
-// a launch and reloaded at the start of the next one (once per control step, not per substep).
-template <typename real>
-__device__ __forceinline__ void d_lds_store(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
-  int nefc = w.istate()[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.AR()[i] = w.lAR[i];
-  SYNC();
-}
-template <typename real>
-__device__ __forceinline__ void d_lds_load(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nM; i += FB_WAVE) w.lLD[i] = w.qLD()[i];
-  int nefc = w.istate()[IS_NEFC];
-  if (nefc <= LdsCfg<real>::AR_ROWS) for (int i = lane; i < nefc*(nefc + 1)/2; i += FB_WAVE) w.lAR[i] = w.AR()[i];
-  SYNC();
-}
 
 // ------------------------------------------------------------------ reference trajectory of an environment
 // inference mode: one root track shared by all environments (fb_batch_set_reference); training mode: the snippet the
@@ -661,7 +644,7 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
 // selectors are wave-uniform.  Order per substep follows dm_control's legacy step: mj_step2
 // (actuation, acceleration, constraint, acceleration-stage sensors), integrate, mj_step1
 // (position + velocity stages for the new state).
-enum { ST_ACT, ST_ACC_PRE, ST_SOLVE, ST_ACC_POST, ST_CONSTR_A, ST_CONSTR_B, ST_SENS, ST_EULER_PRE, ST_FACTOR, ST_EULER_SOLVE,
+enum { ST_ACT, ST_ACC_PRE, ST_SOLVE, ST_ACC_SOLVE, ST_ACC_POST, ST_CONSTR_A, ST_CONSTR_B, ST_SENS, ST_EULER_PRE, ST_FACTOR, ST_EULER_SOLVE,
        ST_EULER_POST, ST_KIN, ST_COLL, ST_SUBEND, ST_DONE };
 enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
 
@@ -697,8 +680,6 @@ FB_STAGE_WRAP(s_actuation, d_actuation(M, w, lane))
 FB_STAGE_WRAP(s_constraint_b, d_constraint_b(M, w, lane))
 FB_STAGE_WRAP(s_sensor_acc, d_sensor_acc(M, w, lane))
 FB_STAGE_WRAP(s_integrate, d_integrate(M, w, lane))
-FB_STAGE_WRAP(s_lds_load, d_lds_load(M, w, lane))
-FB_STAGE_WRAP(s_lds_store, d_lds_store(M, w, lane))
 template <typename real> FB_STAGE_C bool s_constraint_a(const DevModel<real>& M_, const WS<real>& w_, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_); return d_constraint_a(M, w, lane); }
 template <typename real> FB_STAGE_C void s_init(const DevModel<real>& M_, const WS<real>& w_, int env, int lane) {
@@ -727,7 +708,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg);
   bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
-  bool actuate = true, damp = false;
+  bool actuate = true, damp = false, half = false;
   int nsub = uniform_int((mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep), sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   const WS<real> wc = w;                  // the stages are separate functions: they read this copy, `w` itself stays in registers
@@ -738,7 +719,6 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
     pc = ST_KIN;
   } else {
     PROF_BEGIN();
-    s_lds_load(M, wc, lane);
     if (mode == MODE_STEP) s_pre(M, wc, action, lane);
     PROF(27);
     pc = (nsub > 0) ? ST_ACT : ST_DONE;
@@ -757,6 +737,10 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         PROF(P_ACT);
         pc = ST_ACC_PRE; break; }
       case ST_ACC_PRE: {
+        // M is factorised HERE, not behind the inertia stage: the right-hand side of the smooth-acceleration solve is known
+        // now, and the factorisation carries it along (d_factor: x leaves as L^-T x), so the solve is its root-to-leaf half
+        // only.  The constraint projection, the factor's first consumer, follows.  Nothing LDS-resident crosses a launch
+        // boundary any more (the factor and the Delassus matrix used to be parked in the global row between control steps).
         PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) {
           real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.qfrc_actuator()[i];
@@ -764,17 +748,21 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         }
         SYNC();
         PROF(24);
-        ret = ST_ACC_POST; pc = ST_SOLVE; break; }
+        damp = false; fret = ST_ACC_SOLVE; pc = ST_FACTOR; break; }
+      case ST_ACC_SOLVE:
+        half = true; ret = ST_ACC_POST; pc = ST_SOLVE; break;
       case ST_SOLVE: {
         PROF_BEGIN();
-        d_solve(M, wc, w.lLD, w.lx, lane);
+        d_solve(M, wc, w.lLD, w.lx, half, lane);
         PROF(P_ACC);
+        half = false;
         pc = ret; break; }
       case ST_ACC_POST: {
         PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx[i];
         SYNC();
         PROF(24);
+        s_project_constraint(M, wc, lane); PROF(P_PROJ);
         pc = ST_CONSTR_A; break; }
       case ST_CONSTR_A: {
         bool need = uniform_int(s_constraint_a(M, wc, lane) ? 1 : 0) != 0;
@@ -798,11 +786,11 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
-        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, lane);
+        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lx, lane);
         PROF(P_FACTOR);
         pc = fret; break; }
       case ST_EULER_SOLVE:
-        ret = ST_EULER_POST; pc = ST_SOLVE; break;
+        half = true; ret = ST_EULER_POST; pc = ST_SOLVE; break;
       case ST_EULER_POST: {
         PROF_BEGIN();
         s_integrate(M, wc, lane);
@@ -813,12 +801,11 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
         s_kinematics(M, wc, lane); PROF(P_KIN);
         s_com_pos(M, wc, lane); PROF(P_COMPOS);
         s_crb(M, wc, lane); PROF(P_CRB);
-        damp = false; fret = ST_COLL; pc = ST_FACTOR; break; }
+        pc = ST_COLL; break; }
       case ST_COLL: {
         PROF_BEGIN();
         s_collision(M, wc, lane); PROF(P_COLL);
         s_make_constraint(M, wc, lane); PROF(P_MAKEC);
-        s_project_constraint(M, wc, lane); PROF(P_PROJ);
         s_velocity(M, wc, lane); PROF(P_VEL);
         pc = single_pass ? ST_ACT : ST_SUBEND; break; }
       case ST_SUBEND: {
@@ -843,6 +830,5 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
   }
   PROF_BEGIN();
   if (env_logic) s_post(M, wc, resetting, obs, reward, discount, step_type, lane);
-  s_lds_store(M, wc, lane);
   PROF(28);
 }
