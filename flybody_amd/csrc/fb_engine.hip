@@ -37,7 +37,7 @@ struct fb_model {
   std::vector<int> body_nsub, body_depth, body_chlen, body_chain, body_common, dof_depth, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, plane_geoms;
-  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fac_w, fac_band; int ngen = 0, ntrunk = 1;
+  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom, sens_body, dof_jump, dof_vbef, body_veldof;
@@ -273,6 +273,12 @@ static int model_load_impl(fb_model* m, size_t n) {
     m->fwd_tab.assign((size_t)FB_MAXCH*FB_MAXNV, 0);
     for (int k = 0; k < nv; k++)
       for (int a = dofpar[k]; a >= 0; a = dofpar[a]) m->fwd_tab[(size_t)m->dof_depth[a]*FB_MAXNV + k] = a;
+    // ... the same, four levels per word (8-bit dof ids): the solve's root-to-leaf loop fetches one word per four levels, one block
+    // ahead, instead of one table entry per level with a global-memory latency on every level
+    if (nv > 255) return fail("fb_model_load: more than 255 dofs (packed ancestor table)");
+    m->fwd_pack.assign((size_t)((FB_MAXCH + 3)/4)*FB_MAXNV, 0);
+    for (int k = 0; k < nv; k++)
+      for (int a = dofpar[k]; a >= 0; a = dofpar[a]) { int d = m->dof_depth[a]; m->fwd_pack[(size_t)(d >> 2)*FB_MAXNV + k] |= (int)((unsigned)a << (8*(d & 3))); }
   }
   // factorisation work list: every off-diagonal entry (i, j) of the lower triangle with i outside the trunk is
   // owned by one (lane, slot); the diagonal of dof j belongs to lane j & 63.  Entries are spread so that the number
@@ -624,7 +630,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
   UV(dof_jump, dof_jump) UV(dof_vbef, dof_vbef) UV(body_veldof, body_veldof)
-  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
+  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fwd_pack, fwd_pack) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   {

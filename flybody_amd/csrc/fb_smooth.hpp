@@ -680,7 +680,7 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
   const FB_LDS uint32_t* gk = w.lgk;
   const FB_LDS uint16_t* lmadr = w.lmadr;
-  const FB_GLOBAL int* fwd = M.fwd_tab.p;
+  const FB_GLOBAL int* fwp = M.fwd_pack.p;
   int jd[2], dep[2], cl[2], gen[2], base[2], rowt[2]; real a_[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -759,18 +759,30 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
   for (int q = 0; q < 2; q++)
 #pragma unroll
     for (int a = 0; a < FB_MAXTRUNK; a++) a_[q] -= col[q][a]*xt[a];
-  int nxt[2];
+  // level by level: a dof pulls from its ancestor on level d.  The ancestor ids come four levels per word, one block ahead
+  unsigned pw[2], pn[2];
+  const int w0 = nT >> 2;
 #pragma unroll
-  for (int q = 0; q < 2; q++) nxt[q] = (dep[q] != 31 && dep[q] > nT) ? fwd[nT*FB_MAXNV + jd[q]] : 0;
-  for (int d = nT; d < nlevel; d++) {
+  for (int q = 0; q < 2; q++) pw[q] = (dep[q] != 31) ? (unsigned)fwp[w0*FB_MAXNV + jd[q]] : 0u;
+  for (int wi = w0; 4*wi < nlevel; wi++) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (dep[q] == d) x[jd[q]] = a_[q];
-    SYNC();
-    int cur[2] = {nxt[0], nxt[1]};
+    for (int q = 0; q < 2; q++) pn[q] = (4*(wi + 1) < nlevel && dep[q] != 31) ? (unsigned)fwp[(wi + 1)*FB_MAXNV + jd[q]] : 0u;
 #pragma unroll
-    for (int q = 0; q < 2; q++) nxt[q] = (dep[q] != 31 && dep[q] > d + 1) ? fwd[(d + 1)*FB_MAXNV + jd[q]] : 0;
+    for (int u = 0; u < 4; u++) {
+      const int d = 4*wi + u;
+      if (d >= nT && d < nlevel) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) if (dep[q] != 31 && dep[q] > d) a_[q] -= RM[rowt[q] - d]*x[cur[q]];
+        for (int q = 0; q < 2; q++) if (dep[q] == d) x[jd[q]] = a_[q];
+        SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int cur = (int)((pw[q] >> (8*u)) & 255u);
+          if (dep[q] != 31 && dep[q] > d) a_[q] -= RM[rowt[q] - d]*x[cur];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) pw[q] = pn[q];
   }
   PROF(21);
 }

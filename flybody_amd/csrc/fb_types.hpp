@@ -119,6 +119,7 @@ struct DevModel {
   GP<const int> dof_gen;        // [nv] index of a dof outside the trunk whose subtree branches ("general" dof) or -1
   GP<const int> gen_k, gen_m;  // [FB_MAXGEN][FB_MAXCH] descendants of a general dof on a level: 4 dof ids (u8) / 4 row starts (u16)
   GP<const int> fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
+  GP<const int> fwd_pack;       // [FB_MAXCH/4][FB_MAXNV] the same, four levels per word (8-bit dof ids)
   GP<const int> fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
   GP<const int> fac_band;       // [32] per level: chain slots that publish [lo, hi) | pull [lo, hi) << 16, the same for every lane
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
