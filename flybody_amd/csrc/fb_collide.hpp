@@ -414,12 +414,20 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   C_PROF(0);
   int ncand = 0;
   const int maxcand = 2*FB_MAXCON_ + 64;
+  // (software-pipelined: the words of the next four passes are in flight while the current four are tested)
+  int pwn[4]; real mgn[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { int p = u*FB_WAVE + lane, ps = p < M.npair ? p : 0; pwn[u] = M.pair_word[ps]; mgn[u] = M.pair_margin[ps]; }
   for (int base = 0; base < M.npair; base += 4*FB_WAVE) {
     int pw[4]; real mg[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int p = base + u*FB_WAVE + lane, ps = p < M.npair ? p : 0;
-      pw[u] = M.pair_word[ps]; mg[u] = M.pair_margin[ps];
+    for (int u = 0; u < 4; u++) { pw[u] = pwn[u]; mg[u] = mgn[u]; }
+    if (base + 4*FB_WAVE < M.npair) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int p = base + (4 + u)*FB_WAVE + lane, ps = p < M.npair ? p : 0;
+        pwn[u] = M.pair_word[ps]; mgn[u] = M.pair_margin[ps];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {

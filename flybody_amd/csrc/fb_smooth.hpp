@@ -127,14 +127,27 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
   bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
   int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
   int dep2 = has2 ? M.body_depth[has2 ? b2 : 0] : -1;
+  // the record of the lane's own body is fetched before the level loop (every lane at once, one latency for the whole pass instead
+  // of one per level); only the few second bodies load theirs on their level
+  real R1[37];
+  {
+    const real* rec = M.body_rec + (has1 ? b1 : 0)*FB_BODYREC;
+#pragma unroll
+    for (int k = 0; k < 37; k++) R1[k] = rec[k];
+  }
   for (int d = dlo; d <= dhi; d++) {
     int b = (dep1 == d) ? b1 : b2;
     if (dep1 == d || dep2 == d) {
-      // one round of independent loads: the body's flattened record (fb_engine.hip) and the free-joint pose
+      // the body's flattened record (fb_engine.hip) and the free-joint pose
       real R[37];
-      const real* rec = M.body_rec + b*FB_BODYREC;
+      if (dep1 == d) {
 #pragma unroll
-      for (int k = 0; k < 37; k++) R[k] = rec[k];
+        for (int k = 0; k < 37; k++) R[k] = R1[k];
+      } else {
+        const real* rec = M.body_rec + b*FB_BODYREC;
+#pragma unroll
+        for (int k = 0; k < 37; k++) R[k] = rec[k];
+      }
       int par = (int)R[0], ja = (int)R[1], jn = (int)R[2];
       bool free_jnt = R[3] != 0;
       real pos[3], quat[4];
@@ -482,6 +495,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   }
   PROF(17);
   F_PROF(0);
+  int band_next = uniform_int(M.fac_band[nlevel - 1]);
   for (int d = nlevel - 1; d >= nT; d--) {
     const int Td = d*(d + 1)/2;
     // (keep the packed words opaque: otherwise every field of every slot is hoisted into its own register)
@@ -494,7 +508,8 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; x[lane + q*FB_WAVE] = xa[q]; }
     // the chain slots are sorted by depth and dealt to the lanes (fb_engine.hip), so the slots that publish / pull on this level
     // form one narrow band, the same for every lane: everything outside it is skipped by a wave-uniform test
-    const int band = uniform_int(M.fac_band[d]);
+    const int band = band_next;
+    band_next = uniform_int(M.fac_band[d > 0 ? d - 1 : 0]);          // (scalar load: in flight during this level)
     const int pub_lo = band & 255, pub_hi = (band >> 8) & 255, pull_lo = (band >> 16) & 255, pull_hi = (band >> 24) & 255;
 #pragma unroll
     for (int s = 0; s < FB_FSLOT; s++) {
