@@ -610,6 +610,10 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
     int dp = has ? w.ldepth[j] : 31, mj = has ? w.lmadr[j] : 0;
     fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13);
   }
+  // (the work words of the normalisation below: fetched here, ahead of the reductions, so that their latency is covered)
+  int fw[FB_FSLOT];
+#pragma unroll
+  for (int s = 0; s < FB_FSLOT; s++) fw[s] = M.fac_w[s*FB_WAVE + lane];
   // trunk: S[a,b] = M[a,b] - sum_{k >= nT} M~[k,a] M~[k,b] / D[k], then dense LDL (every lane, uniform values)
   real S[FB_NTT], xt[FB_MAXTRUNK];
 #pragma unroll
@@ -647,15 +651,19 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
     }
   SYNC();
   // normalise the published rows: L[i,j] = M~[i,j] / D[i]
+  // (branch-free: all reads in flight together, an empty slot reads row 0 and writes the dummy word behind the factor)
   {
-    int fw[FB_FSLOT];
-#pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) fw[s] = M.fac_w[s*FB_WAVE + lane];
+    real v[FB_FSLOT], dd[FB_FSLOT]; int adr[FB_FSLOT];
 #pragma unroll
     for (int s = 0; s < FB_FSLOT; s++) {
       int wd = fw[s], dep = FW_DEP(wd);
-      if (dep != 31) { int ad = FW_BASE(wd) + dep*(dep + 1)/2; RM[ad + FW_E(wd)] *= RM[ad]; }
+      bool ok = dep != 31;
+      int ad = ok ? FW_BASE(wd) + dep*(dep + 1)/2 : 0;
+      adr[s] = ok ? ad + FW_E(wd) : FB_LDS_SCRATCH - 1;
+      v[s] = RM[adr[s]]; dd[s] = RM[ad];
     }
+#pragma unroll
+    for (int s = 0; s < FB_FSLOT; s++) RM[adr[s]] = v[s]*dd[s];
   }
   // trunk rows: dof k sits at depth k, row start T(k)
   real Lt[FB_NTT];
