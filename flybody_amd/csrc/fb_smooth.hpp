@@ -473,9 +473,18 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
   int fw[FB_FSLOT];
   real acc[FB_FSLOT];
+  // Two rounds, kept apart on purpose: all work words first, then all gathers.  Written as one loop the compiler issues
+  // word 0, waits, gather 0, word 1, waits (vector memory returns in order, so that wait includes gather 0), ... -- 18 dependent
+  // round trips instead of two (measured: 25 k -> 11 k cycles for this prologue).
+#pragma unroll
+  for (int s = 0; s < FB_FSLOT; s++) fw[s] = M.fac_w[s*FB_WAVE + lane];
+#ifndef FB_EMULATE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < FB_FSLOT; s++) FB_OPAQUE(fw[s]);
+#endif
 #pragma unroll
   for (int s = 0; s < FB_FSLOT; s++) {
-    fw[s] = M.fac_w[s*FB_WAVE + lane];
     int dep = FW_DEP(fw[s]);
     real v = qM[dep != 31 ? FW_BASE(fw[s]) + dep*(dep + 1)/2 + FW_E(fw[s]) : 0];     // unconditional: all gathers in flight together
     acc[s] = (dep != 31) ? v : (real)0;
