@@ -276,6 +276,7 @@ static int model_load_impl(fb_model* m, size_t n) {
     // ... the same, four levels per word (8-bit dof ids): the solve's root-to-leaf loop fetches one word per four levels, one block
     // ahead, instead of one table entry per level with a global-memory latency on every level
     if (nv > 255) return fail("fb_model_load: more than 255 dofs (packed ancestor table)");
+    if (m->nbody > 2*FB_WAVE || 6*nv + 10*m->nbody > FB_LDS_SCRATCH + 276) return fail("fb_model_load: bodies / dofs exceed the LDS staging of the inertia stages");
     m->fwd_pack.assign((size_t)((FB_MAXCH + 3)/4)*FB_MAXNV, 0);
     for (int k = 0; k < nv; k++)
       for (int a = dofpar[k]; a >= 0; a = dofpar[a]) { int d = m->dof_depth[a]; m->fwd_pack[(size_t)(d >> 2)*FB_MAXNV + k] |= (int)((unsigned)a << (8*(d & 3))); }

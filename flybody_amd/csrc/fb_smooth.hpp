@@ -270,58 +270,102 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
 // ------------------------------------------------------------------ cinert, cdof, tendons
 template <typename real>
 __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
+  // Written in rounds: every load of a round (for BOTH items a lane owns: bodies l and l + 64, dofs l and l + 64, its tendon) is
+  // issued before anything of the next round is computed.  As a loop per item the stage was 11 dependent trips to the global
+  // row (index -> joint -> axis, twice for the dofs; mass / inertia per body pass; three for the tendons); it is 3 now.
+  // The dofs' motion axes (cdof) are mirrored in LDS (the factor row, free until the factorisation behind the actuation stage):
+  // the inertia stage reads 20 of them per dof.
+  FB_LDS real* Lc = w.lLD;
   const real com[3] = {w.com()[0], w.com()[1], w.com()[2]};
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real* c = w.cinert() + 10*b;
-    if (b == 0) { for (int k = 0; k < 10; k++) c[k] = 0; continue; }
-    const real* R = w.ximat() + 9*b; const real* I = M.body_inertia + 3*b;
-    real mass = M.body_mass[b];
-    real dif[3]; sub3(dif, w.xipos() + 3*b, com);
-    real t00 = 0, t11 = 0, t22 = 0, t01 = 0, t02 = 0, t12 = 0;
-    for (int k = 0; k < 3; k++) {
-      t00 += R[0+k]*I[k]*R[0+k]; t11 += R[3+k]*I[k]*R[3+k]; t22 += R[6+k]*I[k]*R[6+k];
-      t01 += R[0+k]*I[k]*R[3+k]; t02 += R[0+k]*I[k]*R[6+k]; t12 += R[3+k]*I[k]*R[6+k];
-    }
-    c[0] = t00 + mass*(dif[1]*dif[1] + dif[2]*dif[2]);
-    c[1] = t11 + mass*(dif[0]*dif[0] + dif[2]*dif[2]);
-    c[2] = t22 + mass*(dif[0]*dif[0] + dif[1]*dif[1]);
-    c[3] = t01 - mass*dif[0]*dif[1];
-    c[4] = t02 - mass*dif[0]*dif[2];
-    c[5] = t12 - mass*dif[1]*dif[2];
-    c[6] = mass*dif[0]; c[7] = mass*dif[1]; c[8] = mass*dif[2]; c[9] = mass;
+  const int nv = M.nv, nbody = M.nbody;
+  // ---- round 1: bodies (pose of the inertial frame, inertia), dof -> joint / body ids, tendon header
+  int bs[2]; bool bok[2]; real Rm[2][9], In[2][3], ms[2], xi[2][3];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    int b = lane + q*FB_WAVE; bok[q] = b < nbody; bs[q] = bok[q] ? b : 0;
+    const real* R = w.ximat() + 9*bs[q]; const real* I = M.body_inertia + 3*bs[q]; const real* xp = w.xipos() + 3*bs[q];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rm[q][k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { In[q][k] = I[k]; xi[q][k] = xp[k]; }
+    ms[q] = M.body_mass[bs[q]];
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    int j = M.dof_jntid[i], b = M.dof_bodyid[i];
-    real off[3]; sub3(off, com, w.xanchor() + 3*j);
-    real* c = w.cdof() + 6*i;
-    if (M.jnt_type[j] == JNT_FREE) {
-      int k = i - M.jnt_dofadr[j];
-      if (k < 3) { for (int q = 0; q < 6; q++) c[q] = 0; c[3 + k] = 1; }
-      else {
-        const real* R = w.xmat() + 9*b;
-        real ax[3] = {R[k-3], R[3+k-3], R[6+k-3]};
-        copy3(c, ax); cross3(c + 3, ax, off);
+  int is[2], jj[2], db[2]; bool dok[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; dok[q] = i < nv; is[q] = dok[q] ? i : 0; jj[q] = M.dof_jntid[is[q]]; db[q] = M.dof_bodyid[is[q]]; }
+  const bool tok = lane < M.ntendon;
+  const int tadr = M.tendon_adr[tok ? lane : 0], tnum = tok ? M.tendon_num[lane] : 0;
+  // ---- round 2: joint data of the dofs, tendon wraps
+  real anc[2][3], axs[2][3], Rb[2][9]; int jt[2], jda[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const real* pa = w.xanchor() + 3*jj[q]; const real* px = w.xaxis() + 3*jj[q]; const real* R = w.xmat() + 9*db[q];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { anc[q][k] = pa[k]; axs[q][k] = px[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rb[q][k] = R[k];
+    jt[q] = M.jnt_type[jj[q]]; jda[q] = M.jnt_dofadr[jj[q]];
+  }
+  int qa[FB_MAXWRAP]; real cf[FB_MAXWRAP], qv[FB_MAXWRAP];
+#pragma unroll
+  for (int k = 0; k < FB_MAXWRAP; k++) { int kk = (k < tnum) ? tadr + k : 0; int a_ = M.wrap_qadr[kk]; qa[k] = (k < tnum) ? a_ : 0; cf[k] = M.wrap_coef[kk]; }
+  // ---- bodies: inertia about the centre of mass of the model, in the global frame
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (bok[q]) {
+      const real* R = Rm[q]; const real* I = In[q]; const real mass = ms[q];
+      real c[10];
+      real dif[3]; sub3(dif, xi[q], com);
+      real t00 = 0, t11 = 0, t22 = 0, t01 = 0, t02 = 0, t12 = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        t00 += R[0+k]*I[k]*R[0+k]; t11 += R[3+k]*I[k]*R[3+k]; t22 += R[6+k]*I[k]*R[6+k];
+        t01 += R[0+k]*I[k]*R[3+k]; t02 += R[0+k]*I[k]*R[6+k]; t12 += R[3+k]*I[k]*R[6+k];
       }
-    } else if (M.jnt_type[j] == JNT_BALL) {
-      // three rotations about the body axes through the anchor
-      int k = i - M.jnt_dofadr[j];
-      const real* R = w.xmat() + 9*b;
-      real ax[3] = {R[k], R[3+k], R[6+k]};
-      copy3(c, ax); cross3(c + 3, ax, off);
-    } else {
-      copy3(c, w.xaxis() + 3*j); cross3(c + 3, w.xaxis() + 3*j, off);
+      c[0] = t00 + mass*(dif[1]*dif[1] + dif[2]*dif[2]);
+      c[1] = t11 + mass*(dif[0]*dif[0] + dif[2]*dif[2]);
+      c[2] = t22 + mass*(dif[0]*dif[0] + dif[1]*dif[1]);
+      c[3] = t01 - mass*dif[0]*dif[1];
+      c[4] = t02 - mass*dif[0]*dif[2];
+      c[5] = t12 - mass*dif[1]*dif[2];
+      c[6] = mass*dif[0]; c[7] = mass*dif[1]; c[8] = mass*dif[2]; c[9] = mass;
+      const bool world = (lane + q*FB_WAVE) == 0;
+      real* o = w.cinert() + 10*bs[q];
+#pragma unroll
+      for (int k = 0; k < 10; k++) o[k] = world ? (real)0 : c[k];
     }
   }
-  for (int t = lane; t < M.ntendon; t += FB_WAVE) {
-    int adr = M.tendon_adr[t], num = M.tendon_num[t];
-    int qa[FB_MAXWRAP]; real cf[FB_MAXWRAP], qv[FB_MAXWRAP];
+  // ---- round 3 (tendons only): the joint positions the wraps point at
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) { int kk = (k < num) ? adr + k : 0; qa[k] = M.wrap_qadr[kk]; cf[k] = M.wrap_coef[kk]; }
+  for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qpos()[qa[k]];
+  // ---- dofs: motion axis about the centre of mass
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qpos()[qa[k]];
+  for (int q = 0; q < 2; q++) {
+    if (dok[q]) {
+      const int i = is[q], k = i - jda[q];
+      real off[3]; sub3(off, com, anc[q]);
+      real c[6];
+      const int col = (jt[q] == JNT_FREE) ? k - 3 : k;               // column of the body frame (free rotations, ball joints)
+      const real* R = Rb[q];
+      real ax[3] = {col == 0 ? R[0] : (col == 1 ? R[1] : R[2]), col == 0 ? R[3] : (col == 1 ? R[4] : R[5]), col == 0 ? R[6] : (col == 1 ? R[7] : R[8])};
+      if (jt[q] != JNT_FREE && jt[q] != JNT_BALL) { ax[0] = axs[q][0]; ax[1] = axs[q][1]; ax[2] = axs[q][2]; }
+      if (jt[q] == JNT_FREE && k < 3) { for (int u = 0; u < 6; u++) c[u] = 0; c[3] = (k == 0) ? (real)1 : (real)0; c[4] = (k == 1) ? (real)1 : (real)0; c[5] = (k == 2) ? (real)1 : (real)0; }
+      else { copy3(c, ax); cross3(c + 3, ax, off); }
+      real* o = w.cdof() + 6*i;
+#pragma unroll
+      for (int u = 0; u < 6; u++) { o[u] = c[u]; Lc[6*i + u] = c[u]; }
+    }
+  }
+  if (tok) {
     real L = 0;
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) if (k < num) L += cf[k]*qv[k];
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < tnum) L += cf[k]*qv[k];
+    w.ten_length()[lane] = L;
+  }
+  for (int t = lane + FB_WAVE; t < M.ntendon; t += FB_WAVE) {          // (models with more than 64 tendons: plain loop)
+    int adr = M.tendon_adr[t], num = M.tendon_num[t];
+    real L = 0;
+    for (int k = 0; k < num; k++) L += M.wrap_coef[adr + k]*w.qpos()[M.wrap_qadr[adr + k]];
     w.ten_length()[t] = L;
   }
   SYNC();
@@ -330,7 +374,7 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
 // Subtree sums S[b][0..K) = sum of A over the DFS-contiguous subtree of body b ("subtree pull").  The tree root owns
 // every body, so its sum is a 64-lane reduction instead of a 67-iteration serial walk; all other subtrees are short.
 template <int K, typename real>
-__device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real* A, real* S, int lane) {
+__device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real* A, real* S, int lane, FB_LDS real* mirror = nullptr) {
   real tot[K];
 #pragma unroll
   for (int k = 0; k < K; k++) tot[k] = 0;
@@ -361,6 +405,10 @@ __device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real*
     }
 #pragma unroll
     for (int k = 0; k < K; k++) S[K*b + k] = acc[k];
+    if (mirror) {
+#pragma unroll
+      for (int k = 0; k < K; k++) mirror[K*b + k] = acc[k];
+    }
   }
   SYNC();
 }
@@ -368,34 +416,50 @@ __device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real*
 // ------------------------------------------------------------------ composite inertia + mass matrix
 template <typename real>
 __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
-  subtree_sum<10>(M, w.cinert(), w.crb(), lane);
-  for (int i = lane; i < M.nv; i += FB_WAVE) {
-    int adr = M.dof_Madr[i];
-    real buf[6];
-    mulinertvec(buf, w.crb() + 10*M.dof_bodyid[i], w.cdof() + 6*i);
-    real arm = M.dof_armature[i];
-    // row i of M: entries for the ancestors of dof i = the first depth(i)+1 slots of its body's chain (slot depth(i) is i itself)
-    int ch[FB_MAXCH]; load_chain(M, M.dof_bodyid[i], ch);
-    int di = M.dof_depth[i];
+  // composite inertias, mirrored in LDS behind the motion axes the previous stage left there
+  FB_LDS real* Lc = w.lLD;                      // cdof: 6*nv
+  FB_LDS real* Lr = w.lLD + 6*M.nv;             // composite inertia: 10*nbody (runs on into the matrix slot: the pool is contiguous)
+  subtree_sum<10>(M, w.cinert(), w.crb(), lane, Lr);
+  // Row i of M: entries for the ancestors of dof i = the first depth(i)+1 slots of its body's chain (slot depth(i) is i itself).
+  // Two rounds of loads from the model (ids, then the chains) for both dofs of the lane; the 20 motion axes and the composite
+  // inertia come from LDS -- as gathers from the global row they were 2 x 7 dependent round trips.
+  const int nv = M.nv;
+  int is[2], adr[2], body[2], di[2]; real arm[2]; bool ok[2];
 #pragma unroll
-    for (int s0 = 0; s0 < FB_MAXCH; s0 += 5) {
-      if (s0 >= M.chmax) break;
-      real c[5][6];
+  for (int q = 0; q < 2; q++) {
+    int i = lane + q*FB_WAVE; ok[q] = i < nv; is[q] = ok[q] ? i : 0;
+    adr[q] = M.dof_Madr[is[q]]; body[q] = M.dof_bodyid[is[q]]; di[q] = M.dof_depth[is[q]]; arm[q] = M.dof_armature[is[q]];
+  }
+  int ch[2][FB_MAXCH];
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        const real* cp = w.cdof() + 6*((s0 + u <= di) ? ch[s0 + u] : 0);
+  for (int q = 0; q < 2; q++) load_chain(M, body[q], ch[q]);
+  const int chmax = M.chmax;
 #pragma unroll
-        for (int k = 0; k < 6; k++) c[u][k] = cp[k];
-      }
+  for (int q = 0; q < 2; q++) {
+    if (ok[q]) {
+      real ci[10], cd[6], buf[6];
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        int sl = s0 + u;
-        if (sl <= di) {
-          real v = dot6(c[u], buf);
-          if (sl == di) v += arm;
-          w.qM()[adr + (di - sl)] = v;
+      for (int k = 0; k < 10; k++) ci[k] = Lr[10*body[q] + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cd[k] = Lc[6*is[q] + k];
+      mulinertvec(buf, ci, cd);
+      // (no early exit: the loop must unroll completely, ch[] lives in registers; the row is collected in registers and stored in
+      // one go -- a store between two slots makes the next slot's wait for its operands a wait for that store)
+      real val[FB_MAXCH];
+#pragma unroll
+      for (int sl = 0; sl < FB_MAXCH; sl++) {
+        val[sl] = 0;
+        if (sl < chmax && sl <= di[q]) {
+          real c[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) c[k] = Lc[6*ch[q][sl] + k];
+          real v = dot6(c, buf);
+          if (sl == di[q]) v += arm[q];
+          val[sl] = v;
         }
       }
+#pragma unroll
+      for (int sl = 0; sl < FB_MAXCH; sl++) if (sl < chmax && sl <= di[q]) w.qM()[adr[q] + (di[q] - sl)] = val[sl];
     }
   }
   SYNC();
