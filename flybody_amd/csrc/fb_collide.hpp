@@ -11,7 +11,7 @@
 #define MPR_EPS ((real)1e-14)
 
 template <typename real>
-struct CGeom { const real *pos, *mat, *size; int type; real margin; };
+struct CGeom { real pos[3], mat[9], size[3]; int type; real margin; };     // by value: pointers to the caller's arrays pin those arrays in scratch memory
 
 template <typename real>
 FBD void support(const CGeom<real>& g, const real* dir, real* out) {
@@ -37,7 +37,14 @@ FBD void support(const CGeom<real>& g, const real* dir, real* out) {
   add3(out, out, g.pos);
 }
 
+// The portal: Minkowski-difference points v[0..3] and, for the contact position at the end, the support points on the two
+// shapes they came from (a1, a2).  Kept as three separate arrays on purpose: the refinement replaces ONE of the points 1..3 per
+// iteration, chosen by the data.  The v are tested in every iteration, so they are updated with selects and stay in registers;
+// the witnesses are only read once, at the end, so a runtime-indexed store (the compiler keeps such an array in scratch memory:
+// stores nobody waits for) is fine for them.  With all three in one array of structs the whole portal lived in scratch and every
+// iteration started by reloading it through vector memory.
 template <typename real> struct MprPt { real v[3], v1[3], v2[3]; };
+template <typename real> struct Portal { real v[4][3], a1[4][3], a2[4][3]; };
 
 template <typename real>
 FBD void md_support(const CGeom<real>& a, const CGeom<real>& b, const real* dir, MprPt<real>& s) {
@@ -46,28 +53,47 @@ FBD void md_support(const CGeom<real>& a, const CGeom<real>& b, const real* dir,
   support(b, nd, s.v2);
   sub3(s.v, s.v1, s.v2);
 }
+// point j (1..3, runtime) <- s
 template <typename real>
-FBD void portal_dir(const MprPt<real>* p, real* dir) {
+FBD void portal_set(Portal<real>& P, int j, const MprPt<real>& s) {
+#pragma unroll
+  for (int q = 1; q < 4; q++) {
+    const bool sel = (j == q);
+#pragma unroll
+    for (int k = 0; k < 3; k++) P.v[q][k] = sel ? s.v[k] : P.v[q][k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { P.a1[j][k] = s.v1[k]; P.a2[j][k] = s.v2[k]; }
+}
+// point j <- point 3 (j = 1 or 2, runtime)
+template <typename real>
+FBD void portal_from3(Portal<real>& P, int j) {
+  MprPt<real> s;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { s.v[k] = P.v[3][k]; s.v1[k] = P.a1[3][k]; s.v2[k] = P.a2[3][k]; }
+  portal_set(P, j, s);
+}
+template <typename real>
+FBD void portal_dir(const Portal<real>& P, real* dir) {
   real a[3], b[3];
-  sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v);
+  sub3(a, P.v[2], P.v[1]); sub3(b, P.v[3], P.v[1]);
   cross3(dir, a, b); normalize3(dir);
 }
 template <typename real>
-FBD bool reach_tol(const MprPt<real>* p, const MprPt<real>& v4, const real* dir) {
+FBD bool reach_tol(const Portal<real>& P, const MprPt<real>& v4, const real* dir) {
   real dv4 = dot3(v4.v, dir);
-  real d1 = dv4 - dot3(p[1].v, dir), d2 = dv4 - dot3(p[2].v, dir), d3 = dv4 - dot3(p[3].v, dir);
+  real d1 = dv4 - dot3(P.v[1], dir), d2 = dv4 - dot3(P.v[2], dir), d3 = dv4 - dot3(P.v[3], dir);
   real dm = fmin(d1, fmin(d2, d3));
   return dm <= MPR_TOL;
 }
 template <typename real>
-FBD void expand_portal(MprPt<real>* p, const MprPt<real>& v4) {
+FBD void expand_portal(Portal<real>& P, const MprPt<real>& v4) {
   real v4v0[3];
-  cross3(v4v0, v4.v, p[0].v);
-  if (dot3(p[1].v, v4v0) > 0) {
-    if (dot3(p[2].v, v4v0) > 0) p[1] = v4; else p[3] = v4;
-  } else {
-    if (dot3(p[3].v, v4v0) > 0) p[2] = v4; else p[1] = v4;
-  }
+  cross3(v4v0, v4.v, P.v[0]);
+  int j;
+  if (dot3(P.v[1], v4v0) > 0) j = (dot3(P.v[2], v4v0) > 0) ? 1 : 3;
+  else j = (dot3(P.v[3], v4v0) > 0) ? 2 : 1;
+  portal_set(P, j, v4);
 }
 template <typename real>
 FBD real origin_tri_dist2(const real* a, const real* b, const real* c, real* wit) {
@@ -96,85 +122,102 @@ FBD real origin_tri_dist2(const real* a, const real* b, const real* c, real* wit
   return dot3(wit, wit);
 }
 template <typename real>
-FBD void find_pos(const MprPt<real>* p, real* pos) {
+FBD void find_pos(const Portal<real>& P, real* pos) {
   real dir[3], t[3], b[4];
-  portal_dir(p, dir);
-  cross3(t, p[1].v, p[2].v); b[0] = dot3(t, p[3].v);
-  cross3(t, p[3].v, p[2].v); b[1] = dot3(t, p[0].v);
-  cross3(t, p[0].v, p[1].v); b[2] = dot3(t, p[3].v);
-  cross3(t, p[2].v, p[1].v); b[3] = dot3(t, p[0].v);
+  portal_dir(P, dir);
+  cross3(t, P.v[1], P.v[2]); b[0] = dot3(t, P.v[3]);
+  cross3(t, P.v[3], P.v[2]); b[1] = dot3(t, P.v[0]);
+  cross3(t, P.v[0], P.v[1]); b[2] = dot3(t, P.v[3]);
+  cross3(t, P.v[2], P.v[1]); b[3] = dot3(t, P.v[0]);
   real sum = b[0] + b[1] + b[2] + b[3];
   if (sum <= MPR_EPS) {
     b[0] = 0;
-    cross3(t, p[2].v, p[3].v); b[1] = dot3(t, dir);
-    cross3(t, p[3].v, p[1].v); b[2] = dot3(t, dir);
-    cross3(t, p[1].v, p[2].v); b[3] = dot3(t, dir);
+    cross3(t, P.v[2], P.v[3]); b[1] = dot3(t, dir);
+    cross3(t, P.v[3], P.v[1]); b[2] = dot3(t, dir);
+    cross3(t, P.v[1], P.v[2]); b[3] = dot3(t, dir);
     sum = b[1] + b[2] + b[3];
   }
   real inv = (real)1/sum, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
-  for (int i = 0; i < 4; i++) { addscl3(p1, p[i].v1, b[i]); addscl3(p2, p[i].v2, b[i]); }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { addscl3(p1, P.a1[i], b[i]); addscl3(p2, P.a2[i], b[i]); }
+#pragma unroll
   for (int k = 0; k < 3; k++) pos[k] = (real)0.5*inv*(p1[k] + p2[k]);
 }
 
 // Minkowski portal refinement on the margin-inflated shapes; returns penetration depth >= 0
 template <typename real>
 __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos, int* hit_cap) {
-  MprPt<real> p[4], v4;
+  Portal<real> P; MprPt<real> s, v4;
   real d[3], va[3], vb[3];
-  copy3(p[0].v1, a.pos); copy3(p[0].v2, b.pos); sub3(p[0].v, a.pos, b.pos);
-  if (dot3(p[0].v, p[0].v) < MPR_EPS*MPR_EPS) p[0].v[0] += (real)1e-9;
-  scl3(d, p[0].v, (real)-1); normalize3(d);
-  md_support(a, b, d, p[1]);
-  if (dot3(p[1].v, d) < 0) return false;
-  cross3(d, p[0].v, p[1].v);
+  copy3(P.a1[0], a.pos); copy3(P.a2[0], b.pos); sub3(P.v[0], a.pos, b.pos);
+  if (dot3(P.v[0], P.v[0]) < MPR_EPS*MPR_EPS) P.v[0][0] += (real)1e-9;
+  scl3(d, P.v[0], (real)-1); normalize3(d);
+  md_support(a, b, d, s);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { P.v[1][k] = s.v[k]; P.a1[1][k] = s.v1[k]; P.a2[1][k] = s.v2[k]; P.v[2][k] = 0; P.v[3][k] = 0; }
+  if (dot3(P.v[1], d) < 0) return false;
+  cross3(d, P.v[0], P.v[1]);
   if (dot3(d, d) < MPR_EPS*MPR_EPS) {
-    if (dot3(p[1].v, p[1].v) < MPR_EPS*MPR_EPS) { *depth = 0; dir[0] = 1; dir[1] = 0; dir[2] = 0; }
-    else { *depth = norm3(p[1].v); copy3(dir, p[1].v); normalize3(dir); }
-    for (int k = 0; k < 3; k++) pos[k] = (real)0.5*(p[1].v1[k] + p[1].v2[k]);
+    if (dot3(P.v[1], P.v[1]) < MPR_EPS*MPR_EPS) { *depth = 0; dir[0] = 1; dir[1] = 0; dir[2] = 0; }
+    else { *depth = norm3(P.v[1]); copy3(dir, P.v[1]); normalize3(dir); }
+    for (int k = 0; k < 3; k++) pos[k] = (real)0.5*(s.v1[k] + s.v2[k]);
     return true;
   }
   normalize3(d);
-  md_support(a, b, d, p[2]);
-  if (dot3(p[2].v, d) < 0) return false;
-  sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+  md_support(a, b, d, s);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { P.v[2][k] = s.v[k]; P.a1[2][k] = s.v1[k]; P.a2[2][k] = s.v2[k]; }
+  if (dot3(P.v[2], d) < 0) return false;
+  sub3(va, P.v[1], P.v[0]); sub3(vb, P.v[2], P.v[0]);
   cross3(d, va, vb); normalize3(d);
-  if (dot3(d, p[0].v) > 0) { MprPt<real> t = p[1]; p[1] = p[2]; p[2] = t; scl3(d, d, (real)-1); }
+  if (dot3(d, P.v[0]) > 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      real t = P.v[1][k]; P.v[1][k] = P.v[2][k]; P.v[2][k] = t;
+      t = P.a1[1][k]; P.a1[1][k] = P.a1[2][k]; P.a1[2][k] = t;
+      t = P.a2[1][k]; P.a2[1][k] = P.a2[2][k]; P.a2[2][k] = t;
+    }
+    scl3(d, d, (real)-1);
+  }
   for (int it = 0;; it++) {
     if (it > 4*MPR_ITER) { *hit_cap = 1; return false; }
-    md_support(a, b, d, p[3]);
-    if (dot3(p[3].v, d) < 0) return false;
-    bool cont = false;
-    cross3(va, p[1].v, p[3].v);
-    if (dot3(va, p[0].v) < -MPR_EPS) { p[2] = p[3]; cont = true; }
-    if (!cont) {
-      cross3(va, p[3].v, p[2].v);
-      if (dot3(va, p[0].v) < -MPR_EPS) { p[1] = p[3]; cont = true; }
+    md_support(a, b, d, s);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { P.v[3][k] = s.v[k]; P.a1[3][k] = s.v1[k]; P.a2[3][k] = s.v2[k]; }
+    if (dot3(P.v[3], d) < 0) return false;
+    int j = 0;
+    cross3(va, P.v[1], P.v[3]);
+    if (dot3(va, P.v[0]) < -MPR_EPS) j = 2;
+    if (!j) {
+      cross3(va, P.v[3], P.v[2]);
+      if (dot3(va, P.v[0]) < -MPR_EPS) j = 1;
     }
-    if (!cont) break;
-    sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+    if (!j) break;
+    portal_set(P, j, s);
+    sub3(va, P.v[1], P.v[0]); sub3(vb, P.v[2], P.v[0]);
     cross3(d, va, vb); normalize3(d);
   }
   for (int it = 0;; it++) {
-    portal_dir(p, d);
-    if (dot3(d, p[1].v) >= 0) break;
+    portal_dir(P, d);
+    if (dot3(d, P.v[1]) >= 0) break;
     md_support(a, b, d, v4);
     if (it > MPR_ITER) *hit_cap = 1;
-    if (dot3(v4.v, d) < 0 || reach_tol(p, v4, d) || it > MPR_ITER) return false;
-    expand_portal(p, v4);
+    if (dot3(v4.v, d) < 0 || reach_tol(P, v4, d) || it > MPR_ITER) return false;
+    expand_portal(P, v4);
   }
   for (int it = 0;; it++) {
-    portal_dir(p, d);
+    portal_dir(P, d);
     md_support(a, b, d, v4);
-    if (reach_tol(p, v4, d) || it > MPR_ITER) {
-      if (it > MPR_ITER && !reach_tol(p, v4, d)) *hit_cap = 1;
+    if (reach_tol(P, v4, d) || it > MPR_ITER) {
+      if (it > MPR_ITER && !reach_tol(P, v4, d)) *hit_cap = 1;
       real wit[3];
-      real d2 = origin_tri_dist2(p[1].v, p[2].v, p[3].v, wit);
+      real d2 = origin_tri_dist2(P.v[1], P.v[2], P.v[3], wit);
       *depth = fb_sqrt(d2);
       if (*depth < MPR_EPS) copy3(dir, d); else { copy3(dir, wit); normalize3(dir); }
-      find_pos(p, pos);
+      find_pos(P, pos);
       return true;
     }
-    expand_portal(p, v4);
+    expand_portal(P, v4);
   }
 }
 
@@ -379,7 +422,12 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p
     c_sphere_sphere(lc, p1, s1[0], v, s2[0], margin);
   } else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) c_capsule_capsule(lc, p1, m1, s1, p2, m2, s2, margin);
   else {
-    CGeom<real> A = {p1, m1, s1, t1, margin}, B = {p2, m2, s2, t2, margin};
+    CGeom<real> A, B;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A.pos[k] = p1[k]; B.pos[k] = p2[k]; A.size[k] = s1[k]; B.size[k] = s2[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { A.mat[k] = m1[k]; B.mat[k] = m2[k]; }
+    A.type = t1; B.type = t2; A.margin = margin; B.margin = margin;
     real depth, dir[3], pos[3];
     if (mpr_penetration(A, B, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
   }
