@@ -100,8 +100,7 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   if (lane < ncon) { w.con_efc()[lane] = dim ? adr : -1; w.con_dim()[lane] = dim; }
   int b1 = 0, b2 = 0;
   if (dim) {
-    int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-    b1 = M.geom_bodyid[g1]; b2 = M.geom_bodyid[g2];
+    { const int pb = M.pair_body[p]; b1 = pb & 0xffff; b2 = pb >> 16; }
     real K, B, imp;
     kbi(M, M.pair_solref + 2*p, M.pair_solimp + 5*p, dist, incl, false, K, B, imp);
     real tran = M.body_invweight0[2*b1] + M.body_invweight0[2*b2];
@@ -372,7 +371,7 @@ __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<re
   int cb1 = 0, cb2 = 0;
   if (lane < ncon) {
     int p = w.con_pair()[lane];
-    cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
+    { const int pb = M.pair_body[p]; cb1 = pb & 0xffff; cb2 = pb >> 16; }
   }
   int aid = -1; real aforce = 0;
   if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force()[ai]; }

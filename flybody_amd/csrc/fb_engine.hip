@@ -36,7 +36,7 @@ struct fb_model {
   int nq, nv, nbody, njnt, ngeom, nsite, nu, na, ntendon, npair, nM, nsubstep, nobsjnt, napp, nforce, ntouch;
   std::vector<int> body_nsub, body_depth, body_chlen, body_chain, body_common, dof_depth, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
-  std::vector<int> pair_word, plane_geoms;
+  std::vector<int> pair_word, pair_body, plane_geoms;
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
@@ -343,6 +343,10 @@ static int model_load_impl(fb_model* m, size_t n) {
     for (int g = 0; g < m->ngeom; g++) if (gt[g] == GEOM_PLANE) { m->plane_geoms.push_back(g); slot[g] = m->ngeom + (int)m->plane_geoms.size() - 1; }
     if (m->ngeom + (int)m->plane_geoms.size() > 1023 || 4*(m->ngeom + (int)m->plane_geoms.size()) > LdsCfg<double>::AR_ELEMS + FB_MAXNV) { return fail("fb_model_load: too many geoms for the LDS staging area of the collision mid phase"); }
     m->pair_word.assign(std::max(m->npair, 1), 0);
+    // the two bodies of a pair, packed (b1 | b2 << 16): constant, so that a contact's bodies are one lookup behind its pair id
+    // instead of pair -> geom -> body
+    m->pair_body.assign(std::max(m->npair, 1), 0);
+    { const int* gb = m->i("geom_bodyid"); for (int q = 0; q < m->npair; q++) m->pair_body[q] = gb[g1[q]] | (gb[g2[q]] << 16); }
     for (int q = 0; q < m->npair; q++) {
       if (gt[g2[q]] == GEOM_PLANE) { return fail("fb_model_load: a plane must be the first geom of a pair"); }
       m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20);
@@ -662,7 +666,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UV(wrap_qadr, wrap_qadr) UV(act_wn, act_wn) UV(act_wdof, act_wdof) UV(act_lenadr, act_lenadr)
   if (upload<real>(b, m->act_wcoef.data(), m->act_wcoef.size(), &M.act_wcoef)) return -1;
   UI(pair_geom1, "pair_geom1") UI(pair_geom2, "pair_geom2") UI(pair_condim, "pair_condim")
-  UV(pair_word, pair_word) UV(plane_geoms, plane_geoms)
+  UV(pair_word, pair_word) UV(pair_body, pair_body) UV(plane_geoms, plane_geoms)
   { const int* gt_ = m->i("geom_type"); int np_ = 0; for (int g = 0; g < m->ngeom; g++) np_ += gt_[g] == GEOM_PLANE; M.nplane = np_; }
   UI(obs_jnt, "observable_joints") UI(app_sites, "appendage_sites") UI(force_sites, "sensor_force_sites") UI(touch_sites, "sensor_touch_sites") UI(wing_jnt, "wing_jnt")
   UD(body_mass, "body_mass")

@@ -62,17 +62,27 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
   // wrench of each active contact about the tree CoM, in the lane that owns the contact (at most 64 contacts)
   int cb1 = -1, cb2 = -1;
   real cw[6] = {0, 0, 0, 0, 0, 0}, cfn = 0;
-  if (lane < ncon) {
-    int adr = w.con_efc()[lane];
-    if (adr >= 0) {
-      int p = w.con_pair()[lane];
-      cb1 = M.geom_bodyid[M.pair_geom1[p]]; cb2 = M.geom_bodyid[M.pair_geom2[p]];
-      cfn = w.efc_force()[adr];
+  {
+    // two rounds of loads: everything indexed by the contact (= lane), then what hangs off its pair id and row address
+    const bool cv = lane < ncon; const int cs = cv ? lane : 0;
+    const int adr = cv ? w.con_efc()[cs] : -1, p = w.con_pair()[cs], cdim = w.con_dim()[cs];
+    real fr[9], cp[3], cm[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) fr[k] = w.con_frame()[9*cs + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cp[k] = w.con_pos()[3*cs + k]; cm[k] = w.com()[k]; }
+    const bool act = cv && adr >= 0;
+    const int a0 = act ? adr : 0, ps = act ? p : 0;
+    const int pb = M.pair_body[ps];
+    const real f0 = w.efc_force()[a0], f1 = w.efc_force()[a0 + ((act && cdim > 1) ? 1 : 0)], f2 = w.efc_force()[a0 + ((act && cdim > 1) ? 2 : 0)];
+    if (act) {
+      cb1 = pb & 0xffff; cb2 = pb >> 16;
+      cfn = f0;
       real lf[3] = {cfn, 0, 0};
-      if (w.con_dim()[lane] > 1) { lf[1] = w.efc_force()[adr+1]; lf[2] = w.efc_force()[adr+2]; }
+      if (cdim > 1) { lf[1] = f1; lf[2] = f2; }
       real r[3];
-      mulmatT3(cw + 3, w.con_frame() + 9*lane, lf);
-      sub3(r, w.con_pos() + 3*lane, w.com());
+      mulmatT3(cw + 3, fr, lf);
+      sub3(r, cp, cm);
       cross3(cw, r, cw + 3);
     }
   }
@@ -144,7 +154,15 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     int s = M.force_sites[k], b = M.site_bodyid[s];
     real acc[3] = {0, 0, 0};
     int n = M.body_nsub[b];
-    for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc() + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
+    // subtree sum, deepest body first; the first 8 bodies' loads are in flight together (a tarsus subtree has 5)
+    {
+      real c8[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int d = n - 1 - u; const real* c = w.cfrc() + 6*(b + (d >= 0 ? d : 0)) + 3; c8[u][0] = c[0]; c8[u][1] = c[1]; c8[u][2] = c[2]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (n - 1 - u >= 0) { acc[0] += c8[u][0]; acc[1] += c8[u][1]; acc[2] += c8[u][2]; }
+    }
+    for (int d = n - 9; d >= 0; d--) { const real* c = w.cfrc() + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
     mulmatT3(w.sens() + 9 + 3*k, w.sxmat() + 9*s, acc);
   }
   {
