@@ -233,6 +233,8 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
         if (lane == j) invd = inv;
         const real yj = rdlane(y, j)*inv;
         y = (lane == j) ? yj : y - lcol*yj;
+        // the diagonal of every remaining row loses its own lcol^2 (once per pivot, not once per remaining column)
+        dg -= ((mrem >> lane) & 1ull) ? lcol*lcol : (real)0;
         unsigned long long m2 = mrem;
 #pragma unroll
         for (int q = 1; q < FB_NEWTON_NR; q++) {
@@ -240,7 +242,6 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
             const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
             const real lk = rdlane(lcol, kk);
             Kr[q - 1] = Kr[q] - lcol*lk;            // (lanes <= kk update an entry they never use)
-            dg -= (lane == kk) ? lcol*lk : (real)0;
           }
         }
       }
