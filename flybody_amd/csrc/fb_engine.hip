@@ -642,7 +642,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
     // kinematics level loop: bodies beyond the wavefront width ride along on lanes whose own body sits on a
     // different level, so one trip down the levels covers every body (fb_smooth.hpp fk_pass)
     std::vector<int> second(FB_WAVE, -1);
-    bool ok = m->nbody > FB_WAVE && m->nbody <= 2*FB_WAVE;
+    bool ok = m->nbody > FB_WAVE && m->nbody <= 2*FB_WAVE && getenv("FB_NO_FK_MERGE") == nullptr;      // (switch: tests run both paths)
     for (int bq = FB_WAVE; ok && bq < m->nbody; bq++) {
       int pick = -1;
       for (int l = 0; l < FB_WAVE && pick < 0; l++) if (second[l] < 0 && (l == 0 || m->body_depth[l] != m->body_depth[bq])) pick = l;

@@ -77,6 +77,29 @@ def test_env_steps_match_oracle_and_golden(emu_model, oracle_model, reference_tr
     assert B.get('REWARD')[0, 0] == 1.0 and B.get('STEP_TYPE')[0, 0] == 1
 
 
+def test_kinematics_level_loop_merged_equals_separate_passes(emu_lib, walk_arrays, reference_traj, monkeypatch):
+    """fb_engine.hip pairs the four bodies beyond the wavefront width with lanes of another tree level so that the kinematics level loop
+    runs once (`fk_second`); models it cannot pair, or with <= 64 bodies, take one pass per 64 bodies.  Both paths must give the same
+    state to the bit: FB_NO_FK_MERGE=1 at model load selects the separate passes."""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (4, 3, 59)).astype(np.float32)
+    out = []
+    for flag in (None, '1'):
+        if flag is None: monkeypatch.delenv('FB_NO_FK_MERGE', raising=False)
+        else: monkeypatch.setenv('FB_NO_FK_MERGE', flag)
+        M = engine.Model(walk_arrays, lib_path=emu_lib)
+        B = engine.Batch(M, 3, precision=64)
+        B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+        for k in range(4):
+            a = np.ascontiguousarray(acts[k]); B.step_ptr(a.ctypes.data)
+        out.append((B.get('QPOS').copy(), B.get('QVEL').copy(), B.get('XPOS').copy(), B.get('GEOM_XMAT').copy(), B.get('OBS').copy()))
+        del B, M
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_lane_order_independence(emu_lib):
     """Running the 64 lanes in reverse order between barriers must not change a single bit:
     a cheap detector for missing synchronisation."""

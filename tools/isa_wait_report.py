@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Static view of how a stage's vector-memory operations are issued: compiles the engine to gfx950 assembly (hipcc -S, device only)
+and prints, per function, the sequence of loads (L), stores (S) and `s_waitcnt vmcnt(n)` ([n]) in program order, plus counts of
+scratch instructions.  Vector-memory returns are counted in order, so
+  * `L[0]L[0]L[0]...`      is a chain of fully exposed round trips (index load -> gather written in one loop, pointer chasing),
+  * `S L [0]`              makes the load wait for the store's acknowledgement,
+  * scratch_* in a loop    is a local array with a runtime index (or a struct that contains one) living in memory.
+Round 3 used this next to tools/phase_profile.py to find the serialised prologue of the factorisation, the scratch-resident MPR
+portal and the per-level table lookups.  Usage: python tools/isa_wait_report.py [precision: d|f] [name filter]"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+prec = sys.argv[1] if len(sys.argv) > 1 else 'd'
+flt = sys.argv[2] if len(sys.argv) > 2 else ''
+out = os.path.join(tempfile.gettempdir(), 'fb_engine_isa.s')
+subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                       '-o', out, os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')], stderr=subprocess.DEVNULL)
+lines = open(out).read().splitlines()
+heads = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r'^(_Z\w+):', l)] if m]
+tag = 'I%sE' % prec
+for a, name in heads:
+    if tag not in name or flt not in name:
+        continue
+    b = next(i for i in range(a, len(lines)) if lines[i].startswith('.Lfunc_end'))
+    body = [x.strip() for x in lines[a:b] if x.startswith('\t') and not x.strip().startswith(('.', ';'))]
+    seq = []
+    for x in body:
+        if x.startswith(('global_store', 'flat_store')): seq.append('S')
+        elif x.startswith(('global_load', 'flat_load')): seq.append('L')
+        elif x.startswith('scratch_load'): seq.append('l')
+        elif x.startswith('scratch_store'): seq.append('s')
+        elif x.startswith('s_waitcnt') and 'vmcnt' in x: seq.append('[%s]' % re.search(r'vmcnt\((\d+)\)', x).group(1))
+    s = ''.join(seq)
+    try:
+        pretty = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip().split('(')[0]
+    except Exception:
+        pretty = name
+    print(f'== {pretty}: {len(body)} instructions, {s.count("L")} loads, {s.count("S")} stores, {s.count("[0]")} full waits, '
+          f'{s.count("l") + s.count("s")} scratch ops')
+    print('   ' + s)
