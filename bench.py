@@ -162,6 +162,11 @@ def main():
             dist.init_process_group(backend)
     n_env = args.envs_per_gpu
     model = engine.Model.from_asset('walk_imitation')
+    # FP64 batches beyond the 2048 resident slots of the default build run on the 12-environments-per-CU build of the same kernel
+    # (engine.HIP_LIB_DENSE, 3072 resident): with the substep scheduler the extra residency pays in lock-step too (8.2 against 9.0 ms
+    # for 4096 environments; FB_BENCH_DEFAULT_BUILD=1 keeps the default build).  Same source, same arithmetic, own parity tests.
+    dense_headline = (args.precision == 64 and n_env > 2048 and os.path.exists(engine.HIP_LIB_DENSE) and os.environ.get('FB_BENCH_DEFAULT_BUILD') is None)
+    model_headline = engine.Model.from_asset('walk_imitation', dense=True) if dense_headline else model
     qp, qv = default_walking_reference()
     stream = torch.cuda.current_stream().cuda_stream
     nu = model.dim('nu')
@@ -178,7 +183,7 @@ def main():
     def run_leg(precision, extras=None):
         """W untimed + K timed control steps of the whole batch; returns (seconds, kernel ms total, launches, finite).
         extras (dict): filled with the end state of the sampled environments and the FB_WARN population."""
-        batch = engine.Batch(model, n_env, device=local_rank, precision=precision)
+        batch = engine.Batch(model_headline if precision == args.precision else model, n_env, device=local_rank, precision=precision)
         batch.set_reference(qp, qv, terminal_com_dist=float('inf'))
         batch.reset(stream=stream)
         gen = torch.Generator(device='cuda'); gen.manual_seed(seed0)
@@ -213,6 +218,7 @@ def main():
             extras['warn'] = {name: int(((wv & bit) != 0).sum()) for name, bit in engine.WARN_BITS.items()}
             extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
             extras['solver_iterations_mean'] = float(batch.get('SOLVER_NITER').mean())
+            extras['scheduler'] = ('substep tickets: waves draw (environment, substep) units per XCD, the batch exceeds the %d resident slots' % batch.resident_slots) if batch.substep_scheduler else 'one environment per wave, longest first'
         del batch
         return dt, kernel_ms, nlaunch, finite
 
@@ -384,7 +390,8 @@ def main():
                        'parallelism': f'env-shard x{world}, no data-path collective', 'state_finite': finite,
                        'solver': 'Newton (the reference XML sets no solver = MuJoCo default), constraint-space restatement; noslip 3',
                        'solver_iterations_mean': extras.get('solver_iterations_mean'),
-                       'auto_resets': extras.get('auto_resets')},
+                       'auto_resets': extras.get('auto_resets'), 'scheduler': extras.get('scheduler'),
+                       'build': ('libflybody_hip_dense.so: FP64, 12 environments per CU (3072 resident)' if dense_headline else 'libflybody_hip.so: default build (FP64: 8 environments per CU, 2048 resident)')},
             # the binding roofline of this path is the vector ALU (neither HBM nor MFMA bounds it), so the primary
             # achieved/peak/frac are algorithmic FLOP/s against the vector peak of the arithmetic type; the HBM view the
             # contract also asks for (algorithmic bytes / launch time against 8 TB/s, and the PMC traffic) sits in `hbm`

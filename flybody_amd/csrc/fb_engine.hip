@@ -470,7 +470,22 @@ struct Batch {
   int n_env, nobs;
   int* sched;                 // [FB_NSCHED] progress counters, zeroed before every launch
   int* cost;                  // [n_env] duration of the environment's last control step (wall-clock ticks), input of k_order
+  int* tick;                  // substep scheduler (null = off): [nq][16] ticket counters, one per XCD, zeroed before every launch
+  int* done;                  // ... [n_env] substeps of the running control step completed, zeroed before every launch
+  int nq;                     // ... number of XCDs (ticket queues)
 };
+
+// XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ int fb_xcc_id() {
+#ifdef FB_EMULATE
+  return 0;
+#else
+  return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u);
+#endif
+}
+#ifndef FB_EMULATE
+__global__ void k_probe_xcc(unsigned* mask) { if (threadIdx.x == 0) atomicOr(mask, 1u << fb_xcc_id()); }
+#endif
 
 
 template <typename real>
@@ -502,6 +517,65 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
   int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
   int slot = blockIdx.x*EPB + wave;
   if (slot >= nslot) return;
+  if (B.tick && mode == MODE_STEP) {
+    // ---- substep scheduler.  A batch larger than the resident wave slots used to run as "one environment per wave, start
+    // to end": two environments per slot, and a launch as long as its unluckiest pair (1.18 x the mean load per slot with the
+    // previous-step order, 1.13 x with perfect knowledge: tools/order_study.py).  Nothing LDS-resident crosses a substep
+    // boundary any more, so the unit of work is ONE SUBSTEP of one environment: every wave draws tickets from the queue of
+    // its XCD -- ticket t = substep t / cnt of environment (t % cnt) of that XCD's share -- until the queue is empty.  All
+    // environments of an XCD advance together, the waves stay busy until the last round, and the launch ends within one
+    // substep of sum(durations) / slots.  An environment's substeps are ordered by its `done` counter (a ticket waits for its
+    // predecessor, which an earlier ticket -- a running wave -- holds: no deadlock; the wait is iteration-capped all the same).
+    // An environment is bound to one XCD (env % nq), so its row only ever lives in one L2; the hand-over between waves of
+    // different CUs needs the stores drained to that L2 (the vector L1 is write-through) and the reader's L1 invalidated
+    // (acquire fence).  Protocol measured stand-alone in tools/microbench/ticket_proto.hip.
+    const int nq = B.nq, xcc = fb_xcc_id() % nq, nsubm = uniform_int(M.nsubstep);
+    const int cnt = (B.n_env - xcc + nq - 1)/nq;
+    const int total = cnt*nsubm;
+    for (int guard = 0; guard < (1 << 20); guard++) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(B.tick + 16*xcc, 1);
+      t = uniform_int(__shfl(t, 0, FB_WAVE));
+      if (t >= total || cnt <= 0) return;
+      const int round = t / cnt, env = (t % cnt)*nq + xcc;
+      // wait for the predecessor substep (normally long done: it was drawn `cnt` tickets ago)
+      int d = 0;
+      for (int spins = 0; spins < (1 << 22); spins++) {
+#ifndef FB_EMULATE
+        if (lane == 0) d = __hip_atomic_load(B.done + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        if (lane == 0) d = B.done[env];
+#endif
+        d = uniform_int(__shfl(d, 0, FB_WAVE));
+        if (d >= round) break;
+#ifndef FB_EMULATE
+        __builtin_amdgcn_s_sleep(32);
+#endif
+      }
+      if (d > round) continue;                       // the environment was auto-reset by its first ticket: the step is complete
+#ifndef FB_EMULATE
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      WS<real> w;
+      w.o = (const FB_CONST WSOff*)&M.off;
+      w.rb = (FB_GLOBAL real*)(B.rarena + (size_t)env*M.off.nreal); w.ib = (FB_GLOBAL int*)(B.iarena + (size_t)env*M.off.nint);
+      w.lLD = (FB_LDS real*)s_pool[wave]; w.lAR = w.lLD + FB_LDS_SCRATCH; w.lx = w.lAR + LdsCfg<real>::AR_ELEMS;
+      w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
+      w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
+      float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
+      if (lane == 0 && round == 0) { w.istate()[IS_PRIO] = 0; w.istate()[IS_WARN] = 0; }
+      const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
+                                   B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nsubm - 1 ? 2 : 0));
+#ifndef FB_EMULATE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      if (lane == 0) B.done[env] = was_reset ? nsubm + 1 : round + 1;
+#endif
+    }
+    return;
+  }
   int env = uniform_int(env_ids ? env_ids[slot] : slot);
   WS<real> w;
   w.o = (const FB_CONST WSOff*)&M.off;
@@ -578,6 +652,7 @@ struct fb_batch {
   int* d_ids = nullptr;
   int* sched = nullptr;
   int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true;
+  int *tick = nullptr, *done = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
@@ -737,6 +812,27 @@ static int batch_create_impl(fb_batch* b) {
   HIPCHK(hipMemset(b->cost, 0, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->order, n_env*sizeof(int)));
   { const char* e_ = getenv("FB_NO_REORDER"); b->reorder = !(e_ && e_[0] == '1'); }
+  // substep scheduler: for batches larger than the resident wave slots (k_fly)
+  {
+#ifdef FB_EMULATE
+    b->nq = 1; b->slots = 2;                                   // (host emulation: tiny, so that the test batches take the ticket path)
+#else
+    int nb = 0;
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, b->device));
+    if (precision == 64) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fly<double>, FB_WAVE*LdsCfg<double>::EPB, 0)); b->slots = nb*prop.multiProcessorCount*LdsCfg<double>::EPB; }
+    else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fly<float>, FB_WAVE*LdsCfg<float>::EPB, 0)); b->slots = nb*prop.multiProcessorCount*LdsCfg<float>::EPB; }
+    unsigned* dmask; unsigned hmask = 0;
+    HIPCHK(hipMalloc((void**)&dmask, sizeof(unsigned))); HIPCHK(hipMemset(dmask, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(k_probe_xcc, dim3(4096), dim3(FB_WAVE), 0, 0, dmask);
+    HIPCHK(hipMemcpy(&hmask, dmask, sizeof(unsigned), hipMemcpyDeviceToHost)); HIPCHK(hipFree(dmask));
+    int nqq = __builtin_popcount(hmask);
+    b->nq = (nqq > 0 && hmask == (1u << nqq) - 1u) ? nqq : 0;          // XCC ids 0 .. nq-1, all seen; anything else: scheduler off
+    if (const char* e_ = getenv("FB_TICKET_SLOTS")) b->slots = atoi(e_);             // (test switch: pretend fewer resident slots)
+#endif
+    HIPCHK(hipMalloc((void**)&b->tick, 16*16*sizeof(int)));
+    HIPCHK(hipMalloc((void**)&b->done, n_env*sizeof(int)));
+    b->tickets = b->nq > 0 && b->slots > 0 && n_env > b->slots && getenv("FB_NO_TICKETS") == nullptr;
+  }
   b->use_prio = getenv("FB_NO_PRIO") == nullptr;
   HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));
   HIPCHK(hipMemset(b->discount, 0, n_env*sizeof(float)));
@@ -759,7 +855,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -925,13 +1021,19 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
     memcpy(hD, hM, nM);
   }
   HIPCHK(hipMemsetAsync(b->sched, 0, FB_NSCHED*sizeof(int), st));
-  const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder;
+  // a control step of the whole batch: substep scheduler when the batch exceeds the resident slots, otherwise one environment per
+  // wave in longest-first order
+  const bool tickets = (mode == MODE_STEP) && !ids && n == b->n_env && b->tickets;
+  const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder && !tickets;
   if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
+  if (tickets) { HIPCHK(hipMemsetAsync(b->tick, 0, 16*16*sizeof(int), st)); HIPCHK(hipMemsetAsync(b->done, 0, (size_t)n*sizeof(int), st)); }
   if (b->precision == 64) {
-    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost};
+    Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
+                       tickets ? b->tick : nullptr, b->done, b->nq};
     hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
-    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost};
+    Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
+                      tickets ? b->tick : nullptr, b->done, b->nq};
     hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
@@ -1100,6 +1202,12 @@ extern "C" void* fb_batch_device_ptr(fb_batch* b, int field) {
     case FB_STEP_TYPE: return b->step_type;
     default: return nullptr;
   }
+}
+
+extern "C" int fb_batch_scheduler(const fb_batch* b, int* slots) {
+  if (!b) return fail("fb_batch_scheduler: null batch");
+  if (slots) *slots = b->slots;
+  return b->tickets ? 1 : 0;
 }
 
 extern "C" int fb_batch_timing_begin(fb_batch* b, void* stream) {

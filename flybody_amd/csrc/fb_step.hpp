@@ -718,16 +718,20 @@ template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const 
   else d_walk_post(M, w, obs, reward, discount, step_type, lane);
 }
 
+// tk < 0: the whole call (all substeps of a control step, or what `mode` says).  tk >= 0: ONE substep of a control step handed out by
+// the substep scheduler of k_fly (MODE_STEP only): bit 0 = first substep of the step (the action scatter, or the auto-reset, happens
+// here), bit 1 = last (the task epilogue happens here).  Returns true when the call was an auto-reset (the step is complete then).
 template <typename real>
-__device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
-                      float* obs, float* reward, float* discount, int* step_type, int lane) {
+__device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
+                      float* obs, float* reward, float* discount, int* step_type, int lane, int tk = -1) {
   // every selector of the stage machine is wave-uniform: say so (v_readfirstlane), otherwise the interpreter's state lives in
   // VGPRs + saved exec masks across every stage call and counts against the register budget of all stages
-  mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg);
-  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
+  mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg); tk = uniform_int(tk);
+  const bool tk_first = tk < 0 || (tk & 1), tk_last = tk < 0 || (tk & 2);
+  bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && tk_first && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
   bool actuate = true, damp = false, half = false;
-  int nsub = uniform_int((mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep), sub = 0;
+  int nsub = uniform_int(tk >= 0 ? 1 : ((mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep)), sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   const WS<real> wc = w;                  // the stages are separate functions: they read this copy, `w` itself stays in registers
   if (resetting) {
@@ -737,7 +741,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
     pc = ST_KIN;
   } else {
     PROF_BEGIN();
-    if (mode == MODE_STEP) s_pre(M, wc, action, lane);
+    if (mode == MODE_STEP && tk_first) s_pre(M, wc, action, lane);
     PROF(27);
     pc = (nsub > 0) ? ST_ACT : ST_DONE;
   }
@@ -847,6 +851,7 @@ __device__ __forceinline__ void d_run(const DevModel<real>& M, const WS<real>& w
     }
   }
   PROF_BEGIN();
-  if (env_logic) s_post(M, wc, resetting, obs, reward, discount, step_type, lane);
+  if (env_logic && (tk_last || resetting)) s_post(M, wc, resetting, obs, reward, discount, step_type, lane);
   PROF(28);
+  return resetting;
 }

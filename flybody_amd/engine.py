@@ -76,6 +76,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p
     L.fb_batch_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_scheduler.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.fb_batch_scheduler.restype = C.c_int
     L.fb_batch_timing_begin.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _libs[path] = L
@@ -250,6 +251,15 @@ class Batch:
         if not p:
             raise EngineError(f'no device pointer for {name}')
         return p
+
+    @property
+    def substep_scheduler(self) -> bool:
+        """True when fb_batch_step hands out (environment, substep) tickets (batch larger than the resident wave slots); scheduling only."""
+        return self.L.fb_batch_scheduler(self.h, None) == 1
+
+    @property
+    def resident_slots(self) -> int:
+        n = C.c_int(); self.L.fb_batch_scheduler(self.h, C.byref(n)); return n.value
 
     def timing_begin(self, stream=None):
         _check(self.L, self.L.fb_batch_timing_begin(self.h, stream))

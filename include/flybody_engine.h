@@ -170,6 +170,11 @@ int fb_batch_synchronize(fb_batch* b, void* stream);
 int fb_batch_timing_begin(fb_batch* b, void* stream);
 int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launches);
 
+/* How fb_batch_step schedules a control step of this batch: 1 = substep scheduler (the batch exceeds the GPU's resident wave slots:
+ * waves draw (environment, substep) tickets per XCD until the step is complete), 0 = one environment per wave, longest first.
+ * Scheduling only: results are identical.  `slots` (may be NULL) receives the number of resident environments of this build. */
+int fb_batch_scheduler(const fb_batch* b, int* slots);
+
 const char* fb_last_error(void);
 
 /* Build identity of the shared object: "flybody_engine <abi> (<target>, <hash of the kernel sources it was built from>)".

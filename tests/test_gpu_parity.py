@@ -536,7 +536,8 @@ def _headline_run(models, sizes, steps, oracle_model, reference_traj, seed, stre
             fbo.step_batch(ods[p], acts[p][samples[p]].astype(np.float64))
         torch.cuda.synchronize()
         for p, B in enumerate(batches):
-            order = B.get('LAUNCH_ORDER').ravel()
+            # (a batch beyond the resident slots is stepped by the substep scheduler: no launch order, every environment shares the slots)
+            order = np.arange(sizes[p]) if B.substep_scheduler else B.get('LAUNCH_ORDER').ravel()
             if k > 0:
                 pos = np.empty(sizes[p], np.int64); pos[order] = np.arange(sizes[p]); positions[p].append(pos[samples[p]])
     eq = ev = 0.0
@@ -552,15 +553,24 @@ def _headline_run(models, sizes, steps, oracle_model, reference_traj, seed, stre
     return eq, ev, [np.array(x) for x in positions]
 
 
+@pytest.mark.parametrize('sched', ['substep', 'per_wave'])
 @pytest.mark.parametrize('dense', [False, True])
-def test_headline_batch_parity_fp64(gpu_model, oracle_model, reference_traj, dense):
-    """BENCH configuration, checked against the oracle: FP64, 4096 environments in lock-step = two residency rounds of the 2048
-    resident FP64 environments (default build; the 12-per-CU build holds 3072), 30 control steps of the bench's clipped N(0, 1)
-    actions with the longest-first launch order active.  64 sampled environments -- including ids on both sides of the
-    residency boundary and environments that were launched in the SECOND round -- against the CPU oracle at 1e-6."""
+def test_headline_batch_parity_fp64(gpu_model, oracle_model, reference_traj, dense, sched, monkeypatch):
+    """BENCH configuration, checked against the oracle: FP64, 4096 environments in lock-step = twice the 2048 resident FP64
+    environments (default build; the 12-per-CU build holds 3072), 30 control steps of the bench's clipped N(0, 1) actions.
+    Both ways a control step of such a batch can be scheduled: `substep` -- the default: waves draw (environment, substep)
+    tickets, consecutive substeps of an environment run on different waves and CUs of its XCD -- and `per_wave` (FB_NO_TICKETS=1:
+    one environment per wave from the first to the last substep, two residency rounds in longest-first launch order).  64 sampled
+    environments -- ids on both sides of the residency boundary, environments launched in the second round -- against the CPU
+    oracle at 1e-6."""
     import torch
     from flybody_amd import engine
+    if sched == 'per_wave': monkeypatch.setenv('FB_NO_TICKETS', '1')
+    else: monkeypatch.delenv('FB_NO_TICKETS', raising=False)
     M = engine.Model.from_asset('walk_imitation', dense=True) if dense else gpu_model
+    probe = engine.Batch(M, 4096, precision=64)
+    assert probe.substep_scheduler == (sched == 'substep') and probe.resident_slots == (3072 if dense else 2048), (probe.substep_scheduler, probe.resident_slots)
+    del probe
     eq, ev, pos = _headline_run([M], [4096], 30, oracle_model, reference_traj, seed=11, streams=[torch.cuda.current_stream()])
     assert eq < 1e-6 and ev < 1e-6, (eq, ev)
     resident = 3072 if dense else 2048

@@ -100,6 +100,37 @@ def test_kinematics_level_loop_merged_equals_separate_passes(emu_lib, walk_array
         assert np.array_equal(x, y)
 
 
+def test_substep_scheduler_equals_one_environment_per_wave(emu_lib, walk_arrays, reference_traj, monkeypatch):
+    """Batches larger than the resident wave slots are stepped by the substep scheduler of k_fly (tickets: one substep of one
+    environment per draw, `done` counters order an environment's substeps); smaller ones, or FB_NO_TICKETS=1, run one environment
+    per wave from the first to the last substep.  Same stages, same order per environment: the results must agree to the bit --
+    through an auto-reset (the first ticket of a reset environment completes its step) and for every output of the epilogue.
+    (The emulation build has 2 `slots`, so its test batches take the ticket path; what the host cannot show -- the hand-over
+    between CUs through the L2 -- is covered by the 4096-environment parity tests on the GPU and tools/microbench/ticket_proto.hip.)"""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-1, 1, (6, 5, 59)).astype(np.float32)
+    out = []
+    for flag in (None, '1'):
+        if flag is None: monkeypatch.delenv('FB_NO_TICKETS', raising=False)
+        else: monkeypatch.setenv('FB_NO_TICKETS', flag)
+        M = engine.Model(walk_arrays, lib_path=emu_lib)
+        B = engine.Batch(M, 5, precision=64)
+        B.set_reference(qp[:8], qv[:8], future_steps=2, terminal_com_dist=float('inf')); B.reset()       # a short episode: the rollout crosses LAST -> FIRST
+        rec = []
+        for k in range(6):
+            a = np.ascontiguousarray(acts[k]); B.step_ptr(a.ctypes.data)
+            rec.append((B.get('QPOS').copy(), B.get('QVEL').copy(), B.get('OBS').copy(), B.get('REWARD').copy(), B.get('STEP_TYPE').copy(), B.get('SENSORDATA').copy()))
+        out.append(rec)
+        del B, M
+    types = np.array([r[4].ravel() for r in out[0]])
+    assert (types == 2).any() and (types == 0).any()               # the episode ended and restarted inside the rollout
+    for ra, rb in zip(*out):
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+
+
 def test_lane_order_independence(emu_lib):
     """Running the 64 lanes in reverse order between barriers must not change a single bit:
     a cheap detector for missing synchronisation."""
@@ -153,7 +184,7 @@ def test_flight_imitation_matches_oracle(emu_lib):
     assert not np.array_equal(B.get('QPOS')[0], B.get('QPOS')[1])       # a different initial wing phase per environment
 
 
-def test_launch_order_is_longest_first_permutation(emu_model, reference_traj):
+def test_launch_order_is_longest_first_permutation(emu_model, reference_traj, monkeypatch):
     """k_order (fb_engine.hip): after a full-batch step the next launch order is a permutation of the environments, sorted
     by the duration of their last step, longest first, up to the 256-bin resolution of the counting sort.  (On the host
     there is no GPU clock; the emulation build records an arbitrary per-environment number, which is all the sort needs.)
@@ -161,6 +192,7 @@ def test_launch_order_is_longest_first_permutation(emu_model, reference_traj):
     from flybody_amd import engine
     qp, qv = reference_traj
     n = 37
+    monkeypatch.setenv('FB_NO_TICKETS', '1')      # one environment per wave (batches within the resident slots): the path this test is about
     B = engine.Batch(emu_model, n, precision=64)
     B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
     a = np.tile(np.random.default_rng(0).uniform(-0.3, 0.3, 59).astype(np.float32), (n, 1))
