@@ -11,8 +11,8 @@ timeout 600 bash tools/calibrate_traffic.sh final > $O/calibrate.log 2>&1
 timeout 900 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_1000_steps.json 2> $O/bench_1000_steps.err
 timeout 300 python tools/solver_bench.py 4096 30 64 > $O/solver_bench.txt 2>&1
 timeout 300 python tools/solver_bench.py 4096 30 32 >> $O/solver_bench.txt 2>&1
-timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 64 4096 > $O/phase64.txt 2>&1
-timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 32 4096 > $O/phase32.txt 2>&1
+FB_NO_TICKETS=1 timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 64 4096 > $O/phase64.txt 2>&1      # (per-wave path: the phase shares are per environment, the wave-lifetime counter needs one wave per environment)
+FB_NO_TICKETS=1 timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 32 4096 > $O/phase32.txt 2>&1
 for n in 32 256 1024 2048 4096; do timeout 120 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 $n 20 >> $O/batch_sweep.txt 2>&1; done
 for P in 1 2 4; do timeout 120 python tools/split_bench.py 64 4096 $P 20 >> $O/split.txt 2>&1; done
 for P in 1 2; do timeout 120 python tools/split_bench.py 32 4096 $P 20 >> $O/split.txt 2>&1; done
