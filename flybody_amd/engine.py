@@ -18,8 +18,10 @@ from .model_blob import load_npz, pack_model
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, 'libflybody_hip.so')
 # Same sources built with -DFB_F64_DENSE=1: 12 instead of 8 FP64 environments per CU (smaller LDS Delassus matrix, 168-VGPR
-# stages; +24 % per-environment time).  Slower for a 4096-batch in lock-step (1.33 rounds), faster for batches that are
-# multiples of 3072 and for sub-batches pipelined on several streams.  Opt-in: Model(..., dense=True).
+# stages; a longer per-environment chain, more of them resident).  With the substep scheduler (batches beyond the resident slots
+# are handed out per substep, fb_engine.hip) it is the faster FP64 build for large batches -- 4096 walking environments in
+# lock-step: 8.2 ms against 9.0 -- and the slower one for batches that fit the default build's 2048 slots.
+# Model(..., dense=True); fly_envs picks it for FP64 batches of more than 2048 ground-contact environments unless told otherwise.
 HIP_LIB_DENSE = os.path.join(_HERE, 'libflybody_hip_dense.so')
 ASSETS = os.path.join(_HERE, 'assets')
 

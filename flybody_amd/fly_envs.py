@@ -105,7 +105,7 @@ class BatchedFlyEnv:
                  joint_filter: float = 0.01, future_steps: int = 64, time_limit: float = 10.0, task: str = 'walk_imitation',
                  wbpg_tables=None, seed: int = 0, traj_loader=None, env_id_base: int = 0, force_actuators: bool = False,
                  use_wings: Optional[bool] = None, use_legs: Optional[bool] = None, dyntype_filterexact: bool = False,
-                 use_mouth: bool = False, use_antennae: bool = False, adhesion_filter: Optional[float] = None, dense: bool = False):
+                 use_mouth: bool = False, use_antennae: bool = False, adhesion_filter: Optional[float] = None, dense: Optional[bool] = None):
         from . import model_zoo
         self.task_name = task
         # FruitFly._build's configuration space (fruitfly.py:123-386): the compiled tables come from the shipped assets, the
@@ -123,7 +123,12 @@ class BatchedFlyEnv:
             dyn[arrays['actuator_trntype'] != 5] = joint_filter       # fruitfly.py:330-335
             arrays['actuator_dynprm'] = dyn
         self.config = cfg
-        self.model = engine.Model(arrays, dense=dense)          # dense: the 12-environments-per-CU FP64 build (engine.HIP_LIB_DENSE)
+        if dense is None:
+            # the 12-environments-per-CU FP64 build (engine.HIP_LIB_DENSE) is the faster one for batches beyond the default build's
+            # 2048 resident environments (substep scheduler); flight keeps the default build (not measured faster)
+            import os as _os
+            dense = precision == 64 and n_env > 2048 and task != 'flight_imitation' and _os.path.exists(engine.HIP_LIB_DENSE)
+        self.model = engine.Model(arrays, dense=bool(dense))
         self.n_env = n_env; self.device = device
         self.batch = engine.Batch(self.model, n_env, device=device, precision=precision)
         self.future_steps = future_steps; self.terminal_com_dist = terminal_com_dist; self.time_limit = time_limit
