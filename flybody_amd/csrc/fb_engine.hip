@@ -564,6 +564,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
       float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
       if (lane == 0 && round == 0) { w.istate()[IS_PRIO] = 0; w.istate()[IS_WARN] = 0; }
+      if (lane == 0 && d < round) { w.istate()[IS_WARN] |= WARN_SCHED_WAIT; w.istate()[IS_WARN_EVER] |= WARN_SCHED_WAIT; }      // the wait was capped: say so
       const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
                                    B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nsubm - 1 ? 2 : 0));
 #ifndef FB_EMULATE

@@ -72,7 +72,8 @@ enum { FB_MAXCON = 64, FB_MAXEFC = 192, FB_NSENSOR = 33 };
 /* FB_WARN bits: more than FB_MAXCON contacts (the rest were dropped); more than FB_MAXEFC constraint rows (contacts beyond
  * the cap were dropped); the constraint solver stopped at opt.iterations; a convex-pair penetration query (MPR) hit its
  * iteration limit */
-enum { FB_WARN_CONTACT_CAP = 1, FB_WARN_EFC_CAP = 2, FB_WARN_SOLVER_MAXITER = 4, FB_WARN_CCD_MAXITER = 8 };
+enum { FB_WARN_CONTACT_CAP = 1, FB_WARN_EFC_CAP = 2, FB_WARN_SOLVER_MAXITER = 4, FB_WARN_CCD_MAXITER = 8,
+       FB_WARN_SCHED_WAIT = 16 /* substep scheduler: the wait for an environment's previous substep hit its iteration cap (never observed) */ };
 
 /* model dimensions by name: "nq","nv","nu","na","nbody","nobs","nsubstep", ... ; -1 if unknown */
 int fb_model_dim(const fb_model* m, const char* name);
