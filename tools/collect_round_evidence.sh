@@ -9,6 +9,8 @@ timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 1500 bash tools/collect_profiles.sh final > $O/collect.log 2>&1
 timeout 600 bash tools/calibrate_traffic.sh final > $O/calibrate.log 2>&1
 timeout 900 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_1000_steps.json 2> $O/bench_1000_steps.err
+timeout 200 python tools/ticket_check.py 4096 20 > $O/ticket_check.txt 2>&1                  # substep scheduler vs one environment per wave (bit-identical, timing)
+FB_DENSE=1 timeout 200 python tools/solver_bench.py 4096 20 64 >> $O/ticket_check.txt 2>&1
 timeout 300 python tools/solver_bench.py 4096 30 64 > $O/solver_bench.txt 2>&1
 timeout 300 python tools/solver_bench.py 4096 30 32 >> $O/solver_bench.txt 2>&1
 FB_NO_TICKETS=1 timeout 300 python tools/phase_profile.py flybody_amd/libflybody_hip_prof.so 64 4096 > $O/phase64.txt 2>&1      # (per-wave path: the phase shares are per environment, the wave-lifetime counter needs one wave per environment)
