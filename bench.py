@@ -244,7 +244,7 @@ def main():
         ev = max(rel(extras['qvel'][i], envs[i].field('qvel')) for i in range(len(envs)))
         return {'n': len(envs), 'control_steps': args.preroll + args.warmup + args.steps, 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
                 'tolerance': 1e-6, 'ok': bool(eq < 1e-6 and ev < 1e-6),
-                'note': 'FP64 kernel end state of sampled environments (both residency rounds) vs the FP64 CPU oracle replaying the same '
+                'note': 'FP64 kernel end state of sampled environments (ids across the whole batch) vs the FP64 CPU oracle replaying the same '
                         'action streams from the same reset; oracle vs CPU MuJoCo stays unpinned'}
 
     def run_flight_leg(precision, steps, warmup):
