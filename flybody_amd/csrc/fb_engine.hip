@@ -304,8 +304,11 @@ static int model_load_impl(fb_model* m, size_t n) {
     // Chain entries: sorted deepest dof first and DEALT to the lanes in turn, so slot s of every lane holds entries of (nearly) the
     // same depth.  An entry publishes on level dep and pulls on levels dep+1 .. dep+cl; with this order the slots that do
     // anything on a level form a narrow band that is the same for all lanes, and the level loop skips the rest (fac_band).
+    // (first key: the deepest level the entry still pulls on -- the abdomen's rows, which alone reach the last levels, then share a
+    // few slots instead of being spread over all of them by their depth)
     std::stable_sort(chain_ents.begin(), chain_ents.end(), [&](const Ent& a, const Ent& b) {
-      int da = m->dof_depth[a.i], db = m->dof_depth[b.i]; if (da != db) return da > db; return a.work > b.work; });
+      int da = m->dof_depth[a.i], db = m->dof_depth[b.i], la = da + m->dof_cl[a.i], lb = db + m->dof_cl[b.i];
+      if (la != lb) return la > lb; if (da != db) return da > db; return a.work > b.work; });
     const int nchain_slots = FB_FSLOT - FB_FGEN;
     size_t placed = 0;
     for (; placed < chain_ents.size() && placed < (size_t)nchain_slots*FB_WAVE; placed++)
@@ -317,20 +320,18 @@ static int model_load_impl(fb_model* m, size_t n) {
       if (best < 0) { return fail("fb_model_load: lower triangle of M does not fit the factor work list"); }
       if (!put(chain_ents[placed], best, ngs[best]++)) return fail("fb_model_load: factor work list field overflow");
     }
-    // per level: the band of chain slots that publish (dep == d) and the band that pulls (dep < d <= dep + cl), over all lanes
-    m->fac_band.assign(32, 0);
+    // per level: bit masks of the chain slots that publish (dep == d) and that pull (dep < d <= dep + cl), over all lanes
+    m->fac_band.assign(64, 0);
     for (int d = 0; d < 32; d++) {
-      int plo = FB_FSLOT, phi = 0, qlo = FB_FSLOT, qhi = 0;
+      unsigned pub = 0, pull = 0;
       for (int s = FB_FGEN; s < FB_FSLOT; s++)
         for (int l = 0; l < FB_WAVE; l++) {
           int wd = m->fac_w[(size_t)s*FB_WAVE + l], dep = (wd >> 13) & 31, cl_ = (wd >> 18) & 31;
           if (dep == 31) continue;
-          if (dep == d) { plo = std::min(plo, s); phi = std::max(phi, s + 1); }
-          if (dep < d && d <= dep + cl_) { qlo = std::min(qlo, s); qhi = std::max(qhi, s + 1); }
+          if (dep == d) pub |= 1u << s;
+          if (dep < d && d <= dep + cl_) pull |= 1u << s;
         }
-      if (plo > phi) plo = phi = 0;
-      if (qlo > qhi) qlo = qhi = 0;
-      m->fac_band[d] = plo | (phi << 8) | (qlo << 16) | (qhi << 24);
+      m->fac_band[2*d] = (int)pub; m->fac_band[2*d + 1] = (int)pull;
     }
   }
   const int* trn = m->i("actuator_trntype");

@@ -568,7 +568,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   }
   PROF(17);
   F_PROF(0);
-  int band_next = uniform_int(M.fac_band[nlevel - 1]);
+  unsigned pub_next = (unsigned)uniform_int(M.fac_band[2*(nlevel - 1)]), pull_next = (unsigned)uniform_int(M.fac_band[2*(nlevel - 1) + 1]);
   for (int d = nlevel - 1; d >= nT; d--) {
     const int Td = d*(d + 1)/2;
     // (keep the packed words opaque: otherwise every field of every slot is hoisted into its own register)
@@ -579,14 +579,13 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     // publish the rows of level d (unnormalised) and 1/D
 #pragma unroll
     for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; x[lane + q*FB_WAVE] = xa[q]; }
-    // the chain slots are sorted by depth and dealt to the lanes (fb_engine.hip), so the slots that publish / pull on this level
-    // form one narrow band, the same for every lane: everything outside it is skipped by a wave-uniform test
-    const int band = band_next;
-    band_next = uniform_int(M.fac_band[d > 0 ? d - 1 : 0]);          // (scalar load: in flight during this level)
-    const int pub_lo = band & 255, pub_hi = (band >> 8) & 255, pull_lo = (band >> 16) & 255, pull_hi = (band >> 24) & 255;
+    // the chain slots are sorted (deepest level they pull on, then depth) and dealt to the lanes (fb_engine.hip), so only a few
+    // slots publish / pull on a level, the same for every lane: a bit mask per level, everything else is skipped by a wave-uniform test
+    const unsigned pubm = pub_next, pullm = pull_next;
+    pub_next = (unsigned)uniform_int(M.fac_band[2*(d > 0 ? d - 1 : 0)]); pull_next = (unsigned)uniform_int(M.fac_band[2*(d > 0 ? d - 1 : 0) + 1]);   // (scalar loads: in flight during this level)
 #pragma unroll
     for (int s = 0; s < FB_FSLOT; s++) {
-      if (s < FB_FGEN || (s >= pub_lo && s < pub_hi)) {
+      if (s < FB_FGEN || ((pubm >> s) & 1u)) {
         // branch-free inside the band: a slot that is not on level d stores to a dummy word behind the factor
         int adr = (FW_DEP(fw[s]) == d) ? FW_BASE(fw[s]) + Td + FW_E(fw[s]) : FB_LDS_SCRATCH - 1;
         RM[adr] = acc[s];
@@ -599,7 +598,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     // cannot fault) so that a group's reads are in flight together; inactive slots discard the product.
 #pragma unroll
     for (int s0 = 0; s0 < FB_FSLOT; s0 += FB_FGROUP) {
-      if (!(s0 < FB_FGEN || (s0 + FB_FGROUP > pull_lo && s0 < pull_hi))) continue;
+      if (!(s0 < FB_FGEN || (pullm & (((1u << FB_FGROUP) - 1u) << s0)))) continue;
       real la[FB_FGROUP], lb[FB_FGROUP], ld[FB_FGROUP];
 #pragma unroll
       for (int u = 0; u < FB_FGROUP; u++) {

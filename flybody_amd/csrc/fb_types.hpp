@@ -121,7 +121,7 @@ struct DevModel {
   GP<const int> fwd_tab;        // [FB_MAXCH][FB_MAXNV] ancestor of a dof on a level
   GP<const int> fwd_pack;       // [FB_MAXCH/4][FB_MAXNV] the same, four levels per word (8-bit dof ids)
   GP<const int> fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
-  GP<const int> fac_band;       // [32] per level: chain slots that publish [lo, hi) | pull [lo, hi) << 16, the same for every lane
+  GP<const int> fac_band;       // [32][2] per level: bit masks of the chain slots that publish | that pull, the same for every lane
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
   int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
