@@ -102,9 +102,12 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
-    ap.add_argument('--preroll', type=int, default=220,
-                    help='untimed control steps before the warm-up: the episode is 235 steps (walk_imitation.py:104-105), so with the default the '
-                         'timed region crosses the auto-reset (LAST -> FIRST of every environment) even at --steps 20 --warmup 5')
+    ap.add_argument('--preroll', type=int, default=235,
+                    help='untimed control steps before the warm-up.  They STAGGER the episode phases: the environments whose global id is k modulo '
+                         'the pre-roll length are reset again before pre-roll step k, so that after one episode length (235 control steps, '
+                         'walk_imitation.py:104-105) the phases are spread evenly -- the steady state of a long-running actor pool, where every '
+                         'launch carries n_env/236 auto-resetting environments -- instead of all 4096 resetting in ONE launch of the timed window')
+    ap.add_argument('--seed', type=int, default=1234, help='key of the per-environment Philox action streams (fb_random_actions)')
     # The headline leg is the FP64 build: it reproduces the FP64 CPU oracle step for step (<= 2e-11 relative over 100 control
     # steps), i.e. it is inside north_star's 1e-4 tolerance for every environment.  The FP32 build (2.3x faster) drifts
     # chaotically like any single-precision MuJoCo (median environment inside 1e-4 after 100 physics steps, not every one);
@@ -140,6 +143,7 @@ def main():
     import numpy as np
     from flybody_amd import engine
     from flybody_amd.reference import default_walking_reference
+    from flybody_amd.sharding import staggered_preroll
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
@@ -177,31 +181,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # sampled environments for the oracle replay: both ends and the middle of the shard plus a spread -- with the staggered
+    # pre-roll they sit at different episode phases, some of them cross their auto-reset inside the timed region
     sample_ids = np.unique(np.concatenate([[0, 1, n_env - 2, n_env - 1, n_env//2 - 1, n_env//2], np.linspace(0, n_env - 1, 12).astype(int)]))[:16]
-    seed0 = 1234 + rank
+    id_base = rank*n_env                       # global id of this rank's environment 0: action streams and stagger groups are keyed by it
+    P = max(1, args.preroll)
 
     def run_leg(precision, extras=None):
-        """W untimed + K timed control steps of the whole batch; returns (seconds, kernel ms total, launches, finite).
-        extras (dict): filled with the end state of the sampled environments and the FB_WARN population."""
+        """P staggering + W warm-up control steps untimed, then K timed control steps of the whole batch; returns (seconds, kernel ms
+        total, launches, finite).  extras (dict): filled with the end state of the sampled environments and the FB_WARN population."""
         batch = engine.Batch(model_headline if precision == args.precision else model, n_env, device=local_rank, precision=precision)
         batch.set_reference(qp, qv, terminal_com_dist=float('inf'))
         batch.reset(stream=stream)
-        gen = torch.Generator(device='cuda'); gen.manual_seed(seed0)
         action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
+        aptr = action.data_ptr()
 
-        def one_step():
-            # per-env random actions N(0,1) clipped to the canonical range (SURVEY.md 8d config 2)
-            action.normal_(generator=gen).clamp_(-1.0, 1.0)
-            batch.step_ptr(action.data_ptr(), stream)
+        def one_step(t):
+            # per-environment Philox stream keyed by the GLOBAL environment id: N(0,1) clipped to the canonical range (SURVEY.md 8d config 2)
+            batch.random_actions(aptr, t, seed=args.seed, env_id_base=id_base, stream=stream)
+            batch.step_ptr(aptr, stream)
 
-        for _ in range(args.preroll + args.warmup):
-            one_step()
+        staggered_preroll(batch, aptr, P, args.seed, id_base, stream)          # pre-roll step k: group (global id % P == k) is reset, then everyone steps
+        for k in range(args.warmup):
+            one_step(P + k)
         sc0 = batch.get('STEP_COUNT').ravel().astype(np.int64)       # episode step of every environment entering the timed region
         barrier()
         batch.timing_begin(stream)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
+        for k in range(args.steps):
+            one_step(P + args.warmup + k)
         kernel_ms, nlaunch = batch.timing_end(stream)      # HIP events on the launch stream
         barrier()
         dt = time.perf_counter() - t0
@@ -212,8 +220,16 @@ def main():
         finite = bool(np.isfinite(batch.get('QPOS')).all())
         if extras is not None:
             sc1 = batch.get('STEP_COUNT').ravel().astype(np.int64)
-            extras['auto_resets'] = {'envs_reset_inside_timed_region': int((sc1 < sc0 + args.steps).sum()),
-                                     'episode_step_entering': int(sc0[0]), 'episode_step_leaving': int(sc1[0])}
+            # an environment that was auto-reset inside the timed region spent ONE of its K launches on the reset (a forward pass,
+            # no substeps: fb_step.hpp d_run) and shows a step count below sc0 + K
+            n_reset = int((sc1 < sc0 + args.steps).sum())
+            extras['auto_resets'] = {'envs_reset_inside_timed_region': n_reset,
+                                     'reset_env_share': n_reset/float(n_env*args.steps),
+                                     'steady_state_share': 1.0/236.0,
+                                     'episode_phase_min_max_entering': [int(sc0.min()), int(sc0.max())],
+                                     'staggered_preroll': P,
+                                     'note': 'share of (environment, launch) pairs of the timed region that were an auto-reset instead of a control step; '
+                                             'a long-running pool of 235-step episodes sits at 1/236'}
             wv = batch.get('WARN_EVER').ravel()
             extras['warn'] = {name: int(((wv & bit) != 0).sum()) for name, bit in engine.WARN_BITS.items()}
             extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
@@ -223,29 +239,34 @@ def main():
         return dt, kernel_ms, nlaunch, finite
 
     def parity_sample(extras):
-        """OUTSIDE the clock: the recorded action streams of the sampled environments (the generator is re-run from its seed) are
-        replayed on the CPU oracle from the same reset state; the FP64 end states are compared."""
+        """OUTSIDE the clock: the action streams of the sampled environments (regenerated on the GPU from their global ids: the streams are
+        keyed by id, not by position in the batch) are replayed on the CPU oracle from each environment's LAST explicit reset -- pre-roll
+        step (global id % P) -- through its auto-reset(s); the FP64 end states are compared."""
         from flybody_amd.model_blob import pack_model
         from oracle import fbo
-        gen = torch.Generator(device='cuda'); gen.manual_seed(seed0)
-        action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
-        ids_dev = torch.as_tensor(sample_ids, device='cuda')
+        total = P + args.warmup + args.steps
+        tmp = engine.Batch(model, 1, device=local_rank, precision=64)          # (only its library handle is used)
+        gids = torch.as_tensor((id_base + sample_ids).astype(np.int32), device='cuda')
+        a = torch.empty(len(sample_ids), nu, device='cuda', dtype=torch.float32)
         rec = []
-        for _ in range(args.preroll + args.warmup + args.steps):
-            action.normal_(generator=gen).clamp_(-1.0, 1.0)
-            rec.append(action[ids_dev].cpu().numpy())
+        for t in range(total):
+            tmp.random_actions(a.data_ptr(), t, seed=args.seed, stream=stream, env_ids_dev_ptr=gids.data_ptr(), n=len(sample_ids))
+            rec.append(a.cpu().numpy().copy())
+        del tmp
         acts = np.ascontiguousarray(np.stack(rec, axis=1).astype(np.float64))            # [n_sample][steps][nu]
-        om = fbo.OracleModel(pack_model(model.arrays)); envs = []
-        for _ in sample_ids:
-            d = fbo.OracleData(om); d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset(); envs.append(d)
-        fbo.rollout_batch(envs, acts)
-        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
-        eq = max(rel(extras['qpos'][i], envs[i].field('qpos')) for i in range(len(envs)))
-        ev = max(rel(extras['qvel'][i], envs[i].field('qvel')) for i in range(len(envs)))
-        return {'n': len(envs), 'control_steps': args.preroll + args.warmup + args.steps, 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
+        om = fbo.OracleModel(pack_model(model.arrays))
+        rel = lambda x, y: float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-300))
+        eq = ev = 0.0; nsteps = []
+        for i, e in enumerate(sample_ids):
+            first = int((id_base + int(e)) % P)                       # the pre-roll step before which this environment was last reset explicitly
+            d = fbo.OracleData(om); d.configure_env(qp, qv, terminal_com_dist=float('inf')); d.env_reset()
+            fbo.rollout_batch([d], np.ascontiguousarray(acts[i:i + 1, first:]))
+            eq = max(eq, rel(extras['qpos'][i], d.field('qpos'))); ev = max(ev, rel(extras['qvel'][i], d.field('qvel')))
+            nsteps.append(total - first)
+        return {'n': len(sample_ids), 'control_steps_min_max': [int(min(nsteps)), int(max(nsteps))], 'env_ids': [int(e) for e in sample_ids], 'max_rel_qpos': eq, 'max_rel_qvel': ev,
                 'tolerance': 1e-6, 'ok': bool(eq < 1e-6 and ev < 1e-6),
-                'note': 'FP64 kernel end state of sampled environments (ids across the whole batch) vs the FP64 CPU oracle replaying the same '
-                        'action streams from the same reset; oracle vs CPU MuJoCo stays unpinned'}
+                'note': 'FP64 kernel end state of sampled environments (ids across the whole batch, different episode phases) vs the FP64 CPU oracle '
+                        'replaying the same per-environment action streams from the same reset; oracle vs CPU MuJoCo stays unpinned'}
 
     def run_flight_leg(precision, steps, warmup):
         """BASELINE configs[3]: 8192 flight_imitation environments (WBPG + ellipsoid wing fluid forces, 4 substeps of 5e-5 s),
@@ -254,19 +275,18 @@ def main():
         n_f = 8192
         env = flight_imitation(n_env=n_f, device=local_rank, precision=precision, env_id_base=rank*n_f)
         b = env.batch
-        gen = torch.Generator(device='cuda'); gen.manual_seed(4321 + rank)
         a = torch.empty(n_f, b.model.dim('nact'), device='cuda', dtype=torch.float32)
         env.reset_all()
 
-        def one_step():
-            a.uniform_(-1.0, 1.0, generator=gen)
+        def one_step(t):
+            b.random_actions(a.data_ptr(), t, seed=args.seed + 1, env_id_base=rank*n_f, dist=1, stream=stream)      # U(-1, 1), keyed by global id
             b.step_ptr(a.data_ptr(), stream)
-        for _ in range(warmup):
-            one_step()
+        for k in range(warmup):
+            one_step(k)
         barrier()
         b.timing_begin(stream); t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
+        for k in range(steps):
+            one_step(warmup + k)
         kms, nl = b.timing_end(stream)
         barrier()
         dtf = time.perf_counter() - t0
@@ -317,27 +337,26 @@ def main():
         while len(stream_pool) < parts:
             stream_pool.append(torch.cuda.Stream())
         streams = stream_pool[:parts]
-        batches, actions, gens = [], [], []
+        batches, actions, bases = [], [], []
         for p in range(parts):
             sub = sizes[p]
             b = engine.Batch(mdl, sub, device=local_rank, precision=precision)
             b.set_reference(qp, qv, terminal_com_dist=float('inf')); b.reset(stream=stream)
             batches.append(b); actions.append(torch.empty(sub, nu, device='cuda', dtype=torch.float32))
-            g = torch.Generator(device='cuda'); g.manual_seed(1234 + rank*parts + p); gens.append(g)
+            bases.append(id_base + sum(sizes[:p]))
         torch.cuda.synchronize()
 
-        def one_step():
+        def one_step(t):
             for p in range(parts):
-                with torch.cuda.stream(streams[p]):
-                    actions[p].normal_(generator=gens[p]).clamp_(-1.0, 1.0)
-                    batches[p].step_ptr(actions[p].data_ptr(), streams[p].cuda_stream)
+                batches[p].random_actions(actions[p].data_ptr(), t, seed=args.seed, env_id_base=bases[p], stream=streams[p].cuda_stream)
+                batches[p].step_ptr(actions[p].data_ptr(), streams[p].cuda_stream)
 
-        for _ in range(args.warmup):
-            one_step()
+        for k in range(args.warmup):
+            one_step(k)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
+        for k in range(args.steps):
+            one_step(args.warmup + k)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -400,6 +419,8 @@ def main():
                          'traffic': (traffic or {}).get('bytes_per_launch'),
                          'traffic_source': (traffic or {}).get('source'),
                          'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
+                         # (staggered pre-roll: every timed launch carries ~n_env/236 resetting environments, none is reset-only)
+                         'kernel_ms_avg_excl_reset_only': per_launch_s * 1e3,
                          'algorithmic_flop_per_env_step': ALGO_FLOP_PER_ENV_STEP,
                          'algorithmic_bytes_per_env_step': algo_bytes,
                          'hbm': {'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved_gbs / HBM_PEAK_GBS},
@@ -431,7 +452,7 @@ def main():
             out['pipelined_dense_mode'] = {'value': split_dense[2] * world * args.steps / split_dense[0], 'unit': 'env steps/sec',
                                            'ms_per_step': split_dense[0] / args.steps * 1e3, 'state_finite': split_dense[1],
                                            'note': '3 independent sub-batches on 3 HIP streams, FB_F64_DENSE build (12 instead of 8 FP64 environments per CU); '
-                                                   'secondary like two_stream_mode: the headline is the lock-step batch on the default build'}
+                                                   'secondary like two_stream_mode: the headline is the lock-step batch (config.build says on which build)'}
         if flight is not None:
             out['flight_mode'] = {'config': 'configs[3]: flight_imitation, 8192 envs per GPU, U(-1,1)^12 actions, WBPG + ellipsoid wing fluid forces', **flight}
         if dmpo is not None:

@@ -644,6 +644,53 @@ __global__ void __launch_bounds__(FB_ORDER_THREADS) k_order(const int* cost, int
   }
 }
 
+// ------------------------------------------------------------------ synthetic actions
+// Random-action rollouts ("per-env RNG = Philox(seed, stream = env_id)"): one counter-based stream per
+// GLOBAL environment id, so what an environment is fed does not depend on the number of GPUs the batch is sharded over or on its
+// position inside a rank's shard (the reference runs one independent environment per actor process,
+// agents/ray_distributed_dmpo.py:232).  Philox4x32-10 (Salmon et al., SC'11) with key = seed and counter = (control step, global
+// environment id, group of four action entries, distribution tag); outputs -> N(0,1) by Box-Muller in FP32, clipped to [-1, 1]
+// (dist 0), or U(-1, 1) (dist 1).
+FB_HD __forceinline__ void fb_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u*c0, p1 = (uint64_t)0xCD9E8D57u*c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void __launch_bounds__(FB_WAVE) k_actions(float* out, const int* env_ids, int n_env, int nact, uint32_t seed_lo, uint32_t seed_hi, int step, int env_id_base, int dist) {
+  const int ngrp = (nact + 3)/4;
+  const int t = blockIdx.x*FB_WAVE + threadIdx.x;
+  if (t >= n_env*ngrp) return;
+  const int e = t / ngrp, g = t - e*ngrp;
+  const int gid = env_ids ? env_ids[e] : env_id_base + e;
+  uint32_t r[4];
+  fb_philox4x32_10((uint32_t)step, (uint32_t)gid, (uint32_t)g, (uint32_t)dist, seed_lo, seed_hi, r);
+  float v[4];
+  if (dist == 1) {
+    for (int k = 0; k < 4; k++) v[k] = ((float)(r[k] >> 8) + 0.5f)*(2.0f/16777216.0f) - 1.0f;
+  } else {
+    for (int k = 0; k < 4; k += 2) {
+      const float u1 = ((float)(r[k] >> 8) + 0.5f)*(1.0f/16777216.0f), u2 = ((float)(r[k + 1] >> 8) + 0.5f)*(1.0f/16777216.0f);
+      const float rad = sqrtf(-2.0f*logf(u1)), ang = 6.28318530717958647692f*u2;
+      v[k] = rad*cosf(ang); v[k + 1] = rad*sinf(ang);
+    }
+    for (int k = 0; k < 4; k++) v[k] = fminf(1.0f, fmaxf(-1.0f, v[k]));
+  }
+  for (int k = 0; k < 4; k++) if (4*g + k < nact) out[(size_t)e*nact + 4*g + k] = v[k];
+}
+
+extern "C" int fb_random_actions(float* action, const int32_t* env_ids, int n_env, int nact, uint64_t seed, int step, int env_id_base, int dist, void* stream) {
+  if (!action || n_env <= 0 || nact <= 0 || (dist != 0 && dist != 1)) return fail("fb_random_actions: bad arguments");
+  const int total = n_env*((nact + 3)/4);
+  hipLaunchKernelGGL(k_actions, dim3((total + FB_WAVE - 1)/FB_WAVE), dim3(FB_WAVE), 0, (hipStream_t)stream, action, (const int*)env_ids, n_env, nact,
+                     (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step, env_id_base, dist);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ batch
 struct fb_batch {
   const fb_model* m;

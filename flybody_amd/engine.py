@@ -80,6 +80,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_scheduler.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.fb_batch_scheduler.restype = C.c_int
     L.fb_batch_timing_begin.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _libs[path] = L
     return L
@@ -215,6 +216,13 @@ class Batch:
     def step_ptr(self, action_dev_ptr: int, stream=None):
         """action_dev_ptr: device pointer to float32 [n_env][nu]."""
         _check(self.L, self.L.fb_batch_step(self.h, C.c_void_p(action_dev_ptr), stream))
+
+    def random_actions(self, action_dev_ptr: int, step: int, seed: int = 0, env_id_base: int = 0, dist: int = 0, stream=None,
+                       env_ids_dev_ptr: Optional[int] = None, n: Optional[int] = None):
+        """Fill the device array action[n][nact] (float32) for control step `step`: one Philox stream per GLOBAL environment id
+        (env_id_base + e, or the ids behind env_ids_dev_ptr), N(0,1) clipped to [-1, 1] (dist 0) or U(-1, 1) (dist 1)."""
+        _check(self.L, self.L.fb_random_actions(C.c_void_p(action_dev_ptr), C.c_void_p(env_ids_dev_ptr) if env_ids_dev_ptr else None,
+                                                self.n_env if n is None else int(n), self.model.dim('nact'), int(seed), int(step), int(env_id_base), int(dist), stream))
 
     def substep(self, n=1, stream=None):
         _check(self.L, self.L.fb_batch_substep(self.h, n, stream))

@@ -25,6 +25,25 @@ def env_actions(global_ids, step: int, nu: int, seed: int = 0) -> np.ndarray:
     return out
 
 
+def stagger_groups(n_env: int, id_base: int, period: int):
+    """Episode-phase staggering of a random-action rollout (bench.py pre-roll): group k = local ids of the environments whose GLOBAL id
+    is k modulo `period`; group k is reset again before pre-roll step k, so after `period` steps the phases are spread evenly --
+    the steady state of a long-running actor pool (episodes of 235 control steps: walk_imitation.py:104-105)."""
+    gids = id_base + np.arange(n_env)
+    return [np.nonzero(gids % period == k)[0].astype(np.int32) for k in range(period)]
+
+
+def staggered_preroll(batch, action_ptr: int, period: int, seed: int, id_base: int = 0, stream=None, dist: int = 0):
+    """Run `period` control steps of `batch` (freshly reset) with the per-environment Philox action streams, resetting stagger group k
+    before step k.  Environment e's history then starts at global step (id_base + e) % period."""
+    groups = stagger_groups(batch.n_env, id_base, period)
+    for k in range(period):
+        if k > 0 and len(groups[k]):
+            batch.reset(groups[k], stream=stream)
+        batch.random_actions(action_ptr, k, seed=seed, env_id_base=id_base, dist=dist, stream=stream)
+        batch.step_ptr(action_ptr, stream)
+
+
 def max_over_ranks(value: float) -> float:
     """Timing reduction used by bench.py: the slowest rank defines the step time."""
     import torch

@@ -176,6 +176,13 @@ int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launc
  * Scheduling only: results are identical.  `slots` (may be NULL) receives the number of resident environments of this build. */
 int fb_batch_scheduler(const fb_batch* b, int* slots);
 
+/* Synthetic random actions for throughput rollouts (per-environment RNG = Philox(seed, stream = env id)):
+ * fills the DEVICE array action[n_env][nact] (float32) for control step `step`.  One Philox4x32-10 stream per GLOBAL environment id
+ * -- env_ids[e] (device pointer) or env_id_base + e when env_ids is NULL -- so an environment is fed the same actions whatever the
+ * number of ranks its batch is sharded over (the reference steps one independent environment per actor process,
+ * agents/ray_distributed_dmpo.py:232).  dist 0: N(0,1) clipped to [-1, 1]; dist 1: U(-1, 1).  Asynchronous on `stream`. */
+int fb_random_actions(float* action, const int32_t* env_ids, int n_env, int nact, uint64_t seed, int step, int env_id_base, int dist, void* stream);
+
 const char* fb_last_error(void);
 
 /* Build identity of the shared object: "flybody_engine <abi> (<target>, <hash of the kernel sources it was built from>)".
