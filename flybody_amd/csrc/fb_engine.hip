@@ -474,8 +474,13 @@ struct Batch {
   int* tick;                  // substep scheduler (null = off): [nq][16] ticket counters, one per XCD, zeroed before every launch
   int* done;                  // ... [n_env] substeps of the running control step completed, zeroed before every launch
   int nq;                     // ... number of XCDs (ticket queues)
+  int* sched_err;             // ... [1] tickets abandoned because the wait for the predecessor substep hit its cap (sticky; fb_batch_synchronize / fb_batch_get fail)
+  real* park;                 // MODE_STAGE (profiling): [n_env][POOL] the LDS pool between two single-stage launches
 };
 
+#ifndef FB_SCHED_SPIN_CAP
+#define FB_SCHED_SPIN_CAP (1 << 22)       // x s_sleep(32): seconds.  (Test builds lower it to provoke the abandon path.)
+#endif
 // XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
 __device__ __forceinline__ int fb_xcc_id() {
 #ifdef FB_EMULATE
@@ -541,7 +546,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       const int round = t / cnt, env = (t % cnt)*nq + xcc;
       // wait for the predecessor substep (normally long done: it was drawn `cnt` tickets ago)
       int d = 0;
-      for (int spins = 0; spins < (1 << 22); spins++) {
+      for (int spins = 0; spins < FB_SCHED_SPIN_CAP; spins++) {
 #ifndef FB_EMULATE
         if (lane == 0) d = __hip_atomic_load(B.done + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -553,7 +558,24 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
         __builtin_amdgcn_s_sleep(32);
 #endif
       }
-      if (d > round) continue;                       // the environment was auto-reset by its first ticket: the step is complete
+      if (d > round) continue;                       // the environment was auto-reset by its first ticket (or abandoned, below): nothing to do
+      if (d < round) {
+        // The wait was capped (~seconds): the predecessor substep has not been published.  Stepping the row now would race with
+        // whoever still holds it, so the environment's control step is ABANDONED: flagged per environment (FB_WARN_SCHED_WAIT),
+        // counted in the batch's sticky error counter (fb_batch_synchronize / fb_batch_get then fail), and its remaining tickets
+        // are skipped.  Never observed; a launch that can get here has lost a wave.
+        if (lane == 0) {
+          int* is_ = (int*)(B.iarena + (size_t)env*M.off.nint + M.off.istate);
+          is_[IS_WARN] |= WARN_SCHED_WAIT; is_[IS_WARN_EVER] |= WARN_SCHED_WAIT;
+          atomicAdd(B.sched_err, 1);
+#ifndef FB_EMULATE
+          __hip_atomic_store(B.done + env, nsubm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+          B.done[env] = nsubm + 2;
+#endif
+        }
+        continue;
+      }
 #ifndef FB_EMULATE
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
@@ -565,10 +587,16 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
       float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
       if (lane == 0 && round == 0) { w.istate()[IS_PRIO] = 0; w.istate()[IS_WARN] = 0; }
-      if (lane == 0 && d < round) { w.istate()[IS_WARN] |= WARN_SCHED_WAIT; w.istate()[IS_WARN_EVER] |= WARN_SCHED_WAIT; }      // the wait was capped: say so
       const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
                                    B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nsubm - 1 ? 2 : 0));
 #ifndef FB_EMULATE
+      // Release.  What the next holder of this environment (a wave of the SAME XCD: environments are bound to XCDs) must see is this
+      // wave's global stores.  On gfx942 / gfx950 the vector L1 is write-through and an XCD has ONE L2, so "visible to the XCD" =
+      // "acknowledged by the L2" = vmcnt(0); the workgroup-scope release fence keeps the compiler from sinking stores below it, the
+      // relaxed agent-scope store then publishes the counter (atomics bypass the L1).  A formal agent-scope release would add
+      // buffer_wbl2: a write-back of the WHOLE L2 to memory per ticket, for readers (other XCDs) that by construction do not
+      // exist.  The hardware facts this leans on are checked where they can be (fb_batch_create: architecture, all XCDs visible;
+      // launch: the stream reaches every XCD) and the scheduler is switched off otherwise.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -594,8 +622,21 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
 #else
   long long life0_ = wall_clock64();
 #endif
-  if (lane == 0) { w.istate()[IS_PRIO] = 0; if (mode == MODE_STEP || mode == MODE_RESET) w.istate()[IS_WARN] = 0; }
-  d_run(M, w, env, mode, nsub, nslot, B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env, B.discount + env, B.step_type + env, lane);
+  // profiling (fb_batch_stage): ONE stage of a control step per launch; the LDS pool lives in B.park between launches
+  const int only = uniform_int(mode == MODE_STAGE ? nsub : -1);
+  if (only >= 0) {
+    const FB_GLOBAL real* pk = (const FB_GLOBAL real*)(B.park + (size_t)env*LdsCfg<real>::POOL);
+    for (int i = lane; i < LdsCfg<real>::POOL; i += FB_WAVE) w.lLD[i] = pk[i];
+    SYNC();
+  } else if (lane == 0) { w.istate()[IS_PRIO] = 0; if (mode == MODE_STEP || mode == MODE_RESET) w.istate()[IS_WARN] = 0; }
+  d_run(M, w, env, only >= 0 ? (int)MODE_STEP : mode, nsub, nslot, only >= 0 ? (int*)nullptr : B.sched, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
+        B.discount + env, B.step_type + env, lane, -1, only);
+  if (only >= 0) {
+    SYNC();
+    FB_GLOBAL real* pk = (FB_GLOBAL real*)(B.park + (size_t)env*LdsCfg<real>::POOL);
+    for (int i = lane; i < LdsCfg<real>::POOL; i += FB_WAVE) pk[i] = w.lLD[i];
+    return;
+  }
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[29] += clock64() - t0_; pp_[30] += wall_clock64() - r0_; pp_[28] = r0_; /* start tick (replaces the env_post phase counter) */ }
 #endif
@@ -701,7 +742,9 @@ struct fb_batch {
   int* d_ids = nullptr;
   int* sched = nullptr;
   int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true;
-  int *tick = nullptr, *done = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
+  int *tick = nullptr, *done = nullptr, *sched_err = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
+  unsigned xcc_mask = 0; void* probed_stream = nullptr; bool probed = false;               // ... the streams it was validated on
+  void* park = nullptr;               // MODE_STAGE: LDS pools between single-stage launches (allocated on first use)
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
   DevModel<double> M64_dev; DevModel<float> M32_dev;   // what the device copy currently holds
@@ -876,10 +919,16 @@ static int batch_create_impl(fb_batch* b) {
     HIPCHK(hipMemcpy(&hmask, dmask, sizeof(unsigned), hipMemcpyDeviceToHost)); HIPCHK(hipFree(dmask));
     int nqq = __builtin_popcount(hmask);
     b->nq = (nqq > 0 && hmask == (1u << nqq) - 1u) ? nqq : 0;          // XCC ids 0 .. nq-1, all seen; anything else: scheduler off
+    b->xcc_mask = hmask;
+    // the hand-over protocol of the scheduler (k_fly) is written against the cache hierarchy of gfx942 / gfx950: write-through vector
+    // L1, one L2 per XCD, HW_REG_XCC_ID.  Any other architecture takes the per-wave path.
+    if (strncmp(prop.gcnArchName, "gfx942", 6) != 0 && strncmp(prop.gcnArchName, "gfx950", 6) != 0) b->nq = 0;
     if (const char* e_ = getenv("FB_TICKET_SLOTS")) b->slots = atoi(e_);             // (test switch: pretend fewer resident slots)
 #endif
     HIPCHK(hipMalloc((void**)&b->tick, 16*16*sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->done, n_env*sizeof(int)));
+    HIPCHK(hipMalloc((void**)&b->sched_err, sizeof(int)));
+    HIPCHK(hipMemset(b->sched_err, 0, sizeof(int)));
     // ... and for tasks whose environments differ in cost (ground contacts: walking, the ball).  flight_imitation has next to no
     // constraints, its environments take the same time, the longest-first order already packs them, and its substeps are short:
     // there the tickets only cost (measured, 8192 environments: 1.78 M env-steps/s per wave, 1.72 M with tickets; FB_TICKETS=1 forces them)
@@ -908,7 +957,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done, b->sched_err, b->park};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1076,17 +1125,30 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   HIPCHK(hipMemsetAsync(b->sched, 0, FB_NSCHED*sizeof(int), st));
   // a control step of the whole batch: substep scheduler when the batch exceeds the resident slots, otherwise one environment per
   // wave in longest-first order
-  const bool tickets = (mode == MODE_STEP) && !ids && n == b->n_env && b->tickets;
+  bool tickets = (mode == MODE_STEP) && !ids && n == b->n_env && b->tickets;
+#ifndef FB_EMULATE
+  if (tickets && (!b->probed || b->probed_stream != stream)) {
+    // A stream with a CU mask may not reach every XCD: the ticket queues of the unreachable ones would never be drawn.  Probe the
+    // stream once (again whenever the caller switches streams); unless it sees exactly the XCDs the batch was set up for, this
+    // batch keeps the per-wave path for good.
+    unsigned* dmask; unsigned hmask = 0;
+    HIPCHK(hipMalloc((void**)&dmask, sizeof(unsigned))); HIPCHK(hipMemsetAsync(dmask, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_probe_xcc, dim3(4096), dim3(FB_WAVE), 0, st, dmask);
+    HIPCHK(hipMemcpyAsync(&hmask, dmask, sizeof(unsigned), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(dmask));
+    b->probed = true; b->probed_stream = stream;
+    if (hmask != b->xcc_mask) { b->tickets = false; tickets = false; }
+  }
+#endif
   const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder && !tickets;
   if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
   if (tickets) { HIPCHK(hipMemsetAsync(b->tick, 0, 16*16*sizeof(int), st)); HIPCHK(hipMemsetAsync(b->done, 0, (size_t)n*sizeof(int), st)); }
   if (b->precision == 64) {
     Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
-                       tickets ? b->tick : nullptr, b->done, b->nq};
+                       tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (double*)b->park};
     hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
     Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
-                      tickets ? b->tick : nullptr, b->done, b->nq};
+                      tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (float*)b->park};
     hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
@@ -1129,11 +1191,34 @@ extern "C" int fb_batch_forward(fb_batch* b, void* stream) {
   return launch(b, MODE_FORWARD, nullptr, nullptr, b->n_env, 0, stream);
 }
 
+// substep scheduler: a control step that abandoned tickets (capped wait, k_fly) left environments half-stepped -- sticky failure
+static int check_sched_errors(fb_batch* b) {
+  int n = 0;
+  HIPCHK(hipMemcpy(&n, b->sched_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (n) return fail("substep scheduler: " + std::to_string(n) + " ticket(s) were abandoned because the wait for an environment's previous substep hit its cap; "
+                     "the flagged environments (FB_WARN_SCHED_WAIT) are not in a valid state -- reset them, or run with FB_NO_TICKETS=1");
+  return 0;
+}
+
 extern "C" int fb_batch_synchronize(fb_batch* b, void* stream) {
   if (!b) return fail("fb_batch_synchronize: null batch");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  return 0;
+  return check_sched_errors(b);
+}
+
+// Profiling / debug: ONE stage of a control step for every environment (fb_step.hpp MODE_STAGE).  The caller walks the stage sequence
+// of a control step itself (tools/stage_profile.py); results equal fb_batch_step's as long as no environment ends its episode.
+extern "C" int fb_batch_stage(fb_batch* b, int stage_word, const float* action, void* stream) {
+  if (!b || stage_word < 0) return fail("fb_batch_stage: bad arguments");
+  if (!b->have_ref) return fail("fb_batch_stage: call fb_batch_set_reference first");
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->park) {
+    const size_t pool = b->precision == 64 ? (size_t)LdsCfg<double>::POOL*8 : (size_t)LdsCfg<float>::POOL*4;
+    HIPCHK(hipMalloc(&b->park, (size_t)b->n_env*pool));
+    HIPCHK(hipMemset(b->park, 0, (size_t)b->n_env*pool));
+  }
+  return launch(b, MODE_STAGE, action, nullptr, b->n_env, stage_word, stream);
 }
 
 // ------------------------------------------------------------------ field access
@@ -1184,6 +1269,7 @@ extern "C" int fb_batch_get(fb_batch* b, int field, void* dst, size_t bytes) {
   if (!b || !dst) return fail("fb_batch_get: null argument");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
+  if (field != FB_WARN && field != FB_WARN_EVER && check_sched_errors(b)) return -1;      // (the flags stay readable: they say WHICH environments)
   int n = b->n_env;
   if (field == FB_CONTACT) {
     // [n_env][64][8]: dist, pos3, normal3, pair id  (FP64)

@@ -664,7 +664,12 @@ __device__ __forceinline__ void d_flight_post(const DevModel<real>& M, const WS<
 // (position + velocity stages for the new state).
 enum { ST_ACT, ST_ACC_PRE, ST_SOLVE, ST_ACC_SOLVE, ST_ACC_POST, ST_CONSTR_A, ST_CONSTR_B, ST_SENS, ST_EULER_PRE, ST_FACTOR, ST_EULER_SOLVE,
        ST_EULER_POST, ST_KIN, ST_COLL, ST_SUBEND, ST_DONE };
-enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3 };
+enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_FORWARD = 2, MODE_RESET = 3, MODE_STAGE = 4 };
+// MODE_STAGE (fb_batch_stage, profiling only): ONE stage of a control step per launch, so that rocprofv3's per-dispatch counters
+// (instructions, active lanes, traffic) can be attributed to stages.  Stage word: stage id | damp << 8 | half << 9 | part mask << 12
+// (ST_KIN: kinematics / com_pos / crb; ST_COLL: collision / rows / velocity; ST_ACC_POST: copy / projection; 0 = all parts);
+// ST_PRE / ST_POST are the task hooks around the substeps.  The LDS pool is parked in global memory between launches (k_fly).
+enum { ST_PRE = 32, ST_POST = 33 };
 
 // ------------------------------------------------------------------ stage entry points
 // Every stage of the step is compiled as a function of its own: the register allocator then works on one stage at a
@@ -723,17 +728,26 @@ template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const 
 // here), bit 1 = last (the task epilogue happens here).  Returns true when the call was an auto-reset (the step is complete then).
 template <typename real>
 __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
-                      float* obs, float* reward, float* discount, int* step_type, int lane, int tk = -1) {
+                      float* obs, float* reward, float* discount, int* step_type, int lane, int tk = -1, int only = -1) {
   // every selector of the stage machine is wave-uniform: say so (v_readfirstlane), otherwise the interpreter's state lives in
   // VGPRs + saved exec masks across every stage call and counts against the register budget of all stages
-  mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg); tk = uniform_int(tk);
+  mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg); tk = uniform_int(tk); only = uniform_int(only);
   const bool tk_first = tk < 0 || (tk & 1), tk_last = tk < 0 || (tk & 2);
+  int parts = 15;
   bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && tk_first && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
   bool actuate = true, damp = false, half = false;
   int nsub = uniform_int(tk >= 0 ? 1 : ((mode == MODE_SUBSTEP) ? nsub_arg : M.nsubstep)), sub = 0;
   int pc, ret = ST_DONE, fret = ST_DONE;
   const WS<real> wc = w;                  // the stages are separate functions: they read this copy, `w` itself stays in registers
+  if (only >= 0) {
+    // one stage of a control step (profiling): the host walks the stage sequence of d_run itself
+    resetting = false; env_logic = true; nsub = 1;
+    damp = (only >> 8) & 1; half = (only >> 9) & 1; parts = (only >> 12) & 15; if (parts == 0) parts = 15;
+    pc = only & 0xff;
+    if (pc == ST_PRE) { s_pre(M, wc, action, lane); return false; }
+    if (pc == ST_POST) { s_post(M, wc, false, obs, reward, discount, step_type, lane); return false; }
+  } else
   if (resetting) {
     s_init(M, wc, env, lane);
     actuate = false; pc = ST_KIN;
@@ -746,6 +760,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
     pc = (nsub > 0) ? ST_ACT : ST_DONE;
   }
   bool single_pass = resetting || (mode == MODE_FORWARD);     // KIN..COLL then ACT..SENS once, no integration
+  if (only >= 0) single_pass = false;
   while (pc != ST_DONE) {
     switch (pc) {
       case ST_ACT: {
@@ -781,10 +796,13 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         pc = ret; break; }
       case ST_ACC_POST: {
         PROF_BEGIN();
-        for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx[i];
-        SYNC();
+        if (parts & 1) {
+          for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx[i];
+          SYNC();
+        }
         PROF(24);
-        s_project_constraint(M, wc, lane); PROF(P_PROJ);
+        if (parts & 2) s_project_constraint(M, wc, lane);
+        PROF(P_PROJ);
         pc = ST_CONSTR_A; break; }
       case ST_CONSTR_A: {
         bool need = uniform_int(s_constraint_a(M, wc, lane) ? 1 : 0) != 0;
@@ -820,15 +838,21 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         pc = ST_KIN; break; }
       case ST_KIN: {
         PROF_BEGIN();
-        s_kinematics(M, wc, lane); PROF(P_KIN);
-        s_com_pos(M, wc, lane); PROF(P_COMPOS);
-        s_crb(M, wc, lane); PROF(P_CRB);
+        if (parts & 1) s_kinematics(M, wc, lane);
+        PROF(P_KIN);
+        if (parts & 2) s_com_pos(M, wc, lane);
+        PROF(P_COMPOS);
+        if (parts & 4) s_crb(M, wc, lane);
+        PROF(P_CRB);
         pc = ST_COLL; break; }
       case ST_COLL: {
         PROF_BEGIN();
-        s_collision(M, wc, lane); PROF(P_COLL);
-        s_make_constraint(M, wc, lane); PROF(P_MAKEC);
-        s_velocity(M, wc, lane); PROF(P_VEL);
+        if (parts & 1) s_collision(M, wc, lane);
+        PROF(P_COLL);
+        if (parts & 2) s_make_constraint(M, wc, lane);
+        PROF(P_MAKEC);
+        if (parts & 4) s_velocity(M, wc, lane);
+        PROF(P_VEL);
         pc = single_pass ? ST_ACT : ST_SUBEND; break; }
       case ST_SUBEND: {
         PROF_BEGIN();
@@ -849,7 +873,9 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         pc = (sub < nsub) ? ST_ACT : ST_DONE; break; }
       default: pc = ST_DONE;
     }
+    if (only >= 0) break;
   }
+  if (only >= 0) return false;
   PROF_BEGIN();
   if (env_logic && (tk_last || resetting)) s_post(M, wc, resetting, obs, reward, discount, step_type, lane);
   PROF(28);

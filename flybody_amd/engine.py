@@ -36,6 +36,24 @@ WARN_BITS = dict(CONTACT_CAP=1, EFC_CAP=2, SOLVER_MAXITER=4, CCD_MAXITER=8, SCHE
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
 MAXCON, MAXEFC, NSENSOR = 64, 192, 33
 
+# fb_step.hpp stage ids (ST_*) and the stage sequence of one control step as d_run walks it (profiling: fb_batch_stage)
+ST = dict(ACT=0, ACC_PRE=1, SOLVE=2, ACC_SOLVE=3, ACC_POST=4, CONSTR_A=5, CONSTR_B=6, SENS=7, EULER_PRE=8, FACTOR=9, EULER_SOLVE=10,
+          EULER_POST=11, KIN=12, COLL=13, SUBEND=14, PRE=32, POST=33)
+
+
+def stage_sequence(nsubstep: int):
+    """[(name, stage word)] of one control step: the task's before_step hook, `nsubstep` x (mj_step2, integration, mj_step1 in
+    dm_control's legacy order, fb_step.hpp d_run), the task's after_step hook."""
+    DAMP, HALF, P = 1 << 8, 1 << 9, lambda m: m << 12
+    sub = [('actuation', ST['ACT']), ('smooth_rhs', ST['ACC_PRE']), ('factor_M', ST['FACTOR']), ('solve_smooth', ST['SOLVE'] | HALF),
+           ('qacc_smooth_copy', ST['ACC_POST'] | P(1)), ('project_constraint', ST['ACC_POST'] | P(2)), ('constraint_solve', ST['CONSTR_A']),
+           ('solve_constraint', ST['SOLVE']), ('qacc', ST['CONSTR_B']), ('sensor_acc', ST['SENS']), ('euler_rhs', ST['EULER_PRE']),
+           ('factor_M_hD', ST['FACTOR'] | DAMP), ('solve_euler', ST['SOLVE'] | HALF), ('integrate', ST['EULER_POST']),
+           ('kinematics', ST['KIN'] | P(1)), ('com_pos', ST['KIN'] | P(2)), ('crb', ST['KIN'] | P(4)), ('collision', ST['COLL'] | P(1)),
+           ('make_constraint', ST['COLL'] | P(2)), ('velocity', ST['COLL'] | P(4)), ('substep_end', ST['SUBEND'])]
+    return [('task_pre', ST['PRE'])] + sub*nsubstep + [('task_post', ST['POST'])]
+
+
 _libs: Dict[str, C.CDLL] = {}
 
 
@@ -74,6 +92,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_forward.argtypes = [C.c_void_p, C.c_void_p]
+    L.fb_batch_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.fb_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p
@@ -229,6 +248,10 @@ class Batch:
 
     def forward(self, stream=None):
         _check(self.L, self.L.fb_batch_forward(self.h, stream))
+
+    def stage(self, stage_word: int, action_dev_ptr: int = 0, stream=None):
+        """Profiling: one stage of a control step for every environment (fb_batch_stage; sequence: engine.stage_sequence)."""
+        _check(self.L, self.L.fb_batch_stage(self.h, int(stage_word), C.c_void_p(action_dev_ptr) if action_dev_ptr else None, stream))
 
     def synchronize(self, stream=None):
         _check(self.L, self.L.fb_batch_synchronize(self.h, stream))

@@ -73,7 +73,9 @@ enum { FB_MAXCON = 64, FB_MAXEFC = 192, FB_NSENSOR = 33 };
  * the cap were dropped); the constraint solver stopped at opt.iterations; a convex-pair penetration query (MPR) hit its
  * iteration limit */
 enum { FB_WARN_CONTACT_CAP = 1, FB_WARN_EFC_CAP = 2, FB_WARN_SOLVER_MAXITER = 4, FB_WARN_CCD_MAXITER = 8,
-       FB_WARN_SCHED_WAIT = 16 /* substep scheduler: the wait for an environment's previous substep hit its iteration cap (never observed) */ };
+       FB_WARN_SCHED_WAIT = 16 /* substep scheduler: the wait for an environment's previous substep hit its iteration cap (never observed).
+                                  The environment's control step was ABANDONED (its row is not stepped concurrently with its holder);
+                                  fb_batch_synchronize / fb_batch_get fail from then on until the batch is destroyed. */ };
 
 /* model dimensions by name: "nq","nv","nu","na","nbody","nobs","nsubstep", ... ; -1 if unknown */
 int fb_model_dim(const fb_model* m, const char* name);
@@ -156,6 +158,11 @@ int fb_batch_step(fb_batch* b, const float* action, void* stream);
  * position/velocity stage at the current state. */
 int fb_batch_substep(fb_batch* b, int nsub, void* stream);
 int fb_batch_forward(fb_batch* b, void* stream);
+/* Profiling entry point: ONE stage of a control step for every environment, so that per-dispatch hardware counters (rocprofv3
+ * --pmc) can be attributed to stages.  stage_word = stage id | damp << 8 | half << 9 | part mask << 12 (fb_step.hpp: ST_*,
+ * MODE_STAGE); the caller walks the stage sequence of a control step itself (tools/stage_profile.py), `action` is only read by
+ * the first stage (the task's before_step hook).  Same results as fb_batch_step while no environment ends its episode. */
+int fb_batch_stage(fb_batch* b, int stage_word, const float* action, void* stream);
 
 /* Synchronous host copies (physics-real fields are converted to/from FP64; FB_OBS/REWARD/
  * DISCOUNT are float32, the int fields int32).  `bytes` must match exactly. */

@@ -20,7 +20,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-           '--preroll', '231', '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline', '--no-secondary-configs']
+           '--preroll', '235', '--envs-per-gpu', '256', '--no-f32-leg', '--no-cpu-baseline', '--no-secondary-configs']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -29,11 +29,14 @@ def test_bench_two_ranks_on_one_gpu():
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['dtype'] == 'f64'
     assert out['config']['global_envs'] == 512 and out['config']['state_finite']
     assert abs(out['value'] - 512*4/(out['ms_per_step']*4/1e3)) < 1e-6*out['value']       # whole-job aggregate over both ranks
-    # the untimed pre-roll put the auto-reset (episode = 235 control steps) INSIDE the 4 timed steps, and the replay of the sampled
-    # environments on the oracle crossed it too (the timed region used to end before the first reset)
+    # the untimed pre-roll STAGGERS the episode phases by global environment id (one launch of the timed window used to
+    # carry the auto-reset of every environment): stagger group k = ids k mod 235 was last reset before pre-roll step k, so groups 2..5
+    # reach LAST (episode = 235 control steps) inside the 4 timed steps -- rank 0 (ids 0..255) holds two environments of each
     ar = out['config']['auto_resets']
-    assert out['preroll'] == 231 and ar['envs_reset_inside_timed_region'] == 256 and ar['episode_step_entering'] == 233, ar
-    assert out['parity_sample']['ok'] and out['parity_sample']['control_steps'] == 237
+    assert out['preroll'] == 235 and ar['staggered_preroll'] == 235 and ar['envs_reset_inside_timed_region'] == 8, ar
+    assert ar['episode_phase_min_max_entering'][0] <= 2 and ar['episode_phase_min_max_entering'][1] == 235, ar
+    ps = out['parity_sample']
+    assert ps['ok'] and ps['control_steps_min_max'][1] == 241 and ps['control_steps_min_max'][0] < 241, ps        # per-environment replay from its own last reset
 
 
 @pytest.mark.gpu

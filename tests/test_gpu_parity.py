@@ -591,3 +591,104 @@ def test_pipelined_sub_batches_parity_fp64(gpu_model, oracle_model, reference_tr
     streams = [torch.cuda.Stream() for _ in range(parts)]
     eq, ev, _ = _headline_run([M]*parts, sizes, 30, oracle_model, reference_traj, seed=12, streams=streams)
     assert eq < 1e-6 and ev < 1e-6, (eq, ev)
+
+
+def test_random_actions_keyed_by_global_id(gpu_model):
+    """fb_random_actions on the GPU: a shard sees the rows of the whole batch, explicit id lists likewise (tests/test_random_actions.py
+    pins the generator itself on the host build)."""
+    import torch
+    from flybody_amd import engine
+    B = engine.Batch(gpu_model, 8, precision=64)
+    nact = gpu_model.dim('nact')
+    whole = torch.empty(4096, nact, device='cuda'); lo = torch.empty(1000, nact, device='cuda'); hi = torch.empty(3096, nact, device='cuda')
+    B.random_actions(whole.data_ptr(), 7, seed=5, env_id_base=100, n=4096)
+    B.random_actions(lo.data_ptr(), 7, seed=5, env_id_base=100, n=1000); B.random_actions(hi.data_ptr(), 7, seed=5, env_id_base=1100, n=3096)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([lo, hi]), whole) and bool((whole.abs() <= 1).all())
+    ids = torch.tensor([4195, 100, 2000], dtype=torch.int32, device='cuda'); pick = torch.empty(3, nact, device='cuda')
+    B.random_actions(pick.data_ptr(), 7, seed=5, env_ids_dev_ptr=ids.data_ptr(), n=3); torch.cuda.synchronize()
+    assert torch.equal(pick, whole[[4095, 0, 1900]])
+    inside = whole[whole.abs() < 1]
+    assert abs(float(inside.mean())) < 0.01 and abs(float((whole.abs() >= 1).float().mean()) - 0.3173) < 0.01
+
+
+@pytest.mark.parametrize('dense', [False, True])
+def test_single_stage_launches_equal_fused_step_gpu(gpu_model, reference_traj, dense):
+    """fb_batch_stage (one stage of a control step per launch: the unit tools/stage_profile.py attributes hardware counters to) walks the
+    stage sequence of the fused kernel: bit-identical state and observations after three control steps, both builds."""
+    import torch
+    from flybody_amd import engine
+    M = engine.Model.from_asset('walk_imitation', dense=True) if dense else gpu_model
+    qp, qv = reference_traj
+    out = []
+    for staged in (False, True):
+        B = engine.Batch(M, 96, precision=64); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+        a = torch.empty(96, M.dim('nact'), device='cuda'); st = torch.cuda.current_stream().cuda_stream
+        seq = engine.stage_sequence(M.dim('nsubstep'))
+        for k in range(3):
+            B.random_actions(a.data_ptr(), k, seed=3, stream=st)
+            if staged:
+                for _, word in seq:
+                    B.stage(word, a.data_ptr(), st)
+            else:
+                B.step_ptr(a.data_ptr(), st)
+        B.synchronize(st)
+        out.append([B.get(f).copy() for f in ('QPOS', 'QVEL', 'ACT', 'OBS', 'SENSORDATA', 'QACC', 'STEP_COUNT')])
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
+def _sched_rollout(M, n, steps, seed, reference_traj, stream=None):
+    import torch
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    st = (stream or torch.cuda.current_stream()).cuda_stream
+    B = engine.Batch(M, n, precision=64); B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset(stream=st)
+    a = torch.empty(n, M.dim('nact'), device='cuda')
+    return B, a, st
+
+
+@pytest.mark.parametrize('n', [64, 6144])
+def test_substep_scheduler_stress_bit_equal_to_per_wave(gpu_model, reference_traj, n, monkeypatch):
+    """Substep scheduler under stress: FB_TICKET_SLOTS=1 forces the ticket path for ANY batch.  64 environments on a GPU
+    with thousands of idle wave slots: every ticket's successor is drawn at once by another wave, so nearly every ticket WAITS for its
+    predecessor (the hand-over protocol runs hot); 6144 = three times the resident slots of the default build.  50 control steps,
+    bit-equal to the one-environment-per-wave path, no FB_WARN bit."""
+    import torch
+    res = []
+    for tickets in (True, False):
+        if tickets: monkeypatch.setenv('FB_TICKET_SLOTS', '1'); monkeypatch.delenv('FB_NO_TICKETS', raising=False)
+        else: monkeypatch.delenv('FB_TICKET_SLOTS', raising=False); monkeypatch.setenv('FB_NO_TICKETS', '1')
+        B, a, st = _sched_rollout(gpu_model, n, 50, 21, reference_traj)
+        assert B.substep_scheduler == tickets
+        for k in range(50):
+            B.random_actions(a.data_ptr(), k, seed=21, stream=st); B.step_ptr(a.data_ptr(), st)
+        B.synchronize(st)
+        assert (B.get('WARN_EVER') == 0).all()
+        res.append((B.get('QPOS').copy(), B.get('QVEL').copy(), B.get('OBS').copy()))
+        del B
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+
+
+def test_two_ticket_batches_on_two_streams(gpu_model, reference_traj, monkeypatch):
+    """Two fb_batch handles of 4096 environments, each under the substep scheduler (own ticket and progress counters), stepped
+    CONCURRENTLY on two HIP streams: each equals the same batch stepped alone, bit for bit."""
+    import torch
+    monkeypatch.delenv('FB_NO_TICKETS', raising=False); monkeypatch.delenv('FB_TICKET_SLOTS', raising=False)
+    alone = []
+    for seed in (31, 32):
+        B, a, st = _sched_rollout(gpu_model, 4096, 12, seed, reference_traj)
+        assert B.substep_scheduler
+        for k in range(12):
+            B.random_actions(a.data_ptr(), k, seed=seed, stream=st); B.step_ptr(a.data_ptr(), st)
+        B.synchronize(st); alone.append(B.get('QPOS').copy()); del B
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    pair = [_sched_rollout(gpu_model, 4096, 12, seed, reference_traj, s) for seed, s in ((31, s1), (32, s2))]
+    torch.cuda.synchronize()
+    for k in range(12):
+        for (B, a, st), seed in zip(pair, (31, 32)):
+            B.random_actions(a.data_ptr(), k, seed=seed, stream=st); B.step_ptr(a.data_ptr(), st)
+    for (B, a, st), ref in zip(pair, alone):
+        B.synchronize(st)
+        assert (B.get('WARN_EVER') == 0).all() and np.array_equal(B.get('QPOS'), ref)
