@@ -222,13 +222,28 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
 }
 
 // ---- per-lane narrow phase: up to 4 contacts (dist, pos, normal) for one pair
+// Where a lane's contacts go until the wave knows their final positions (a prefix sum over the lanes' counts): the FIRST contact of
+// every lane into LDS (field-major, [7][64]: behind the motion axes the inertia stage mirrored at the start of the pool, which the
+// velocity stage still reads), contacts 2-4 -- a capsule lying on the floor, parallel capsules, a cylinder rim: rare -- into a
+// per-lane overflow area of the environment's global row (the chain-compressed Y slot, rewritten before its next use).  Rounds 1-3
+// returned them in a struct by reference: 232 bytes per lane of scratch memory, written and re-read through vector memory by every
+// wave in every substep.
 template <typename real>
-struct LaneContacts { real dist[4], pos[12], nrm[12]; int n, ccd_cap; };
+struct LaneContacts { FB_LDS real* first; FB_GLOBAL real* more; int lane, n, ccd_cap; };
 
 template <typename real>
 FBD void lc_add(LaneContacts<real>& lc, real dist, const real* pos, const real* n) {
   if (lc.n >= 4) return;
-  lc.dist[lc.n] = dist; copy3(lc.pos + 3*lc.n, pos); copy3(lc.nrm + 3*lc.n, n); lc.n++;
+  const real v[7] = {dist, pos[0], pos[1], pos[2], n[0], n[1], n[2]};
+  if (lc.n == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) lc.first[k*FB_WAVE + lc.lane] = v[k];
+  } else {
+    FB_GLOBAL real* o = lc.more + (lc.lane*3 + (lc.n - 1))*7;
+#pragma unroll
+    for (int k = 0; k < 7; k++) o[k] = v[k];
+  }
+  lc.n++;
 }
 template <typename real>
 FBD void c_sphere_sphere(LaneContacts<real>& lc, const real* p1, real r1, const real* p2, real r2, real margin) {
@@ -378,9 +393,12 @@ FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) 
                          (real)M.pair_margin[p]);
 }
 
+// returns the number of contacts | (penetration query at its iteration limit) << 8
 template <typename real>
-FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p, LaneContacts<real>& lc) {
+FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  LaneContacts<real> lc;
+  lc.first = w.lLD + 6*M.nv; lc.more = (FB_GLOBAL real*)w.efc_Y(); lc.lane = lane; lc.n = 0; lc.ccd_cap = 0;
   int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   real margin = M.pair_margin[p];
@@ -411,7 +429,7 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p
       real dist = dot3(dif, n);
       if (dist <= margin) { real pos[3]; copy3(pos, pt); addscl3(pos, n, -(real)0.5*dist); lc_add(lc, dist, pos, n); }
     } else if (t2 == GEOM_CYLINDER) c_plane_cylinder(lc, p1, n, p2, m2, s2, margin);
-    return;
+    return lc.n;
   }
   if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) c_sphere_sphere(lc, p1, s1[0], p2, s2[0], margin);
   else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
@@ -431,6 +449,7 @@ FB_STAGE_B void narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p
     real depth, dir[3], pos[3];
     if (mpr_penetration(A, B, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
   }
+  return lc.n | (lc.ccd_cap ? 256 : 0);
 }
 
 template <typename real>
@@ -523,25 +542,37 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   PROF(25);
   // ---- narrow phase (not inlined: it gets a copy of the descriptor, the caller's stays in registers)
   int ncon = 0;
+  const FB_LDS real* first = w.lLD + 6*M.nv; const FB_GLOBAL real* more = (const FB_GLOBAL real*)w.efc_Y();
   for (int base = 0; base < ncand; base += FB_WAVE) {
-    LaneContacts<real> lc; lc.n = 0; lc.ccd_cap = 0;
-    int c = base + lane, p = -1;
-    if (c < ncand) { p = w.cand()[c]; narrow_phase(M, wc, p, lc); }
+    int c = base + lane, p = -1, res = 0;
+    if (c < ncand) { p = w.cand()[c]; res = narrow_phase(M, wc, p, lane); }
+    const int n = res & 255;
+    SYNC();                                        // the lanes' first contacts are in LDS, further ones in the overflow area
     C_PROF(3);
-    int off = ncon + wave_excl_scan(lc.n, lane);
-    for (int k = 0; k < lc.n; k++) {
+    int off = ncon + wave_excl_scan(n, lane);
+    for (int k = 0; k < n; k++) {
       int ci = off + k;
       if (ci >= FB_MAXCON_) break;
-      w.con_dist()[ci] = lc.dist[k];
-      copy3(w.con_pos() + 3*ci, lc.pos + 3*k);
+      real v[7];
+      if (k == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; q++) v[q] = first[q*FB_WAVE + lane];
+      } else {
+        const FB_GLOBAL real* o = more + (lane*3 + (k - 1))*7;
+#pragma unroll
+        for (int q = 0; q < 7; q++) v[q] = o[q];
+      }
+      w.con_dist()[ci] = v[0];
+      copy3(w.con_pos() + 3*ci, v + 1);
       real f[9];
-      copy3(f, lc.nrm + 3*k); f[3] = f[4] = f[5] = f[6] = f[7] = f[8] = 0;
+      copy3(f, v + 4); f[3] = f[4] = f[5] = f[6] = f[7] = f[8] = 0;
       makeframe(f);
       for (int q = 0; q < 9; q++) w.con_frame()[9*ci + q] = f[q];
       w.con_pair()[ci] = p;
     }
-    ncon += wave_sum_i(lc.n);
-    if (__ballot(lc.ccd_cap != 0)) warn |= WARN_CCD_MAXITER;
+    ncon += wave_sum_i(n);
+    if (__ballot((res & 256) != 0)) warn |= WARN_CCD_MAXITER;
+    SYNC_LDS();                                    // (the next block of candidates reuses the LDS slots)
   }
   C_PROF(4);
   if (ncon > FB_MAXCON_) { ncon = FB_MAXCON_; warn |= WARN_CONTACT_CAP; }

@@ -183,7 +183,10 @@ static int model_load_impl(fb_model* m, size_t n) {
   for (int b = nb - 1; b > 0; b--) m->body_nsub[parent[b]] += m->body_nsub[b];
   for (int b = 1; b < nb; b++) {
     if (m->body_depth[b] > FB_MAXDEPTH) { return fail("fb_model_load: body tree deeper than FB_MAXDEPTH"); }
-    if (nb > 2*FB_WAVE || 7*nb + 4*m->njnt > FB_LDS_SCRATCH || m->nM + 1 > FB_LDS_SCRATCH) { return fail("fb_model_load: model exceeds the per-environment LDS scratch (bodies / dofs)"); }
+    // LDS staging of the position / velocity stages (fb_smooth.hpp): frames + joint rotations + anchors / axes; motion axes + inertias;
+    // motion axes + body velocities + per-body wrenches -- all inside the smallest LDS pool of this build
+    { const int pool = std::min(LdsCfg<double>::POOL, LdsCfg<float>::POOL);
+      if (nb > 2*FB_WAVE || 7*nb + 10*m->njnt > pool || 6*nv + 10*nb > pool || 6*nv + 12*nb > pool || m->nM + 1 > FB_LDS_SCRATCH) { return fail("fb_model_load: model exceeds the per-environment LDS pool (bodies / joints / dofs)"); } }
     // DFS contiguity: every body in (b, b+nsub) must descend from b
     for (int d = b + 1; d < b + m->body_nsub[b]; d++) {
       int a = d; while (a > b) a = parent[a];

@@ -115,18 +115,27 @@ FBD void chain_axpy6x2(const int* ch, int n, int nmax, const real* X1, const rea
 }
 
 // ------------------------------------------------------------------ kinematics (level-synchronous)
-// Body frames by depth level: a body composes its parent's frame (staged in LDS scratch, 7 values per body) with
-// its own joints.  One environment is one wavefront, so a level boundary costs a fence, not a barrier.  The joint
-// rotations (the sin/cos of every joint angle) are computed lane-parallel over joints beforehand and staged in
-// LDS, which takes the trigonometry off the serial level chain.  The scratch is the LDS row of the mass-matrix
-// factor, which is dead between the Euler solve and the next factorisation.
+// Body frames by depth level: a body composes its parent's frame (staged in LDS, 7 values per body) with its own joints.  One
+// environment is one wavefront, so a level boundary costs a fence, not a barrier.  The joint rotations (the sin/cos of every joint
+// angle) are computed lane-parallel over joints beforehand and staged in LDS, which takes the trigonometry off the serial level
+// chain.  The staging area is the environment's LDS pool, dead between the Euler solve and the next factorisation:
+//   S  [7 nbody]  body frames (position, quaternion)      -- read by the geoms / sites, the centre of mass and the inertia stage
+//   JQ [4 njnt]   joint rotations                          -- level loop only
+//   A  [6 njnt]   joint anchors and axes in the world      -- read by the inertia stage (motion axes of the dofs)
+// Round 4: the frames no longer round-trip through the environment's global row.  Only what later stages (or the C-ABI) read is
+// stored there: xpos, xquat (7 reals per body instead of 28: the rotation matrices and the inertial frames are recomputed by their
+// two consumers from the quaternion -- ~40 flops against a cold 72-byte-stride gather), the geoms and sites.
+template <typename real> FBD int fk_off_jq(const DevModel<real>& M) { return 7*M.nbody; }
+template <typename real> FBD int fk_off_a(const DevModel<real>& M) { return 7*M.nbody + 4*M.njnt; }
+
 template <typename real>
-FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, int b1, int b2, int dlo, int dhi, int lane) {
+FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, FB_LDS real* A, int b1, int b2, int dlo, int dhi, int lane) {
   // a lane may own a second body (b2, on a different level than b1: fb_engine.hip pairs them) so that a model
   // with a few bodies beyond the wavefront width still takes one trip down the levels
   bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
   int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
   int dep2 = has2 ? M.body_depth[has2 ? b2 : 0] : -1;
+  const bool keep_axes = M.ds_qpos.p != nullptr;          // walk_imitation training mode: the reward reads the joint axes (fb_step.hpp)
   // the record of the lane's own body is fetched before the level loop (every lane at once, one latency for the whole pass instead
   // of one per level); only the few second bodies load theirs on their level
   real R1[37];
@@ -158,9 +167,10 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
         pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
         quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
         normquat(quat);
-        copy3(w.xanchor() + 3*ja, pos);
-        real ax[3] = {0, 0, 1};
-        rotvecquat(w.xaxis() + 3*ja, ax, quat);
+        real ax[3] = {0, 0, 1}, axw[3];
+        rotvecquat(axw, ax, quat);
+        for (int k = 0; k < 3; k++) { A[6*ja + k] = pos[k]; A[6*ja + 3 + k] = axw[k]; }
+        if (keep_axes) copy3(w.xaxis() + 3*ja, axw);
       } else {
         real t[3], qn[4];
         rotvecquat(t, R + 4, quat);
@@ -173,11 +183,12 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
         if (k < jn && !(free_jnt && k == 0)) {
           int j = ja + k;
           real qloc[4] = {JQ[4*j], JQ[4*j + 1], JQ[4*j + 2], JQ[4*j + 3]};
-          real anc[3], t[3], qn[4];
+          real anc[3], t[3], qn[4], axw[3];
           rotvecquat(t, R + 18 + 6*k, quat);
           add3(anc, t, pos);
-          copy3(w.xanchor() + 3*j, anc);
-          rotvecquat(w.xaxis() + 3*j, R + 21 + 6*k, quat);
+          rotvecquat(axw, R + 21 + 6*k, quat);
+          for (int c = 0; c < 3; c++) { A[6*j + c] = anc[c]; A[6*j + 3 + c] = axw[c]; }
+          if (keep_axes) copy3(w.xaxis() + 3*j, axw);
           mulquat(qn, quat, qloc);
           quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
           rotvecquat(t, R + 18 + 6*k, quat);
@@ -187,18 +198,22 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
       normquat(quat);
       for (int k = 0; k < 3; k++) S[7*b + k] = pos[k];
       for (int k = 0; k < 4; k++) S[7*b + 3 + k] = quat[k];
-      real mat[9], t[3], qi[4];
-      quat2mat(mat, quat);
       copy3(w.xpos() + 3*b, pos);
       for (int k = 0; k < 4; k++) w.xquat()[4*b + k] = quat[k];
-      for (int k = 0; k < 9; k++) w.xmat()[9*b + k] = mat[k];
-      mulmat3(t, mat, R + 11);
-      add3(w.xipos() + 3*b, pos, t);
-      mulquat(qi, quat, R + 14);
-      quat2mat(w.ximat() + 9*b, qi);
     }
     SYNC_LDS();                      // the next level reads the frames from LDS; the global copies are read after the pass
   }
+}
+
+// inertial frame of a body from its frame (pos, quat) and the constants (ipos, iquat) of its record: xipos, ximat
+template <typename real>
+FBD void inertial_frame(const real* pos, const real* quat, const real* ipos, const real* iquat, real* xipos, real* ximat) {
+  real mat[9], t[3], qi[4];
+  quat2mat(mat, quat);
+  mulmat3(t, mat, ipos);
+  add3(xipos, pos, t);
+  mulquat(qi, quat, iquat);
+  quat2mat(ximat, qi);
 }
 
 template <typename real>
@@ -210,8 +225,9 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
 #else
 #define K_PROF(k) do {} while (0)
 #endif
-  FB_LDS real* S = w.lLD;                       // body frames: 7*nbody
-  FB_LDS real* JQ = w.lLD + 7*M.nbody;          // joint rotations: 4*njnt
+  FB_LDS real* S = w.lLD;                          // body frames: 7*nbody
+  FB_LDS real* JQ = w.lLD + fk_off_jq(M);          // joint rotations: 4*njnt
+  FB_LDS real* A = w.lLD + fk_off_a(M);            // joint anchors / axes: 6*njnt (runs on into the matrix slot: the pool is contiguous)
   for (int j = lane; j < M.njnt; j += FB_WAVE) {
     real q[4] = {1, 0, 0, 0};
     int jt = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -222,42 +238,52 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   if (lane == 0) {
     // world body: identity frame
     for (int k = 0; k < 7; k++) S[k] = (k == 3) ? (real)1 : (real)0;
-    for (int k = 0; k < 3; k++) { w.xpos()[k] = 0; w.xipos()[k] = 0; }
+    for (int k = 0; k < 3; k++) w.xpos()[k] = 0;
     for (int k = 0; k < 4; k++) w.xquat()[k] = (k == 0) ? (real)1 : (real)0;
-    for (int k = 0; k < 9; k++) { real v = (k % 4 == 0) ? (real)1 : (real)0; w.xmat()[k] = v; w.ximat()[k] = v; }
   }
   SYNC();
   K_PROF(0);
-  if (M.fk_second) fk_pass(M, w, S, JQ, lane, M.fk_second[lane], 1, M.fk_dmax, lane);
+  if (M.fk_second) fk_pass(M, w, S, JQ, A, lane, M.fk_second[lane], 1, M.fk_dmax, lane);
   else {
-    fk_pass(M, w, S, JQ, lane, -1, 1, M.fk_dmax, lane);
-    for (int b0 = FB_WAVE; b0 < M.nbody; b0 += FB_WAVE) fk_pass(M, w, S, JQ, lane + b0, -1, M.fk2_dlo, M.fk_dmax, lane);
+    fk_pass(M, w, S, JQ, A, lane, -1, 1, M.fk_dmax, lane);
+    for (int b0 = FB_WAVE; b0 < M.nbody; b0 += FB_WAVE) fk_pass(M, w, S, JQ, A, lane + b0, -1, M.fk2_dlo, M.fk_dmax, lane);
   }
   PROF(25);
-  SYNC();
+  SYNC_LDS();
   K_PROF(1);
-  // geoms and sites hang off their body frames
+  // geoms and sites hang off their body frames (read from LDS)
   for (int g = lane; g < M.ngeom; g += FB_WAVE) {
     int b = M.geom_bodyid[g];
-    real t[3], q[4];
-    mulmat3(t, w.xmat() + 9*b, M.geom_pos + 3*g);
-    add3(w.gxpos() + 3*g, w.xpos() + 3*b, t);
-    mulquat(q, w.xquat() + 4*b, M.geom_quat + 4*g);
+    real bp[3] = {S[7*b], S[7*b + 1], S[7*b + 2]}, bq[4] = {S[7*b + 3], S[7*b + 4], S[7*b + 5], S[7*b + 6]};
+    real mat[9], t[3], q[4];
+    quat2mat(mat, bq);
+    mulmat3(t, mat, M.geom_pos + 3*g);
+    add3(w.gxpos() + 3*g, bp, t);
+    mulquat(q, bq, M.geom_quat + 4*g);
     quat2mat(w.gxmat() + 9*g, q);
   }
   for (int s = lane; s < M.nsite; s += FB_WAVE) {
     int b = M.site_bodyid[s];
-    real t[3], q[4];
-    mulmat3(t, w.xmat() + 9*b, M.site_pos + 3*s);
-    add3(w.sxpos() + 3*s, w.xpos() + 3*b, t);
-    mulquat(q, w.xquat() + 4*b, M.site_quat + 4*s);
+    real bp[3] = {S[7*b], S[7*b + 1], S[7*b + 2]}, bq[4] = {S[7*b + 3], S[7*b + 4], S[7*b + 5], S[7*b + 6]};
+    real mat[9], t[3], q[4];
+    quat2mat(mat, bq);
+    mulmat3(t, mat, M.site_pos + 3*s);
+    add3(w.sxpos() + 3*s, bp, t);
+    mulquat(q, bq, M.site_quat + 4*s);
     quat2mat(w.sxmat() + 9*s, q);
   }
   PROF(26);
   K_PROF(2);
   // centre of mass of the (single) kinematic tree
   real c[3] = {0, 0, 0};
-  for (int b = lane; b < M.nbody; b += FB_WAVE) addscl3(c, w.xipos() + 3*b, M.body_mass[b]);
+  for (int b = lane; b < M.nbody; b += FB_WAVE) {
+    real bp[3] = {S[7*b], S[7*b + 1], S[7*b + 2]}, bq[4] = {S[7*b + 3], S[7*b + 4], S[7*b + 5], S[7*b + 6]};
+    real mat[9], t[3], xi[3];
+    quat2mat(mat, bq);
+    mulmat3(t, mat, M.body_rec + b*FB_BODYREC + 11);
+    add3(xi, bp, t);
+    addscl3(c, xi, M.body_mass[b]);
+  }
   c[0] = wave_sum(c[0]); c[1] = wave_sum(c[1]); c[2] = wave_sum(c[2]);
   if (lane == 0) { real inv = (real)1 / M.totalmass; w.com()[0] = c[0]*inv; w.com()[1] = c[1]*inv; w.com()[2] = c[2]*inv; }
   SYNC();
@@ -271,23 +297,25 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
 template <typename real>
 __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real>& w, int lane) {
   // Written in rounds: every load of a round (for BOTH items a lane owns: bodies l and l + 64, dofs l and l + 64, its tendon) is
-  // issued before anything of the next round is computed.  As a loop per item the stage was 11 dependent trips to the global
-  // row (index -> joint -> axis, twice for the dofs; mass / inertia per body pass; three for the tendons); it is 3 now.
-  // The dofs' motion axes (cdof) are mirrored in LDS (the factor row, free until the factorisation behind the actuation stage):
-  // the inertia stage reads 20 of them per dof.
-  FB_LDS real* Lc = w.lLD;
+  // issued before anything of the next round is computed.  Round 4: the body frames and the joint anchors / axes come from LDS
+  // (the kinematics stage left them there), the inertial frames are recomputed from the body frame and the record's constants --
+  // the stage reads nothing of this environment from global memory but the tendons' joint positions.
+  // The dofs' motion axes (cdof) and the bodies' inertias (cinert) are mirrored in LDS (the factor row, free until the
+  // factorisation behind the actuation stage): the inertia stage reads 20 motion axes per dof and sums the inertias over subtrees.
+  const FB_LDS real* S = w.lLD; const FB_LDS real* A = w.lLD + fk_off_a(M);
+  FB_LDS real* Lc = w.lLD; FB_LDS real* Li = w.lLD + 6*M.nv;
   const real com[3] = {w.com()[0], w.com()[1], w.com()[2]};
   const int nv = M.nv, nbody = M.nbody;
-  // ---- round 1: bodies (pose of the inertial frame, inertia), dof -> joint / body ids, tendon header
-  int bs[2]; bool bok[2]; real Rm[2][9], In[2][3], ms[2], xi[2][3];
+  // ---- round 1: bodies (frame from LDS; inertial-frame constants, inertia, mass), dof -> joint / body ids, tendon header
+  int bs[2]; bool bok[2]; real bp[2][3], bq[2][4], ip[2][3], iq[2][4], In[2][3], ms[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     int b = lane + q*FB_WAVE; bok[q] = b < nbody; bs[q] = bok[q] ? b : 0;
-    const real* R = w.ximat() + 9*bs[q]; const real* I = M.body_inertia + 3*bs[q]; const real* xp = w.xipos() + 3*bs[q];
+    const real* rec = M.body_rec + bs[q]*FB_BODYREC; const real* I = M.body_inertia + 3*bs[q];
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rm[q][k] = R[k];
+    for (int k = 0; k < 3; k++) { bp[q][k] = S[7*bs[q] + k]; ip[q][k] = rec[11 + k]; In[q][k] = I[k]; }
 #pragma unroll
-    for (int k = 0; k < 3; k++) { In[q][k] = I[k]; xi[q][k] = xp[k]; }
+    for (int k = 0; k < 4; k++) { bq[q][k] = S[7*bs[q] + 3 + k]; iq[q][k] = rec[14 + k]; }
     ms[q] = M.body_mass[bs[q]];
   }
   int is[2], jj[2], db[2]; bool dok[2];
@@ -295,27 +323,29 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
   for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; dok[q] = i < nv; is[q] = dok[q] ? i : 0; jj[q] = M.dof_jntid[is[q]]; db[q] = M.dof_bodyid[is[q]]; }
   const bool tok = lane < M.ntendon;
   const int tadr = M.tendon_adr[tok ? lane : 0], tnum = tok ? M.tendon_num[lane] : 0;
-  // ---- round 2: joint data of the dofs, tendon wraps
-  real anc[2][3], axs[2][3], Rb[2][9]; int jt[2], jda[2];
+  // ---- round 2: joint data of the dofs (LDS), tendon wraps
+  real anc[2][3], axs[2][3], dq[2][4]; int jt[2], jda[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const real* pa = w.xanchor() + 3*jj[q]; const real* px = w.xaxis() + 3*jj[q]; const real* R = w.xmat() + 9*db[q];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { anc[q][k] = pa[k]; axs[q][k] = px[k]; }
+    for (int k = 0; k < 3; k++) { anc[q][k] = A[6*jj[q] + k]; axs[q][k] = A[6*jj[q] + 3 + k]; }
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rb[q][k] = R[k];
+    for (int k = 0; k < 4; k++) dq[q][k] = S[7*db[q] + 3 + k];
     jt[q] = M.jnt_type[jj[q]]; jda[q] = M.jnt_dofadr[jj[q]];
   }
   int qa[FB_MAXWRAP]; real cf[FB_MAXWRAP], qv[FB_MAXWRAP];
 #pragma unroll
   for (int k = 0; k < FB_MAXWRAP; k++) { int kk = (k < tnum) ? tadr + k : 0; int a_ = M.wrap_qadr[kk]; qa[k] = (k < tnum) ? a_ : 0; cf[k] = M.wrap_coef[kk]; }
+  SYNC_LDS();                                   // every lane holds its frames / anchors: the mirrors below overwrite that part of the pool
   // ---- bodies: inertia about the centre of mass of the model, in the global frame
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     if (bok[q]) {
-      const real* R = Rm[q]; const real* I = In[q]; const real mass = ms[q];
+      real xi[3], R[9];
+      inertial_frame(bp[q], bq[q], ip[q], iq[q], xi, R);
+      const real* I = In[q]; const real mass = ms[q];
       real c[10];
-      real dif[3]; sub3(dif, xi[q], com);
+      real dif[3]; sub3(dif, xi, com);
       real t00 = 0, t11 = 0, t22 = 0, t01 = 0, t02 = 0, t12 = 0;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -332,7 +362,7 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
       const bool world = (lane + q*FB_WAVE) == 0;
       real* o = w.cinert() + 10*bs[q];
 #pragma unroll
-      for (int k = 0; k < 10; k++) o[k] = world ? (real)0 : c[k];
+      for (int k = 0; k < 10; k++) { const real v = world ? (real)0 : c[k]; o[k] = v; Li[10*bs[q] + k] = v; }
     }
   }
   // ---- round 3 (tendons only): the joint positions the wraps point at
@@ -346,7 +376,7 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
       real off[3]; sub3(off, com, anc[q]);
       real c[6];
       const int col = (jt[q] == JNT_FREE) ? k - 3 : k;               // column of the body frame (free rotations, ball joints)
-      const real* R = Rb[q];
+      real R[9]; quat2mat(R, dq[q]);
       real ax[3] = {col == 0 ? R[0] : (col == 1 ? R[1] : R[2]), col == 0 ? R[3] : (col == 1 ? R[4] : R[5]), col == 0 ? R[6] : (col == 1 ? R[7] : R[8])};
       if (jt[q] != JNT_FREE && jt[q] != JNT_BALL) { ax[0] = axs[q][0]; ax[1] = axs[q][1]; ax[2] = axs[q][2]; }
       if (jt[q] == JNT_FREE && k < 3) { for (int u = 0; u < 6; u++) c[u] = 0; c[3] = (k == 0) ? (real)1 : (real)0; c[4] = (k == 1) ? (real)1 : (real)0; c[5] = (k == 2) ? (real)1 : (real)0; }
@@ -371,55 +401,61 @@ __device__ __forceinline__ void d_com_pos(const DevModel<real>& M, const WS<real
   SYNC();
 }
 
-// Subtree sums S[b][0..K) = sum of A over the DFS-contiguous subtree of body b ("subtree pull").  The tree root owns
-// every body, so its sum is a 64-lane reduction instead of a 67-iteration serial walk; all other subtrees are short.
+// Subtree sums X[b][0..K) <- sum of X over the DFS-contiguous subtree of body b ("subtree pull"), IN PLACE in LDS: every lane sums
+// the subtrees of its (<= 2) bodies in registers, then all write back.  The tree root owns every body, so its sum is a 64-lane
+// reduction instead of a 67-iteration serial walk; all other subtrees are short.  (Rounds 1-3 summed from one global array into
+// another: 2 x K x nbody reals through the environment's row per call, three calls per substep.)
 template <int K, typename real>
-__device__ __forceinline__ void subtree_sum(const DevModel<real>& M, const real* A, real* S, int lane, FB_LDS real* mirror = nullptr) {
+__device__ __forceinline__ void subtree_sum_lds(const DevModel<real>& M, FB_LDS real* X, int lane) {
   real tot[K];
 #pragma unroll
   for (int k = 0; k < K; k++) tot[k] = 0;
   const int nsub1 = (M.nbody > 1) ? M.body_nsub[1] : 0;        // body 1 and its subtree (the fly); further trees take the generic path
   for (int b = 1 + lane; b < 1 + nsub1; b += FB_WAVE) {
 #pragma unroll
-    for (int k = 0; k < K; k++) tot[k] += A[K*b + k];
+    for (int k = 0; k < K; k++) tot[k] += X[K*b + k];
   }
 #pragma unroll
   for (int k = 0; k < K; k++) tot[k] = wave_sum(tot[k]);
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real acc[K];
-    if (b == 0) {
+  real acc[2][K];
 #pragma unroll
-      for (int k = 0; k < K; k++) acc[k] = 0;
-    } else if (b == 1) {
+  for (int q = 0; q < 2; q++) {
+    const int b = lane + q*FB_WAVE;
 #pragma unroll
-      for (int k = 0; k < K; k++) acc[k] = tot[k];
-    } else {
+    for (int k = 0; k < K; k++) acc[q][k] = 0;
+    if (b < M.nbody && b >= 1) {
+      if (b == 1) {
 #pragma unroll
-      for (int k = 0; k < K; k++) acc[k] = 0;
-      int n = M.body_nsub[b];
+        for (int k = 0; k < K; k++) acc[q][k] = tot[k];
+      } else {
+        const int n = M.body_nsub[b];
 #pragma unroll 4
-      for (int d = n - 1; d >= 0; d--) {
+        for (int d = n - 1; d >= 0; d--) {
 #pragma unroll
-        for (int k = 0; k < K; k++) acc[k] += A[K*(b + d) + k];
+          for (int k = 0; k < K; k++) acc[q][k] += X[K*(b + d) + k];
+        }
       }
     }
+  }
+  SYNC_LDS();
 #pragma unroll
-    for (int k = 0; k < K; k++) S[K*b + k] = acc[k];
-    if (mirror) {
+  for (int q = 0; q < 2; q++) {
+    const int b = lane + q*FB_WAVE;
+    if (b < M.nbody) {
 #pragma unroll
-      for (int k = 0; k < K; k++) mirror[K*b + k] = acc[k];
+      for (int k = 0; k < K; k++) X[K*b + k] = acc[q][k];
     }
   }
-  SYNC();
+  SYNC_LDS();
 }
 
 // ------------------------------------------------------------------ composite inertia + mass matrix
 template <typename real>
 __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w, int lane) {
-  // composite inertias, mirrored in LDS behind the motion axes the previous stage left there
+  // composite inertias: subtree sums of the bodies' inertias, in place in the LDS mirror the previous stage left behind the motion axes
   FB_LDS real* Lc = w.lLD;                      // cdof: 6*nv
-  FB_LDS real* Lr = w.lLD + 6*M.nv;             // composite inertia: 10*nbody (runs on into the matrix slot: the pool is contiguous)
-  subtree_sum<10>(M, w.cinert(), w.crb(), lane, Lr);
+  FB_LDS real* Lr = w.lLD + 6*M.nv;             // inertia -> composite inertia: 10*nbody (runs on into the matrix slot: the pool is contiguous)
+  subtree_sum_lds<10>(M, Lr, lane);
   // Row i of M: entries for the ancestors of dof i = the first depth(i)+1 slots of its body's chain (slot depth(i) is i itself).
   // Two rounds of loads from the model (ids, then the chains) for both dofs of the lane; the 20 motion axes and the composite
   // inertia come from LDS -- as gathers from the global row they were 2 x 7 dependent round trips.
@@ -724,18 +760,22 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
   SYNC();
   // normalise the published rows: L[i,j] = M~[i,j] / D[i]
   // (branch-free: all reads in flight together, an empty slot reads row 0 and writes the dummy word behind the factor)
-  {
-    real v[FB_FSLOT], dd[FB_FSLOT]; int adr[FB_FSLOT];
+  // (in two halves of the slots: all 18 in flight at once need 90 registers next to the 54 of the trunk's Schur complement, which the
+  // 168-register budget of the 12-per-CU build answered with 42 scratch stores + 42 reloads per factorisation)
 #pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) {
-      int wd = fw[s], dep = FW_DEP(wd);
+  for (int h = 0; h < 2; h++) {
+    constexpr int HS = FB_FSLOT/2;
+    real v[HS], dd[HS]; int adr[HS];
+#pragma unroll
+    for (int s = 0; s < HS; s++) {
+      int wd = fw[h*HS + s], dep = FW_DEP(wd);
       bool ok = dep != 31;
       int ad = ok ? FW_BASE(wd) + dep*(dep + 1)/2 : 0;
       adr[s] = ok ? ad + FW_E(wd) : FB_LDS_SCRATCH - 1;
       v[s] = RM[adr[s]]; dd[s] = RM[ad];
     }
 #pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) RM[adr[s]] = v[s]*dd[s];
+    for (int s = 0; s < HS; s++) RM[adr[s]] = v[s]*dd[s];
   }
   // trunk rows: dof k sits at depth k, row start T(k)
   real Lt[FB_NTT];
@@ -918,24 +958,34 @@ FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
   }
 }
 
-// cvel, cdof_dot and the bias acceleration sum of every body (cabias, without gravity)
+// LDS layout of the velocity stage (fb_step.hpp s_velocity).  The motion axes (cdof) the inertia stage mirrored at the start of
+// the pool are still there (the collision stage stages its spheres in the matrix slot, the row stage uses no LDS); behind them:
+//   Lv [6 nbody]  body velocities (cvel)       X [6 nbody]  per-body wrenches, summed over subtrees in place
+// Round 4: the per-body force arrays of the passive and bias stages (cfrc_ext, cfrc, two generations of cacc) and cdof_dot no
+// longer exist in the environment's global row; cvel and the bias accelerations are still stored there for the sensor stage.
+template <typename real> FBD int vel_off_v(const DevModel<real>& M) { return 6*M.nv; }
+template <typename real> FBD int vel_off_x(const DevModel<real>& M) { return 6*M.nv + 6*M.nbody; }
+
+// cvel of every body (LDS + global) and the bias acceleration sums (cabias, without gravity: registers of lane == body, and global)
 template <typename real>
-__device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, int lane) {
+__device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real>& w, FB_LDS real* Lv, real (*ab)[6], int lane) {
   const int nv = M.nv;
+  const FB_LDS real* Lc = w.lLD;
   const int ia = lane, ib = lane + FB_WAVE;
   const bool ha = ia < nv, hb = ib < nv;
   real ca[6], cb[6];
   const real qa = ha ? w.qvel()[ia] : (real)0, qb = hb ? w.qvel()[ib] : (real)0;
   DofPair<real> V;
 #pragma unroll
-  for (int c = 0; c < 6; c++) { ca[c] = ha ? w.cdof()[6*ia + c] : (real)0; cb[c] = hb ? w.cdof()[6*ib + c] : (real)0; V.a[c] = ca[c]*qa; V.b[c] = cb[c]*qb; }
+  for (int c = 0; c < 6; c++) { ca[c] = ha ? Lc[6*ia + c] : (real)0; cb[c] = hb ? Lc[6*ib + c] : (real)0; V.a[c] = ca[c]*qa; V.b[c] = cb[c]*qb; }
   tree_prefix6(M, V, lane);
   // body velocities: the prefix of the last dof on the body's chain
-  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
-    const int b = b0 + lane;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int b = q*FB_WAVE + lane;
     real v[6];
     dof_fetch6(V, b < M.nbody ? M.body_veldof[b] : -1, v);
-    if (b < M.nbody) for (int c = 0; c < 6; c++) w.cvel()[6*b + c] = v[c];
+    if (b < M.nbody) for (int c = 0; c < 6; c++) { w.cvel()[6*b + c] = v[c]; Lv[6*b + c] = v[c]; }
   }
   // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i (dof_vbef, fb_engine.hip)
   DofPair<real> A;
@@ -946,43 +996,45 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
     crossmotion(da, ua, ca); crossmotion(db, ub, cb);
 #pragma unroll
     for (int c = 0; c < 6; c++) { da[c] = (va == -2) ? (real)0 : da[c]; db[c] = (vb == -2) ? (real)0 : db[c]; A.a[c] = da[c]*qa; A.b[c] = db[c]*qb; }
-    if (ha) for (int c = 0; c < 6; c++) w.cdof_dot()[6*ia + c] = da[c];
-    if (hb) for (int c = 0; c < 6; c++) w.cdof_dot()[6*ib + c] = db[c];
   }
   tree_prefix6(M, A, lane);
-  for (int b0 = 0; b0 < M.nbody; b0 += FB_WAVE) {
-    const int b = b0 + lane;
-    real v[6];
-    dof_fetch6(A, b < M.nbody ? M.body_veldof[b] : -1, v);
-    if (b < M.nbody) for (int c = 0; c < 6; c++) w.cabias()[6*b + c] = v[c];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int b = q*FB_WAVE + lane;
+    dof_fetch6(A, b < M.nbody ? M.body_veldof[b] : -1, ab[q]);
+    if (b < M.nbody) for (int c = 0; c < 6; c++) w.cabias()[6*b + c] = ab[q][c];
   }
-  SYNC();
+  SYNC_LDS();
 }
 
-// 6-D velocity of a frame (pos, rot) rigidly attached to `body`, expressed in that frame
+// 6-D velocity of a frame (pos, rot) rigidly attached to a body with spatial velocity cv (about the tree CoM), expressed in that frame
+template <typename real, typename CV>
+FBD void frame_velocity(const CV cv, const real* com, const real* pos, const real* rot, real* lvel) {
+  const real c6[6] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5]};
+  real dif[3], lin[3], t[3];
+  sub3(dif, pos, com);
+  cross3(t, dif, c6);
+  sub3(lin, c6 + 3, t);
+  mulmatT3(lvel, rot, c6);
+  mulmatT3(lvel + 3, rot, lin);
+}
 template <typename real>
 FBD void object_velocity(const WS<real>& w, int body, const real* pos, const real* rot, real* lvel) {
-  const real* cv = w.cvel() + 6*body;
-  real dif[3], lin[3], t[3];
-  sub3(dif, pos, w.com());
-  cross3(t, dif, cv);
-  sub3(lin, cv + 3, t);
-  mulmatT3(lvel, rot, cv);
-  mulmatT3(lvel + 3, rot, lin);
+  frame_velocity(w.cvel() + 6*body, (const real*)w.com(), pos, rot, lvel);
 }
 
 // Ellipsoid fluid model for one fluid geom (wing): added mass, Magnus and Kutta lift, blunt / slender /
 // angular drag, Stokes terms.  Follows the reference's restatement flybody/ellipsoid_fluid_model.py:88-310
 // (coefficient layout :229-237).  Writes the wrench about the tree CoM as [torque; force].
 template <typename real>
-__device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& w, int b, int g, real* out) {
+__device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* Lv, int b, int g, real* out) {
   const real PI = (real)3.14159265358979323846;
   const real* gf = M.geom_fluid + 12*g;
   const real* size = M.geom_size + 3*g;
   real blunt = gf[1], slender = gf[2], angc = gf[3], kutta = gf[4], magnus = gf[5];
   const real* vmass = gf + 6; const real* vinert = gf + 9;
   real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-  object_velocity(w, b, w.gxpos() + 3*g, w.gxmat() + 9*g, lvel);
+  frame_velocity(Lv + 6*b, (const real*)w.com(), (const real*)(w.gxpos() + 3*g), (const real*)(w.gxmat() + 9*g), lvel);
   const real* om = lvel; const real* v = lvel + 3;
   real plin[3], pang[3], t[3];
   for (int k = 0; k < 3; k++) { plin[k] = M.density*vmass[k]*v[k]; pang[k] = M.density*vinert[k]*om[k]; }
@@ -1028,46 +1080,55 @@ __device__ __forceinline__ void ellipsoid_fluid_wrench(const DevModel<real>& M, 
 
 // passive forces: joint springs/dampers + per-body inertia-box fluid drag (density, viscosity)
 template <typename real>
-__device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real>& w, int lane) {
-  // per-body fluid wrench about the tree CoM, stored in cfrc_ext as [torque; force] (scratch use)
+__device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* Lv, FB_LDS real* X, int lane) {
+  // per-body fluid wrench about the tree CoM as [torque; force], staged in LDS and summed over subtrees in place
+  const FB_LDS real* Lc = w.lLD;
   bool fluid = (M.density > 0 || M.viscosity > 0);
   for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real* out = w.cfrc_ext() + 6*b;
-    for (int k = 0; k < 6; k++) out[k] = 0;
-    if (!fluid || b == 0 || M.body_mass[b] < FB_MINV) continue;
-    int fg = M.body_fluid_geom[b];
-    if (fg >= 0) { ellipsoid_fluid_wrench(M, w, b, fg, out); continue; }
-    const real* box = M.body_box + 3*b;
-    real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-    object_velocity(w, b, w.xipos() + 3*b, w.ximat() + 9*b, lvel);
-    if (M.viscosity > 0) {
-      real diam = (box[0] + box[1] + box[2]) / (real)3;
-      for (int k = 0; k < 3; k++) {
-        lfrc[k] = -(real)3.14159265358979323846 * diam*diam*diam * M.viscosity * lvel[k];
-        lfrc[3+k] = -(real)3 * (real)3.14159265358979323846 * diam * M.viscosity * lvel[3+k];
+    real out[6] = {0, 0, 0, 0, 0, 0};
+    if (fluid && b != 0 && M.body_mass[b] >= FB_MINV) {
+      int fg = M.body_fluid_geom[b];
+      if (fg >= 0) ellipsoid_fluid_wrench(M, w, Lv, b, fg, out);
+      else {
+        const real* box = M.body_box + 3*b;
+        // inertial frame of the body from its frame and the record's constants (the kinematics stage stores xpos / xquat only)
+        real bp[3], bq[4], xi[3], Ri[9];
+        for (int k = 0; k < 3; k++) bp[k] = w.xpos()[3*b + k];
+        for (int k = 0; k < 4; k++) bq[k] = w.xquat()[4*b + k];
+        inertial_frame(bp, bq, (const real*)(M.body_rec + b*FB_BODYREC + 11), (const real*)(M.body_rec + b*FB_BODYREC + 14), xi, Ri);
+        real lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+        frame_velocity(Lv + 6*b, (const real*)w.com(), xi, Ri, lvel);
+        if (M.viscosity > 0) {
+          real diam = (box[0] + box[1] + box[2]) / (real)3;
+          for (int k = 0; k < 3; k++) {
+            lfrc[k] = -(real)3.14159265358979323846 * diam*diam*diam * M.viscosity * lvel[k];
+            lfrc[3+k] = -(real)3 * (real)3.14159265358979323846 * diam * M.viscosity * lvel[3+k];
+          }
+        }
+        if (M.density > 0) {
+          real b0 = box[0], b1 = box[1], b2 = box[2];
+          real b04 = b0*b0*b0*b0, b14 = b1*b1*b1*b1, b24 = b2*b2*b2*b2;
+          lfrc[3] -= (real)0.5*M.density*b1*b2*fabs(lvel[3])*lvel[3];
+          lfrc[4] -= (real)0.5*M.density*b0*b2*fabs(lvel[4])*lvel[4];
+          lfrc[5] -= (real)0.5*M.density*b0*b1*fabs(lvel[5])*lvel[5];
+          lfrc[0] -= M.density*b0*(b14 + b24)*fabs(lvel[0])*lvel[0]/(real)64;
+          lfrc[1] -= M.density*b1*(b04 + b24)*fabs(lvel[1])*lvel[1]/(real)64;
+          lfrc[2] -= M.density*b2*(b04 + b14)*fabs(lvel[2])*lvel[2]/(real)64;
+        }
+        real trq[3], frc[3], off[3], t[3];
+        mulmat3(trq, Ri, lfrc);
+        mulmat3(frc, Ri, lfrc + 3);
+        // move the wrench to the CoM reference point: torque += off x force
+        sub3(off, xi, w.com());
+        cross3(t, off, frc);
+        out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
+        out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
       }
     }
-    if (M.density > 0) {
-      real b0 = box[0], b1 = box[1], b2 = box[2];
-      real b04 = b0*b0*b0*b0, b14 = b1*b1*b1*b1, b24 = b2*b2*b2*b2;
-      lfrc[3] -= (real)0.5*M.density*b1*b2*fabs(lvel[3])*lvel[3];
-      lfrc[4] -= (real)0.5*M.density*b0*b2*fabs(lvel[4])*lvel[4];
-      lfrc[5] -= (real)0.5*M.density*b0*b1*fabs(lvel[5])*lvel[5];
-      lfrc[0] -= M.density*b0*(b14 + b24)*fabs(lvel[0])*lvel[0]/(real)64;
-      lfrc[1] -= M.density*b1*(b04 + b24)*fabs(lvel[1])*lvel[1]/(real)64;
-      lfrc[2] -= M.density*b2*(b04 + b14)*fabs(lvel[2])*lvel[2]/(real)64;
-    }
-    real trq[3], frc[3], off[3], t[3];
-    mulmat3(trq, w.ximat() + 9*b, lfrc);
-    mulmat3(frc, w.ximat() + 9*b, lfrc + 3);
-    // move the wrench to the CoM reference point: torque += off x force
-    sub3(off, w.xipos() + 3*b, w.com());
-    cross3(t, off, frc);
-    out[0] = trq[0] + t[0]; out[1] = trq[1] + t[1]; out[2] = trq[2] + t[2];
-    out[3] = frc[0]; out[4] = frc[1]; out[5] = frc[2];
+    for (int k = 0; k < 6; k++) X[6*b + k] = out[k];
   }
-  SYNC();
-  if (fluid) subtree_sum<6>(M, w.cfrc_ext(), w.cacc(), lane);       // cacc is free scratch until the sensor stage
+  SYNC_LDS();
+  if (fluid) subtree_sum_lds<6>(M, X, lane);
   // qfrc_passive[i] = spring + damper + cdof_i . (sum of fluid wrenches over the dof's subtree)
   for (int i = lane; i < M.nv; i += FB_WAVE) {
     int j = M.dof_jntid[i];
@@ -1076,28 +1137,46 @@ __device__ __forceinline__ void d_passive(const DevModel<real>& M, const WS<real
       int qa = M.jnt_qposadr[j];
       f -= M.jnt_stiffness[j]*(w.qpos()[qa] - M.qpos_spring[qa]);
     }
-    if (fluid) f += dot6(w.cdof() + 6*i, w.cacc() + 6*M.dof_bodyid[i]);
+    if (fluid) {
+      const int bd = M.dof_bodyid[i];
+      real c[6], x[6];
+      for (int k = 0; k < 6; k++) { c[k] = Lc[6*i + k]; x[k] = X[6*bd + k]; }
+      f += dot6(c, x);
+    }
     w.qfrc_passive()[i] = f;
   }
-  SYNC();
+  SYNC_LDS();
 }
 
-// bias forces by RNE: chain walk for the body accelerations, subtree pull for the forces
+// bias forces by RNE: body accelerations from the prefix sums (registers of lane == body), subtree pull for the forces (LDS)
 template <typename real>
-__device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int b = lane; b < M.nbody; b += FB_WAVE) {
-    real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]};
-    real* out = w.cfrc() + 6*b;
-    if (b == 0) { for (int k = 0; k < 6; k++) out[k] = 0; continue; }
-    for (int k = 0; k < 6; k++) a[k] += w.cabias()[6*b + k];            // sum of cdof_dot qvel along the body's chain (d_com_vel)
-    real t[6], t1[6], t2[6];
-    mulinertvec(t, w.cinert() + 10*b, a);
-    mulinertvec(t1, w.cinert() + 10*b, w.cvel() + 6*b);
-    crossforce(t2, w.cvel() + 6*b, t1);
-    for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k];
+__device__ __forceinline__ void d_rne_bias(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* Lv, FB_LDS real* X, const real (*ab)[6], int lane) {
+  const FB_LDS real* Lc = w.lLD;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int b = q*FB_WAVE + lane;
+    if (b < M.nbody) {
+      real out[6] = {0, 0, 0, 0, 0, 0};
+      if (b != 0) {
+        real a[6] = {ab[q][0], ab[q][1], ab[q][2], ab[q][3] - M.grav[0], ab[q][4] - M.grav[1], ab[q][5] - M.grav[2]};   // sum of cdof_dot qvel along the body's chain (d_com_vel) - g
+        real ci[10], cv[6], t[6], t1[6], t2[6];
+        for (int k = 0; k < 10; k++) ci[k] = w.cinert()[10*b + k];
+        for (int k = 0; k < 6; k++) cv[k] = Lv[6*b + k];
+        mulinertvec(t, ci, a);
+        mulinertvec(t1, ci, cv);
+        crossforce(t2, cv, t1);
+        for (int k = 0; k < 6; k++) out[k] = t[k] + t2[k];
+      }
+      for (int k = 0; k < 6; k++) X[6*b + k] = out[k];
+    }
   }
-  SYNC();
-  subtree_sum<6>(M, w.cfrc(), w.cacc(), lane);
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_bias()[i] = dot6(w.cdof() + 6*i, w.cacc() + 6*M.dof_bodyid[i]);
+  SYNC_LDS();
+  subtree_sum_lds<6>(M, X, lane);
+  for (int i = lane; i < M.nv; i += FB_WAVE) {
+    const int bd = M.dof_bodyid[i];
+    real c[6], x[6];
+    for (int k = 0; k < 6; k++) { c[k] = Lc[6*i + k]; x[k] = X[6*bd + k]; }
+    w.qfrc_bias()[i] = dot6(c, x);
+  }
   SYNC();
 }

@@ -90,10 +90,93 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
   // (fruit fly: thorax + 6 x 5 tarsus segments = 31 of 68 bodies -> ONE pass of the wave instead of two, the second of which
   // would run the whole chain walk for four bodies).  A model with more than 64 such bodies takes the all-bodies passes.
   const int nsb = M.nsensbody;
-  const int npass = nsb > 0 ? 1 : (M.nbody + FB_WAVE - 1)/FB_WAVE;
+  // body accelerations: -g + sum of cdof_dot qvel along the chain (cabias, from the velocity stage) + sum of cdof qacc (tree
+  // prefix over the dofs in registers, fb_smooth.hpp), and body forces
+  DofPair<real> Q;
+  {
+    const int ia = lane, ib = lane + FB_WAVE;
+    const bool ha = ia < M.nv, hb = ib < M.nv;
+    const real qa = ha ? w.qacc()[ia] : (real)0, qb = hb ? w.qacc()[ib] : (real)0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) { Q.a[c] = ha ? w.cdof()[6*ia + c]*qa : (real)0; Q.b[c] = hb ? w.cdof()[6*ib + c]*qb : (real)0; }
+    tree_prefix6(M, Q, lane);
+  }
+  if (nsb > 0) {
+    // ---- lane == sensor body: the external wrench, the acceleration and the body force stay in the lane's registers; the
+    // accelerometer reads the thorax lane's acceleration by v_readlane, the force sensors sum their subtree (DFS-contiguous in the
+    // body list, hence in the lanes) by ds_bpermute.  (Rounds 1-3 passed all three through the environment's global row.)
+    const int b = lane < nsb ? M.sens_body[lane] : -1;
+    real ext[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < ncon; c++) {
+      int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
+      if (rb1 < 0 || rb1 == rb2) continue;
+      real wr[6];
+      for (int k = 0; k < 6; k++) wr[k] = rdlane(cw[k], c);
+      if (b > 0 && (b == rb1 || b == rb2)) {
+        real sgn = (b == rb2) ? (real)1 : (real)-1;
+        for (int k = 0; k < 6; k++) ext[k] += sgn*wr[k];
+      }
+    }
+    real qsum[6];
+    dof_fetch6(Q, b >= 0 ? M.body_veldof[b] : -1, qsum);               // (wave collective)
+    real a[6] = {0, 0, 0, -M.grav[0], -M.grav[1], -M.grav[2]}, frc[3] = {0, 0, 0};
+    if (b > 0) {
+      real ci[10], cv[6], t[6], t1[6], t2[6];
+      for (int k = 0; k < 6; k++) a[k] += w.cabias()[6*b + k] + qsum[k];
+      for (int k = 0; k < 10; k++) ci[k] = w.cinert()[10*b + k];
+      for (int k = 0; k < 6; k++) cv[k] = w.cvel()[6*b + k];
+      mulinertvec(t, ci, a);
+      mulinertvec(t1, ci, cv);
+      crossforce(t2, cv, t1);
+      for (int k = 0; k < 3; k++) frc[k] = t[3 + k] + t2[3 + k] - ext[3 + k];
+    }
+    // accelerometer: the thorax site's body
+    {
+      const int s = M.site_thorax, bt = M.site_bodyid[s];
+      const unsigned long long mt = __ballot(b == bt);
+      const int src = mt ? __ffsll((long long)mt) - 1 : 0;
+      real ca[6];
+      for (int k = 0; k < 6; k++) ca[k] = rdlane(a[k], src);
+      if (lane == 0) {
+        real dif[3], t[3], lin[3], la[3], lvel[6], cor[3];
+        sub3(dif, w.sxpos() + 3*s, w.com());
+        cross3(t, dif, ca);
+        sub3(lin, ca + 3, t);
+        mulmatT3(la, w.sxmat() + 9*s, lin);
+        object_velocity(w, bt, w.sxpos() + 3*s, w.sxmat() + 9*s, lvel);
+        cross3(cor, lvel, lvel + 3);
+        for (int k = 0; k < 3; k++) w.sens()[k] = la[k] + cor[k];
+      }
+    }
+    // force sensors: interaction force of the site's body = subtree sum of body forces, deepest body first
+    {
+      const bool fs = lane >= 8 && lane < 8 + M.nforce;
+      const int kf = fs ? lane - 8 : 0;
+      const int s = M.force_sites[kf], bf = M.site_bodyid[s];
+      const int n = fs ? M.body_nsub[bf] : 0;
+      int first = 0, nmax = 0;                                    // lane of the sensor body inside the sensor-body list; longest subtree
+      for (int q = 0; q < M.nforce; q++) {
+        const int bq = M.site_bodyid[M.force_sites[q]];
+        const unsigned long long mq = __ballot(b == bq);
+        const int lq = mq ? __ffsll((long long)mq) - 1 : 0;
+        if (kf == q) first = lq;
+        const int nq = M.body_nsub[bq];
+        nmax = nq > nmax ? nq : nmax;
+      }
+      real acc[3] = {0, 0, 0};
+      for (int u = 0; u < nmax; u++) {
+        const int d = n - 1 - u;                                  // (every lane takes part in the shuffles)
+        const int srcl = first + (d >= 0 ? d : 0);
+        const real f0 = __shfl(frc[0], srcl, 64), f1 = __shfl(frc[1], srcl, 64), f2 = __shfl(frc[2], srcl, 64);
+        if (d >= 0) { acc[0] += f0; acc[1] += f1; acc[2] += f2; }
+      }
+      if (fs) mulmatT3(w.sens() + 9 + 3*kf, w.sxmat() + 9*s, acc);
+    }
+  } else {
+  const int npass = (M.nbody + FB_WAVE - 1)/FB_WAVE;
   // external wrench per body: lane == body, the contacts are broadcast one at a time (in contact order)
   for (int ps = 0; ps < npass; ps++) {
-    const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
+    const int b = (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
     real acc[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ncon; c++) {
       int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
@@ -108,19 +191,8 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     if (b >= 0) for (int k = 0; k < 6; k++) w.cfrc_ext()[6*b + k] = acc[k];
   }
   SYNC();
-  // body accelerations: -g + sum of cdof_dot qvel along the chain (cabias, from the velocity stage) + sum of cdof qacc (tree
-  // prefix over the dofs in registers, fb_smooth.hpp), and body forces
-  DofPair<real> Q;
-  {
-    const int ia = lane, ib = lane + FB_WAVE;
-    const bool ha = ia < M.nv, hb = ib < M.nv;
-    const real qa = ha ? w.qacc()[ia] : (real)0, qb = hb ? w.qacc()[ib] : (real)0;
-#pragma unroll
-    for (int c = 0; c < 6; c++) { Q.a[c] = ha ? w.cdof()[6*ia + c]*qa : (real)0; Q.b[c] = hb ? w.cdof()[6*ib + c]*qb : (real)0; }
-    tree_prefix6(M, Q, lane);
-  }
   for (int ps = 0; ps < npass; ps++) {
-    const int b = nsb > 0 ? (lane < nsb ? M.sens_body[lane] : -1) : (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
+    const int b = (ps*FB_WAVE + lane < M.nbody ? ps*FB_WAVE + lane : -1);
     real qsum[6];
     dof_fetch6(Q, b >= 0 ? M.body_veldof[b] : -1, qsum);               // (wave collective: before any lane leaves the iteration)
     if (b < 0) continue;
@@ -154,16 +226,9 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     int s = M.force_sites[k], b = M.site_bodyid[s];
     real acc[3] = {0, 0, 0};
     int n = M.body_nsub[b];
-    // subtree sum, deepest body first; the first 8 bodies' loads are in flight together (a tarsus subtree has 5)
-    {
-      real c8[8][3];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int d = n - 1 - u; const real* c = w.cfrc() + 6*(b + (d >= 0 ? d : 0)) + 3; c8[u][0] = c[0]; c8[u][1] = c[1]; c8[u][2] = c[2]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) if (n - 1 - u >= 0) { acc[0] += c8[u][0]; acc[1] += c8[u][1]; acc[2] += c8[u][2]; }
-    }
-    for (int d = n - 9; d >= 0; d--) { const real* c = w.cfrc() + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
+    for (int d = n - 1; d >= 0; d--) { const real* c = w.cfrc() + 6*(b + d) + 3; acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2]; }
     mulmatT3(w.sens() + 9 + 3*k, w.sxmat() + 9*s, acc);
+  }
   }
   {
     bool on = lane >= 16 && lane < 16 + M.ntouch;
@@ -256,7 +321,8 @@ template <typename real> FBD void ref_root(const RefView<real>& r, int idx, real
 template <typename real>
 __device__ __forceinline__ void d_pack_obs(const DevModel<real>& M, const WS<real>& w, const real* sm, float* obs, int lane) {
   int thorax = M.site_bodyid[M.site_thorax];
-  const real* R = w.xmat() + 9*thorax;
+  real R[9];
+  { const real tq[4] = {w.xquat()[4*thorax], w.xquat()[4*thorax + 1], w.xquat()[4*thorax + 2], w.xquat()[4*thorax + 3]}; quat2mat(R, tq); }   // (the kinematics stage stores quaternions only)
   const real* tp = w.xpos() + 3*thorax;
   int step = w.istate()[IS_STEP];
   int o = 0;
@@ -698,7 +764,11 @@ FB_STAGE_WRAP(s_crb, d_crb(M, w, lane))
 FB_STAGE_WRAP(s_collision, d_collision(M, w, lane))
 FB_STAGE_WRAP(s_make_constraint, d_make_constraint(M, w, lane))
 FB_STAGE_WRAP(s_project_constraint, d_project_constraint(M, w, lane))
-FB_STAGE_WRAP(s_velocity, d_com_vel(M, w, lane); d_passive(M, w, lane); d_rne_bias(M, w, lane); d_sensor_vel(M, w, lane))
+template <typename real> FB_STAGE_C void s_velocity(const DevModel<real>& M_, const WS<real>& w_, int lane) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  FB_LDS real* Lv = w.lLD + vel_off_v(M); FB_LDS real* X = w.lLD + vel_off_x(M);        // body velocities / per-body wrenches (fb_smooth.hpp)
+  real ab[2][6];                                                                         // bias accelerations of the lane's two bodies
+  d_com_vel(M, w, Lv, ab, lane); d_passive(M, w, Lv, X, lane); d_rne_bias(M, w, Lv, X, ab, lane); d_sensor_vel(M, w, lane); }
 FB_STAGE_WRAP(s_actuation, d_actuation(M, w, lane))
 FB_STAGE_WRAP(s_constraint_b, d_constraint_b(M, w, lane))
 FB_STAGE_WRAP(s_sensor_acc, d_sensor_acc(M, w, lane))

@@ -73,9 +73,9 @@ template <typename T> struct GP {
 #define FB_WS_REAL(X) \
   X(qpos, M.nq) X(qvel, M.nv) X(act, M.na + 1) X(ctrl, M.nu) X(qacc, M.nv) X(qacc_ws, M.nv) X(act_dot, M.na + 1) \
   X(sens, FB_NSENS) X(sens_acc, FB_NSENS) X(simtime, 1) X(wbfreq, 1) X(dsshift, 2) X(rfac, 6) \
-  X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) X(xmat, 9*M.nbody) X(xipos, 3*M.nbody) X(ximat, 9*M.nbody) \
-  X(xanchor, 3*M.njnt) X(xaxis, 3*M.njnt) X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
-  X(cinert, 10*M.nbody) X(crb, 10*M.nbody) X(cdof, 6*M.nv) X(cdof_dot, 6*M.nv) X(cvel, 6*M.nbody) \
+  X(xpos, 3*M.nbody) X(xquat, 4*M.nbody) /* rotation matrices, inertial frames, joint anchors: LDS / registers only (fb_smooth.hpp) */ \
+  X(xaxis, 3*M.njnt) /* walk_imitation training reward only */ X(gxpos, 3*M.ngeom) X(gxmat, 9*M.ngeom) X(sxpos, 3*M.nsite) X(sxmat, 9*M.nsite) X(com, 4) \
+  X(cinert, 10*M.nbody) X(cdof, 6*M.nv) X(cvel, 6*M.nbody) \
   X(qM, M.nM) X(qLD, M.nM) \
   X(qfrc_bias, M.nv) X(qfrc_passive, M.nv) X(qfrc_actuator, M.nv) X(qfrc_smooth, M.nv) X(qacc_smooth, M.nv) \
   X(qfrc_constraint, M.nv) X(ten_length, M.ntendon + 1) X(act_force, M.nu) \

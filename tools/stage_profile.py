@@ -8,7 +8,7 @@ Two halves:
               the fused step, tests/test_kernel_emulation.py::test_single_stage_launches_equal_fused_step) and writes the launch -> stage map.
               Run it under `rocprofv3 --pmc ... --kernel-trace` (tools/collect_stage_profile.sh does, one counter group per pass).
   report   -- joins the per-dispatch counter CSVs of the passes with the stage map and prints, per stage: launches per substep, VALU / SALU /
-              LDS / VMEM instructions per environment-substep, mean active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4 when available),
+              LDS / VMEM instructions per environment-substep, mean active lanes (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU),
               share of FP64 arithmetic instructions, wave-cycles and wait share, bytes fetched / written, and the ISA-level scratch
               instruction count of the stage function (tools/resource_report.py).
 
@@ -83,10 +83,12 @@ def report(a):
     print(f'# tools/stage_profile.py: {mp["build"]} FP64 build ({mp["version"]}), {n_env} walk_imitation environments, {steps} control steps walked one stage per launch')
     print(f'# (fb_batch_stage), mean nefc {mp["nefc_mean"]:.1f}, ncon {mp["ncon_mean"]:.1f}.  Per ENVIRONMENT-SUBSTEP (task_pre / task_post: per control step / {nsub}); every row has the')
     print('# single-stage launch overhead (LDS pool load + store = the substep_end row, itself shown raw) SUBTRACTED.  lanes = mean active lanes of a VALU')
-    print('# instruction; f64% = FP64 add/mul/fma/transcendental share of the VALU instructions; wait% = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the')
+    print('# instruction BY EXEC MASK (wave-uniform solver algebra runs with all lanes enabled although only nefc rows carry data);')
+    print('# f64% = FP64 add/mul/fma/transcendental share of the VALU instructions; int% = INT32 share (address arithmetic, unpacking);')
+    print('# wait% = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the')
     print('# stage launch (cold L2: every stage streams the whole batch, so waits and bytes are UPPER bounds of what the fused kernel sees);')
     print('# KB rd/wr = 2 x FETCH_SIZE / WRITE_SIZE (calibration: profiles/r3/pmc_calibration.json); scr = scratch instructions in the stage function(s) (static).')
-    hdr = '%-20s %5s %8s %8s %7s %7s %6s %5s %9s %6s %7s %7s %5s' % ('stage', 'n/sub', 'VALU', 'SALU', 'LDS', 'VMEM', 'lanes', 'f64%', 'wavecyc', 'wait%', 'KB_rd', 'KB_wr', 'scr')
+    hdr = '%-20s %5s %8s %8s %7s %7s %6s %5s %5s %9s %6s %7s %7s %5s' % ('stage', 'n/sub', 'VALU', 'SALU', 'LDS', 'VMEM', 'lanes', 'f64%', 'int%', 'wavecyc', 'wait%', 'KB_rd', 'KB_wr', 'scr')
     print(hdr)
     tot = collections.defaultdict(float)
     for n in order:
@@ -98,17 +100,20 @@ def report(a):
         valu, salu, lds = g('SQ_INSTS_VALU'), g('SQ_INSTS_SALU'), g('SQ_INSTS_LDS')
         vmem = g('SQ_INSTS_VMEM_RD') + g('SQ_INSTS_VMEM_WR')
         act_, thr = c.get('SQ_ACTIVE_INST_VALU', 0.0) - (0 if n == 'substep_end' else base.get('SQ_ACTIVE_INST_VALU', 0.0)*k/nb), c.get('SQ_THREAD_CYCLES_VALU', 0.0) - (0 if n == 'substep_end' else base.get('SQ_THREAD_CYCLES_VALU', 0.0)*k/nb)
-        lanes = thr/act_/4.0 if act_ > 0 and thr > 0 else float('nan')
+        lanes = thr/act_ if act_ > 0 and thr > 0 else float('nan')      # (rocprofv3's VALUThreadUtilization: THREAD_CYCLES / (ACTIVE_INST x 64))
         f64 = sum(g(x) for x in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_TRANS_F64'))
         wc = g('SQ_WAVE_CYCLES')*4; wt = c.get('SQ_WAIT_ANY', 0.0)/max(c.get('SQ_WAVE_CYCLES', 1.0), 1.0)
         rd, wr = 2*g('FETCH_SIZE'), g('WRITE_SIZE')
         fns = fn_of.get(n, ''); sc = sum(scr.get(f, (0, 0, 0))[2] for f in fns.split('+')) if fns else 0
-        print('%-20s %5.1f %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %9.0f %6.1f %7.2f %7.2f %5d' % (n, k/float(nsub*steps), valu, salu, lds, vmem, lanes, 100*f64/max(valu, 1e-9), wc, 100*wt, rd, wr, sc))
+        i32 = g('SQ_INSTS_VALU_INT32')
+        print('%-20s %5.1f %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %5.1f %9.0f %6.1f %7.2f %7.2f %5d' % (n, k/float(nsub*steps), valu, salu, lds, vmem, lanes, 100*f64/valu if valu > 50 else float('nan'),
+              100*i32/valu if valu > 50 else float('nan'), wc, 100*wt, rd, wr, sc))
+        tot['i32'] += 0 if n == 'substep_end' else i32
         if n != 'substep_end':
             for key, v in (('VALU', valu), ('SALU', salu), ('LDS', lds), ('VMEM', vmem), ('wc', wc), ('rd', rd), ('wr', wr), ('f64', f64), ('thr', thr/envsub), ('act', act_/envsub)):
                 tot[key] += v
-    print('%-20s %5s %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %9.0f %6s %7.2f %7.2f' % ('SUM (per env-substep)', '', tot['VALU'], tot['SALU'], tot['LDS'], tot['VMEM'],
-          tot['thr']/max(tot['act'], 1e-9)/4.0, 100*tot['f64']/max(tot['VALU'], 1e-9), tot['wc'], '', tot['rd'], tot['wr']))
+    print('%-20s %5s %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %5.1f %9.0f %6s %7.2f %7.2f' % ('SUM (per env-substep)', '', tot['VALU'], tot['SALU'], tot['LDS'], tot['VMEM'],
+          tot['thr']/max(tot['act'], 1e-9), 100*tot['f64']/max(tot['VALU'], 1e-9), 100*tot['i32']/max(tot['VALU'], 1e-9), tot['wc'], '', tot['rd'], tot['wr']))
     print('# x %d substeps = per env-step: VALU %.0f  SALU %.0f  LDS %.0f  VMEM %.0f ; KB fetched %.1f written %.1f' % (nsub, nsub*tot['VALU'], nsub*tot['SALU'], nsub*tot['LDS'], nsub*tot['VMEM'], nsub*tot['rd'], nsub*tot['wr']))
 
 
