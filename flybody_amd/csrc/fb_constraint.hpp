@@ -71,7 +71,8 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       w.efc_type()[r] = CN_LIMIT; w.efc_id()[r] = j;
       w.efc_bA()[r] = M.jnt_bodyid[j]; w.efc_lA()[r] = len; w.efc_bB()[r] = 0; w.efc_lB()[r] = 0;
       w.efc_pos()[r] = dist; w.efc_margin()[r] = M.jnt_margin[j];
-      for (int s = 0; s < FB_MAXCH; s++) { w.efc_J()[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0; w.efc_J()[JIDX(1, s, r)] = 0; }
+      // (only the slots a reader looks at: every consumer of a row masks its chain slots with the row's chain lengths, lA = len, lB = 0)
+      for (int s = 0; s < len; s++) w.efc_J()[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0;
       real K, B, imp;
       kbi(M, M.jnt_solref + 2*j, M.jnt_solimp + 5*j, dist, M.jnt_margin[j], false, K, B, imp);
       w.efc_K()[r] = K; w.efc_B()[r] = B; w.efc_imp()[r] = imp; w.efc_mu()[r] = 0;
@@ -132,13 +133,14 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       const int cdim = __shfl(dim, c, 64), cadr = __shfl(adr, c, 64);
       const int sb1 = __shfl(cb1, c, 64), sb2 = __shfl(cb2, c, 64);          // (both shuffles by every lane: they are wave collectives)
       const int body = side ? sb2 : sb1;
-      if (t < nitem && cdim) {
+      // (slots beyond the body's chain are never read: a floor contact's world side -- chain length 0 -- used to cost 20 zero stores per row)
+      if (t < nitem && cdim && sl < M.body_chlen[body]) {
         const int len = M.body_chlen[body];
         const int dof = M.body_chain[body*FB_MAXCH + sl];
         real jp[3] = {0, 0, 0};
         const real* pos = w.con_pos() + 3*c;
         const real* frame = w.con_frame() + 9*c;
-        const real* cp = w.cdof() + 6*((sl < len) ? dof : 0);
+        const FB_LDS real* cp = w.lLD + 6*((sl < len) ? dof : 0);          // motion axes: the inertia stage's LDS mirror (same substep)
         real cd[6], off[3], fr[9];
 #pragma unroll
         for (int k = 0; k < 6; k++) cd[k] = cp[k];
@@ -948,7 +950,10 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     // The Newton solver needs a second triangle of the same size (its work matrix K): behind AR in the matrix slot when both
     // fit, in the (parked) factor row otherwise, in the environment's global row as the last resort.
     const bool wide = nefc > LdsCfg<real>::AR_ROWS;
-    const bool k_in_slot = newton && !wide && 2*tri <= LdsCfg<real>::AR_ELEMS;
+    // (the solve vector behind the matrix slot is free during the solve -- the projection's sqrt(1/D) staging is dead, J^T f is written
+    // afterwards -- and the pool is contiguous: K may run on into it.  12-per-CU build: systems of up to 19 rows instead of 16 keep
+    // the factor where it is; every parked factor is a 9.7 KB write and re-read of the environment's row)
+    const bool k_in_slot = newton && !wide && 2*tri <= LdsCfg<real>::AR_ELEMS + FB_MAXNV;
     const bool park = wide || (newton && !k_in_slot);
     if (park) {
       for (int i = lane; i < M.nM; i += FB_WAVE) w.qLD()[i] = w.lLD[i];
