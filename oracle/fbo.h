@@ -4,15 +4,20 @@
  * dm_control -> MuJoCo `mj_step` (reference call sites
  * flybody/fly_envs.py:152, tasks/base.py:197-225, tasks/walk_imitation.py:92-203),
  * specialised to the fruit-fly model class (free root + hinge tree, fixed tendons,
- * plane/sphere/capsule/ellipsoid/cylinder geoms, elliptic cones, PGS + noslip).
+ * plane/sphere/capsule/ellipsoid/cylinder geoms, elliptic cones; constraint solver = the model's own: Newton on MuJoCo's
+ * primal cost, the default the reference XML leaves in place (fruitfly.xml:4), restated in constraint space
+ * (fbo_constraint.c: solve_newton); block PGS behind opt_solver = 0 and for systems wider than 64 rows; noslip post-pass).
  *
  * Third-party algorithm: MuJoCo (C engine) via dm_control; the reference requires dm_control WITHOUT a version pin
  * (pyproject.toml:10), mujoco is a transitive unpinned dependency.  Restated here: the published MuJoCo 3.x forward /
- * constraint / PGS / collision pipeline ("Computation" chapter of the MuJoCo documentation).
+ * constraint / Newton / PGS / noslip / collision pipeline ("Computation" chapter of the MuJoCo documentation).
  *
  * PARITY STATUS: "parity unpinned".  MuJoCo is not importable in the build container and the
- * reference pins no trajectory; the oracle is pinned against the
- * reference's model-constant tests (tests/test_flybare.py) and physical invariants only.
+ * reference pins no trajectory.  What pins the restatement instead: the reference's model-constant
+ * tests (tests/test_flybare.py), reference-generated vectors for everything the reference implements in numpy
+ * (tests/golden/reference_functions.npz), ~30 per-stage closed-form / independent-solver checks (tests/test_oracle_closed_form*.py,
+ * test_collision_geometry.py) and -- round 4 -- a whole-step comparison with an independent dense numpy integrator that shares
+ * no routine with this directory (tests/independent_step.py, test_independent_whole_step.py: 10 substeps from 20 rollout states at 1e-7).
  */
 #ifndef FBO_H
 #define FBO_H
