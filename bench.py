@@ -118,6 +118,9 @@ def main():
     ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary two-half-batches-on-two-streams measurement')
     ap.add_argument('--no-secondary-configs', action='store_true', help='skip the flight_imitation (configs[3]) and DMPO (configs[2]) legs')
     ap.add_argument('--no-parity-sample', action='store_true', help='skip the post-run replay of sampled environments on the CPU oracle')
+    ap.add_argument('--no-flight-leg', action='store_true', help='skip the flight_imitation leg (configs[3]) only')
+    ap.add_argument('--dmpo-envs', type=int, default=4096, help='environments per GPU of the DMPO leg (configs[2] on one rank, configs[4] on several)')
+    ap.add_argument('--dmpo-iters', type=int, default=12); ap.add_argument('--dmpo-warmup', type=int, default=4); ap.add_argument('--dmpo-min-replay', type=int, default=8192)
     ap.add_argument('--rccl-dry-run', action='store_true', help='with --gpus N > 1: use RCCL when N devices are visible; otherwise run the N ranks on the '
                     'one visible device over gloo (same code path up to the backend) and say `rccl: unexercised` in the JSON')
     args = ap.parse_args()
@@ -308,7 +311,8 @@ def main():
         """BASELINE configs[2]: DMPO training, 4096 environments on this GPU, the reference's rate limiter (15 samples per insert =
         240 learner steps per control step).  Own process (it owns the torch RNG and the HIP graphs); FP32 physics as in training."""
         import subprocess
-        cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', '4096', '--iters', '12', '--warmup', '4', '--min-replay', '8192', '--precision', '32']
+        cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', str(args.dmpo_envs), '--iters', str(args.dmpo_iters), '--warmup', str(args.dmpo_warmup),
+               '--min-replay', str(args.dmpo_min_replay), '--precision', '32']
         t0 = time.perf_counter()
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
         try:
@@ -323,6 +327,23 @@ def main():
                 'learner_steps_per_env_step': o['learner_steps_per_env_step'], 'batch_size': o['batch_size'], 'samples_per_insert': o['samples_per_insert'],
                 'dtype': o['dtype'], 'reward': o['reward'], 'wall_s_incl_startup': time.perf_counter() - t0,
                 'note': 'one GPU, physics and learner on the same device; 12 timed control steps after 4 warm-up steps'}
+
+    def run_dmpo_leg_ranks():
+        """BASELINE configs[4]: the same DMPO loop on EVERY rank of this job -- per-rank environment shard and replay, one flat gradient
+        all-reduce per learner step over the job's process group (RCCL under the driver), hidden behind the next step's target-network
+        forwards (dmpo/learner.py: _step_overlapped).  In-process: the ranks and their process group are this benchmark's own."""
+        from flybody_amd.dmpo import DMPOConfig
+        from flybody_amd.train_dmpo import Trainer, measure
+        t0 = time.perf_counter()
+        tr = Trainer(n_env=args.dmpo_envs, precision=32, config=DMPOConfig(min_replay_size=args.dmpo_min_replay, samples_per_insert=15.0),
+                     terminal_com_dist=float('inf'))
+        res = measure(tr, args.dmpo_warmup, args.dmpo_iters)
+        res.update({'dtype': 'f32 physics / f32 learner', 'reward': 'inference mode (== 1): synthetic reference, throughput run',
+                    'wall_s_incl_startup': time.perf_counter() - t0,
+                    'note': '%d ranks x %d environments, physics and learner on the same device; %d timed control steps after %d warm-up steps'
+                            % (world, args.dmpo_envs, args.dmpo_iters, args.dmpo_warmup)})
+        del tr
+        return res
 
     stream_pool = []
 
@@ -380,9 +401,12 @@ def main():
         f32 = run_leg(32)
     flight = dmpo = None
     if not args.no_secondary_configs:
-        flight = {f'f{p}': run_flight_leg(p, max(10, args.steps), max(5, args.warmup)) for p in ((64, 32) if args.precision == 64 else (32,))}
-        if rank == 0 and world == 1:
+        if not args.no_flight_leg:
+            flight = {f'f{p}': run_flight_leg(p, max(10, args.steps), max(5, args.warmup)) for p in ((64, 32) if args.precision == 64 else (32,))}
+        if world == 1:
             dmpo = run_dmpo_leg()
+        else:
+            dmpo = run_dmpo_leg_ranks()                 # every rank takes part (configs[4]); rank 0 reports
     parity = None
     if rank == 0 and args.precision == 64 and not args.no_parity_sample:
         parity = parity_sample(extras)
@@ -432,7 +456,7 @@ def main():
             'parity_sample': parity,
             'warn': {'envs_with_flag_since_reset': extras.get('warn'), 'note': 'FB_WARN_EVER population over the batch: contact cap (64), constraint-row cap (192), '
                      'solver at opt.iterations, MPR at its iteration limit -- MuJoCo reports the first two as nconmax / njmax warnings (fruitfly.xml:6)'},
-            'rccl': ('exercised: init_process_group(nccl) + all_reduce(MAX) + barrier over %d ranks' % world) if (world > 1 and backend == 'nccl') else
+            'rccl': ('exercised: init_process_group(nccl) + all_reduce(MAX) + barrier over %d ranks%s' % (world, '; dmpo_mode: one flat gradient all-reduce per learner step' if dmpo is not None else '')) if (world > 1 and backend == 'nccl') else
                     ('unexercised (gloo substitute)' if world > 1 else 'unexercised (single rank: no collective on the data path)'),
             'parity': 'FP64 kernel vs in-repo FP64 C oracle (1e-6 over 100 control steps, tests/test_gpu_parity.py); '
                       'parity vs CPU MuJoCo is UNPINNED (no MuJoCo here; tools/dump_mujoco_golden.py + tests/test_mujoco_golden.py)',
@@ -456,7 +480,10 @@ def main():
         if flight is not None:
             out['flight_mode'] = {'config': 'configs[3]: flight_imitation, 8192 envs per GPU, U(-1,1)^12 actions, WBPG + ellipsoid wing fluid forces', **flight}
         if dmpo is not None:
-            out['dmpo_mode'] = {'config': 'configs[2]: walk_imitation DMPO training, 4096 envs, on-GPU rollout + learner + replay, SPI 15', **dmpo}
+            cfg_name = ('configs[2]: walk_imitation DMPO training, %d envs, on-GPU rollout + learner + replay, SPI 15' % args.dmpo_envs) if world == 1 else \
+                       ('configs[4]: walk_imitation DMPO, %d envs sharded across %d GPUs (%d per GPU), gradient all-reduce over %s, SPI 15'
+                        % (args.dmpo_envs*world, world, args.dmpo_envs, 'RCCL / xGMI' if backend == 'nccl' else 'gloo (one-GPU functional run)'))
+            out['dmpo_mode'] = {'config': cfg_name, **dmpo}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -990,7 +990,13 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane, !newton); if (!newton) niter = it2; }
   }
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
-  if (lane == 0) { w.istate()[IS_NITER] = niter; if (niter >= M.iterations) { w.istate()[IS_WARN] |= WARN_SOLVER_MAXITER; w.istate()[IS_WARN_EVER] |= WARN_SOLVER_MAXITER; } }
+  if (lane == 0) {
+    w.istate()[IS_NITER] = niter;
+    // the model asks for Newton and the system is wider than one row per lane: block PGS ran instead (the one algorithmic deviation
+    // from the reference solver; MuJoCo runs Newton at every size) -- observable per environment, like the caps
+    int wbits = (niter >= M.iterations ? WARN_SOLVER_MAXITER : 0) | ((uniform_int(M.solver) == FB_SOLVER_NEWTON && !newton) ? WARN_SOLVER_FALLBACK : 0);
+    if (wbits) { w.istate()[IS_WARN] |= wbits; w.istate()[IS_WARN_EVER] |= wbits; }
+  }
   SYNC();
   if (nefc <= FB_WAVE) {
     // ---- qfrc_constraint = J^T f, one lane per dof: lane == row keeps (force, last dof of each chain) in registers and

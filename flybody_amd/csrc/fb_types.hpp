@@ -42,7 +42,7 @@ enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 
        IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_PRIO = 14, IS_WARN = 15, IS_WARN_EVER = 16, IS_N = 20 };
 // IS_WARN bits (include/flybody_engine.h FB_WARN_*): raised during a launch, cleared at the start of the next control step;
 // IS_WARN_EVER accumulates them since the last reset of the environment
-enum { WARN_CONTACT_CAP = 1, WARN_EFC_CAP = 2, WARN_SOLVER_MAXITER = 4, WARN_CCD_MAXITER = 8, WARN_SCHED_WAIT = 16 };
+enum { WARN_CONTACT_CAP = 1, WARN_EFC_CAP = 2, WARN_SOLVER_MAXITER = 4, WARN_CCD_MAXITER = 8, WARN_SCHED_WAIT = 16, WARN_SOLVER_FALLBACK = 32 };
 
 
 // Address spaces are part of the pointer types.  Pointers that come out of a struct in memory carry no provenance the

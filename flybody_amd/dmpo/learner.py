@@ -49,6 +49,12 @@ class DMPOLearner:
         self.critic_params = list(self.online.critic.parameters())
         self.dual_params = list(self.loss.parameters())
         self._graph_fb = None; self._graph_opt = None; self._static = None; self._sampler = None
+        # Pipelined step (round 4): the step is captured as graphs A (replay draw + target-network forwards: reads nothing the optimizer
+        # writes), B (online forwards + losses + backward + gradient gather) and OPT (clip + Adam), A and B twice with their own
+        # buffers, so that A of step t + 1 runs on a side stream WHILE B / the gradient all-reduce / OPT of step t run
+        self._sets = None; self._cur = 0; self._a_ready = False; self._comm_stream = None; self._pipe_stream = None
+        self.overlap_allreduce = os.environ.get('FB_ALLREDUCE_OVERLAP', '1') == '1'
+        self.pipeline = os.environ.get('FB_LEARNER_PIPELINE', '1') == '1'
         self.num_steps = 0
         # ONE flat parameter buffer and ONE flat gradient buffer: [policy | critic | duals]; every parameter (and its .grad) is
         # a view.  The gradient buffer is what the single all-reduce of a data-parallel step sends; the parameter buffer is what
@@ -119,7 +125,29 @@ class DMPOLearner:
                 for _ in range(3):
                     self._forward_backward(self._static); self._apply_gradients()
             torch.cuda.current_stream().wait_stream(s)
-            if capture:
+            if capture and self.fused and self.pipeline and (self.overlap_allreduce or not self._distributed()):
+                # split capture (A | B, two buffer sets | OPT), see _step_pipelined
+                self._sets = []
+                for _ in range(2 if sampler is not None else 1):
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga):
+                        batch_a = sampler() if sampler is not None else self._static
+                        tgt = self._phase_targets(batch_a)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        fused.zero_pool.begin_step(self.device)
+                        try:
+                            st = self._phase_online(batch_a, tgt)
+                        finally:
+                            fused.zero_pool.end_step()
+                    self._sets.append((ga, gb, st, batch_a, tgt))
+                self._graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_opt):
+                    self._apply_gradients()
+                self._comm_stream = torch.cuda.Stream(device=self.device); self._pipe_stream = torch.cuda.Stream(device=self.device)
+                self._ev_b = torch.cuda.Event(); self._ev_a = torch.cuda.Event(); self._ev_main = torch.cuda.Event()
+                self._a_ready = False; self._cur = 0
+            elif capture:
                 self._graph_fb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_fb):
                     # with a sampler the replay draw (uniform indices from the device-side fill level + five gathers) is part
@@ -148,8 +176,12 @@ class DMPOLearner:
     def _apply_gradients(self):
         self.opt.step()              # global-norm clipping per group (policy, critic) + Adam for everything
 
-    def step(self, batch=None) -> Dict[str, torch.Tensor]:
-        """One update.  `batch` may be omitted when the graphs were captured with a sampler."""
+    def step(self, batch=None, prefetch: bool = True) -> Dict[str, torch.Tensor]:
+        """One update.  `batch` may be omitted when the graphs were captured with a sampler.  prefetch = False: the caller is about
+        to change what the next step's replay draw sees (the trainer appends to the replay between bursts of updates), so the
+        overlapped data-parallel step must not draw the next batch ahead."""
+        if self._sets is not None:
+            return self._step_pipelined(batch, prefetch)
         self._sync_targets()
         self.num_steps += 1
         if self._graph_fb is not None:
@@ -161,6 +193,59 @@ class DMPOLearner:
         stats = self._forward_backward(batch)
         self._allreduce()
         self._apply_gradients()
+        return stats
+
+    def _will_sync_targets(self, step_index: int) -> bool:
+        return step_index % self.cfg.target_policy_update_period == 0 or step_index % self.cfg.target_critic_update_period == 0
+
+    def _step_pipelined(self, batch=None, prefetch: bool = True) -> Dict[str, torch.Tensor]:
+        """The step as a two-stage pipeline (single rank and data-parallel; reference step: flybody/agents/learning_dmpo.py:169-317,
+        topology of configs[4]: flybody/train_dmpo_ray.py:188-241):
+
+            A_t   (replay draw, target policy -> sampled actions -> target critic)   reads: replay, TARGET weights
+            B_t   (online forwards, losses, backward, gradient gather)                reads: A_t's outputs, ONLINE weights; writes flat_grad
+            all-reduce_t (flat_grad; several ranks only)                              on the communication stream
+            OPT_t (clip + Adam)                                                       writes ONLINE weights
+
+        A_{t+1} touches nothing B_t / OPT_t write (the targets change every 101 / 107 steps: before such a step A waits for OPT) and
+        has its own buffers (two sets of A / B graphs), so it is replayed on a side stream while B_t, the collective and OPT_t run:
+        the M = 256 kernels of B leave most of the GPU idle, and the all-reduce is off the critical path.  Same kernels, same inputs,
+        same random numbers (only A draws any, and the A graphs are replayed in step order): bit-identical to the serial order."""
+        main = torch.cuda.current_stream(self.device)
+        if self._sampler is None:
+            for dst, src in zip(self._static, batch):
+                dst.copy_(src)
+            self._a_ready = False                       # (an externally supplied batch cannot be processed ahead)
+        self._sync_targets()
+        self.num_steps += 1
+        k = self._cur
+        ga, gb, stats = self._sets[k][:3]
+        if self._a_ready:
+            main.wait_event(self._ev_a)                 # A_t ran on the side stream during step t - 1
+        else:
+            ga.replay()
+        # A of the NEXT step on the side stream -- unless that step starts with a target update (its A must see the copied weights),
+        # or the caller is about to append to the replay (prefetch = False), or batches are supplied from outside
+        nxt = prefetch and len(self._sets) == 2 and not self._will_sync_targets(self.num_steps)
+        if nxt:
+            self._ev_main.record(main)                  # B_{t-1}, the last reader of the other buffer set, is behind this point
+            with torch.cuda.stream(self._pipe_stream):
+                self._pipe_stream.wait_event(self._ev_main)
+                self._sets[1 - k][0].replay()
+                self._ev_a.record(self._pipe_stream)
+        gb.replay()
+        if self._distributed():
+            self._ev_b.record(main)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(self._ev_b)
+                work = dist.all_reduce(self.flat_grad, async_op=True)
+            work.wait()                                  # compute stream <- collective (NCCL: stream dependency; gloo: host wait)
+            main.wait_stream(self._comm_stream)
+            self.flat_grad.div_(dist.get_world_size())
+        self._graph_opt.replay()
+        self._a_ready = nxt
+        if nxt:
+            self._cur = 1 - k
         return stats
 
     def _forward_backward(self, batch) -> Dict[str, torch.Tensor]:
@@ -193,10 +278,28 @@ class DMPOLearner:
     def _forward_backward_fused(self, batch) -> Dict[str, torch.Tensor]:
         """The GPU step.  Everything that is not a GEMM is a hand-written kernel (dmpo/fused.py), and the two loss kernels return
         the loss gradients wrt the network OUTPUTS directly (d logits, d mean, d stddev, d duals, d logits-bias): autograd only
-        runs the networks' own backward, seeded with those -- no loss graph, no unit-cotangent multiplies, no per-tensor fills."""
+        runs the networks' own backward, seeded with those -- no loss graph, no unit-cotangent multiplies, no per-tensor fills.
+        Two phases (captured as one graph on a single rank, as two when the gradient all-reduce is overlapped: _step_overlapped)."""
+        return self._phase_online(batch, None)
+
+    def _phase_targets(self, batch):
+        """Phase A: target policy -> N sampled actions -> target critic.  Reads the batch and the TARGET networks only."""
         cfg = self.cfg
         o_tm1, a_tm1, r_t, d_t, o_t = batch
         N, B = cfg.num_samples, o_t.shape[0]
+        tc = self.target.critic
+        with torch.no_grad():
+            t_mean, t_std = self.target.policy(o_t)
+            noise = torch.randn(N, B, t_mean.shape[-1], device=self.device)
+            sampled, clipped = fused.sample_actions(t_mean, t_std, noise)
+            q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True)       # [N, B, atoms], logits bias not added yet
+        return t_mean, t_std, sampled, q_t_raw
+
+    def _phase_online(self, batch, tgt) -> Dict[str, torch.Tensor]:
+        """Phase B: online forwards, losses, backward, gradient gather.  tgt = phase A's outputs (None: computed here, overlapped
+        with the online forwards on side streams while a graph is being captured)."""
+        cfg = self.cfg
+        o_tm1, a_tm1, r_t, d_t, o_t = batch
         oc, tc = self.online.critic, self.target.critic
         # Three independent forward chains -- target policy -> sampled actions -> target critic (the long one), online policy,
         # online critic -- run on three HIP streams: the M = 256 layers occupy 32-64 of the 256 CUs each, so the chains overlap
@@ -212,11 +315,7 @@ class DMPOLearner:
             o_mean, o_std = self.online.policy(o_t)
         with torch.cuda.stream(s_crt):
             q_tm1_raw = oc.forward_raw(o_tm1, a_tm1)
-        with torch.no_grad():
-            t_mean, t_std = self.target.policy(o_t)
-            noise = torch.randn(N, B, t_mean.shape[-1], device=self.device)
-            sampled, clipped = fused.sample_actions(t_mean, t_std, noise)
-            q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True)       # [N, B, atoms], logits bias not added yet
+        t_mean, t_std, sampled, q_t_raw = tgt if tgt is not None else self._phase_targets(batch)
         main.wait_stream(s_crt)
         critic_loss, sampled_q, d_logits, d_logits_bias = fused.td_loss_grad(q_tm1_raw, oc.logits.bias, q_t_raw, tc.logits.bias, oc.values,
                                                                              r_t, d_t, cfg.discount)

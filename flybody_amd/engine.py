@@ -32,7 +32,7 @@ FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA
               STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26, GEOM_XPOS=27, GEOM_XMAT=28, CVEL=29, STEP_TICKS=30, LAUNCH_ORDER=31, WARN=32, WARN_EVER=33)
 _INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF', 'STEP_TICKS', 'LAUNCH_ORDER', 'WARN', 'WARN_EVER'}
 # bits of WARN / WARN_EVER (include/flybody_engine.h): the caps MuJoCo reports as nconmax / njmax warnings, and iteration limits
-WARN_BITS = dict(CONTACT_CAP=1, EFC_CAP=2, SOLVER_MAXITER=4, CCD_MAXITER=8, SCHED_WAIT=16)
+WARN_BITS = dict(CONTACT_CAP=1, EFC_CAP=2, SOLVER_MAXITER=4, CCD_MAXITER=8, SCHED_WAIT=16, SOLVER_FALLBACK=32)
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
 MAXCON, MAXEFC, NSENSOR = 64, 192, 33
 

@@ -161,11 +161,12 @@ class Trainer:
             else:
                 self._gate_checked = True
         if allowed > 0:
-            if self.use_graphs and self.learner._graph_fb is None:
+            if self.use_graphs and self.learner._graph_fb is None and self.learner._sets is None:
                 self.learner.enable_graphs(self.replay.sample(B), sampler=lambda: self.replay.sample(B))
             sampled_in_graph = self.learner._sampler is not None
-            for _ in range(allowed):
-                stats = self.learner.step(None if sampled_in_graph else self.replay.sample(B))
+            for k in range(allowed):
+                # (the last update of the burst must not draw the next batch ahead: the replay is appended to before the next burst)
+                stats = self.learner.step(None if sampled_in_graph else self.replay.sample(B), prefetch=k + 1 < allowed)
             self.learner_steps += allowed; self.limiter.sample(allowed * B)
             now = time.time()
             self.counter.increment(learner_steps=allowed, learner_walltime=(now - self._t_learn) if self._t_learn else 0.0)
@@ -187,6 +188,37 @@ class Trainer:
                              env_id_base=10_000_000 + self.rank*n_env, **self._eval_kw) if not hasattr(self, '_eval_env') else self._eval_env
         self._eval_env = env
         return evaluate(env, lambda o: self.learner.act(o, deterministic=True), self.a_min, self.a_scale, episodes_per_env)
+
+
+def measure(tr: 'Trainer', warmup: int, iters: int):
+    """`warmup` untimed + `iters` timed control steps of the trainer (barrier + synchronize on both sides, slowest rank): the
+    throughput fields of BASELINE configs[2] / [4].  Used by main() and by bench.py's multi-rank DMPO leg."""
+    for _ in range(warmup):
+        tr.iterate()
+    torch.cuda.synchronize()
+    if tr.world > 1:
+        dist.barrier()
+    e0, l0 = tr.env_steps, tr.learner_steps
+    t0 = time.perf_counter(); stats = None
+    for _ in range(iters):
+        stats = tr.iterate() or stats
+    torch.cuda.synchronize()
+    if tr.world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if tr.world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=tr.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    lr = tr.learner
+    return {'n_gpus': tr.world, 'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
+            'envs_per_gpu': tr.env.n_env, 'learner_steps_per_env_step': (tr.learner_steps - l0) / max(1, iters), 'batch_size': tr.cfg.batch_size,
+            'samples_per_insert': {'configured': tr.cfg.samples_per_insert if tr.lsteps_per is None else None, 'achieved': tr.limiter.achieved_samples_per_insert,
+                                   'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
+            'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size,
+            'gradient_allreduce': ('none (single rank)' if tr.world == 1 else
+                                   ('one flat buffer of %d floats per learner step over %s, %s' % (lr.flat_grad.numel(), dist.get_backend(),
+                                    'overlapped with the next step\'s target-network forwards (side stream)' if lr._sets is not None else 'serial'))),
+            'stats': {k: float(v) for k, v in (stats or {}).items() if k in ('critic_loss', 'policy_loss', 'dual_temperature', 'kl_q_rel')}}
 
 
 def main():
@@ -213,30 +245,13 @@ def main():
     tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
                  config=DMPOConfig(min_replay_size=a.min_replay, samples_per_insert=spi), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
                  ref_path=a.ref_path, directory=a.directory, checkpoint_to_load=a.checkpoint_to_load, time_delta_minutes=a.checkpoint_minutes)
-    for _ in range(a.warmup):
-        tr.iterate()
-    torch.cuda.synchronize()
-    if tr.world > 1:
-        dist.barrier()
-    e0, l0 = tr.env_steps, tr.learner_steps
-    t0 = time.perf_counter(); stats = None
-    for _ in range(a.iters):
-        stats = tr.iterate() or stats
-    torch.cuda.synchronize()
-    if tr.world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    res = measure(tr, a.warmup, a.iters)
     if tr.rank == 0 and tr.checkpointer is not None:
         tr.checkpointer.save(force=True); tr.snapshotter.save(force=True, actor_steps=int(tr.counter.counts.get('actor_steps', 0))); tr.log()
     if tr.rank == 0:
-        out = {'metric': 'env steps/sec + learner steps/sec, walk_imitation DMPO on-GPU training', 'n_gpus': tr.world,
-               'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
-               'envs_per_gpu': a.envs, 'learner_steps_per_env_step': (tr.learner_steps - l0) / max(1, a.iters), 'batch_size': tr.cfg.batch_size,
-               'samples_per_insert': {'configured': spi if a.learner_steps is None else None, 'achieved': tr.limiter.achieved_samples_per_insert,
-                                      'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
-               'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'dtype': f'f{a.precision} physics / f32 learner',
-               'reward': 'inference mode (== 1): synthetic reference, throughput run' if a.ref_path is None else f'training mode (DeepMimic factors) on {a.ref_path}',
-               'stats': {k: float(v) for k, v in (stats or {}).items() if k in ('critic_loss', 'policy_loss', 'dual_temperature', 'kl_q_rel')}}
+        out = {'metric': 'env steps/sec + learner steps/sec, walk_imitation DMPO on-GPU training', **res,
+               'dtype': f'f{a.precision} physics / f32 learner',
+               'reward': 'inference mode (== 1): synthetic reference, throughput run' if a.ref_path is None else f'training mode (DeepMimic factors) on {a.ref_path}'}
         print(json.dumps(out))
     if tr.world > 1:
         dist.destroy_process_group()

@@ -45,6 +45,7 @@ typedef struct {
   int nobsjnt, napp, nforce, ntouch, nsubstep;
   double timestep, control_timestep, gravity[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia;
   int noslip_iterations, iterations, cone_elliptic, solver;
+  int newton_maxrows;        /* > 0: systems with more rows fall back to PGS (what the HIP kernel does beyond one row per lane: 64); 0 = Newton at every size, like MuJoCo */
   const int *body_parent, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_rootid;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;

@@ -381,7 +381,10 @@ static void solve_noslip(fbo_data* d) {
  * 1/2 r'Ar on the attainable improvement, scaled like MuJoCo's `improvement` (1/(meaninertia nv)), drops below opt.tolerance. */
 #define NEWTON_LS_TOL 0.01
 #define NEWTON_LS_MAX 20
-#define NEWTON_MAXROWS 64      /* the kernel's Newton keeps one row per lane of a wavefront; larger systems fall back to PGS there, hence here too */
+/* Newton at every system size (MuJoCo).  The HIP kernel keeps one row per lane of a wavefront and falls back to PGS beyond 64 rows
+ * (flagged there: FB_WARN_SOLVER_FALLBACK); a model blob with opt_newton_maxrows = 64 makes this oracle do the same, for the tests that
+ * check the kernel's fallback path itself. */
+#define NEWTON_OK(m, n) ((m)->solver == FBO_SOLVER_NEWTON && ((m)->newton_maxrows <= 0 || (n) <= (m)->newton_maxrows))
 
 typedef struct { double f, cost; int base; double frow[3], fcol[3]; } nrow;
 
@@ -536,9 +539,9 @@ void fbo_fwd_constraint(fbo_data* d) {
       jar[i] = s - d->efc_aref[i];
     }
     constraint_update(d, jar);
-    if (!(m->solver == FBO_SOLVER_NEWTON && n <= NEWTON_MAXROWS) && dual_cost(d, d->efc_force) > 0) memset(d->efc_force, 0, sizeof(double)*n);
+    if (!NEWTON_OK(m, n) && dual_cost(d, d->efc_force) > 0) memset(d->efc_force, 0, sizeof(double)*n);
   }
-  if (m->solver == FBO_SOLVER_NEWTON && n <= NEWTON_MAXROWS) solve_newton(d);
+  if (NEWTON_OK(m, n)) solve_newton(d);
   else solve_pgs(d);
   if (m->noslip_iterations > 0) solve_noslip(d);
   /* qfrc_constraint = J^T f ; qacc = qacc_smooth + M^-1 qfrc_constraint */

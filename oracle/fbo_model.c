@@ -93,6 +93,11 @@ int fbo_model_load(const void* blob_in, size_t n, fbo_model** out) {
   /* opt_solver (optional array, mjtSolver numbering): absent = MuJoCo's default, Newton -- what fruitfly.xml:4 selects */
   { const blob_entry* e = find(b, "opt_solver"); m->solver = FBO_SOLVER_NEWTON;
     if (e && e->dtype == 1 && e->nbytes >= 4 && ((const int*)((const char*)b + e->offset))[0] == FBO_SOLVER_PGS) m->solver = FBO_SOLVER_PGS; }
+  /* opt_newton_maxrows (optional, test switch): mirror the kernel's fallback to PGS for systems wider than this many rows.  Absent = 0 =
+   * Newton at every size, which is what MuJoCo does (with the cap copied into the oracle, kernel-vs-oracle parity could not
+   * see the kernel's one algorithmic deviation from the reference solver). */
+  { const blob_entry* e = find(b, "opt_newton_maxrows"); m->newton_maxrows = 0;
+    if (e && e->dtype == 1 && e->nbytes >= 4) m->newton_maxrows = ((const int*)((const char*)b + e->offset))[0]; }
   m->nsubstep = (int)floor(m->control_timestep / m->timestep + 0.5);
   m->na = 0;
   for (int i = 0; i < m->nu; i++) if (m->actuator_actadr[i] >= 0) m->na++;

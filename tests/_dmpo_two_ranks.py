@@ -30,5 +30,8 @@ obs = tr.replay.action[:1024].sum().reshape(1).clone(); o2 = [torch.empty_like(o
 dist.all_gather(o2, obs)
 assert float(o2[0]) != float(o2[1])
 if dist.get_rank() == 0:
-    print('TWO_RANKS_OK graphs=%s steps=%d' % (graphs, tr.learner.num_steps))
+    if os.environ.get('FB_TEST_PARAMS_OUT'):
+        import numpy as np
+        np.save(os.environ['FB_TEST_PARAMS_OUT'], mine.cpu().numpy())
+    print('TWO_RANKS_OK graphs=%s steps=%d pipelined=%s' % (graphs, tr.learner.num_steps, tr.learner._sets is not None))
 dist.destroy_process_group()

@@ -242,7 +242,7 @@ def test_flight_dataset_on_gpu(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('graphs', ['1', '0'])
-def test_dmpo_two_ranks_stay_identical(graphs):
+def test_dmpo_two_ranks_stay_identical(graphs, tmp_path):
     """BASELINE configs[4] plumbing on ONE GPU: two ranks (gloo, both on cuda:0), per-rank environment shard + replay, one flat
     gradient all-reduce per learner step between the forward/backward graph and the optimizer graph; replicas stay identical."""
     import os, socket, subprocess, sys
@@ -254,6 +254,28 @@ def test_dmpo_two_ranks_stay_identical(graphs):
            '--master-port', str(port), os.path.join(ROOT, 'tests', '_dmpo_two_ranks.py')]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'TWO_RANKS_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    if graphs == '1':
+        # the PIPELINED step ran (target-network forwards of step t + 1 on a side stream against B / all-reduce / OPT of step t,
+        # learner.py _step_pipelined) -- and the serial order (FB_LEARNER_PIPELINE=0: one forward/backward graph, all-reduce, optimizer
+        # graph) ends with the same parameters.  Not bit for bit across RUNS: the backward kernels accumulate column sums with float
+        # atomics, whose order varies from run to run (measured between two runs of one mode: ~1e-8); a pipeline bug -- a stale batch,
+        # a half-written buffer -- moves parameters by the learning-rate scale (1e-4 per update, 20 updates).
+        import numpy as np
+        assert 'pipelined=True' in r.stdout, r.stdout[-500:]
+        outs = []
+        for mode, extra in (('pipe', {}), ('pipe2', {}), ('serial', {'FB_LEARNER_PIPELINE': '0'})):
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+            cmd[cmd.index('--master-port') + 1] = str(port)
+            path = os.path.join(str(tmp_path), mode + '.npy')
+            r2 = subprocess.run(cmd, cwd=ROOT, env=dict(env, FB_TEST_PARAMS_OUT=path, **extra), capture_output=True, text=True, timeout=900)
+            assert r2.returncode == 0 and ('pipelined=%s' % (mode != 'serial')) in r2.stdout, (r2.stdout[-1500:], r2.stderr[-3000:])
+            outs.append(np.load(path))
+        # (relative: the dual variables are O(100 ... 1000), one float32 ulp there is 6e-5)
+        rel = lambda x, y: float((np.abs(x - y)/np.maximum(np.abs(y), 1.0)).max())
+        noise, diff = rel(outs[0], outs[1]), rel(outs[0], outs[2])
+        print('two runs of the pipelined step differ by %.2e (relative), pipelined vs serial by %.2e' % (noise, diff))
+        assert noise < 2e-6 and diff < 2e-6, (noise, diff)
 
 
 @pytest.mark.gpu

@@ -451,20 +451,25 @@ def test_solver_paths_by_system_size_gpu(gpu_model, oracle_model, walk_arrays, p
     """Same as tests/test_kernel_emulation.py::test_solver_paths_by_system_size, on the GPU: Delassus matrix in LDS, small
     system from the global row, wide system (> 64 rows) -- all three against the oracle's constraint forces."""
     from flybody_amd import engine
+    from flybody_amd.model_blob import pack_model
+    from oracle import fbo
     from conftest import random_state
     cases = [(1, 0.14), (1, 0.135), (1, 0.13), (1, 0.125), (3, 0.12)]     # nefc 24, 36, 54, 66, 114
+    capped = fbo.OracleModel(pack_model(dict(walk_arrays, opt_newton_maxrows=np.array(64, np.int32))))     # (mirrors the kernel's fallback: see the host test)
     B = engine.Batch(gpu_model, len(cases), precision=precision)
     ods, Q, V = [], [], []
     for seed, z in cases:
         q, v = random_state(walk_arrays, np.random.default_rng(seed), z=z)
         if precision == 32:
             q = q.astype(np.float32).astype(float); v = v.astype(np.float32).astype(float)
-        od = _oracle(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+        od = _oracle(capped); od._keep = capped; od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
         ods.append(od); Q.append(q); V.append(v)
     B.set('QPOS', np.array(Q)); B.set('QVEL', np.array(V))
     B.forward()
     nefc = [int(od.scalar('nefc')) for od in ods]
     assert min(nefc) <= 29 and any(36 < n <= 64 for n in nefc) and max(nefc) > 64
+    fb = (B.get('WARN').ravel() & engine.WARN_BITS['SOLVER_FALLBACK']) != 0          # the PGS fallback beyond 64 rows is flagged
+    assert fb.tolist() == [n > 64 for n in nefc], (fb, nefc)
     if precision == 64:
         assert B.get('NEFC').ravel().tolist() == nefc
     for e, od in enumerate(ods):

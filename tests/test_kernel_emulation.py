@@ -213,20 +213,27 @@ def test_solver_paths_by_system_size(emu_model, oracle_model, walk_arrays, preci
     FP32), small system with the matrix in the global row (<= 64 rows: one register per lane), wide system (> 64 rows).
     States pressed into the floor to different depths hit all three; each must reproduce the oracle's forces."""
     from flybody_amd import engine
+    from flybody_amd.model_blob import pack_model
     from oracle import fbo
     cases = [(1, 0.14), (1, 0.135), (1, 0.13), (1, 0.125), (3, 0.12)]     # nefc 24, 36, 54, 66, 114
+    # the oracle follows MuJoCo (Newton at every size); for THIS test it mirrors the kernel's fallback (PGS beyond 64 rows), which is the
+    # code path under test.  The deviation of that fallback from Newton is bounded in tests/test_oracle.py::test_newton_row_cap_deviation.
+    capped = fbo.OracleModel(pack_model(dict(walk_arrays, opt_newton_maxrows=np.array(64, np.int32))))
     B = engine.Batch(emu_model, len(cases), precision=precision)
     ods, Q, V = [], [], []
     for seed, z in cases:
         q, v = random_state(walk_arrays, np.random.default_rng(seed), z=z)
         if precision == 32:
             q = q.astype(np.float32).astype(float); v = v.astype(np.float32).astype(float)
-        od = fbo.OracleData(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+        od = fbo.OracleData(capped); od._keep = capped; od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
         ods.append(od); Q.append(q); V.append(v)
     B.set('QPOS', np.array(Q)); B.set('QVEL', np.array(V))
     B.forward()
     nefc = [int(od.scalar('nefc')) for od in ods]
     assert min(nefc) <= 29 and any(36 < n <= 64 for n in nefc) and max(nefc) > 64
+    # beyond one row per lane the kernel runs block PGS although the model selects Newton, and says so (FB_WARN_SOLVER_FALLBACK)
+    fb = (B.get('WARN').ravel() & engine.WARN_BITS['SOLVER_FALLBACK']) != 0
+    assert fb.tolist() == [n > 64 for n in nefc], (fb, nefc)
     if precision == 64:
         assert B.get('NEFC').ravel().tolist() == nefc
     for e, od in enumerate(ods):
@@ -241,9 +248,11 @@ def test_maximum_system_size_is_capped_like_the_oracle(emu_model, oracle_model, 
     """Edge case: a fly pushed far into the floor produces more candidate contacts than the 64-contact / 192-row capacity.
     Kernel and oracle keep the same first 64 contacts (pair order) and agree on the solve at the cap."""
     from flybody_amd import engine
+    from flybody_amd.model_blob import pack_model
     from oracle import fbo
     q, v = random_state(walk_arrays, np.random.default_rng(1), z=0.05)
-    od = fbo.OracleData(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+    capped = fbo.OracleModel(pack_model(dict(walk_arrays, opt_newton_maxrows=np.array(64, np.int32))))      # (the kernel's PGS fallback beyond 64 rows)
+    od = fbo.OracleData(capped); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
     B = engine.Batch(emu_model, 1, precision=64); B.set('QPOS', q); B.set('QVEL', v); B.forward()
     assert int(od.scalar('ncon')) == 64 and int(od.scalar('nefc')) == 192
     assert int(B.get('NCON')[0, 0]) == 64 and int(B.get('NEFC')[0, 0]) == 192

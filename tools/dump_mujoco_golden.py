@@ -4,8 +4,13 @@ reference package `flybody` are installed (they are not installable in the build
 parity statement of this repository says "MuJoCo parity unpinned").
 
     pip install mujoco dm_control  &&  pip install -e <reference checkout>
-    python tools/dump_mujoco_golden.py [--out tests/golden] [--steps 100] [--flight]
+    python tools/dump_mujoco_golden.py [--out tests/golden] [--steps 100] [--flight] [--ball] [--timing] | --all
     python tools/dump_mujoco_golden.py --check [--out tests/golden]      # back in this repository: first-divergence report
+
+`--all` = every artefact north_star names in ONE off-box run: the walking rollout + constants (always), `--flight` (flight_imitation:
+wing-beat pattern generator state + ellipsoid fluid forces of the wings, fly_envs.py:30-97), `--ball` (walk_on_ball, fly_envs.py:158-191)
+and `--timing` (CPU MuJoCo throughput of BASELINE.md section 3 case A on the recording machine: one core with and without the Python
+hooks, then one environment per core on all cores).
 
 It drives exactly the workload the reference's env test drives (tests/test_walking_env.py:60-72: `walk_imitation(
 terminal_com_dist=inf)`, the default inference trajectory, 100 x `env.step(U(-0.5, 0.5)^59)`), with `np.random.seed(0)`,
@@ -21,7 +26,12 @@ and writes
                                               dof/body/tendon_invweight0, geom_fluid (virtual mass / inertia of the wing
                                               ellipsoids), options, actuator parameters, geom sizes / rbound, contact-pair
                                               candidates after filtering
-    ... + `mujoco_flight_rollout.npz` with --flight (flight_imitation defaults, U(-1, 1)^12 actions)
+    ... + `mujoco_flight_rollout.npz` (+ `mujoco_flight_model_constants.npz`) with --flight: flight_imitation defaults, U(-1, 1)^12
+        actions; additionally per control step the wing-beat pattern generator's state (step index, frequency index, filtered
+        frequency), `qfrc_passive` / `qfrc_fluid` (the ellipsoid wing forces live there) and the wing joints' qpos
+    ... + `mujoco_ball_rollout.npz` (+ constants) with --ball: walk_on_ball defaults, U(-0.5, 0.5) actions
+    ... + `mujoco_cpu_timing.json` with --timing: env-steps/s of `env.step` (1 core), of the raw `mj_step` loop (1 core, engine
+        only) and of one environment per core on all cores (multiprocessing), with the CPU model and core count
 
 plus `mujoco.__version__` / `dm_control.__version__` in both files (behaviour differs across MuJoCo 3.x: native CCD,
 mesh-inertia defaults, implicit damping).  `tests/test_mujoco_golden.py` consumes the files: it replays the recorded actions
@@ -39,7 +49,18 @@ def _flat_obs(timestep):
     return np.concatenate([np.asarray(v, np.float64).ravel() for v in timestep.observation.values()])
 
 
-def record_env(env, n_steps, nact, lo, hi, substeps_of_first=True):
+def _wbpg_state(env):
+    """(step, frequency index, filtered control frequency) of the task's wing-beat pattern generator (pattern_generators.py:131-203);
+    attribute names differ between reference versions, so this is best effort."""
+    for name in ('_wbpg', 'wbpg', '_wing_beat_pattern_generator'):
+        g = getattr(env.task, name, None)
+        if g is not None:
+            get = lambda *ks: next((float(getattr(g, k)) for k in ks if hasattr(g, k)), np.nan)
+            return [get('step', '_step'), get('freq_idx', '_freq_idx', 'ctrl_freq_idx'), get('ctrl_freq', '_ctrl_freq', 'ctrl_filter_freq')]
+    return [np.nan, np.nan, np.nan]
+
+
+def record_env(env, n_steps, nact, lo, hi, substeps_of_first=True, extras=False):
     import mujoco
     physics = env.physics
     m, d = physics.model.ptr, physics.data.ptr
@@ -74,6 +95,11 @@ def record_env(env, n_steps, nact, lo, hi, substeps_of_first=True):
         rec['niter'].append(int(np.sum(d.solver_niter))); rec['obs'].append(_flat_obs(ts))
         rec['reward'].append(0.0 if ts.reward is None else float(ts.reward)); rec['discount'].append(1.0 if ts.discount is None else float(ts.discount))
         rec['step_type'].append(int(ts.step_type)); rec['time'].append(d.time)
+        if extras:
+            rec.setdefault('wbpg_state', []).append(_wbpg_state(env))
+            rec.setdefault('qfrc_passive', []).append(d.qfrc_passive.copy())
+            if hasattr(d, 'qfrc_fluid'): rec.setdefault('qfrc_fluid', []).append(d.qfrc_fluid.copy())
+            rec.setdefault('qfrc_actuator', []).append(d.qfrc_actuator.copy())
         if k < 5:
             c = np.zeros((d.ncon, 16))
             for i in range(d.ncon):
@@ -111,6 +137,50 @@ def model_constants(physics):
     d = mujoco.MjData(m); mujoco.mj_forward(m, d)
     M = np.zeros((m.nv, m.nv)); mujoco.mj_fullM(m, M, d.qM); out['M0_full'] = M
     return out
+
+
+def _time_worker(n_steps):
+    import time
+    from flybody.fly_envs import walk_imitation
+    env = walk_imitation(terminal_com_dist=float('inf')); env.reset()
+    rng = np.random.default_rng(os.getpid())
+    for _ in range(50):
+        env.step(np.clip(rng.normal(size=59), -1, 1))
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        env.step(np.clip(rng.normal(size=59), -1, 1))
+    return n_steps/(time.perf_counter() - t0)
+
+
+def cpu_timing(n_steps=1000):
+    """BASELINE.md section 3 case A: CPU MuJoCo on THIS machine -- `env.step` in-process on one core (Python hooks included), the raw
+    `mj_step` loop on the same model (engine only), and one environment per core on all cores."""
+    import multiprocessing as mp, platform, time
+    import mujoco
+    from flybody.fly_envs import walk_imitation
+    one = _time_worker(n_steps)
+    env = walk_imitation(terminal_com_dist=float('inf')); env.reset()
+    m, d = env.physics.model.ptr, env.physics.data.ptr
+    nsub = int(round(env.control_timestep()/env.physics.timestep()))
+    rng = np.random.default_rng(0)
+    for _ in range(200): mujoco.mj_step(m, d)
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        d.ctrl[:] = np.clip(rng.normal(size=m.nu), -1, 1)
+        for _ in range(nsub): mujoco.mj_step(m, d)
+    raw = n_steps/(time.perf_counter() - t0)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    with mp.get_context('spawn').Pool(ncpu) as pool:
+        rates = pool.map(_time_worker, [n_steps]*ncpu)
+    cpu = platform.processor() or ''
+    try:
+        cpu = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except Exception:                                                              # noqa: BLE001
+        pass
+    return {'unit': 'env steps/sec (one env step = %d x mj_step)' % nsub, 'env_step_one_core': one, 'raw_mj_step_one_core': raw,
+            'all_cores': float(np.sum(rates)), 'cores': ncpu, 'per_core_in_pool': float(np.mean(rates)), 'cpu': cpu,
+            'workload': 'walk_imitation(terminal_com_dist=inf), N(0,1) actions clipped to [-1, 1], %d control steps per process after 50 warm-up steps' % n_steps,
+            'mujoco_version': mujoco.__version__}
 
 
 def _rel(a, b):
@@ -228,10 +298,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden'))
     ap.add_argument('--steps', type=int, default=100); ap.add_argument('--flight', action='store_true')
+    ap.add_argument('--ball', action='store_true', help='also record walk_on_ball (fly_envs.py:158-191)')
+    ap.add_argument('--timing', action='store_true', help='also time CPU MuJoCo on this machine (BASELINE.md section 3 case A)')
+    ap.add_argument('--all', action='store_true', help='= --flight --ball --timing')
     ap.add_argument('--check', action='store_true', help='no MuJoCo needed: compare the golden files in --out with the in-repo oracle, stage by stage')
     a = ap.parse_args()
     if a.check:
         sys.exit(1 if check(a.out) else 0)
+    if a.all:
+        a.flight = a.ball = a.timing = True
     try:
         import mujoco, dm_control
         from flybody.fly_envs import walk_imitation, flight_imitation
@@ -248,10 +323,26 @@ def main():
     if a.flight:
         np.random.seed(0)
         env = flight_imitation()
-        out = record_env(env, a.steps, 12, -1.0, 1.0, substeps_of_first=False)
+        out = record_env(env, a.steps, 12, -1.0, 1.0, substeps_of_first=False, extras=True)
+        out['wing_qpos_adr'] = np.array([env.physics.model.ptr.jnt_qposadr[j] for j in range(env.physics.model.ptr.njnt)
+                                         if 'wing' in (env.physics.model.id2name(j, 'joint') or '')])
         np.savez_compressed(os.path.join(a.out, 'mujoco_flight_rollout.npz'), **out, **ver)
         np.savez_compressed(os.path.join(a.out, 'mujoco_flight_model_constants.npz'), **model_constants(env.physics), **ver)
-        print('wrote mujoco_flight_rollout.npz')
+        print('wrote mujoco_flight_rollout.npz, mujoco_flight_model_constants.npz')
+    if a.ball:
+        from flybody.fly_envs import walk_on_ball
+        np.random.seed(0)
+        env = walk_on_ball()
+        nact = int(env.action_spec().shape[0])
+        out = record_env(env, a.steps, nact, -0.5, 0.5, substeps_of_first=False, extras=True)
+        np.savez_compressed(os.path.join(a.out, 'mujoco_ball_rollout.npz'), **out, **ver)
+        np.savez_compressed(os.path.join(a.out, 'mujoco_ball_model_constants.npz'), **model_constants(env.physics), **ver)
+        print('wrote mujoco_ball_rollout.npz, mujoco_ball_model_constants.npz')
+    if a.timing:
+        import json
+        t = cpu_timing()
+        json.dump(t, open(os.path.join(a.out, 'mujoco_cpu_timing.json'), 'w'), indent=1)
+        print('wrote mujoco_cpu_timing.json:', t)
 
 
 if __name__ == '__main__':
