@@ -125,6 +125,25 @@ class _ZeroPool:
 zero_pool = _ZeroPool()
 
 
+class pool_scope:
+    """`with pool_scope(p):` the kernels' zero-initialised outputs are carved from pool `p` instead of the module's default pool.  The
+    learner captures its critic and policy branches into separate HIP graphs that are replayed CONCURRENTLY on two streams; each
+    branch then owns (and zeroes) its own pool."""
+
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __enter__(self):
+        global zero_pool
+        self.saved = zero_pool; zero_pool = self.pool
+        return self.pool
+
+    def __exit__(self, *exc):
+        global zero_pool
+        zero_pool = self.saved
+        return False
+
+
 # ------------------------------------------------------------------ categorical TD loss
 def td_loss_grad(q_tm1_raw, bias_tm1, q_t_raw, bias_t, values, reward, discount, gamma):
     """Loss AND gradient in one launch (GPU): returns (mean loss [scalar], sampled_q [N, B], d_logits [B, K], d_bias [K]).

@@ -55,6 +55,7 @@ class DMPOLearner:
         self._sets = None; self._cur = 0; self._a_ready = False; self._comm_stream = None; self._pipe_stream = None
         self.overlap_allreduce = os.environ.get('FB_ALLREDUCE_OVERLAP', '1') == '1'
         self.pipeline = os.environ.get('FB_LEARNER_PIPELINE', '1') == '1'
+        self._n_branch_streams = int(os.environ.get('FB_LEARNER_BRANCH_STREAMS', '1'))      # streams beside the compute stream for the critic / policy branches (measured: profiles/r4/learner_streams.txt)
         self.num_steps = 0
         # ONE flat parameter buffer and ONE flat gradient buffer: [policy | critic | duals]; every parameter (and its .grad) is
         # a view.  The gradient buffer is what the single all-reduce of a data-parallel step sends; the parameter buffer is what
@@ -126,26 +127,49 @@ class DMPOLearner:
                     self._forward_backward(self._static); self._apply_gradients()
             torch.cuda.current_stream().wait_stream(s)
             if capture and self.fused and self.pipeline and (self.overlap_allreduce or not self._distributed()):
-                # split capture (A | B, two buffer sets | OPT), see _step_pipelined
+                # split capture, see _step_pipelined: per buffer set the graphs A | C1, C2 (critic branch) | P1, P2 (policy branch) | G
                 self._sets = []
+                if not hasattr(self, '_pools'):
+                    self._pools = (fused._ZeroPool(), fused._ZeroPool())
+                    for pl in self._pools: pl.want = max(fused.zero_pool.want, 1 << 14)
+
+                def cap(fn, pool=None, resume=False):
+                    # pool: the branch's zero-initialised scratch (zeroed by the branch's FIRST graph of a step; `resume`: a later graph
+                    # of the same branch keeps carving from the same pass -- its predecessor's outputs live there and are still needed)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        if pool is None:
+                            out = fn()
+                        else:
+                            with fused.pool_scope(pool):
+                                if resume:
+                                    pool.active = True
+                                else:
+                                    pool.begin_step(self.device)
+                                try:
+                                    out = fn()
+                                finally:
+                                    pool.end_step()
+                    return g, out
                 for _ in range(2 if sampler is not None else 1):
-                    ga = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(ga):
-                        batch_a = sampler() if sampler is not None else self._static
-                        tgt = self._phase_targets(batch_a)
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb):
-                        fused.zero_pool.begin_step(self.device)
-                        try:
-                            st = self._phase_online(batch_a, tgt)
-                        finally:
-                            fused.zero_pool.end_step()
-                    self._sets.append((ga, gb, st, batch_a, tgt))
-                self._graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph_opt):
-                    self._apply_gradients()
-                self._comm_stream = torch.cuda.Stream(device=self.device); self._pipe_stream = torch.cuda.Stream(device=self.device)
+                    ga, (batch_a, tgt) = cap(lambda: (lambda bt: (bt, self._phase_targets(bt, with_q=True)))(sampler() if sampler is not None else self._static))
+                    gc, cr = cap(lambda: self._phase_critic(batch_a, tgt), self._pools[0])
+                    gp, pol = cap(lambda: self._phase_policy(batch_a, tgt), self._pools[1])
+                    if self._distributed():
+                        gg, stats = cap(lambda: self._phase_gather(cr, pol)); gopt = None
+                    else:                   # single rank: nothing happens between the gather and the optimizer -> one graph
+                        gg, stats = cap(lambda: (lambda st_: (self._apply_gradients(), st_)[1])(self._phase_gather(cr, pol))); gopt = False
+                    self._sets.append(dict(ga=ga, gc=gc, gp=gp, gg=gg, stats=stats, batch=batch_a, tgt=tgt, cr=cr, pol=pol))
+                self._graph_opt = None
+                if self._distributed():
+                    self._graph_opt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph_opt):
+                        self._apply_gradients()
+                own = self._streams_on_own_queues(3)       # [A's stream, policy branch, critic branch (if it leaves the compute stream)]
+                self._pipe_stream = own[0]; self._br_streams = (own[2], own[1])
+                self._comm_stream = torch.cuda.Stream(device=self.device)
                 self._ev_b = torch.cuda.Event(); self._ev_a = torch.cuda.Event(); self._ev_main = torch.cuda.Event()
+                self._ev_fork = torch.cuda.Event(); self._ev_c = torch.cuda.Event(); self._ev_p = torch.cuda.Event()
                 self._a_ready = False; self._cur = 0
             elif capture:
                 self._graph_fb = torch.cuda.CUDAGraph()
@@ -195,6 +219,36 @@ class DMPOLearner:
         self._apply_gradients()
         return stats
 
+    def _streams_on_own_queues(self, want: int):
+        """`want` HIP streams that do NOT share a hardware queue with the compute (current) stream, nor with each other.
+
+        HIP multiplexes streams onto a few hardware queues (4 by default; raising GPU_MAX_HW_QUEUES makes the command processor
+        time-slice and is far slower, profiles/r4/learner_streams.txt), handed out round-robin as streams are first used -- so which
+        stream shares a queue with which depends on every stream the process touched before.  Two graphs on streams of one queue
+        serialise: the pipelined step then costs its extra launches and returns nothing (measured: 2 400 instead of 3 500 steps/s).
+        Four fresh streams, touched one after the other, cover four consecutive queues; the ones that can overtake a long kernel on the
+        compute stream are the ones on other queues."""
+        main = torch.cuda.current_stream(self.device)
+        cands = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+        x = torch.zeros(64, device=self.device)
+        for c in cands:                                   # first use, in order: consecutive hardware queues
+            with torch.cuda.stream(c):
+                x.add_(0)
+        torch.cuda.synchronize(self.device)
+        free = []
+        for c in cands:
+            ev_main = torch.cuda.Event(enable_timing=True); ev_c = torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(4_000_000)                  # ~2 ms of spinning on the compute stream
+            ev_main.record(main)
+            with torch.cuda.stream(c):
+                x.add_(0); ev_c.record(c)
+            torch.cuda.synchronize(self.device)
+            if ev_c.elapsed_time(ev_main) > 0.5:          # the candidate finished (>= 0.5 ms) BEFORE the spin ended: it ran beside it
+                free.append(c)
+        while len(free) < want:                           # fewer independent queues than asked for: share (correct, only slower)
+            free.append(free[len(free) % max(1, len(free))] if free else main)
+        return free[:want]
+
     def _will_sync_targets(self, step_index: int) -> bool:
         return step_index % self.cfg.target_policy_update_period == 0 or step_index % self.cfg.target_critic_update_period == 0
 
@@ -219,7 +273,7 @@ class DMPOLearner:
         self._sync_targets()
         self.num_steps += 1
         k = self._cur
-        ga, gb, stats = self._sets[k][:3]
+        S = self._sets[k]; ga, stats = S['ga'], S['stats']
         if self._a_ready:
             main.wait_event(self._ev_a)                 # A_t ran on the side stream during step t - 1
         else:
@@ -231,9 +285,26 @@ class DMPOLearner:
             self._ev_main.record(main)                  # B_{t-1}, the last reader of the other buffer set, is behind this point
             with torch.cuda.stream(self._pipe_stream):
                 self._pipe_stream.wait_event(self._ev_main)
-                self._sets[1 - k][0].replay()
+                self._sets[1 - k]['ga'].replay()
                 self._ev_a.record(self._pipe_stream)
-        gb.replay()
+        # B_t as two concurrent branches -- critic (forward, TD loss, backward) and policy (forward, MPO loss, backward; the sampled
+        # actions' Q values it needs come from the TARGET critic, i.e. from A) -- joined by the gradient gather
+        nbr = self._n_branch_streams
+        if nbr == 0:                                     # both branches on the compute stream (only A runs beside them)
+            S['gc'].replay(); S['gp'].replay()
+        else:
+            s_c, s_p = self._br_streams
+            self._ev_fork.record(main)
+            with torch.cuda.stream(s_p):
+                s_p.wait_event(self._ev_fork); S['gp'].replay(); self._ev_p.record(s_p)
+            if nbr == 1:                                 # the critic branch stays on the compute stream
+                S['gc'].replay()
+            else:
+                with torch.cuda.stream(s_c):
+                    s_c.wait_event(self._ev_fork); S['gc'].replay(); self._ev_c.record(s_c)
+                main.wait_event(self._ev_c)
+            main.wait_event(self._ev_p)
+        S['gg'].replay()                                 # gradient gather (+ clip + Adam on a single rank)
         if self._distributed():
             self._ev_b.record(main)
             with torch.cuda.stream(self._comm_stream):
@@ -242,7 +313,7 @@ class DMPOLearner:
             work.wait()                                  # compute stream <- collective (NCCL: stream dependency; gloo: host wait)
             main.wait_stream(self._comm_stream)
             self.flat_grad.div_(dist.get_world_size())
-        self._graph_opt.replay()
+            self._graph_opt.replay()
         self._a_ready = nxt
         if nxt:
             self._cur = 1 - k
@@ -282,8 +353,10 @@ class DMPOLearner:
         Two phases (captured as one graph on a single rank, as two when the gradient all-reduce is overlapped: _step_overlapped)."""
         return self._phase_online(batch, None)
 
-    def _phase_targets(self, batch):
-        """Phase A: target policy -> N sampled actions -> target critic.  Reads the batch and the TARGET networks only."""
+    def _phase_targets(self, batch, with_q: bool = False):
+        """Phase A: target policy -> N sampled actions -> target critic.  Reads the batch and the TARGET networks only.  with_q: also
+        the expected return of every sampled action under the target critic (the E-step input of the policy loss; on the serial path
+        the TD kernel returns it as a by-product) -- the policy branch then does not depend on the critic branch at all."""
         cfg = self.cfg
         o_tm1, a_tm1, r_t, d_t, o_t = batch
         N, B = cfg.num_samples, o_t.shape[0]
@@ -293,7 +366,39 @@ class DMPOLearner:
             noise = torch.randn(N, B, t_mean.shape[-1], device=self.device)
             sampled, clipped = fused.sample_actions(t_mean, t_std, noise)
             q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True)       # [N, B, atoms], logits bias not added yet
+            if with_q:
+                return t_mean, t_std, sampled, q_t_raw, tc.mean_q(q_t_raw + tc.logits.bias)
         return t_mean, t_std, sampled, q_t_raw
+
+    def _phase_critic(self, batch, tgt):
+        """Critic branch: online critic forward, categorical TD loss with its gradient wrt the logits, the network's backward pass."""
+        o_tm1, a_tm1, r_t, d_t, o_t = batch
+        oc, tc = self.online.critic, self.target.critic
+        q_tm1_raw = oc.forward_raw(o_tm1, a_tm1)
+        critic_loss, _, d_logits, d_logits_bias = fused.td_loss_grad(q_tm1_raw, oc.logits.bias, tgt[3], tc.logits.bias, oc.values, r_t, d_t, self.cfg.discount)
+        ps = [p for p in self.critic_params if p is not oc.logits.bias]
+        grads = dict(zip(ps, torch.autograd.grad([q_tm1_raw], ps, [d_logits])))
+        grads[oc.logits.bias] = d_logits_bias
+        return critic_loss, grads
+
+    def _phase_policy(self, batch, tgt):
+        """Policy branch: online policy forward, MPO loss (value, statistics, every gradient), the network's backward pass."""
+        o_mean, o_std = self.online.policy(batch[4])
+        t_mean, t_std, sampled, _, sampled_q = tgt
+        st, g_mean, g_std, g_duals = fused.mpo_loss_grad(self.loss, o_mean, o_std, t_mean, t_std, sampled, sampled_q)
+        grads = dict(zip(self.policy_params, torch.autograd.grad([o_mean, o_std], self.policy_params, [g_mean, g_std])))
+        grads.update(g_duals)
+        return st, grads
+
+    def _phase_gather(self, cr, pol):
+        """Join: ONE launch lays every gradient out in the flat buffer (and, on a single rank, accumulates the clipping norms)."""
+        st, by_param = pol
+        by_param = dict(by_param); by_param.update(cr[1])
+        allp = self.policy_params + self.critic_params + self.dual_params
+        self.opt.set_grads([by_param[p] for p in allp], with_norms=not self._distributed())
+        stats = fused.mpo_stats_dict(self.loss, st)
+        stats['critic_loss'] = cr[0]; stats['policy_loss'] = st[0]
+        return stats
 
     def _phase_online(self, batch, tgt) -> Dict[str, torch.Tensor]:
         """Phase B: online forwards, losses, backward, gradient gather.  tgt = phase A's outputs (None: computed here, overlapped

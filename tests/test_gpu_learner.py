@@ -352,3 +352,44 @@ def test_gaussian_head_pair_launch():
     _close(mean, mr, rtol=2e-5, atol=2e-5); _close(std, sr, rtol=2e-5, atol=2e-5)
     for g, t, at in zip(got, (h, wm, bm, ws, bs), (5e-5, 3e-4, 3e-4, 3e-4, 3e-4)):
         _close(g, t.grad, rtol=1e-4, atol=at)
+
+
+def test_pipelined_learner_step_equals_serial_graphs():
+    """The learner step as a pipeline of HIP graphs on four streams (dmpo/learner.py _step_pipelined: target-network forwards of step
+    t + 1 | critic branch | policy branch | join + Adam) against the serial capture (one forward/backward graph + one optimizer graph):
+    same replay, same seeds, eight updates across a burst boundary (prefetch off for the last update of a burst) -- the parameters agree
+    to float32 rounding (the column sums of the backward kernels are atomic accumulations whose order is not reproducible)."""
+    from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, NStepReplay, make_networks
+    from flybody_amd.dmpo.losses import PenalizationCostRealActions
+    dev = torch.device('cuda', 0)
+    nobs, nu, B = 741, 59, 256
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        loss = MPOLoss(nu, epsilon=0.1, epsilon_mean=0.0025, epsilon_stddev=1e-7, action_penalization=True, epsilon_penalty=0.1,
+                       penalization_cost=PenalizationCostRealActions(-np.ones(nu, np.float32), np.ones(nu, np.float32), dev))
+        L = DMPOLearner(make_networks(nobs, nu), loss, DMPOConfig(), device=dev); L.pipeline = pipeline
+        rep = NStepReplay(512, nobs, nu, 20_000, device=dev, seed=3)
+        g = torch.Generator(device='cuda').manual_seed(7)
+        obs = torch.randn(512, nobs, device=dev, generator=g)
+        for t in range(8):
+            nxt = torch.randn(512, nobs, device=dev, generator=g)
+            rep.add(obs, torch.rand(512, nu, device=dev, generator=g)*2 - 1, torch.rand(512, device=dev, generator=g), torch.ones(512, device=dev), nxt,
+                    torch.zeros(512, dtype=torch.bool, device=dev), torch.zeros(512, dtype=torch.bool, device=dev))
+            obs = nxt
+        sampler = lambda: rep.sample(B)
+        torch.manual_seed(11)
+        L.enable_graphs(sampler(), sampler=sampler)
+        assert (L._sets is not None) == pipeline
+        torch.manual_seed(12)
+        for burst in range(2):
+            for k in range(4):
+                st = L.step(prefetch=k < 3)
+            rep.add(obs, torch.rand(512, nu, device=dev, generator=g)*2 - 1, torch.rand(512, device=dev, generator=g), torch.ones(512, device=dev), obs,
+                    torch.zeros(512, dtype=torch.bool, device=dev), torch.zeros(512, dtype=torch.bool, device=dev))
+        torch.cuda.synchronize()
+        return L.flat_param.clone(), {k: float(v) for k, v in st.items()}
+    (pa, sa), (pb, sb) = run(True), run(False)
+    rel = ((pa - pb).abs()/pb.abs().clamp_min(1.0)).max()
+    assert float(rel) < 2e-6, float(rel)
+    assert abs(sa['critic_loss'] - sb['critic_loss']) < 1e-4*abs(sb['critic_loss']) and abs(sa['policy_loss'] - sb['policy_loss']) < 1e-3*abs(sb['policy_loss']) + 1e-3
