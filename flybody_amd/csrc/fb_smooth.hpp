@@ -551,152 +551,112 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
                               FB_LDS real* RM, FB_LDS real* x, int lane);
 
 // The factorisation carries a right-hand side along: x (LDS, nv reals) leaves as L^-T x.  The leaf-to-root half of a solve visits
-// the levels in the order of the elimination and pulls through the same three LDS words as a diagonal entry (row entry, 1/D, and
-// the descendant's x), so it costs one more read and one more fma per level here against a level loop of its own (publish,
-// fence, pull: ~20 k cycles) in d_solve -- both factorisations of a substep are followed by a solve whose right-hand side is
-// known before they start (fb_step.hpp).  The products are formed in d_solve's order: the results are bit-identical.
+// the levels in the order of the elimination and pulls through the same LDS words as the row updates (row entry, 1/D, and the
+// descendant's x), so it costs one more read and one more fma per level here against a level loop of its own (publish, fence, pull:
+// ~20 k cycles) in d_solve -- both factorisations of a substep are followed by a solve whose right-hand side is known before they
+// start (fb_step.hpp).
+//
+// Round 4: ROW-PER-LANE.  Rounds 1-3 gave every off-diagonal entry (i, j) to a (lane, slot) of a packed work list and pulled, per
+// level, the product of three LDS words into it -- 12 integer instructions of unpacking and addressing around 3 flops per entry and
+// level (stage profile: 8.2 k vector instructions per factorisation, 49 % INT32, 19 % FP64).  The sparsity of M is the dof TREE: row i
+// holds exactly the ancestors of dof i, and eliminating a descendant k of i (on level d) updates the WHOLE row i by a multiple of a
+// CONTIGUOUS piece of row k:   M[i, anc_t(i)] -= (M~[k, i] / D[k]) M~[k, anc_t(i)],   t = 0 .. depth(i),
+// where M~[k, anc_t(i)] sits at offset (d - depth(i)) + t of row k.  So lane l keeps the rows of its (<= 2) dofs in registers, and a
+// level costs each row one scalar coefficient and depth(i) + 1 LDS reads + FMAs at consecutive addresses -- no work list, no
+// per-entry address arithmetic.  Rows still leave unnormalised with 1/D in the diagonal slot (d_factor_tail normalises them and
+// forms the trunk's Schur complement exactly as before).
 template <typename real>
 FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
                          FB_LDS real* RM, FB_LDS real* x, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
+  const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
+  const FB_LDS uint32_t* gk = w.lgk;
+  // the rows of the two dofs this lane owns: row[q][t] = M[i, ancestor of i at distance t] (t = 0: the diagonal), t <= depth(i)
+  int dep[2], mj[2], cl[2], gen[2], base[2]; bool has[2];
+  real row[2][FB_MAXCH], xa[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int j = lane + q*FB_WAVE;
+    has[q] = j < nv && j >= nT;
+    dep[q] = has[q] ? w.ldepth[j] : 31; mj[q] = has[q] ? w.lmadr[j] : 0; cl[q] = has[q] ? w.lcl[j] : 0;
+    { const int g = has[q] ? w.lgen[j] : 255; gen[q] = (g == 255) ? -1 : g; }
+    base[q] = mj[q] - dep[q]*(dep[q] + 1)/2;
+  }
+  // all loads of both rows in flight together (consecutive lanes own consecutive rows: the wave reads one contiguous piece of qM)
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+#pragma unroll
+    for (int t = 0; t < FB_MAXCH; t++) { const bool ok = has[q] && t <= dep[q]; const real v = qM[ok ? mj[q] + t : 0]; row[q][t] = ok ? v : (real)0; }
+    real da = (real)0;
+    if (diag_add) da = hscale*diag_add[has[q] ? lane + q*FB_WAVE : 0];
+    row[q][0] += has[q] ? da : (real)0;
+    xa[q] = has[q] ? x[lane + q*FB_WAVE] : (real)0;
+  }
+  PROF(17);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
-  long long fp_[6] = {0, 0, 0, 0, 0, 0}, ft_ = clock64();
+  long long fp_[5] = {0, 0, 0, 0, 0}, ft_ = clock64();
 #define F_PROF(k) do { long long n_ = clock64(); fp_[k] += n_ - ft_; ft_ = n_; } while (0)
 #else
 #define F_PROF(k) do {} while (0)
 #endif
-  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
-  const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
-  const FB_LDS uint32_t* gk = w.lgk;
-  // off-diagonal slots: packed word (general slots carry the general-dof index in bits 28..31, 15 = none)
-  int fw[FB_FSLOT];
-  real acc[FB_FSLOT];
-  // Two rounds, kept apart on purpose: all work words first, then all gathers.  Written as one loop the compiler issues
-  // word 0, waits, gather 0, word 1, waits (vector memory returns in order, so that wait includes gather 0), ... -- 18 dependent
-  // round trips instead of two (measured: 25 k -> 11 k cycles for this prologue).
-#pragma unroll
-  for (int s = 0; s < FB_FSLOT; s++) fw[s] = M.fac_w[s*FB_WAVE + lane];
-#ifndef FB_EMULATE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int s = 0; s < FB_FSLOT; s++) FB_OPAQUE(fw[s]);
-#endif
-#pragma unroll
-  for (int s = 0; s < FB_FSLOT; s++) {
-    int dep = FW_DEP(fw[s]);
-    real v = qM[dep != 31 ? FW_BASE(fw[s]) + dep*(dep + 1)/2 + FW_E(fw[s]) : 0];     // unconditional: all gathers in flight together
-    acc[s] = (dep != 31) ? v : (real)0;
-  }
-  // diagonal entries of the two dofs this lane owns, same packed format (e field = general-dof index, 31 = none)
-  int fd[2]; real accd[2], xa[2];
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    int j = lane + q*FB_WAVE;
-    bool has = j < nv && j >= nT;
-    int dp = has ? w.ldepth[j] : 31, mj = has ? w.lmadr[j] : 0, g = has ? w.lgen[j] : 255;
-    fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13) | ((has ? w.lcl[j] : 0) << 18) | ((g == 255 ? 31 : g) << 23);
-    real v = 0;
-    if (has) { v = qM[mj]; if (diag_add) v += hscale*diag_add[j]; }
-    accd[q] = v;
-    xa[q] = has ? x[j] : (real)0;
-  }
-  PROF(17);
-  F_PROF(0);
-  unsigned pub_next = (unsigned)uniform_int(M.fac_band[2*(nlevel - 1)]), pull_next = (unsigned)uniform_int(M.fac_band[2*(nlevel - 1) + 1]);
   for (int d = nlevel - 1; d >= nT; d--) {
     const int Td = d*(d + 1)/2;
-    // (keep the packed words opaque: otherwise every field of every slot is hoisted into its own register)
+    F_PROF(4);
+    // ---- publish the rows of level d (unnormalised, 1/D in the diagonal slot) and their x
 #pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) FB_OPAQUE(fw[s]);
+    for (int q = 0; q < 2; q++) {
+      if (dep[q] == d) {
+        const real di = fb_inv(row[q][0]);
+        RM[mj[q]] = di; x[lane + q*FB_WAVE] = xa[q];
 #pragma unroll
-    for (int q = 0; q < 2; q++) FB_OPAQUE(fd[q]);
-    // publish the rows of level d (unnormalised) and 1/D
-#pragma unroll
-    for (int q = 0; q < 2; q++) if (FW_DEP(fd[q]) == d) { real di = fb_inv(accd[q]); RM[FW_BASE(fd[q]) + Td] = di; x[lane + q*FB_WAVE] = xa[q]; }
-    // the chain slots are sorted (deepest level they pull on, then depth) and dealt to the lanes (fb_engine.hip), so only a few
-    // slots publish / pull on a level, the same for every lane: a bit mask per level, everything else is skipped by a wave-uniform test
-    const unsigned pubm = pub_next, pullm = pull_next;
-    pub_next = (unsigned)uniform_int(M.fac_band[2*(d > 0 ? d - 1 : 0)]); pull_next = (unsigned)uniform_int(M.fac_band[2*(d > 0 ? d - 1 : 0) + 1]);   // (scalar loads: in flight during this level)
-#pragma unroll
-    for (int s = 0; s < FB_FSLOT; s++) {
-      if (s < FB_FGEN || ((pubm >> s) & 1u)) {
-        // branch-free inside the band: a slot that is not on level d stores to a dummy word behind the factor
-        int adr = (FW_DEP(fw[s]) == d) ? FW_BASE(fw[s]) + Td + FW_E(fw[s]) : FB_LDS_SCRATCH - 1;
-        RM[adr] = acc[s];
+        for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];
       }
     }
+    F_PROF(0);
+    SYNC_LDS();
     F_PROF(1);
-    SYNC();
-    F_PROF(2);
-    // pull the contribution of level d into every shallower entry.  The chain loads are unconditional (an LDS read
-    // cannot fault) so that a group's reads are in flight together; inactive slots discard the product.
+    // ---- every shallower row pulls the contribution of its descendant(s) on level d
 #pragma unroll
-    for (int s0 = 0; s0 < FB_FSLOT; s0 += FB_FGROUP) {
-      if (!(s0 < FB_FGEN || (pullm & (((1u << FB_FGROUP) - 1u) << s0)))) continue;
-      real la[FB_FGROUP], lb[FB_FGROUP], ld[FB_FGROUP];
+    for (int q = 0; q < 2; q++) {
+      if (q == 1) F_PROF(2);
+      const int tr = d - dep[q] - 1;                 // >= 0: dof q sits above level d
+      if (tr < 0 || dep[q] == 31) continue;
+      if (tr < cl[q]) {
+        // unbranched chain below the dof: the descendant's row starts at base + T(d) (rows of a chain grow by one entry per level)
+        const int rk = base[q] + Td, o = d - dep[q];
+        const real c = RM[rk + o]*RM[rk];            // M~[k, i] / D[k] = L[k, i] as the normalisation will round it
+        xa[q] -= c*x[lane + q*FB_WAVE + tr + 1];
 #pragma unroll
-      for (int u = 0; u < FB_FGROUP; u++) {
-        int wd = fw[s0 + u];
-        int aD = FW_BASE(wd) + Td, aI = aD + d - FW_DEP(wd);
-        ld[u] = RM[aD]; la[u] = RM[aI]; lb[u] = RM[aI + FW_E(wd)];
-      }
+        for (int t = 0; t < FB_MAXCH; t++) if (t < d) row[q][t] -= c*RM[rk + o + t];       // (t <= depth(i) <= d - 1 matters; the wave-uniform bound
+                                                                                              //  costs no exec-mask juggling, entries beyond the row are never read back)
+      } else if (gen[q] >= 0) {
+        // branching dof: <= 4 listed descendant rows on this level
+        const int oo = 2*(gen[q]*FB_MAXCH + d), o = d - dep[q];
+        const unsigned pk = gk[gen[q]*FB_MAXCH + d], m01 = gm[oo], m23 = gm[oo + 1];
 #pragma unroll
-      for (int u = 0; u < FB_FGROUP; u++) {
-        int wd = fw[s0 + u];
-        unsigned t = (unsigned)(d - FW_DEP(wd) - 1);
-        real pr = la[u]*lb[u]*ld[u];
-        acc[s0 + u] -= (t < (unsigned)FW_CL(wd)) ? pr : (real)0;
+        for (int c4 = 0; c4 < 4; c4++) {
+          const int mk = ((c4 < 2 ? m01 : m23) >> (16*(c4 & 1))) & 0xffff, k = (pk >> (8*c4)) & 255;
+          if (mk != 0xffff) {
+            const real c = RM[mk + o]*RM[mk];
+            xa[q] -= c*x[k];
+#pragma unroll
+            for (int t = 0; t < FB_MAXCH; t++) if (t < d) row[q][t] -= c*RM[mk + o + t];
+          }
+        }
       }
     }
     F_PROF(3);
-#pragma unroll
-    for (int s = 0; s < FB_FGEN; s++) {
-      int wd = fw[s], dep = FW_DEP(wd), g = (wd >> 28) & 15;
-      if (g != 15 && d - dep - 1 >= FW_CL(wd)) {
-        int oi = d - dep, o = 2*(g*FB_MAXCH + d);
-        acc[s] -= gen_pull3(RM, gm[o], gm[o + 1], oi, oi + FW_E(wd), FW_BASE(wd) + (dep + 1)*(dep + 2)/2);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      int wd = fd[q], dep = FW_DEP(wd), t = d - dep - 1;
-      if (t >= 0) {
-        const int j = lane + q*FB_WAVE;
-        if (t < FW_CL(wd)) {
-          int aD = FW_BASE(wd) + Td; real l = RM[aD + t + 1], di = RM[aD], xk = x[j + t + 1];
-          accd[q] -= l*l*di;
-          xa[q] -= (l*di)*xk;                                   // L[k,j] x[k], L rounded as the normalisation will round it
-        }
-        else if (FW_E(wd) != 31) {
-          // branching dof: <= 4 listed descendant rows on this level; the diagonal's and x's pulls share the row entry and 1/D
-          int o = 2*(FW_E(wd)*FB_MAXCH + d);
-          const int ms = FW_BASE(wd) + (dep + 1)*(dep + 2)/2;
-          const unsigned pk = gk[FW_E(wd)*FB_MAXCH + d], m01 = gm[o], m23 = gm[o + 1];
-          real pd[4], px[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            int mk = ((c < 2 ? m01 : m23) >> (16*(c & 1))) & 0xffff, k = (pk >> (8*c)) & 255;
-            bool ok = mk != 0xffff;
-            int mm = ok ? mk : ms, kk = ok ? k : j + 1;
-            real l = RM[mm + t + 1], di = RM[mm], xk = x[kk];
-            real vd = l*l*di, vx = (l*di)*xk;
-            pd[c] = ok ? vd : (real)0; px[c] = ok ? vx : (real)0;
-          }
-          accd[q] -= (pd[0] + pd[1]) + (pd[2] + pd[3]);
-          xa[q] -= (px[0] + px[1]) + (px[2] + px[3]);
-        }
-      }
-    }
-    F_PROF(4);
   }
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
-  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[17] += fp_[0]; pp_[16] += fp_[1]; pp_[18] += fp_[2]; pp_[22] += fp_[3]; pp_[23] += fp_[4]; }
+  if (lane == 0) { long long* pp_ = (long long*)w.prof(); pp_[16] += fp_[0]; pp_[18] += fp_[1]; pp_[22] += fp_[2]; pp_[23] += fp_[3]; pp_[24] += fp_[4]; }
 #endif
+  PROF(P_FACTOR);
   PROF_RESET();
-  // the register accumulators are dead from here on (every entry was published, unnormalised, on its own level): the trunk
-  // and the normalisation run as a function of their own, with their own register allocation
+  // the rows are dead from here on (every one was published, unnormalised, on its own level): the trunk and the normalisation run
+  // as a function of their own, with their own register allocation
   d_factor_tail(M, w_, qM, diag_add, hscale, RM, x, lane);
 }
 

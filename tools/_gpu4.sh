@@ -1,8 +1,9 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r4i; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r4o; mkdir -p $O
 export TMPDIR=/tmp
-cd /tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/lt_pipe -o lt -- python $GRAFT_REPO_ROOT/tools/learner_bench.py --steps 60 > $O/lt_pipe.log 2>&1
-FB_LEARNER_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/lt_serial -o lt -- python $GRAFT_REPO_ROOT/tools/learner_bench.py --steps 60 > $O/lt_serial.log 2>&1
-cd $GRAFT_REPO_ROOT
-for m in pipe serial; do echo "== $m"; f=$(find $O/lt_$m -name "*kernel_trace.csv" | head -1); python tools/learner_timeline.py $f; done
+timeout 300 python bench.py --steps 100 --warmup 10 --no-secondary-configs --no-cpu-baseline --no-split-leg > $O/bench_100.json 2> $O/bench.err; python -c "
+import json; d=json.load(open('$O/bench_100.json')); print('dense', d['value'], d['ms_per_step'], 'f32', d['f32_mode']['value'], d['parity_sample']['max_rel_qpos'], d['parity_sample']['ok'])"
+FB_BENCH_DEFAULT_BUILD=1 timeout 300 python bench.py --steps 100 --warmup 10 --no-secondary-configs --no-cpu-baseline --no-f32-leg --no-split-leg --no-parity-sample > $O/bench_100_default.json 2> $O/benchd.err; python -c "
+import json; d=json.load(open('$O/bench_100_default.json')); print('default', d['value'], d['ms_per_step'])"
+FB_TASK=flight_imitation timeout 200 python tools/quick_bench.py flybody_amd/libflybody_hip.so 64 8192 30
+FB_TASK=flight_imitation timeout 200 python tools/quick_bench.py flybody_amd/libflybody_hip.so 32 8192 30

@@ -31,7 +31,7 @@ for _ in range(K):
 torch.cuda.synchronize(); dt = time.time() - t0
 p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
 # (sub-buckets 16-27 are parts of factor / pgs / kin / coll / acc and overlap their parents; 'cfin' spans the whole constraint stage)
-names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish(stores)', 'f_setup', 'f_sync', 'f_tail', 'sol_fwd', 'sol_bwd', 'f_pull', 'f_gen_diag', 'small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated',
+names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'f_setup(row loads)', 'f_sync', 'f_tail', 'sol_fwd', 'sol_bwd', 'f_pull_dof_lo', 'f_pull_dof_hi', 'f_loop_overhead+small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated',
          'nw_setup', 'nw_residual', 'nw_kbuild', 'nw_chol', 'nw_backsub', 'nw_direction', 'nw_linesearch', 'nw_iterations(count)', 'nw_ls_evals(count)', 'nw_solves(count)', 'co_stage_spheres', 'co_mid_phase', 'co_box_filter', 'co_narrow', 'co_write', '-',
          'ki_joint_rot', 'ki_fk_levels', 'ki_geoms_sites', 'ki_com', 've_com_vel', 've_passive', 've_rne', '-']
 tot = p[:, names.index('TOTAL_clock64')].mean()          # denominator: the wave's own clock64 lifetime (col 28 holds a start tick, not a duration)
