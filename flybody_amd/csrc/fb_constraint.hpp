@@ -227,7 +227,12 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
   int nefc = w.istate()[IS_NEFC];
   if (nefc == 0) return;
   // sqrt(1/D) of every dof, once (two passes of the wave) instead of once per row and chain slot (40 square roots per lane).
-  // The solve vector is free between the Euler solve and the next acceleration stage.
+  // Staged in the solve vector lx.  Who uses lx inside the constraint stage, in order (fb_step.hpp ST_ACC_POST .. ST_CONSTR_B):
+  //   1. the half solve leaves qacc_smooth in lx; ST_ACC_POST copies it to the global qacc_smooth BEFORE this function runs
+  //      (d_constraint_a reads the global copy) -- this function may only be called behind that copy;
+  //   2. here: sqrt(1/D), dead when the projection returns;
+  //   3. d_constraint_a: the tail of Newton's work matrix K when K runs on behind the Delassus matrix (k_in_slot);
+  //   4. d_constraint_a: J^T f, the right-hand side of the solve that follows.
   FB_LDS real* sd = w.lx;
   for (int i = lane; i < M.nv; i += FB_WAVE) sd[i] = sqrt(w.lLD[w.lmadr[i]]);          // 1/D of the dof: diagonal slot = start of its row
   SYNC();

@@ -127,8 +127,16 @@ class BatchedFlyEnv:
             # the 12-environments-per-CU FP64 build (engine.HIP_LIB_DENSE) is the faster one for batches beyond the default build's
             # 2048 resident environments (substep scheduler); flight keeps the default build (not measured faster)
             import os as _os
-            dense = precision == 64 and n_env > 2048 and task != 'flight_imitation' and _os.path.exists(engine.HIP_LIB_DENSE)
+            want = precision == 64 and n_env > 2048 and task != 'flight_imitation'
+            dense = want and _os.path.exists(engine.HIP_LIB_DENSE)
+            if want and not dense:
+                import warnings
+                warnings.warn(f'{engine.HIP_LIB_DENSE} is missing: FP64 batch of {n_env} environments runs on the default build '
+                              '(8 instead of 12 environments per CU; build it with __graft_entry__.build())')
         self.model = engine.Model(arrays, dense=bool(dense))
+        # which binary steps this environment (the implicit choice used to leave no trace): part of the config, logged once
+        self.build = 'libflybody_hip_dense.so (FP64, 12 environments per CU)' if dense else 'libflybody_hip.so (default build)'
+        if isinstance(self.config, dict): self.config['engine_build'] = self.build
         self.n_env = n_env; self.device = device
         self.batch = engine.Batch(self.model, n_env, device=device, precision=precision)
         self.future_steps = future_steps; self.terminal_com_dist = terminal_com_dist; self.time_limit = time_limit
