@@ -612,7 +612,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         const real di = fb_inv(row[q][0]);
         RM[mj[q]] = di; x[lane + q*FB_WAVE] = xa[q];
 #pragma unroll
-        for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];
+        for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];        // (exactly the row: the next row in memory belongs to a DEEPER dof, published earlier and still needed)
       }
     }
     F_PROF(0);
@@ -630,8 +630,14 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         const real c = RM[rk + o]*RM[rk];            // M~[k, i] / D[k] = L[k, i] as the normalisation will round it
         xa[q] -= c*x[lane + q*FB_WAVE + tr + 1];
 #pragma unroll
-        for (int t = 0; t < FB_MAXCH; t++) if (t < d) row[q][t] -= c*RM[rk + o + t];       // (t <= depth(i) <= d - 1 matters; the wave-uniform bound
-                                                                                              //  costs no exec-mask juggling, entries beyond the row are never read back)
+        for (int t0 = 0; t0 < FB_MAXCH; t0 += 4) {
+          // (t <= depth(i) <= d - 1 is what matters.  The bound is wave-uniform and tested once per four entries: a lane-varying
+          //  bound costs an exec-mask round trip per entry, and what lands beyond a row's end is never read back)
+          if (t0 < d) {
+#pragma unroll
+            for (int t = t0; t < t0 + 4; t++) row[q][t] -= c*RM[rk + o + t];
+          }
+        }
       } else if (gen[q] >= 0) {
         // branching dof: <= 4 listed descendant rows on this level
         const int oo = 2*(gen[q]*FB_MAXCH + d), o = d - dep[q];
@@ -643,7 +649,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
             const real c = RM[mk + o]*RM[mk];
             xa[q] -= c*x[k];
 #pragma unroll
-            for (int t = 0; t < FB_MAXCH; t++) if (t < d) row[q][t] -= c*RM[mk + o + t];
+            for (int t0 = 0; t0 < FB_MAXCH; t0 += 4) {
+              if (t0 < d) {
+#pragma unroll
+                for (int t = t0; t < t0 + 4; t++) row[q][t] -= c*RM[mk + o + t];
+              }
+            }
           }
         }
       }
