@@ -175,10 +175,13 @@ FBD void project_row(const DevModel<real>& M, const WS<real>& w, int side, int r
   load_chain(M, body, chain);
 #pragma unroll
   for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
-  // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t
+  // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t.  The bound is the wave-uniform longest chain: a slot beyond
+  // the lane's own chain carries y[s] = 0 and reads a trunk row (chain[] is padded with dof 0: finite factor entries), so it subtracts
+  // exact zeros -- cheaper than an exec-mask round trip per slot for the lane-varying `s < len`
+  const int chmax = M.chmax;
 #pragma unroll
   for (int s = FB_MAXCH - 1; s >= 1; s--) {
-    if (s < len && y[s] != 0) {
+    if (s < chmax) {
       const FB_LDS real* row = w.lLD + rowadr[s];
 #pragma unroll
       for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
@@ -206,13 +209,20 @@ FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, i
       cAA = common[rbA*nb + bA]; cAB = common[rbA*nb + bB]; cBA = common[rbB*nb + bA]; cBB = common[rbB*nb + bB];
     }
     real acc = 0;
+    // (the chain-length bounds of row r are wave-uniform: tested once per four slots -- Y is exactly zero beyond a chain's end)
 #pragma unroll
-    for (int s = 0; s < FB_MAXCH; s++) {
-      if (s < rlA) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
+    for (int s0 = 0; s0 < FB_MAXCH; s0 += 4) {
+      if (s0 < rlA) {
+#pragma unroll
+        for (int s = s0; s < s0 + 4; s++) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
+      }
     }
 #pragma unroll
-    for (int s = 0; s < FB_MAXCH; s++) {
-      if (s < rlB) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
+    for (int s0 = 0; s0 < FB_MAXCH; s0 += 4) {
+      if (s0 < rlB) {
+#pragma unroll
+        for (int s = s0; s < s0 + 4; s++) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
+      }
     }
     if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
       if (c == r) acc += Rc;

@@ -485,12 +485,12 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
 #pragma unroll
       for (int sl = 0; sl < FB_MAXCH; sl++) {
         val[sl] = 0;
-        if (sl < chmax && sl <= di[q]) {
+        if (sl < chmax) {                  // (wave-uniform bound; slots beyond the dof's own depth read dof 0's axis -- ch[] is padded -- and are not stored)
           real c[6];
 #pragma unroll
           for (int k = 0; k < 6; k++) c[k] = Lc[6*ch[q][sl] + k];
           real v = dot6(c, buf);
-          if (sl == di[q]) v += arm[q];
+          v += (sl == di[q]) ? arm[q] : (real)0;
           val[sl] = v;
         }
       }
