@@ -307,43 +307,35 @@ def main():
         del env
         return out
 
-    def run_dmpo_leg():
-        """BASELINE configs[2]: DMPO training, 4096 environments on this GPU, the reference's rate limiter (15 samples per insert =
-        240 learner steps per control step).  Own process (it owns the torch RNG and the HIP graphs); FP32 physics as in training."""
+    def run_dmpo_leg(n_ranks=1):
+        """BASELINE configs[2] (one rank) / configs[4] (n_ranks > 1): DMPO training, 4096 environments per GPU, the reference's rate
+        limiter (15 samples per insert = 240 learner steps per control step of a rank's shard).  Own process (it owns the torch RNG and
+        the HIP graphs) -- for several ranks its own JOB: `train_dmpo --gpus N` re-executes itself under torch.distributed.run with one
+        rank per GPU (per-rank shard + replay, one flat gradient all-reduce per learner step over RCCL, hidden behind the next step's
+        target-network forwards), while this benchmark's ranks wait at a barrier.  A failure or a hang of that job costs this leg, not
+        the benchmark line.  FP32 physics as in training."""
         import subprocess
         cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', str(args.dmpo_envs), '--iters', str(args.dmpo_iters), '--warmup', str(args.dmpo_warmup),
-               '--min-replay', str(args.dmpo_min_replay), '--precision', '32']
+               '--min-replay', str(args.dmpo_min_replay), '--precision', '32'] + (['--gpus', str(n_ranks)] if n_ranks > 1 else [])
         t0 = time.perf_counter()
-        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
+                                                                 'ROLE_RANK', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT',
+                                                                 'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE', 'TORCHELASTIC_ERROR_FILE')}
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420, env=env)
         except subprocess.TimeoutExpired:
             return {'error': 'timeout'}
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if not line:
-            return {'error': r.stderr[-400:]}
+            return {'error': r.stderr[-600:]}
         o = json.loads(line[-1])
-        return {'env_steps_per_sec': o['env_steps_per_sec'], 'learner_steps_per_sec': o['learner_steps_per_sec'], 'envs_per_gpu': o['envs_per_gpu'],
-                'learner_steps_per_env_step': o['learner_steps_per_env_step'], 'batch_size': o['batch_size'], 'samples_per_insert': o['samples_per_insert'],
-                'dtype': o['dtype'], 'reward': o['reward'], 'wall_s_incl_startup': time.perf_counter() - t0,
-                'note': 'one GPU, physics and learner on the same device; 12 timed control steps after 4 warm-up steps'}
-
-    def run_dmpo_leg_ranks():
-        """BASELINE configs[4]: the same DMPO loop on EVERY rank of this job -- per-rank environment shard and replay, one flat gradient
-        all-reduce per learner step over the job's process group (RCCL under the driver), hidden behind the next step's target-network
-        forwards (dmpo/learner.py: _step_overlapped).  In-process: the ranks and their process group are this benchmark's own."""
-        from flybody_amd.dmpo import DMPOConfig
-        from flybody_amd.train_dmpo import Trainer, measure
-        t0 = time.perf_counter()
-        tr = Trainer(n_env=args.dmpo_envs, precision=32, config=DMPOConfig(min_replay_size=args.dmpo_min_replay, samples_per_insert=15.0),
-                     terminal_com_dist=float('inf'))
-        res = measure(tr, args.dmpo_warmup, args.dmpo_iters)
-        res.update({'dtype': 'f32 physics / f32 learner', 'reward': 'inference mode (== 1): synthetic reference, throughput run',
-                    'wall_s_incl_startup': time.perf_counter() - t0,
-                    'note': '%d ranks x %d environments, physics and learner on the same device; %d timed control steps after %d warm-up steps'
-                            % (world, args.dmpo_envs, args.dmpo_iters, args.dmpo_warmup)})
-        del tr
-        return res
+        keep = ('n_gpus', 'env_steps_per_sec', 'learner_steps_per_sec', 'envs_per_gpu', 'learner_steps_per_env_step', 'batch_size', 'samples_per_insert',
+                'gradient_allreduce', 'dtype', 'reward')
+        out = {k: o[k] for k in keep if k in o}
+        out.update({'wall_s_incl_startup': time.perf_counter() - t0,
+                    'note': '%d rank(s) x %d environments, physics and learner on the same device(s); %d timed control steps after %d warm-up steps'
+                            % (n_ranks, args.dmpo_envs, args.dmpo_iters, args.dmpo_warmup)})
+        return out
 
     stream_pool = []
 
@@ -403,10 +395,16 @@ def main():
     if not args.no_secondary_configs:
         if not args.no_flight_leg:
             flight = {f'f{p}': run_flight_leg(p, max(10, args.steps), max(5, args.warmup)) for p in ((64, 32) if args.precision == 64 else (32,))}
-        if world == 1:
-            dmpo = run_dmpo_leg()
-        else:
-            dmpo = run_dmpo_leg_ranks()                 # every rank takes part (configs[4]); rank 0 reports
+        if rank == 0:
+            dmpo = run_dmpo_leg(world)                  # configs[2] on one rank, configs[4] (its own N-rank job) on several
+        if world > 1:                                   # the other ranks wait on the HOST (rendezvous store), not in a device-side collective that would
+            from datetime import timedelta              # keep a polling kernel on the GPUs the DMPO job is measured on
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set('fb_dmpo_leg_done', '1')
+            else:
+                store.wait(['fb_dmpo_leg_done'], timedelta(seconds=480))
+        barrier()
     parity = None
     if rank == 0 and args.precision == 64 and not args.no_parity_sample:
         parity = parity_sample(extras)

@@ -932,11 +932,10 @@ static int batch_create_impl(fb_batch* b) {
     HIPCHK(hipMalloc((void**)&b->done, n_env*sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->sched_err, sizeof(int)));
     HIPCHK(hipMemset(b->sched_err, 0, sizeof(int)));
-    // ... and for tasks whose environments differ in cost (ground contacts: walking, the ball).  flight_imitation has next to no
-    // constraints, its environments take the same time, the longest-first order already packs them, and its substeps are short:
-    // there the tickets only cost (measured, 8192 environments: 1.78 M env-steps/s per wave, 1.72 M with tickets; FB_TICKETS=1 forces them)
-    const bool uneven = m->i("task_id")[0] != 1 || getenv("FB_TICKETS") != nullptr;
-    b->tickets = b->nq > 0 && b->slots > 0 && n_env > b->slots && uneven && getenv("FB_NO_TICKETS") == nullptr;
+    // (round 3 kept flight_imitation -- equal-cost environments, short substeps -- on the per-wave path: tickets cost 3 % there.  With
+    // the round-4 kernel they win for flight too: 8192 FP64 environments 2.21 -> 2.25 M env-steps/s on the default build, 2.52 -> 2.63 M
+    // on the 12-per-CU build, profiles/r4/flight_variants.txt.  FB_NO_TICKETS=1 still forces the per-wave path.)
+    b->tickets = b->nq > 0 && b->slots > 0 && n_env > b->slots && getenv("FB_NO_TICKETS") == nullptr;
   }
   b->use_prio = getenv("FB_NO_PRIO") == nullptr;
   HIPCHK(hipMemset(b->reward, 0, n_env*sizeof(float)));

@@ -125,9 +125,10 @@ class BatchedFlyEnv:
         self.config = cfg
         if dense is None:
             # the 12-environments-per-CU FP64 build (engine.HIP_LIB_DENSE) is the faster one for batches beyond the default build's
-            # 2048 resident environments (substep scheduler); flight keeps the default build (not measured faster)
+            # 2048 resident environments (substep scheduler) -- since round 4 for flight as well (8192 environments:
+            # 2.63 M env-steps/s against 2.25 M, profiles/r4/flight_variants.txt)
             import os as _os
-            want = precision == 64 and n_env > 2048 and task != 'flight_imitation'
+            want = precision == 64 and n_env > 2048
             dense = want and _os.path.exists(engine.HIP_LIB_DENSE)
             if want and not dense:
                 import warnings
@@ -307,8 +308,8 @@ def walk_on_ball(force_actuators: bool = False, disable_wings: bool = True, rand
 def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[str] = None, force_actuators: bool = False,
                      disable_legs: bool = True, traj_indices: Optional[Sequence[int]] = None, randomize_start_step: bool = True,
                      joint_filter: float = 0.0, future_steps: int = 5, random_state=None, terminal_com_dist: float = 2.0,
-                     n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0, env_id_base: int = 0) -> BatchedFlyEnv:
-    """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed / env_id_base.
+                     n_env: int = 1, device: int = 0, precision: int = 64, seed: int = 0, env_id_base: int = 0, dense=None) -> BatchedFlyEnv:
+    """Same keyword surface as flybody/fly_envs.py:30-39, plus n_env / device / precision / seed / env_id_base / dense (engine build).
 
     ref_path: the reference's hdf5 flight dataset (needs h5py), its .npz conversion (trajectory_loaders.FlightDataset.save) or an
     already constructed loader; None = InferenceFlightTrajectoryLoader (the synthetic straight flight)."""
@@ -330,4 +331,4 @@ def flight_imitation(ref_path: Optional[str] = None, wpg_pattern_path: Optional[
     return BatchedFlyEnv(n_env=n_env, device=device, precision=precision, terminal_com_dist=terminal_com_dist,
                          joint_filter=joint_filter, future_steps=future_steps, time_limit=0.6, task='flight_imitation',
                          wbpg_tables=tables, seed=seed, traj_loader=traj_loader, env_id_base=env_id_base,
-                         force_actuators=force_actuators, use_legs=not disable_legs)
+                         force_actuators=force_actuators, use_legs=not disable_legs, dense=dense)

@@ -424,6 +424,45 @@ def test_flight_rollout_parity_fp64():
         assert len(last) >= 1 and (t[last + 1, e] == 0).all(), e   # ... and restarted with FIRST on the next step
 
 
+@pytest.mark.parametrize('dense', [False, True])
+def test_flight_batch_substep_scheduler_bit_equal_to_per_wave(dense, monkeypatch):
+    """BASELINE configs[3] at its bench size: 8192 flight_imitation environments exceed the resident wave slots of both builds, so
+    the batch is stepped by the substep scheduler (round 4: flight as well -- profiles/r4/flight_variants.txt).  Same keyed U(-1, 1)
+    actions, 12 control steps (48 physics steps, own wing-beat phases): state, observations and rewards are bit-identical to the
+    one-wave-per-environment path (FB_NO_TICKETS=1), whose rollouts test_flight_rollout_parity_fp64 holds against the oracle."""
+    import os
+    import torch
+    from conftest import ROOT
+    from flybody_amd import engine
+    from flybody_amd.mjcf_compile import qrot
+    from flybody_amd.model_blob import load_npz
+    from flybody_amd.reference import constant_speed_trajectory
+    from flybody_amd.wbpg import build_tables
+    arr = load_npz(os.path.join(ROOT, 'flybody_amd', 'assets', 'flight_imitation.npz'))
+    cq, cv = constant_speed_trajectory(200, 20.0, init_pos=(0, 0, 1), body_rot_angle_y=-47.5, control_timestep=2e-4)
+    root = cq.copy()
+    for i in range(len(root)):
+        root[i, :3] = cq[i, :3] + qrot(cq[i, 3:], -arr['com_offset'])
+    tabs = build_tables(); n = 8192; out = []
+    for tickets in (True, False):
+        if tickets: monkeypatch.delenv('FB_NO_TICKETS', raising=False)
+        else: monkeypatch.setenv('FB_NO_TICKETS', '1')
+        M = engine.Model(arr, lib_path=engine.HIP_LIB_DENSE if dense else None)
+        B = engine.Batch(M, n, precision=64)
+        assert B.substep_scheduler == tickets and B.resident_slots == (3072 if dense else 2048)
+        B.set_wbpg(tabs, seed=5); B.set_reference(root, cv, future_steps=5, terminal_com_dist=2.0, time_limit=0.6); B.reset()
+        a = torch.empty(n, 12, device='cuda'); st = torch.cuda.current_stream().cuda_stream
+        for k in range(12):
+            B.random_actions(a.data_ptr(), k, seed=9, dist=1, stream=st); B.step_ptr(a.data_ptr(), st)
+        B.synchronize(st)
+        assert (B.get('WARN_EVER') == 0).all()
+        out.append([B.get(f).copy() for f in ('QPOS', 'QVEL', 'ACT', 'OBS', 'REWARD', 'STEP_COUNT')])
+        del B, M
+    assert np.isfinite(out[0][0]).all() and len({tuple(np.round(q, 9)) for q in out[0][0][:256]}) > 128
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_launch_order_on_gpu(gpu_model, reference_traj):
     """Scheduling state of the step kernel: every environment records the duration of its control step (100 MHz ticks),
     and k_order sorts the next launch longest-first.  Results do not depend on the order (same actions, same states)."""
