@@ -547,8 +547,13 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       t = uniform_int(__shfl(t, 0, FB_WAVE));
       if (t >= total || cnt <= 0) return;
       const int round = t / cnt, env = (t % cnt)*nq + xcc;
-      // wait for the predecessor substep (normally long done: it was drawn `cnt` tickets ago)
-      int d = 0;
+      // wait for the predecessor substep (normally long done: it was drawn `cnt` tickets ago).  An environment whose predecessor is still
+      // running when its next ticket comes up is BEHIND the round-robin: its ten substeps in sequence are what the launch will wait for
+      // at the end (tools/ticket_trace.py), so that ticket runs at the highest issue priority.
+      int d = 0, late = 0;
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+      const long long tw0_ = wall_clock64();
+#endif
       for (int spins = 0; spins < FB_SCHED_SPIN_CAP; spins++) {
 #ifndef FB_EMULATE
         if (lane == 0) d = __hip_atomic_load(B.done + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -557,6 +562,7 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
 #endif
         d = uniform_int(__shfl(d, 0, FB_WAVE));
         if (d >= round) break;
+        late = 3;
 #ifndef FB_EMULATE
         __builtin_amdgcn_s_sleep(32);
 #endif
@@ -589,7 +595,11 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
       w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
       float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
-      if (lane == 0 && round == 0) { w.istate()[IS_PRIO] = 0; w.istate()[IS_WARN] = 0; }
+      if (lane == 0) { w.istate()[IS_PRIO] = late; if (round == 0) w.istate()[IS_WARN] = 0; }
+      FB_SETPRIO(late);
+#if defined(FB_PROFILE) && !defined(FB_EMULATE)
+      const long long tw1_ = wall_clock64();       // (tools/ticket_trace.py) per environment: wait for the predecessor, first start, last end, busy ticks
+#endif
       const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
                                    B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nsubm - 1 ? 2 : 0));
 #ifndef FB_EMULATE
@@ -600,6 +610,13 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
       // buffer_wbl2: a write-back of the WHOLE L2 to memory per ticket, for readers (other XCDs) that by construction do not
       // exist.  The hardware facts this leans on are checked where they can be (fb_batch_create: architecture, all XCDs visible;
       // launch: the stream reaches every XCD) and the scheduler is switched off otherwise.
+#ifdef FB_PROFILE
+      if (lane == 0) {
+        long long* pp_ = (long long*)w.prof(); const long long tw2_ = wall_clock64();
+        if (round == 0) { pp_[52] = 0; pp_[53] = tw0_; pp_[55] = 0; }
+        pp_[52] += tw1_ - tw0_; pp_[54] = tw2_; pp_[55] += tw2_ - tw1_;
+      }
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

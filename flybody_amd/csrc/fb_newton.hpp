@@ -27,9 +27,7 @@
 
 #define FB_NEWTON_LS_MAX 20
 #define FB_NEWTON_MAXROWS 64
-#ifndef FB_NEWTON_NR
-#define FB_NEWTON_NR 16     // active columns of the work matrix up to which the Cholesky factorisation runs in registers
-#endif
+#define FB_NEWTON_NT 16     // rows up to which a system is solved in the 16 x 16 tile layout (4 entries per lane)
 #ifndef FB_NEWTON_F32_FLOOR
 #define FB_NEWTON_F32_FLOOR 1e-10
 #endif
@@ -81,6 +79,7 @@ FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<r
 // values of lanes base, base+1, base+2 (ds_bpermute; every lane must call)
 FBD double nw_lane(double v, int src) { return __shfl(v, src, 64); }
 FBD float nw_lane(float v, int src) { return __shfl(v, src, 64); }
+FBD int nw_lane_i(int v, int src) { return __shfl(v, src, 64); }
 
 // ARP / KP: LDS (address_space(3)) or global pointers to the packed lower triangles of AR and of the work matrix K.
 // Returns the number of Newton iterations; the forces are left in efc_force.
@@ -122,16 +121,48 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   const int ra0 = min(base, n - 1), ra1 = min(base + 1, n - 1), ra2 = min(base + 2, n - 1);
   const int ta0 = ra0*(ra0 + 1)/2, ta1 = ra1*(ra1 + 1)/2, ta2 = ra2*(ra2 + 1)/2;
   const real Rb0 = w.efc_R()[ra0], Rb1 = w.efc_R()[ra1], Rb2 = w.efc_R()[ra2];
-  // y = A x  (A = AR - diag R): column k of the packed triangle per step, x_k by v_readlane
-  auto amul = [&](real x) -> real {
-    real acc0 = 0, acc1 = 0;
-    int kk = 0;
-    for (; kk + 1 < n; kk += 2) {
-      const real x0 = rdlane(x, kk), x1 = rdlane(x, kk + 1);
-      const real e0 = AR[rl >= kk ? tri_l + kk : kk*(kk + 1)/2 + rl], e1 = AR[rl >= kk + 1 ? tri_l + kk + 1 : (kk + 1)*(kk + 2)/2 + rl];
-      acc0 += e0*x0; acc1 += e1*x1;
+  // Systems of up to FB_NEWTON_NT = 16 rows (93 % of the solves of the bench workload) run on a 16 x 16 TILE over the wave: lane (ti, tc) =
+  // (lane >> 2, lane & 3) holds the entries [ti][4 tc + 0..3] of a matrix in four registers.  A = AR - diag R is loaded into that layout
+  // once per solve; a product A x is four multiply-adds on shuffled x plus a sum over the quad, the work matrix K and its factorisation
+  // never leave the registers (below).  Larger systems keep lane == row and the packed triangles in LDS.
+#ifdef FB_NEWTON_NO_TILE_AMUL
+  const bool tile = false;
+#else
+  const bool tile = n <= FB_NEWTON_NT;
+#endif
+  if (n > FB_NEWTON_NT) FB_SETPRIO(3);              // the large systems are what a lock-step launch ends on: let them win issue arbitration (restored by the caller)
+  const int ti = lane >> 2, tc = lane & 3;
+  const int tir = min(ti, n - 1);                   // (rows beyond the system: clamped addresses, zero factors)
+  real At[4] = {0, 0, 0, 0};
+  if (tile) {
+    const real Rt = nw_lane(R, tir);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int tj = 4*tc + s, tjr = min(tj, n - 1);
+      const real e = AR[tir >= tjr ? tir*(tir + 1)/2 + tjr : tjr*(tjr + 1)/2 + tir];
+      At[s] = (ti < n && tj < n) ? (ti == tj ? e - Rt : e) : (real)0;
     }
-    if (kk < n) { const real x0 = rdlane(x, kk); acc0 += AR[rl >= kk ? tri_l + kk : kk*(kk + 1)/2 + rl]*x0; }
+  }
+  // y = A x  (A = AR - diag R).  lane == row: column k of the packed triangle per step, x_k by v_readlane
+  auto amul = [&](real x) -> real {
+    if (tile) {
+      real acc = 0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) acc += At[s]*nw_lane(x, 4*tc + s);
+      acc = quad_sum(acc);
+      const real yr = nw_lane(acc, 4*(lane & 15));
+      return on ? yr : (real)0;
+    }
+    real acc0 = 0, acc1 = 0;                          // (even / odd columns; eight entries of the row per LDS round trip)
+    for (int kk = 0; kk < n; kk += 8) {
+      real e[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int k2 = min(kk + u, n - 1); e[u] = AR[rl >= k2 ? tri_l + k2 : k2*(k2 + 1)/2 + rl]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (kk + u < n) { const real xu = rdlane(x, kk + u); if (u & 1) acc1 += e[u]*xu; else acc0 += e[u]*xu; }
+      }
+    }
     return on ? (acc0 + acc1) - R*x : (real)0;
   };
   const real scale = (real)1 / (M.meaninertia * (real)(M.nv > 1 ? M.nv : 1));
@@ -174,112 +205,275 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       const real q0 = nw_lane(q, base), q1 = nw_lane(q, base + 1), q2 = nw_lane(q, base + 2);
       y = o.fc0*q0 + o.fc1*q1 + o.fc2*q2;
     }
-    // Only the non-zero columns of F take part: K is the identity in the others.  Row `lane` keeps its entries of the
-    // active columns left of it, compacted (entry p = the p-th active column), at K[tri_l + p].
-    const int n_act = __popcll(m_act);
-    const int my_ci = __popcll(m_act & ((1ull << lane) - 1ull));          // compact index of this lane's own column
-    real dg = 1;                                    // running diagonal K[lane][lane]: stays in the owner's registers
-    for (int bk = 0; bk < n;) {
-      const int nk = ((m_first >> bk) & 1ull) ? 3 : 1;
-      if (!((m_act >> bk) & (nk == 3 ? 7ull : 1ull))) { bk += nk; continue; }      // identity columns
-      // v_cc = sum_a F[block row a][lane] A[block row a][bk + cc]
-      real v0 = 0, v1 = 0, v2 = 0;
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) {
-        if (cc < nk) {
-          const int col = bk + cc, tcol = col*(col + 1)/2;
-          real e0 = AR[ra0 >= col ? ta0 + col : tcol + ra0], e1 = AR[ra1 >= col ? ta1 + col : tcol + ra1], e2 = AR[ra2 >= col ? ta2 + col : tcol + ra2];
-          e0 -= (ra0 == col) ? Rb0 : (real)0; e1 -= (ra1 == col) ? Rb1 : (real)0; e2 -= (ra2 == col) ? Rb2 : (real)0;
-          const real vv = o.fc0*e0 + o.fc1*e1 + o.fc2*e2;
-          if (cc == 0) v0 = vv; else if (cc == 1) v1 = vv; else v2 = vv;
-        }
-      }
-      int ci = __popcll(m_act & ((1ull << bk) - 1ull));
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) {
-        if (cc < nk) {
-          const int col = bk + cc;
-          if ((m_act >> col) & 1ull) {
-            real kv = v0*rdlane(o.fc0, col);
-            if (nk == 3) kv += v1*rdlane(o.fc1, col) + v2*rdlane(o.fc2, col);
-            if (on && col < lane) K[tri_l + ci] = kv;
-            if (col == lane) dg = kv + 1;
-            ci++;
-          }
-        }
-      }
-      bk += nk;
-    }
-    NW_PROF(2);
-    // ---- Cholesky K = L L' (right-looking), forward substitution folded in.  The column of a pivot travels by v_readlane,
-    // every lane updates its own row.  Up to FB_NEWTON_NR active columns the rows live in registers (the loops over the
-    // compact column index are unrolled, so the register index is static; they leave at the first exhausted bit mask);
-    // larger systems update their rows in LDS.
-    real invd = 1;
-    if (n_act <= FB_NEWTON_NR) {
-      // Kr[q] = this row's entry of the q-th REMAINING active column: every elimination step shifts the row by one register
-      // (the shift rides on the update's FMA), so the pivot column is always Kr[0], the register indices are static, and the
-      // outer loop stays rolled -- one short loop body instead of NR^2/2 unrolled updates streaming through the instruction cache
-      real Kr[FB_NEWTON_NR];
-#pragma unroll
-      for (int q = 0; q < FB_NEWTON_NR; q++) Kr[q] = (q < n_act) ? K[tri_l + q] : (real)0;
-      unsigned long long mrem = m_act;
-      for (int pp = 0; mrem; pp++) {
-        const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
-        const real inv = fb_rsqrt(rdlane(dg, j));
-        const bool below = on && lane > j;
-        const real lcol = below ? Kr[0]*inv : (real)0;
-        if (below) K[tri_l + pp] = lcol;            // L goes back to LDS: the back substitution reads row j across lanes
-        if (lane == j) invd = inv;
-        const real yj = rdlane(y, j)*inv;
-        y = (lane == j) ? yj : y - lcol*yj;
-        // the diagonal of every remaining row loses its own lcol^2 (once per pivot, not once per remaining column)
-        dg -= ((mrem >> lane) & 1ull) ? lcol*lcol : (real)0;
-        unsigned long long m2 = mrem;
-#pragma unroll
-        for (int q = 1; q < FB_NEWTON_NR; q++) {
-          if (m2) {
-            const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
-            const real lk = rdlane(lcol, kk);
-            Kr[q - 1] = Kr[q] - lcol*lk;            // (lanes <= kk update an entry they never use)
-          }
-        }
-      }
-    } else {
-      unsigned long long mrem = m_act;
-      for (int pp = 0; mrem; pp++) {
-        const int j = __ffsll((long long)mrem) - 1; mrem &= mrem - 1;
-        const real inv = fb_rsqrt(rdlane(dg, j));
-        real lcol = 0;
-        if (on && lane > j) { lcol = K[tri_l + pp]*inv; K[tri_l + pp] = lcol; }
-        if (lane == j) invd = inv;
-        const real yj = rdlane(y, j)*inv;
-        y = (lane == j) ? yj : y - lcol*yj;
-        unsigned long long m2 = mrem;
-        for (int p2 = pp + 1; m2; p2++) {
-          const int kk = __ffsll((long long)m2) - 1; m2 &= m2 - 1;
-          const real lk = rdlane(lcol, kk);
-          if (lane == kk) dg -= lcol*lk;
-          else if (on && lane > kk) K[tri_l + p2] -= lcol*lk;
-        }
-      }
-    }
-    SYNC();                                         // the rows of L are read across lanes below
-    NW_PROF(3);
-    // ---- back substitution L' z = y over the active columns, last first
     real z = 0;
+#ifdef FB_NEWTON_KTILE
+    if (tile) {
+      // ---- K = I + F'AF in the tile layout, two passes over the block structure of F (column j of F = the three entries fc0..2 of lane j
+      // at the rows base_j .. base_j + 2):  G = A F from three entries of AR per register, then K[i][j] = delta_ij + sum_a fc_a(i) G[base_i + a][j],
+      // where G[base_i + a][j] is the SAME register of lane (base_i + a, tc).  Inactive columns have zero factors: K is the identity there
+      // without any compaction, and their pivots are skipped.
+      real Kr[4];
+      {
+        const int bi = nw_lane_i(base, ti);
+        const real fi0 = nw_lane(o.fc0, ti), fi1 = nw_lane(o.fc1, ti), fi2 = nw_lane(o.fc2, ti);
+        const int g0 = 4*min(bi, 15) + tc, g1 = 4*min(bi + 1, 15) + tc, g2 = 4*min(bi + 2, 15) + tc;
+        real G[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int tj = 4*tc + s;
+          const int bj = nw_lane_i(base, tj);
+          const real fj0 = nw_lane(o.fc0, tj), fj1 = nw_lane(o.fc1, tj), fj2 = nw_lane(o.fc2, tj);
+          const int c0 = min(bj, n - 1), c1 = min(bj + 1, n - 1), c2 = min(bj + 2, n - 1);
+          real e0 = AR[tir >= c0 ? tir*(tir + 1)/2 + c0 : c0*(c0 + 1)/2 + tir];
+          real e1 = AR[tir >= c1 ? tir*(tir + 1)/2 + c1 : c1*(c1 + 1)/2 + tir];
+          real e2 = AR[tir >= c2 ? tir*(tir + 1)/2 + c2 : c2*(c2 + 1)/2 + tir];
+          const real Rt = nw_lane(R, tir);
+          e0 -= (tir == c0) ? Rt : (real)0; e1 -= (tir == c1) ? Rt : (real)0; e2 -= (tir == c2) ? Rt : (real)0;
+          G[s] = (ti < n) ? fj0*e0 + fj1*e1 + fj2*e2 : (real)0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          Kr[s] = ((ti == 4*tc + s) ? (real)1 : (real)0) + fi0*nw_lane(G[s], g0) + fi1*nw_lane(G[s], g1) + fi2*nw_lane(G[s], g2);
+      }
+      NW_PROF(2);
+      // ---- factorisation of the tile (right-looking, symmetric scaling: K = L~ U~ with U~ = L~' up to rounding), forward substitution
+      // folded in.  One elimination step is ONE multiply-add per register for the whole trailing matrix: the pivot row reaches a lane as
+      // K[p][4 tc + s] = lane (p, tc)'s own register s, the pivot column as K[ti][p] = lane (ti, p >> 2)'s register p & 3 (static: the
+      // pivot loop is unrolled by four).  Both images of a finished column are scaled in place, which lets the back substitution read
+      // U[ti][p] from a lane of its own row.
+      real yv = nw_lane(y, ti), invd = 1;
+      const int PN = (n - 1) >> 2;
+      for (int P = 0; P <= PN; P++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int pv = 4*P + q;
+          if ((m_act >> pv) & 1ull) {
+            const real inv = fb_rsqrt(rdlane(Kr[q], 4*pv + P));
+            const real Lip = nw_lane(Kr[q], 4*ti + P)*inv;
+            real Lpj[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) Lpj[s] = nw_lane(Kr[s], 4*pv + tc)*inv;
+            const real yp = rdlane(yv, 4*pv)*inv;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+              const int tj = 4*tc + s;
+              if (ti > pv && tj > pv) Kr[s] -= Lip*Lpj[s];
+              else if (ti == pv && tj > pv) Kr[s] = Lpj[s];
+              else if (tj == pv && ti > pv) Kr[s] = Lip;
+            }
+            if (ti == pv) { invd = inv; yv = yp; }
+            else if (ti > pv) yv -= Lip*yp;
+          }
+        }
+      }
+      NW_PROF(3);
+      // ---- back substitution, last column first
+      for (int P = PN; P >= 0; P--) {
+#pragma unroll
+        for (int q = 3; q >= 0; q--) {
+          const int pv = 4*P + q;
+          if ((m_act >> pv) & 1ull) {
+            const real zp = rdlane(yv, 4*pv)*rdlane(invd, 4*pv);
+            const real Upi = nw_lane(Kr[q], 4*ti + P);
+            if (ti == pv) yv = zp;
+            else if (ti < pv) yv -= Upi*zp;
+          }
+        }
+      }
+      const real zr = nw_lane(yv, 4*(lane & 15));
+      z = (on && ((m_act >> lane) & 1ull)) ? zr : (real)0;
+      NW_PROF(4);
+    } else
+#endif
     {
-      unsigned long long mrem = m_act;
+      // ---- lane == row of K (lower triangle in LDS).  Only the non-zero columns of F take part: K is the identity in the others.
+      // Row `lane` keeps its entries of the active columns left of it, compacted (entry p = the p-th active column), at K[tri_l + p].
+      const int n_act = __popcll(m_act);
+      const int my_ci = __popcll(m_act & ((1ull << lane) - 1ull));          // compact index of this lane's own column
+      real dg = 1;                                    // running diagonal K[lane][lane]: stays in the owner's registers
+      for (int bk = 0; bk < n;) {
+        const int nk = ((m_first >> bk) & 1ull) ? 3 : 1;
+        if (!((m_act >> bk) & (nk == 3 ? 7ull : 1ull))) { bk += nk; continue; }      // identity columns
+        // v_cc = sum_a F[block row a][lane] A[block row a][bk + cc]
+        real v0 = 0, v1 = 0, v2 = 0;
+  #pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          if (cc < nk) {
+            const int col = bk + cc, tcol = col*(col + 1)/2;
+            real e0 = AR[ra0 >= col ? ta0 + col : tcol + ra0], e1 = AR[ra1 >= col ? ta1 + col : tcol + ra1], e2 = AR[ra2 >= col ? ta2 + col : tcol + ra2];
+            e0 -= (ra0 == col) ? Rb0 : (real)0; e1 -= (ra1 == col) ? Rb1 : (real)0; e2 -= (ra2 == col) ? Rb2 : (real)0;
+            const real vv = o.fc0*e0 + o.fc1*e1 + o.fc2*e2;
+            if (cc == 0) v0 = vv; else if (cc == 1) v1 = vv; else v2 = vv;
+          }
+        }
+        int ci = __popcll(m_act & ((1ull << bk) - 1ull));
+  #pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          if (cc < nk) {
+            const int col = bk + cc;
+            if ((m_act >> col) & 1ull) {
+              real kv = v0*rdlane(o.fc0, col);
+              if (nk == 3) kv += v1*rdlane(o.fc1, col) + v2*rdlane(o.fc2, col);
+              if (on && col < lane) K[tri_l + ci] = kv;
+              if (col == lane) dg = kv + 1;
+              ci++;
+            }
+          }
+        }
+        bk += nk;
+      }
+      NW_PROF(2);
+      if (n_act <= FB_NEWTON_NT) {
+        // ---- tile factorisation (98.5 % of the iterations of the bench workload have <= 16 ACTIVE columns): the compacted K as a full
+        // symmetric 16 x 16 tile over the wave -- lane (ti, tc) = (lane >> 2, lane & 3) holds K[ti][4 tc + 0..3] -- so that one elimination
+        // step is ONE multiply-add per register for the whole trailing matrix instead of a v_readlane per remaining column: the pivot row
+        // reaches a lane as K[p][4 tc + s] = lane (p, tc)'s own register s, the pivot column as K[ti][p] = lane (ti, p >> 2)'s register p & 3
+        // (static: the pivot loop is unrolled by four).  Both mirror images of a finished column are scaled in place (the tile ends as
+        // L + L' - diag), which lets the back substitution read L[p][ti] from a lane of its own row.  Nothing of L returns to LDS.
+        const bool mine = on && ((m_act >> lane) & 1ull);
+        if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;     // row of compact index my_ci, parked in the diagonal slot of packed row my_ci (unused: the diagonals live in registers)
+        SYNC();
+        const bool iv = ti < n_act;
+        const int ri = iv ? (int)K[ti*(ti + 1)/2 + ti] : 0, tri_i = ri*(ri + 1)/2;
+        const real dgt = nw_lane(dg, ri);
+        real yv = nw_lane(y, ri);
+        real Kr[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int tj = 4*tc + s;
+          const bool jv = tj < n_act;
+          const int rj = jv ? (int)K[tj*(tj + 1)/2 + tj] : 0;
+          const real e = K[(iv && jv) ? (tj < ti ? tri_i + tj : rj*(rj + 1)/2 + ti) : 0];          // (tj == ti reads a table slot: replaced below)
+          Kr[s] = (iv && jv) ? (tj == ti ? dgt : e) : (tj == ti ? (real)1 : (real)0);
+        }
+        if (!iv) yv = 0;
+        real invd = 1;
+        for (int P = 0; 4*P < n_act; P++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int pv = 4*P + q;
+            if (pv < n_act) {
+              const real inv = fb_rsqrt(rdlane(Kr[q], 4*pv + P));
+              const real Lip = nw_lane(Kr[q], 4*ti + P)*inv;
+              real Lpj[4];
+#pragma unroll
+              for (int s = 0; s < 4; s++) Lpj[s] = nw_lane(Kr[s], 4*pv + tc)*inv;
+              const real yp = rdlane(yv, 4*pv)*inv;
+#pragma unroll
+              for (int s = 0; s < 4; s++) {
+                const int tj = 4*tc + s;
+                if (ti > pv && tj > pv) Kr[s] -= Lip*Lpj[s];
+                else if (ti == pv && tj > pv) Kr[s] = Lpj[s];
+                else if (tj == pv && ti > pv) Kr[s] = Lip;
+              }
+              if (ti == pv) { invd = inv; yv = yp; }
+              else if (ti > pv) yv -= Lip*yp;
+            }
+          }
+        }
+        NW_PROF(3);
+        // ---- back substitution L' z = y, last column first: row ti < p reads L[p][ti] from the mirror image in its own row
+        for (int P = (n_act - 1) >> 2; P >= 0; P--) {
+#pragma unroll
+          for (int q = 3; q >= 0; q--) {
+            const int pv = 4*P + q;
+            if (pv < n_act) {
+              const real zp = rdlane(yv, 4*pv)*rdlane(invd, 4*pv);
+              const real Lpi = nw_lane(Kr[q], 4*ti + P);
+              if (ti == pv) yv = zp;
+              else if (ti < pv) yv -= Lpi*zp;
+            }
+          }
+        }
+        const real zr = nw_lane(yv, mine ? 4*my_ci : 0);
+        z = mine ? zr : (real)0;
+        SYNC();                                       // (K is rewritten by the next iteration)
+        NW_PROF(4);
+      } else {
+      // Larger systems: right-looking factorisation on the rows in LDS.  These are the environments a lock-step launch WAITS for
+      // (tools/ticket_trace.py: the last environments of a launch spent 5-20 x the mean here), so the loop is built for instruction count:
+      //  * the ACTIVE rows are re-mapped onto the first n_act lanes (lane c = compact row c; the inactive rows of K are identity rows and
+      //    take no part), which turns every "next active column" bit scan into a plain lane index and puts the diagonal into the row's
+      //    own storage (slot c) -- the trailing update of an entry is two v_readlane, one compare, the multiply-adds and one masked store;
+      //  * two pivots per pass over the trailing rows (rank-2 update: one LDS read and write per entry for two multiply-adds), eight
+      //    entries of a row per LDS round trip; the next pivot's column entry stays in a register.
       const bool mine = on && ((m_act >> lane) & 1ull);
-      while (mrem) {
-        const int j = 63 - __clzll((long long)mrem); mrem &= ~(1ull << j);
-        const real zj = rdlane(y, j)*rdlane(invd, j);
-        if (lane == j) z = zj;
-        if (mine && lane < j) y -= K[j*(j + 1)/2 + my_ci]*zj;
+      if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;       // row of compact index my_ci, parked in the diagonal slot of packed row my_ci
+      SYNC();
+      const int cl = lane;
+      const bool act = cl < n_act;
+      const int ac = act ? (int)K[cl*(cl + 1)/2 + cl] : 0;
+      const int tcr = ac*(ac + 1)/2;                               // this compact row's storage: the packed row of lane ac, entries [0, cl], slot cl = diagonal
+      {
+        const real dgc = nw_lane(dg, ac);
+        if (act) K[tcr + cl] = dgc;
+      }
+      real yc = nw_lane(y, ac);
+      if (!act) yc = 0;
+      real carry = act ? K[tcr] : (real)1, invd = 1;
+      for (int pp = 0; pp < n_act; pp += 2) {
+        const real invA = fb_rsqrt(rdlane(carry, pp));
+        const bool belowA = act && cl > pp;
+        const real lA = belowA ? carry*invA : (real)0;
+        if (belowA) K[tcr + pp] = lA;
+        if (cl == pp) invd = invA;
+        const real yA = rdlane(yc, pp)*invA;
+        yc = (cl == pp) ? yA : yc - lA*yA;
+        if (pp + 1 < n_act) {
+          // second pivot of the pass: its column is brought up to date first
+          real e1 = K[tcr + min(pp + 1, cl)];
+          e1 -= lA*rdlane(lA, pp + 1);
+          const real invB = fb_rsqrt(rdlane(e1, pp + 1));
+          const bool belowB = act && cl > pp + 1;
+          const real lB = belowB ? e1*invB : (real)0;
+          if (belowB) K[tcr + pp + 1] = lB;
+          if (cl == pp + 1) invd = invB;
+          const real yB = rdlane(yc, pp + 1)*invB;
+          yc = (cl == pp + 1) ? yB : yc - lB*yB;
+          for (int p2 = pp + 2; p2 < n_act; p2 += 8) {
+            real kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kv[u] = K[tcr + min(p2 + u, cl)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              if (p2 + u < n_act) {
+                const real ka = rdlane(lA, p2 + u), kb = rdlane(lB, p2 + u);
+                if (act && cl >= p2 + u) { kv[u] = (kv[u] - lA*ka) - lB*kb; K[tcr + p2 + u] = kv[u]; }
+              }
+            }
+            if (p2 == pp + 2) carry = kv[0];
+          }
+        }
+      }
+      SYNC();                                         // the rows of L are read across lanes below
+      NW_PROF(3);
+      // ---- back substitution L' z = y, last column first; eight entries of the column L[.][cl] per LDS round trip
+      real zc = 0;
+      for (int j0 = n_act - 1; j0 >= 0; j0 -= 8) {
+        real kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = max(j0 - u, 0), aj = rdlane(ac, j);
+          kv[u] = K[aj*(aj + 1)/2 + min(cl, j)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = j0 - u;
+          if (j >= 0) {
+            const real zj = rdlane(yc, j)*rdlane(invd, j);
+            if (cl == j) zc = zj;
+            if (cl < j) yc -= kv[u]*zj;
+          }
+        }
+      }
+      {
+        const real zr = nw_lane(zc, mine ? my_ci : 0);
+        z = mine ? zr : (real)0;
+      }
+      SYNC();                                         // (K is rewritten by the next iteration)
+      NW_PROF(4);
       }
     }
-    SYNC();                                         // (K is rewritten by the next iteration)
-    NW_PROF(4);
     real dl;
     {
       const real z0 = nw_lane(z, base), z1 = nw_lane(z, base + 1), z2 = nw_lane(z, base + 2);
@@ -313,6 +507,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   }
   nw_update(c, jb0, jb1, jb2, o);
   if (on) w.efc_force()[lane] = o.f;
+  if (n > FB_NEWTON_NT) FB_SETPRIO(uniform_int(w.istate()[IS_PRIO]));
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 7; k_++) pp_[32 + k_] += nwp_[k_]; pp_[39] += nwc_[0]; pp_[40] += nwc_[1]; pp_[41] += 1; }
 #endif
