@@ -15,11 +15,18 @@
 // convex 1-D function P(lam + alpha dlam) by safeguarded Newton steps on its derivative.  Typical: 4-5 iterations where block
 // PGS needs ~60 sweeps (and stalls at the 100-sweep cap in 13 % of the solves).
 //
-// Mapping: lane i owns row i of everything -- b, R, lam, jar in registers; row i of AR and of K in LDS (packed lower
-// triangles).  The three lanes of a contact evaluate the contact's cone zone redundantly (same inputs, same bits), so
-// the per-row force / factor entries need no exchange; wave-uniform quantities travel by v_readlane, block-local ones by
-// ds_bpermute; the Cholesky pivots stay in the owning lane's registers.  Columns of F that are zero (inactive rows, the
-// third column of a middle-zone contact) make K an identity row / column there and are skipped in all three passes.
+// Mapping: lane i owns row i of every per-row quantity -- b, R, lam, jar in registers.  The three lanes of a contact evaluate the
+// contact's cone zone redundantly (same inputs, same bits), so the per-row force / factor entries need no exchange.  Columns of F that
+// are zero (inactive rows, the third column of a middle-zone contact) make K an identity row / column there and are skipped.
+// The matrices take one of three shapes, by system size (round 4; shares of the bench workload in brackets):
+//   n <= 16 rows [93 % of the solves]  16 x 16 register TILE over the wave (lane (ti, tc) holds entries [ti][4 tc + 0..3]): A = AR - diag R
+//       loaded once per solve, A x = four multiply-adds + a quad sum, K built and factorised in registers (one multiply-add per register
+//       and elimination step for the whole trailing matrix), nothing of K or L in LDS;
+//   n > 16, <= 16 ACTIVE columns       K built with lane == row (packed rows in LDS), compacted into the same tile for the factorisation;
+//   more active columns                the active rows re-mapped onto the first lanes, rank-2 right-looking factorisation on the rows in
+//       LDS, eight entries per round trip.  Rare -- and exactly the environments a lock-step launch ends on: an environment's ten substeps
+//       run one after the other, so the launch lasts at least ten times its SLOWEST environment's substep (tools/ticket_trace.py; before
+//       round 4 this path cost 5-20 x the mean solve and the launch waited ~1 ms for one or two such environments).
 #pragma once
 #include "fb_types.hpp"
 #include "fb_math.hpp"
@@ -125,11 +132,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   // (lane >> 2, lane & 3) holds the entries [ti][4 tc + 0..3] of a matrix in four registers.  A = AR - diag R is loaded into that layout
   // once per solve; a product A x is four multiply-adds on shuffled x plus a sum over the quad, the work matrix K and its factorisation
   // never leave the registers (below).  Larger systems keep lane == row and the packed triangles in LDS.
-#ifdef FB_NEWTON_NO_TILE_AMUL
-  const bool tile = false;
-#else
   const bool tile = n <= FB_NEWTON_NT;
-#endif
   if (n > FB_NEWTON_NT) FB_SETPRIO(3);              // the large systems are what a lock-step launch ends on: let them win issue arbitration (restored by the caller)
   const int ti = lane >> 2, tc = lane & 3;
   const int tir = min(ti, n - 1);                   // (rows beyond the system: clamped addresses, zero factors)
@@ -206,7 +209,6 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       y = o.fc0*q0 + o.fc1*q1 + o.fc2*q2;
     }
     real z = 0;
-#ifdef FB_NEWTON_KTILE
     if (tile) {
       // ---- K = I + F'AF in the tile layout, two passes over the block structure of F (column j of F = the three entries fc0..2 of lane j
       // at the rows base_j .. base_j + 2):  G = A F from three entries of AR per register, then K[i][j] = delta_ij + sum_a fc_a(i) G[base_i + a][j],
@@ -283,9 +285,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       const real zr = nw_lane(yv, 4*(lane & 15));
       z = (on && ((m_act >> lane) & 1ull)) ? zr : (real)0;
       NW_PROF(4);
-    } else
-#endif
-    {
+    } else {
       // ---- lane == row of K (lower triangle in LDS).  Only the non-zero columns of F take part: K is the identity in the others.
       // Row `lane` keeps its entries of the active columns left of it, compacted (entry p = the p-th active column), at K[tri_l + p].
       const int n_act = __popcll(m_act);
