@@ -6,20 +6,20 @@
 # would blur the per-launch averages these summaries are about.)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
 # wait split: in-flight instruction levels per memory class -- LEVEL / count = mean latency of that class in
 # cycles; LEVEL / WAVE_CYCLES = mean number of outstanding instructions of the class per wave-cycle
-rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq3 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq4 -o s -- python $R/bench.py --steps 10 --warmup 5 --preroll 0 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq3 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq4 -o s -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-split-leg --no-secondary-configs --no-parity-sample > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
 import csv, json, sys, os, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -31,8 +31,8 @@ def counters(path):
         for k, name in KER.items():
             if name in r['Kernel_Name']: acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     return acc
-def mean_tail(v, skip=6):                     # skip the reset launch and the warm-up launches
-    v = v[skip:] if len(v) > skip + 2 else v
+def mean_tail(v, last=10):                    # the timed launches: the last `--steps 10` of the pass (before them: reset, staggered pre-roll, warm-up)
+    v = v[-last:] if len(v) > last else v
     return sum(v)/max(len(v), 1)
 f = counters(os.path.join(out, 'pmc_fetch', 'f_counter_collection.csv'))
 w = counters(os.path.join(out, 'pmc_write', 'w_counter_collection.csv'))
@@ -42,7 +42,7 @@ s3 = counters(os.path.join(out, 'pmc_sq3', 's_counter_collection.csv'))
 s4 = counters(os.path.join(out, 'pmc_sq4', 's_counter_collection.csv'))
 stats = [r for r in csv.DictReader(open(os.path.join(out, 'trace', 'bench_kernel_stats.csv'))) if 'k_fly' in r['Name']]
 summary = {'tag': tag, 'kernel_stats': stats, 'per_kernel': {}}
-src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 10 --warmup 5`, mean over the steady-state '
+src = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 10 --warmup 5` (staggered pre-roll as in the default run), mean over the 10 timed '
        'launches of the kernel; FETCH_SIZE is NOT doubled here (raw counter values)')
 for k in KER:
     fk = mean_tail(f[k].get('FETCH_SIZE', [0])); wk = mean_tail(w[k].get('WRITE_SIZE', [0]))
