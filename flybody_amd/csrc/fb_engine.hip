@@ -498,7 +498,7 @@ __global__ void k_probe_xcc(unsigned* mask) { if (threadIdx.x == 0) atomicOr(mas
 
 
 template <typename real>
-__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES_PER_SIMD) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+__device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch<real>& B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
   // per-wave (per-environment) hot arrays
   constexpr int EPB = LdsCfg<real>::EPB;
   __shared__ real s_pool[EPB][LdsCfg<real>::POOL];          // [factor row | Delassus matrix | solve vector] of each environment
@@ -668,6 +668,18 @@ __global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES
     B.cost[env] = (int)(wall_clock64() - life0_);
 #endif
   }
+}
+
+// The kernels proper.  k_fly: control steps, forward passes and single stages.  k_fly_reset: the (partial) resets of fb_batch_reset under a
+// name of their own -- same device code with the mode folded in -- so that a kernel trace of k_fly holds control steps only (the staggered
+// pre-roll of bench.py resets 1/235 of the batch between any two steps: 236 short launches that used to be averaged into the step kernel).
+template <typename real>
+__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES_PER_SIMD) k_fly(const DevModel<real>* Mp, Batch<real> B, const float* action, const int* env_ids, int mode, int nsub, int nslot) {
+  fly_kernel<real>(Mp, B, action, env_ids, mode, nsub, nslot);
+}
+template <typename real>
+__global__ void __launch_bounds__(FB_WAVE*LdsCfg<real>::EPB, LdsCfg<real>::WAVES_PER_SIMD) k_fly_reset(const DevModel<real>* Mp, Batch<real> B, const int* env_ids, int nsub, int nslot) {
+  fly_kernel<real>(Mp, B, nullptr, env_ids, (int)MODE_RESET, nsub, nslot);
 }
 
 // Launch order for the next control step: environments sorted by the duration of their last step, longest first (counting
@@ -1164,11 +1176,13 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   if (b->precision == 64) {
     Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
                        tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (double*)b->park};
-    hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
+    if (mode == MODE_RESET) hipLaunchKernelGGL((k_fly_reset<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, ids, nsub, n);
+    else hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
     Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
                       tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (float*)b->park};
-    hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
+    if (mode == MODE_RESET) hipLaunchKernelGGL((k_fly_reset<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, ids, nsub, n);
+    else hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
   HIPCHK(hipGetLastError());
