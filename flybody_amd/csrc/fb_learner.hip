@@ -932,6 +932,119 @@ extern "C" int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, con
   return 0;
 }
 
+// ------------------------------------------------------------------ n-step adder (acme adders.NStepTransitionAdder semantics; flybody_amd/dmpo/replay.py)
+// One control step of E environments in two launches.  k_nstep_plan (one workgroup): advances the per-environment window length, writes
+// this step's reward / discount into the ring, and decides for every (emit, environment) -- emit 0 = the transition that ends at this
+// step, emits 1 .. n-1 = the shorter tails of an episode that just ended -- whether a transition is appended, where (rows are appended
+// in environment order, emit after emit: exclusive prefix sums over the workgroup), and its accumulated reward / discount and first ring
+// slot; it also advances the replay's head / size / inserted counters.  k_nstep_copy (one workgroup per environment): writes this step's
+// observation / action into the ring and copies the rows of the planned transitions.  The arithmetic keeps the operations and the order of the tensor formulation
+// (R + D*r without contraction into an FMA, (D*d)*gamma, D/gamma): both paths fill identical replays.
+#define FBL_NSTEP_MAX 8
+__global__ void __launch_bounds__(1024) k_nstep_plan(int E, int n, long long t, float gamma, long long cap, const float* __restrict__ reward, const float* __restrict__ discount,
+                                                     const unsigned char* __restrict__ first, const unsigned char* __restrict__ last, float* __restrict__ w_rew,
+                                                     float* __restrict__ w_disc, long long* __restrict__ w_len, long long* __restrict__ head, long long* __restrict__ size,
+                                                     long long* __restrict__ inserted, int* __restrict__ dest, float* __restrict__ Rout, float* __restrict__ Dout, int* __restrict__ start) {
+  __shared__ int s_scan[1024];
+  __shared__ long long s_base;
+  const int tid = threadIdx.x, slot = (int)(t % n);
+  for (int e = tid; e < E; e += 1024) { w_rew[(size_t)slot*E + e] = reward[e]; w_disc[(size_t)slot*E + e] = discount[e]; }
+  if (tid == 0) s_base = head[0];
+  __syncthreads();
+  long long total = 0;
+  for (int j = 0; j < n; j++) {
+    for (int e0 = 0; e0 < E; e0 += 1024) {
+      const int e = e0 + tid;
+      bool m = false; int len = 0;
+      if (e < E) {
+        const bool valid = !first[e];
+        long long wl = w_len[e];
+        if (j == 0) { wl = valid ? (wl + 1 < n ? wl + 1 : n) : 0; w_len[e] = wl; m = valid; len = (int)wl; }
+        else { m = valid && last[e] && wl > j; len = (int)wl - j; }
+      }
+      // exclusive prefix count over the chunk
+      s_scan[tid] = m ? 1 : 0;
+      __syncthreads();
+      for (int d = 1; d < 1024; d <<= 1) { int v = tid >= d ? s_scan[tid - d] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
+      const int incl = s_scan[tid], cnt = s_scan[1023];
+      if (e < E) {
+        int dst = -1; float R = 0.f, D = 1.f; int st = 0;
+        if (m) {
+          dst = (int)((s_base + (incl - 1)) % cap);
+          {
+#pragma clang fp contract(off)                     // (separate multiply and add, as the tensor formulation's two operations round)
+            for (int back = n - 1; back >= 0; back--) {
+              if (back < len) {
+                const int sb = (int)((t - back) % n);
+                const float p = D*w_rew[(size_t)sb*E + e];
+                R = R + p;
+                D = (D*w_disc[(size_t)sb*E + e])*gamma;
+              }
+            }
+            D = D/gamma;
+          }
+          st = (int)((t - (len > 1 ? len - 1 : 0)) % n);
+        }
+        dest[(size_t)j*E + e] = dst; Rout[(size_t)j*E + e] = R; Dout[(size_t)j*E + e] = D; start[(size_t)j*E + e] = st;
+      }
+      __syncthreads();
+      if (tid == 0) { s_base += cnt; }
+      total += cnt;
+      __syncthreads();
+    }
+  }
+  // window reset of the environments whose episode ended; counters
+  for (int e = tid; e < E; e += 1024) if (!first[e] && last[e]) w_len[e] = 0;
+  if (tid == 0) {
+    head[0] = s_base % cap;
+    long long sz = size[0] + total; size[0] = sz < cap ? sz : cap;
+    inserted[0] += total;
+  }
+}
+
+struct NstepCopyArgs {
+  int E, n, slot, obs_dim, act_dim;
+  const float *obs, *action, *next_obs; float *w_obs, *w_act;
+  const int* dest; const float *R, *D; const int* start;
+  float *r_obs, *r_act, *r_rew, *r_disc, *r_next;
+};
+__global__ void __launch_bounds__(256) k_nstep_copy(NstepCopyArgs a) {
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const float* o_in = a.obs + (size_t)e*a.obs_dim; const float* a_in = a.action + (size_t)e*a.act_dim; const float* nx = a.next_obs + (size_t)e*a.obs_dim;
+  for (int j = 0; j < a.n; j++) {
+    const int dst = a.dest[(size_t)j*a.E + e];
+    if (dst < 0) continue;
+    const int st = a.start[(size_t)j*a.E + e];
+    // the transition's first step: this step's own observation when the window holds one step, otherwise a row of the ring
+    const float* so = st == a.slot ? o_in : a.w_obs + ((size_t)st*a.E + e)*a.obs_dim;
+    const float* sa = st == a.slot ? a_in : a.w_act + ((size_t)st*a.E + e)*a.act_dim;
+    float* dob = a.r_obs + (size_t)dst*a.obs_dim; float* dnx = a.r_next + (size_t)dst*a.obs_dim; float* dac = a.r_act + (size_t)dst*a.act_dim;
+    for (int c = tid; c < a.obs_dim; c += 256) { dob[c] = so[c]; dnx[c] = nx[c]; }
+    for (int c = tid; c < a.act_dim; c += 256) dac[c] = sa[c];
+    if (tid == 0) { a.r_rew[dst] = a.R[(size_t)j*a.E + e]; a.r_disc[dst] = a.D[(size_t)j*a.E + e]; }
+  }
+  float* wo = a.w_obs + ((size_t)a.slot*a.E + e)*a.obs_dim; float* wa = a.w_act + ((size_t)a.slot*a.E + e)*a.act_dim;
+  for (int c = tid; c < a.obs_dim; c += 256) wo[c] = o_in[c];
+  for (int c = tid; c < a.act_dim; c += 256) wa[c] = a_in[c];
+}
+
+extern "C" int fbl_nstep_add(int E, int n, int64_t t, float gamma, int64_t capacity, int obs_dim, int act_dim, const float* obs, const float* action,
+                             const float* reward, const float* discount, const float* next_obs, const uint8_t* first, const uint8_t* last,
+                             float* w_obs, float* w_act, float* w_rew, float* w_disc, int64_t* w_len, int64_t* head, int64_t* size, int64_t* inserted,
+                             float* r_obs, float* r_act, float* r_rew, float* r_disc, float* r_next, int32_t* plan_i, float* plan_f, void* stream) {
+  if (E <= 0 || n <= 0 || n > FBL_NSTEP_MAX || t < 0 || capacity <= 0 || obs_dim <= 0 || act_dim <= 0 || !(gamma > 0.f)) return lfail("fbl_nstep_add: bad size");
+  if (!obs || !action || !reward || !discount || !next_obs || !first || !last || !w_obs || !w_act || !w_rew || !w_disc || !w_len || !head || !size || !inserted ||
+      !r_obs || !r_act || !r_rew || !r_disc || !r_next || !plan_i || !plan_f) return lfail("fbl_nstep_add: null argument");
+  if ((int64_t)E*n > capacity) return lfail("fbl_nstep_add: capacity below one control step of transitions");
+  int* dest = plan_i; int* start = plan_i + (size_t)n*E; float* R = plan_f; float* D = plan_f + (size_t)n*E;
+  hipLaunchKernelGGL(k_nstep_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, E, n, (long long)t, gamma, (long long)capacity, reward, discount, first, last, w_rew, w_disc,
+                     (long long*)w_len, (long long*)head, (long long*)size, (long long*)inserted, dest, R, D, start);
+  NstepCopyArgs a = {E, n, (int)(t % n), obs_dim, act_dim, obs, action, next_obs, w_obs, w_act, dest, R, D, start, r_obs, r_act, r_rew, r_disc, r_next};
+  hipLaunchKernelGGL(k_nstep_copy, dim3(E), dim3(256), 0, (hipStream_t)stream, a);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ replay sampling: uniform row index + gather of all fields
 struct GatherArgs { int narr; const float* src[8]; float* dst[8]; int width[8]; };
 __global__ void __launch_bounds__(256) k_replay_gather(const float* __restrict__ u, const long long* __restrict__ size, long long capacity, GatherArgs g) {

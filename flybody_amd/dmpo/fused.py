@@ -64,6 +64,7 @@ def lib():
         L.fbl_bias_elu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_elu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fbl_replay_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbl_nstep_add.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int64, C.c_int, C.c_int] + [C.c_void_p]*23
         L.fbl_sgemm_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fbl_gauss_head_bwd_std.argtypes = [C.c_void_p]*3 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
         _lib = L
@@ -476,6 +477,18 @@ def replay_gather(u, size, capacity, fields):
     src = (C.c_void_p*n)(*[f.data_ptr() for f in fields]); dst = (C.c_void_p*n)(*[o.data_ptr() for o in outs]); wid = (C.c_int32*n)(*widths)
     _check(lib().fbl_replay_gather(u.data_ptr(), size.data_ptr(), int(capacity), B, n, src, dst, wid, _stream()))
     return outs
+
+
+def nstep_add(rep, obs, action, reward, discount, next_obs, first, last):
+    """NStepReplay.add on the GPU (rep._t already counts this step): ring update, n-step accumulation, appends and counters in two launches."""
+    obs, action, next_obs, reward, discount = (_f32c(x) for x in (obs, action, next_obs, reward, discount))
+    first = first.contiguous(); last = last.contiguous()
+    assert first.dtype == torch.bool and last.dtype == torch.bool and obs.shape == (rep.n_env, rep.obs.shape[1]) and action.shape == (rep.n_env, rep.action.shape[1])
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _check(lib().fbl_nstep_add(rep.n_env, rep.n, int(rep._t), float(rep.gamma), int(rep.capacity), int(rep.obs.shape[1]), int(rep.action.shape[1]),
+                               p(obs), p(action), p(reward), p(discount), p(next_obs), p(first), p(last),
+                               p(rep.w_obs), p(rep.w_act), p(rep.w_rew), p(rep.w_disc), p(rep.w_len), p(rep._head), p(rep._size), p(rep._inserted),
+                               p(rep.obs), p(rep.action), p(rep.reward), p(rep.discount), p(rep.next_obs), p(rep._plan_i), p(rep._plan_f), _stream()))
 
 
 # ------------------------------------------------------------------ clipped Adam on one flat buffer

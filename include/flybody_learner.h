@@ -124,6 +124,17 @@ int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, const float* s
 int fbl_replay_gather(const float* u, const int64_t* size, int64_t capacity, int B, int narr, const float* const* src, float* const* dst,
                       const int32_t* width, void* stream);
 
+/* n-step transition adder (acme adders.NStepTransitionAdder as used by the reference's actors, agents/ray_distributed_dmpo.py:205-208;
+ * host mirror: flybody_amd/dmpo/replay.py NStepReplay.add): one control step of E environments appended to the device-resident replay in two
+ * launches.  t = control steps added INCLUDING this one (ring slot t mod n); first / last = dm_env step types of the reply (uint8);
+ * w_* = the ring of the last n steps ([n][E][dim] / [n][E]) and the per-environment window length (int64); head / size / inserted = the
+ * replay's device counters (int64[1]); r_* = the replay's fields ([capacity + E][dim]: rows are appended in environment order, emit after
+ * emit, exactly as the tensor formulation does); plan_i = int32[2 n E], plan_f = float[2 n E] scratch. */
+int fbl_nstep_add(int E, int n, int64_t t, float gamma, int64_t capacity, int obs_dim, int act_dim, const float* obs, const float* action,
+                  const float* reward, const float* discount, const float* next_obs, const uint8_t* first, const uint8_t* last,
+                  float* w_obs, float* w_act, float* w_rew, float* w_disc, int64_t* w_len, int64_t* head, int64_t* size, int64_t* inserted,
+                  float* r_obs, float* r_act, float* r_rew, float* r_disc, float* r_next, int32_t* plan_i, float* plan_f, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,39 @@ def test_replay_gather_kernel():
     assert idx.max() < n and len(set(idx.tolist())) > 0.9*n
 
 
+@pytest.mark.parametrize('n_env,cap', [(300, 4000), (2500, 30_000)])
+def test_nstep_adder_kernels_equal_the_tensor_formulation(n_env, cap):
+    """fbl_nstep_add (plan + copy kernels: the GPU path of NStepReplay.add) against the tensor formulation of the same adder on the CPU (the
+    definition, itself pinned to Acme's NStepTransitionAdder semantics by tests/test_dmpo.py): episodes of random length with the
+    dm_env order LAST -> FIRST, 40 control steps, a ring that wraps (more transitions than rows), several prefix-sum chunks (2500 > 1024
+    environments).  Every field of every row, the ring and the counters: bit-identical."""
+    from flybody_amd.dmpo import NStepReplay
+    rng = np.random.default_rng(3); no, na = 37, 5
+    G = NStepReplay(n_env, no, na, capacity=cap, n_step=5, discount=0.99, device='cuda')
+    Cc = NStepReplay(n_env, no, na, capacity=cap, n_step=5, discount=0.99, device='cpu')
+    remaining = rng.integers(1, 12, n_env); first = np.ones(n_env, bool)          # (the very first reply of an environment is a FIRST step)
+    obs = rng.standard_normal((n_env, no)).astype(np.float32)
+    for t in range(40):
+        act = rng.uniform(-1, 1, (n_env, na)).astype(np.float32); nxt = rng.standard_normal((n_env, no)).astype(np.float32)
+        rew = rng.uniform(0, 1, n_env).astype(np.float32)
+        last = ~first & (remaining <= 1)
+        disc = np.where(last & (rng.random(n_env) < 0.5), 0.0, 1.0).astype(np.float32)
+        for R, dev in ((G, 'cuda'), (Cc, 'cpu')):
+            R.add(*(torch.from_numpy(x).to(dev) for x in (obs, act, rew, disc, nxt, first, last)))
+        remaining = np.where(first | last, rng.integers(1, 12, n_env), remaining - 1)
+        first = last.copy()                       # dm_env: the step after LAST is the FIRST of the next episode
+        obs = nxt
+    torch.cuda.synchronize()
+    assert G.inserted == Cc.inserted > cap and G.size == Cc.size == cap and G.head == Cc.head
+    for f in ('obs', 'action', 'reward', 'discount', 'next_obs'):
+        assert torch.equal(getattr(G, f)[:cap].cpu(), getattr(Cc, f)[:cap]), f
+    for f in ('w_obs', 'w_act', 'w_rew', 'w_disc', 'w_len'):
+        assert torch.equal(getattr(G, f).cpu(), getattr(Cc, f)), f
+    # and what sampling sees afterwards is a row of the same table
+    o, a, r, d, n2 = G.sample(64)
+    assert o.shape == (64, no) and bool(torch.isfinite(o).all())
+
+
 def test_td_loss_bias_and_bias_gradient():
     """fbl_td_loss adds the logits layers' biases itself and returns d loss / d bias and the batch-mean loss (atomics)."""
     from flybody_amd.dmpo import fused
