@@ -171,6 +171,7 @@ class DMPOLearner:
                 self._ev_b = torch.cuda.Event(); self._ev_a = torch.cuda.Event(); self._ev_main = torch.cuda.Event()
                 self._ev_fork = torch.cuda.Event(); self._ev_c = torch.cuda.Event(); self._ev_p = torch.cuda.Event()
                 self._a_ready = False; self._cur = 0
+                self._pick_streams_by_measurement()
             elif capture:
                 self._graph_fb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_fb):
@@ -245,9 +246,50 @@ class DMPOLearner:
             torch.cuda.synchronize(self.device)
             if ev_c.elapsed_time(ev_main) > 0.5:          # the candidate finished (>= 0.5 ms) BEFORE the spin ended: it ran beside it
                 free.append(c)
+        self.independent_queues_found = len(free)         # (reported by tools/learner_bench.py and train_dmpo)
+        self._free_streams = list(free)
         while len(free) < want:                           # fewer independent queues than asked for: share (correct, only slower)
             free.append(free[len(free) % max(1, len(free))] if free else main)
         return free[:want]
+
+    def _pick_streams_by_measurement(self):
+        """Which of the independent streams carries which part of the pipeline is decided by the clock: being able to overtake a kernel
+        on the compute stream (the probe above) does not tell whether two of the CANDIDATES share a hardware queue with each other, or
+        with the communication stream / a stream the process opened earlier -- and the assignment depends on every stream the process
+        touched before (tools/learner_bench.py: 2 640 learner steps/s with the first three candidates, 3 990 with any other triple; the
+        training loop happened to get a good one).  Every rotation of the candidate list runs a short burst of real steps inside the
+        warm-up (rolled back with it: parameters, moments, targets, step counter); the fastest stays.  FB_LEARNER_QUEUE_OFFSET pins it."""
+        free = getattr(self, '_free_streams', [])
+        if len(free) < 2:
+            return
+        def assign(off):
+            rot = free[off:] + free[:off]
+            while len(rot) < 3: rot.append(rot[len(rot) % len(free)])
+            self._pipe_stream = rot[0]; self._br_streams = (rot[2], rot[1]); self._a_ready = False; self._cur = 0
+        pinned = os.environ.get('FB_LEARNER_QUEUE_OFFSET')
+        if pinned is not None:
+            assign(int(pinned) % len(free)); self.stream_rotation = int(pinned) % len(free); return
+        saved_t = [t.clone() for t in list(self.target.policy.state_dict().values()) + list(self.target.critic.state_dict().values())]
+        saved_steps = self.num_steps
+        rng = torch.cuda.get_rng_state(self.device)       # (the A graphs draw: the burst must not shift the random stream of the run)
+        main = torch.cuda.current_stream(self.device)
+        batch = None if self._sampler is not None else self._static
+        times = []
+        for off in range(len(free)):
+            assign(off)
+            for _ in range(4): self._step_pipelined(batch, True)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            for _ in range(24): self._step_pipelined(batch, True)
+            e1.record(main); torch.cuda.synchronize(self.device)
+            times.append(e0.elapsed_time(e1))
+        best = min(range(len(free)), key=lambda o: times[o])
+        assign(best); self.stream_rotation = best; self.stream_rotation_ms = [t/24 for t in times]
+        self.num_steps = saved_steps
+        torch.cuda.set_rng_state(rng, self.device)
+        with torch.no_grad():
+            for t, sv in zip(list(self.target.policy.state_dict().values()) + list(self.target.critic.state_dict().values()), saved_t):
+                t.copy_(sv)
 
     def _will_sync_targets(self, step_index: int) -> bool:
         return step_index % self.cfg.target_policy_update_period == 0 or step_index % self.cfg.target_critic_update_period == 0

@@ -214,7 +214,7 @@ def measure(tr: 'Trainer', warmup: int, iters: int):
             'envs_per_gpu': tr.env.n_env, 'learner_steps_per_env_step': (tr.learner_steps - l0) / max(1, iters), 'batch_size': tr.cfg.batch_size,
             'samples_per_insert': {'configured': tr.cfg.samples_per_insert if tr.lsteps_per is None else None, 'achieved': tr.limiter.achieved_samples_per_insert,
                                    'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
-            'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size,
+            'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'independent_queues_found': getattr(lr, 'independent_queues_found', None),
             'gradient_allreduce': ('none (single rank)' if tr.world == 1 else
                                    ('one flat buffer of %d floats per learner step over %s, %s' % (lr.flat_grad.numel(), dist.get_backend(),
                                     'overlapped with the next step\'s target-network forwards (side stream)' if lr._sets is not None else 'serial'))),

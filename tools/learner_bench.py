@@ -53,4 +53,5 @@ flop = 2*(a.batch*(nobs*256 + 256*256*2 + 256*2*nu)*4                           
 print(json.dumps({'metric': 'DMPO learner steps/sec (learner alone, synthetic replay)', 'value': a.steps/dt, 'ms_per_step': dt/a.steps*1e3,
                   'graphs': not a.no_graphs, 'batch': a.batch, 'num_samples': a.samples, 'gemm_gflop_per_step': flop/1e9,
                   'gemm_tflops': flop/(dt/a.steps)/1e12, 'replay_add_ms_4096_envs': t_add*1e3,
-                  'critic_loss': float(stats['critic_loss']), 'policy_loss': float(stats['policy_loss']), 'replay_size': rep.size}))
+                  'critic_loss': float(stats['critic_loss']), 'policy_loss': float(stats['policy_loss']), 'replay_size': rep.size, 'independent_queues_found': getattr(L, 'independent_queues_found', None), 'stream_rotation': getattr(L, 'stream_rotation', None),
+                  'stream_rotation_ms_per_step': getattr(L, 'stream_rotation_ms', None)}))
