@@ -321,13 +321,20 @@ def main():
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
                                                                  'ROLE_RANK', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT',
                                                                  'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE', 'TORCHELASTIC_ERROR_FILE')}
+        import signal
+        pr = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420, env=env)
+            so, se = pr.communicate(timeout=240)
         except subprocess.TimeoutExpired:
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)          # the job's own process group: launcher and ranks (nothing else lives in it)
+            except ProcessLookupError:
+                pass
+            pr.communicate()
             return {'error': 'timeout'}
-        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        line = [l for l in so.splitlines() if l.startswith('{')]
         if not line:
-            return {'error': r.stderr[-600:]}
+            return {'error': se[-600:]}
         o = json.loads(line[-1])
         keep = ('n_gpus', 'env_steps_per_sec', 'learner_steps_per_sec', 'envs_per_gpu', 'learner_steps_per_env_step', 'batch_size', 'samples_per_insert',
                 'gradient_allreduce', 'dtype', 'reward')
@@ -403,7 +410,7 @@ def main():
             if rank == 0:
                 store.set('fb_dmpo_leg_done', '1')
             else:
-                store.wait(['fb_dmpo_leg_done'], timedelta(seconds=480))
+                store.wait(['fb_dmpo_leg_done'], timedelta(seconds=300))
         barrier()
     parity = None
     if rank == 0 and args.precision == 64 and not args.no_parity_sample:
