@@ -109,6 +109,7 @@ class Trainer:
             self._ev_act.record(main)
             with torch.cuda.stream(self._env_stream):
                 self._env_stream.wait_event(self._ev_act)
+                real.record_stream(self._env_stream)                                # (allocated on the main stream, consumed on the physics stream)
                 v = self.env.step_tensor(real)
                 self._ev_phys.record(self._env_stream)
             stats = self._learn(learn)                                             # concurrent with the physics kernel
