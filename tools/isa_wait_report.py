@@ -6,14 +6,15 @@ scratch instructions.  Vector-memory returns are counted in order, so
   * `S L [0]`              makes the load wait for the store's acknowledgement,
   * scratch_* in a loop    is a local array with a runtime index (or a struct that contains one) living in memory.
 Round 3 used this next to tools/phase_profile.py to find the serialised prologue of the factorisation, the scratch-resident MPR
-portal and the per-level table lookups.  Usage: python tools/isa_wait_report.py [precision: d|f] [name filter]"""
+portal and the per-level table lookups.  Usage: python tools/isa_wait_report.py [precision: d|f] [name filter] [-Dflags...]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 prec = sys.argv[1] if len(sys.argv) > 1 else 'd'
-flt = sys.argv[2] if len(sys.argv) > 2 else ''
+flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else ''
+flags = [a for a in sys.argv[2:] if a.startswith('-')]        # extra hipcc flags, e.g. -DFB_F64_DENSE=1
 out = os.path.join(tempfile.gettempdir(), 'fb_engine_isa.s')
 subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
-                       '-o', out, os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')], stderr=subprocess.DEVNULL)
+                       '-o', out] + flags + [os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')], stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
 heads = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r'^(_Z\w+):', l)] if m]
 tag = 'I%sE' % prec
@@ -30,10 +31,7 @@ for a, name in heads:
         elif x.startswith('scratch_store'): seq.append('s')
         elif x.startswith('s_waitcnt') and 'vmcnt' in x: seq.append('[%s]' % re.search(r'vmcnt\((\d+)\)', x).group(1))
     s = ''.join(seq)
-    try:
-        pretty = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True).stdout.strip().split('(')[0]
-    except Exception:
-        pretty = name
+    pretty = re.split(r'I[df]E', re.sub(r'^_Z\d+', '', name))[0]
     print(f'== {pretty}: {len(body)} instructions, {s.count("L")} loads, {s.count("S")} stores, {s.count("[0]")} full waits, '
           f'{s.count("l") + s.count("s")} scratch ops')
     print('   ' + s)
