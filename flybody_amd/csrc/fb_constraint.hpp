@@ -76,7 +76,8 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       real K, B, imp;
       kbi(M, M.jnt_solref + 2*j, M.jnt_solimp + 5*j, dist, M.jnt_margin[j], false, K, B, imp);
       w.efc_K()[r] = K; w.efc_B()[r] = B; w.efc_imp()[r] = imp; w.efc_mu()[r] = 0;
-      w.efc_R()[r] = fmax(FB_MINV, (1 - imp)*M.dof_invweight0[dof]/imp);
+      const real Rl = fmax(FB_MINV, (1 - imp)*M.dof_invweight0[dof]/imp);
+      w.efc_R()[r] = Rl; w.efc_D()[r] = (real)1 / Rl;
     }
     nlimit += wave_sum_i(has);
   }
@@ -117,7 +118,8 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       w.efc_lA()[r] = M.body_chlen[b1]; w.efc_lB()[r] = M.body_chlen[b2];
       w.efc_pos()[r] = dist; w.efc_margin()[r] = incl;
       w.efc_K()[r] = (k == 0) ? K : (real)0; w.efc_B()[r] = B; w.efc_imp()[r] = imp;
-      w.efc_R()[r] = (k == 0) ? R0 : (k == 1 ? R1 : R2);
+      const real Rk = (k == 0) ? R0 : (k == 1 ? R1 : R2);
+      w.efc_R()[r] = Rk; w.efc_D()[r] = (real)1 / Rk;          // (1 / R here, not in a pass of its own behind a fence: one global round trip less)
       w.efc_mu()[r] = mu;
     }
   }
@@ -158,7 +160,6 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   }
   if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
   SYNC();
-  for (int r = lane; r < nefc; r += FB_WAVE) w.efc_D()[r] = (real)1 / w.efc_R()[r];
 }
 
 // the Delassus matrix is symmetric: packed lower triangle, element (r, c), r >= c, at r(r+1)/2 + c
@@ -347,80 +348,121 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M_, const WS<real>& w_, ARP AR,
 }
 
 // ------------------------------------------------------------------ adhesion + actuator forces
+// First stage of a substep, i.e. of a substep TICKET: nothing is in LDS, every input comes from the environment's global row, and the
+// stage is a handful of instructions behind a chain of memory round trips (round 4: 0.4 k vector instructions, 40 k cycles, 82 % of them
+// waiting).  So the loads are issued in as few dependent rounds as the data allows: round 1 = everything addressed by lane alone
+// (controls, contact list, the motion axes of the lane's two dofs -- staged into the free factor-row slot of the LDS pool, where the
+// adhesion loop reads them like the constraint rows do), round 2 = what round 1's indices address; the forces are accumulated in LDS
+// (the solve vector, free until the smooth right-hand side is formed from it) and stored to the global row once, behind the last use.
 template <typename real>
 __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator()[i] = 0;
-  SYNC();
+  FB_LDS real* qf = w.lx;                     // qfrc_actuator while it is being assembled (ST_ACC_PRE reads it from here)
+  FB_LDS real* Lc = w.lLD;                    // [6 nv] motion axes (cdof), re-staged for the adhesion moment arms
+  for (int i = lane; i < M.nv; i += FB_WAVE) qf[i] = 0;
+  SYNC_LDS();                                 // (the zeroes before the transmissions' stores below; no memory operation is in flight yet)
+  // ---- round 1: contact list and motion axes into registers (independent of the actuator loop below, whose own first loads join them)
+  // (not predicated on the contact count: a branch on it would wait for that load before the others are even issued; the contact
+  // arrays hold FB_MAXCON_ = one entry per lane, what the lanes beyond the count read is never used)
+  const int ncon_l = w.istate()[IS_NCON];
+  int cb1 = 0, cb2 = 0, cp = 0;
+  real coff[3] = {0, 0, 0}, cnrm[3] = {0, 0, 0};
+  constexpr int NCD = (6*FB_MAXNV + FB_WAVE - 1)/FB_WAVE;
+  real cdr[NCD];
+  if (M.nadh > 0) {
+    cp = w.con_pair()[lane];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { coff[k] = w.con_pos()[3*lane + k]; cnrm[k] = w.con_frame()[9*lane + k]; }
+#pragma unroll
+    for (int j = 0; j < NCD; j++) { const int i = lane + FB_WAVE*j; cdr[j] = i < 6*M.nv ? w.cdof()[i] : (real)0; }
+  }
   for (int i = lane; i < M.nu; i += FB_WAVE) {
-    real ctrl = w.ctrl()[i];
-    if (M.act_ctrllimited[i]) ctrl = clampr(ctrl, M.act_ctrlrange[2*i], M.act_ctrlrange[2*i+1]);
-    real input = ctrl;
-    int aa = M.act_actadr[i];
-    if (aa >= 0) {
-      w.act_dot()[aa] = (ctrl - w.act()[aa]) / fmax(FB_MINV, M.act_dynprm[i]);
-      input = w.act()[aa];
-    }
-    // flattened transmission record (fb_engine.hip): every dof / moment arm with one round of independent loads
-    int tt = M.act_trntype[i], wn = M.act_wn[i], la = M.act_lenadr[i];
+    // the actuator's record first -- model tables, addressed by the lane alone: ONE round of loads next to the ones above --, then
+    // what the record addresses in the environment's row (activation, joint velocities, length): a second round, then arithmetic
+    const int limited = M.act_ctrllimited[i], aa = M.act_actadr[i], tt = M.act_trntype[i], wn = M.act_wn[i], la = M.act_lenadr[i];
+    const int biastype = M.act_biastype[i], flimited = M.act_forcelimited[i];
+    const real c_lo = M.act_ctrlrange[2*i], c_hi = M.act_ctrlrange[2*i+1], dyn = M.act_dynprm[i], gain = M.act_gainprm[3*i];
+    const real b0 = M.act_biasprm[3*i], b1 = M.act_biasprm[3*i+1], b2 = M.act_biasprm[3*i+2], f_lo = M.act_forcerange[2*i], f_hi = M.act_forcerange[2*i+1];
     int wd[FB_MAXWRAP]; real wc[FB_MAXWRAP], qv[FB_MAXWRAP];
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) { wd[k] = M.act_wdof[FB_MAXWRAP*i + k]; wc[k] = M.act_wcoef[FB_MAXWRAP*i + k]; }
+    real ctrl = w.ctrl()[i];
+    // round 2 (flattened transmission record, fb_engine.hip: every dof / moment arm with independent loads)
+    const real actv = w.act()[aa >= 0 ? aa : 0];
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) qv[k] = w.qvel()[wd[k]];
-    real lq = w.qpos()[tt == TRN_JOINT ? la : 0];
+    const real lq = w.qpos()[tt == TRN_JOINT ? la : 0];
+    const real lt = w.ten_length()[tt == TRN_TENDON ? la : 0];
+    if (limited) ctrl = clampr(ctrl, c_lo, c_hi);
+    real input = ctrl;
+    if (aa >= 0) {
+      w.act_dot()[aa] = (ctrl - actv) / fmax(FB_MINV, dyn);
+      input = actv;
+    }
     real length = 0, vel = 0;
     if (tt == TRN_JOINT) length = lq;
-    else if (tt == TRN_TENDON) length = w.ten_length()[la];
+    else if (tt == TRN_TENDON) length = lt;
 #pragma unroll
     for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) vel += wc[k]*qv[k];
-    real force = M.act_gainprm[3*i]*input;
-    if (M.act_biastype[i] == 1) force += M.act_biasprm[3*i] + M.act_biasprm[3*i+1]*length + M.act_biasprm[3*i+2]*vel;
-    if (M.act_forcelimited[i]) force = clampr(force, M.act_forcerange[2*i], M.act_forcerange[2*i+1]);
+    real force = gain*input;
+    if (biastype == 1) force += b0 + b1*length + b2*vel;
+    if (flimited) force = clampr(force, f_lo, f_hi);
     w.act_force()[i] = force;
     // joint / tendon transmissions own their dofs (checked at model load): plain stores over the zeroed array
 #pragma unroll
-    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) w.qfrc_actuator()[wd[k]] = wc[k]*force;
+    for (int k = 0; k < FB_MAXWRAP; k++) if (k < wn) qf[wd[k]] = wc[k]*force;
   }
-  SYNC();
-  // adhesion (body transmission): pull along the mean contact normal of the body's contacts.
-  // lane == contact holds the two bodies, lane == adhesion actuator holds (body, force); both are broadcast by readlane.
-  int ncon = w.istate()[IS_NCON];
-  int cb1 = 0, cb2 = 0;
-  if (lane < ncon) {
-    int p = w.con_pair()[lane];
-    { const int pb = M.pair_body[p]; cb1 = pb & 0xffff; cb2 = pb >> 16; }
+  const int ncon = uniform_int(ncon_l);
+  const bool adh = M.nadh > 0 && ncon > 0;
+  if (adh) {
+#pragma unroll
+    for (int j = 0; j < NCD; j++) { const int i = lane + FB_WAVE*j; if (i < 6*M.nv) Lc[i] = cdr[j]; }
   }
-  int aid = -1; real aforce = 0;
-  if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force()[ai]; }
-  for (int a = 0; a < M.nadh; a++) {
-    int id = rdlane(aid, a);
-    real force = rdlane(aforce, a);
-    bool mine = lane < ncon && (cb1 == id || cb2 == id);
-    unsigned long long bal = __ballot(mine);
-    int cnt = __popcll(bal);
-    if (cnt == 0 || force == 0) continue;
-    real scale = -force / (real)cnt;
-    while (bal) {
-      int c = __ffsll((long long)bal) - 1;
-      bal &= bal - 1;
-      int b1c = rdlane(cb1, c), b2c = rdlane(cb2, c);
-      real off[3]; sub3(off, w.con_pos() + 3*c, w.com());
-      const real* nrm = w.con_frame() + 9*c;
-      // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
-      for (int side = 0; side < 2; side++) {
-        int body = side ? b2c : b1c;
-        if (body <= 0) continue;
-        if (lane < M.body_chlen[body]) {
-          int dof = M.body_chain[body*FB_MAXCH + lane];
-          const real* cd = w.cdof() + 6*dof;
-          real t[3]; cross3(t, cd, off);
-          real jp[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-          w.qfrc_actuator()[dof] += (side ? scale : -scale)*dot3(nrm, jp);
+  SYNC();                                     // act_force is read across lanes below; qf and Lc across lanes in the adhesion loop
+  if (adh) {
+    // adhesion (body transmission): pull along the mean contact normal of the body's contacts.
+    // lane == contact holds the two bodies, the offset from the centre of mass and the normal; lane == adhesion actuator holds
+    // (body, force); everything is broadcast by v_readlane, the only memory inside the loop is the chain table and LDS.
+    if (lane < ncon) {
+      const int pb = M.pair_body[cp]; cb1 = pb & 0xffff; cb2 = pb >> 16;
+#pragma unroll
+      for (int k = 0; k < 3; k++) coff[k] -= w.com()[k];
+    }
+    int aid = -1; real aforce = 0;
+    if (lane < M.nadh) { int ai = M.adh_act[lane]; aid = M.act_trnid[ai]; aforce = w.act_force()[ai]; }
+    for (int a = 0; a < M.nadh; a++) {
+      int id = rdlane(aid, a);
+      real force = rdlane(aforce, a);
+      bool mine = lane < ncon && (cb1 == id || cb2 == id);
+      unsigned long long bal = __ballot(mine);
+      int cnt = __popcll(bal);
+      if (cnt == 0 || force == 0) continue;
+      real scale = -force / (real)cnt;
+      while (bal) {
+        int c = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        int b1c = rdlane(cb1, c), b2c = rdlane(cb2, c);
+        const real off[3] = {rdlane(coff[0], c), rdlane(coff[1], c), rdlane(coff[2], c)};
+        const real nrm[3] = {rdlane(cnrm[0], c), rdlane(cnrm[1], c), rdlane(cnrm[2], c)};
+        // lane == chain slot; a dof is only ever touched by the lane of its own depth, so no conflicts.
+        for (int side = 0; side < 2; side++) {
+          int body = side ? b2c : b1c;
+          if (body <= 0) continue;
+          if (lane < M.body_chlen[body]) {
+            int dof = M.body_chain[body*FB_MAXCH + lane];
+            const FB_LDS real* cdp = Lc + 6*dof;
+            real cd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cd[k] = cdp[k];
+            real t[3]; cross3(t, cd, off);
+            real jp[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+            qf[dof] += (side ? scale : -scale)*dot3(nrm, jp);
+          }
         }
       }
     }
+    SYNC_LDS();
   }
-  SYNC();
+  for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator()[i] = qf[i];
 }
 
 // ------------------------------------------------------------------ QCQP for the 2 friction dims

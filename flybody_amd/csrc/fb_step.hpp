@@ -835,9 +835,9 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
     switch (pc) {
       case ST_ACT: {
         PROF_BEGIN();
-        if (actuate) s_actuation(M, wc, lane);
+        if (actuate) s_actuation(M, wc, lane);      // (leaves qfrc_actuator in the solve vector lx as well as in the global row)
         else {
-          for (int i = lane; i < M.nv; i += FB_WAVE) w.qfrc_actuator()[i] = 0;
+          for (int i = lane; i < M.nv; i += FB_WAVE) { w.qfrc_actuator()[i] = 0; w.lx[i] = 0; }
           for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot()[i] = 0;
           SYNC();
         }
@@ -850,7 +850,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         // boundary any more (the factor and the Delassus matrix used to be parked in the global row between control steps).
         PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) {
-          real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.qfrc_actuator()[i];
+          real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.lx[i];          // lx = qfrc_actuator (assembled there by ST_ACT)
           w.qfrc_smooth()[i] = f; w.lx[i] = f;
         }
         SYNC();
