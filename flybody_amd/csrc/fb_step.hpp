@@ -62,6 +62,7 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
   // wrench of each active contact about the tree CoM, in the lane that owns the contact (at most 64 contacts)
   int cb1 = -1, cb2 = -1;
   real cw[6] = {0, 0, 0, 0, 0, 0}, cfn = 0;
+  real cnr[3] = {0, 0, 0}, cps[3] = {0, 0, 0};            // the lane's contact normal and position (the touch sensors read them by v_readlane)
   {
     // two rounds of loads: everything indexed by the contact (= lane), then what hangs off its pair id and row address
     const bool cv = lane < ncon; const int cs = cv ? lane : 0;
@@ -71,6 +72,8 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     for (int k = 0; k < 9; k++) fr[k] = w.con_frame()[9*cs + k];
 #pragma unroll
     for (int k = 0; k < 3; k++) { cp[k] = w.con_pos()[3*cs + k]; cm[k] = w.com()[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cnr[k] = fr[k]; cps[k] = cp[k]; }
     const bool act = cv && adr >= 0;
     const int a0 = act ? adr : 0, ps = act ? p : 0;
     const int pb = M.pair_body[ps];
@@ -156,11 +159,12 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
       const int n = fs ? M.body_nsub[bf] : 0;
       int first = 0, nmax = 0;                                    // lane of the sensor body inside the sensor-body list; longest subtree
       for (int q = 0; q < M.nforce; q++) {
-        const int bq = M.site_bodyid[M.force_sites[q]];
+        // (sensor q's body and subtree size sit in lane 8 + q: two v_readlane instead of three dependent table loads per sensor)
+        const int bq = rdlane(bf, 8 + q);
         const unsigned long long mq = __ballot(b == bq);
         const int lq = mq ? __ffsll((long long)mq) - 1 : 0;
         if (kf == q) first = lq;
-        const int nq = M.body_nsub[bq];
+        const int nq = rdlane(n, 8 + q);
         nmax = nq > nmax ? nq : nmax;
       }
       real acc[3] = {0, 0, 0};
@@ -234,15 +238,24 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     bool on = lane >= 16 && lane < 16 + M.ntouch;
     int k = lane - 16;
     int s = on ? M.touch_sites[k] : 0, b = on ? M.site_bodyid[s] : -2;
+    // the site's pose and shape once, in one round of loads; the contacts' normals and positions come from the lanes that own them
+    // (rounds 1-3 re-read both from the global row inside the loop: two dependent round trips per contact)
+    real tpos[3], tmat[9], tsize[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { tpos[q] = w.sxpos()[3*s + q]; tsize[q] = M.site_size[3*s + q]; }
+#pragma unroll
+    for (int q = 0; q < 9; q++) tmat[q] = w.sxmat()[9*s + q];
+    const int ttype = M.site_type[s];
     real sum = 0;
     for (int c = 0; c < ncon; c++) {
       int rb1 = rdlane(cb1, c), rb2 = rdlane(cb2, c);
       real fn = rdlane(cfn, c);
       if (rb1 < 0 || fn <= 0) continue;
+      real ray[3] = {rdlane(cnr[0], c), rdlane(cnr[1], c), rdlane(cnr[2], c)};
+      const real pnt[3] = {rdlane(cps[0], c), rdlane(cps[1], c), rdlane(cps[2], c)};
       if (b != rb1 && b != rb2) continue;
-      real ray[3]; copy3(ray, w.con_frame() + 9*c);
       if (b == rb2) scl3(ray, ray, (real)-1);
-      if (ray_site(w.sxpos() + 3*s, w.sxmat() + 9*s, M.site_size + 3*s, M.site_type[s], w.con_pos() + 3*c, ray) >= 0) sum += fn;
+      if (ray_site(tpos, tmat, tsize, ttype, pnt, ray) >= 0) sum += fn;
     }
     if (on) w.sens()[9 + 3*M.nforce + k] = sum;
   }
