@@ -84,9 +84,16 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   // ---- contacts: lane == contact
   int ncon = w.istate()[IS_NCON];
   int dim = 0, p = 0; real dist = 0, incl = 0;
+  // the lane's contact: offset of its position from the tree CoM and its frame, for the Jacobian loop below (which used to fetch both
+  // from the global row once per pass of the wave: a dependent round trip per 64 (contact, side, slot) items)
+  real coff[3] = {0, 0, 0}, cfr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (lane < ncon) {
     p = w.con_pair()[lane];
     dist = w.con_dist()[lane];
+#pragma unroll
+    for (int k = 0; k < 3; k++) coff[k] = w.con_pos()[3*lane + k] - w.com()[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cfr[k] = w.con_frame()[9*lane + k];
     incl = M.pair_margin[p] - M.pair_gap[p];
     if (dist < incl) dim = (M.pair_condim[p] == 1) ? 1 : 3;
   }
@@ -135,20 +142,20 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       const int cdim = __shfl(dim, c, 64), cadr = __shfl(adr, c, 64);
       const int sb1 = __shfl(cb1, c, 64), sb2 = __shfl(cb2, c, 64);          // (both shuffles by every lane: they are wave collectives)
       const int body = side ? sb2 : sb1;
+      real off[3], fr[9];                                                   // (wave collectives as well)
+#pragma unroll
+      for (int k = 0; k < 3; k++) off[k] = __shfl(coff[k], c, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) fr[k] = __shfl(cfr[k], c, 64);
       // (slots beyond the body's chain are never read: a floor contact's world side -- chain length 0 -- used to cost 20 zero stores per row)
       if (t < nitem && cdim && sl < M.body_chlen[body]) {
         const int len = M.body_chlen[body];
         const int dof = M.body_chain[body*FB_MAXCH + sl];
         real jp[3] = {0, 0, 0};
-        const real* pos = w.con_pos() + 3*c;
-        const real* frame = w.con_frame() + 9*c;
         const FB_LDS real* cp = w.lLD + 6*((sl < len) ? dof : 0);          // motion axes: the inertia stage's LDS mirror (same substep)
-        real cd[6], off[3], fr[9];
+        real cd[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) cd[k] = cp[k];
-#pragma unroll
-        for (int k = 0; k < 9; k++) fr[k] = frame[k];
-        sub3(off, pos, w.com());
         if (sl < len) {
           real tt[3]; cross3(tt, cd, off);
           jp[0] = cd[3] + tt[0]; jp[1] = cd[4] + tt[1]; jp[2] = cd[5] + tt[2];
