@@ -355,6 +355,13 @@ class _Linear(torch.autograd.Function):
             _check(lib().fbl_bias_elu_bwd(dy.data_ptr(), y.data_ptr(), M, N, dz.data_ptr(), db.data_ptr(), _stream()))
         else:
             dz = dy
+        if M == N and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # batch = layer width (the 256-wide layers at B = 256): d x [M, K] = d z W and d W [N, K] = d z^T x have the SAME shape and
+            # reduction length -- one launch with the two products side by side in the grid instead of two launches one after the other
+            dx = torch.empty(M, K, device=dy.device); dw = torch.empty(N, K, device=dy.device)
+            o0 = _op(dz, N, 1, w, K, 1, dx); o1 = _op(dz, 1, N, x, K, 1, dw)
+            _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, K, M, K, N, _stream()))
+            return dx, dw, db, None
         dx = _sgemm(dz, N, 1, w, K, 1, M, K, N) if ctx.needs_input_grad[0] else None          # [M, K] = d z [M, N] W [N, K]
         dw = _sgemm(dz, 1, N, x, K, 1, N, K, M) if ctx.needs_input_grad[1] else None          # [N, K] = d z^T [N, M] x [M, K]
         return dx, dw, db, None
