@@ -802,6 +802,8 @@ static int upload_i(fb_batch* b, const int* src, size_t n, P* dst) {
   void* p;
   HIPCHK(hipMalloc(&p, (n ? n : 1)*sizeof(int)));
   if (n) HIPCHK(hipMemcpy(p, src, n*sizeof(int), hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(p, 0, sizeof(int)));        // an EMPTY table keeps one ZERO entry: the kernels read entry 0 of a table unpredicated in places
+                                                    // (flight_imitation has no force sensors: a garbage site id from here indexed site_bodyid wildly)
   b->allocs.push_back(p);
   *dst = (const int*)p;
   return 0;

@@ -155,7 +155,7 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
     {
       const bool fs = lane >= 8 && lane < 8 + M.nforce;
       const int kf = fs ? lane - 8 : 0;
-      const int s = M.force_sites[kf], bf = M.site_bodyid[s];
+      const int s = fs ? M.force_sites[kf] : 0, bf = M.site_bodyid[s];
       const int n = fs ? M.body_nsub[bf] : 0;
       int first = 0, nmax = 0;                                    // lane of the sensor body inside the sensor-body list; longest subtree
       for (int q = 0; q < M.nforce; q++) {

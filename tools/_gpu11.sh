@@ -1,4 +1,4 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_learner.py -m gpu -x -q 2>&1 | grep -v "^$" | tail -3
-timeout 200 python tools/learner_bench.py --steps 1000 2>&1 | tail -1 | cut -c60-110,400-
-timeout 300 python -m flybody_amd.train_dmpo --envs 4096 --warmup 4 --iters 12 --min-replay 8192 --precision 32 2>&1 | tail -1 | cut -c80-200
+O=gpurun_out/r4x; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/full.txt 2>&1; echo "full rc=$?"; grep -v '^Extension' $O/full.txt | tail -3
+timeout 600 python -m pytest tests/test_gpu_fly_envs.py -m gpu -q -x > $O/fly2.txt 2>&1; echo "fly rc=$?"; tail -2 $O/fly2.txt
