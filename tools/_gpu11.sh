@@ -1,4 +1,2 @@
 #!/bin/bash
-O=gpurun_out/r4x; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x > $O/full.txt 2>&1; echo "full rc=$?"; grep -v '^Extension' $O/full.txt | tail -3
-timeout 600 python -m pytest tests/test_gpu_fly_envs.py -m gpu -q -x > $O/fly2.txt 2>&1; echo "fly rc=$?"; tail -2 $O/fly2.txt
+timeout 900 bash tools/collect_stage_profile.sh final --dense > gpurun_out/final_stage.log 2>&1; tail -4 gpurun_out/stage_final/stage_lanes.txt | cut -c1-150
