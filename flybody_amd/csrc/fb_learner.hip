@@ -932,6 +932,116 @@ extern "C" int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, con
   return 0;
 }
 
+// ------------------------------------------------------------------ policy network behind its first layer, one launch
+// The 256-wide part of the policy MLP (network_factory.py:66-109 with the reference's layer sizes (256, 256, 256): ELU layers 2 and 3
+// and MultivariateNormalDiagHead) as ONE kernel: h2 = ELU(h1 W2' + b2), h3 = ELU(h2 W3' + b3), mean = h3 Wm' + bm,
+// stddev = softplus(h3 Ws' + bs) mul + min.  A workgroup owns 16 rows of the batch from the first layer to the heads: the activations
+// stay in LDS (two 16 x 256 buffers), the weights stream from the L2 (a layer's 256 KB per workgroup), the products run on
+// v_mfma_f32_16x16x4_f32 (exact f32).  Per wave and layer: 64 output columns = four 16 x 16 tiles, K in blocks of 16 -- one float4 of
+// the activations from LDS and four float4 of the weights feed 16 MFMAs.  16 rows per workgroup, not 32: a 256-row learner batch then
+// fills 16 CUs for ~3.4 us per layer, and four launches with their gaps become one (the actors' 4096-row batch fills all 256 CUs).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define PT_ROWS 16
+#define PT_W 256
+#define PT_LD (PT_W + 4)                      // LDS row stride: the four k-slices of a 16-row fragment land in different banks
+__device__ __forceinline__ void pt_layer(const float (*in)[PT_LD], float (*out)[PT_LD], const float* __restrict__ W, const float* __restrict__ b,
+                                         float* __restrict__ gout, int row0, int M, int wave, int r, int s) {
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int cb = wave*64;
+  const float* wp = W + (size_t)(cb + r)*PT_W + 4*s;                 // B fragment: column = lane % 16 of the tile, k = 16 kb + 4 s + j
+#pragma unroll 4
+  for (int kb = 0; kb < PT_W/16; kb++) {
+    const float4 a4 = *reinterpret_cast<const float4*>(&in[r][16*kb + 4*s]);
+    float4 b4[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) b4[ct] = *reinterpret_cast<const float4*>(wp + (size_t)16*ct*PT_W + 16*kb);
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[ct].x, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[ct].y, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[ct].z, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[ct].w, acc[ct], 0, 0, 0);
+    }
+  }
+  // D[i][j]: lane l holds column j = l % 16, rows i = 4 (l / 16) + q
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    const int col = cb + 16*ct + r; const float bias = b[col];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = 4*s + q;
+      float y = acc[ct][q] + bias;
+      y = y > 0.f ? y : expm1f(y);
+      out[row][col] = y;
+      if (gout && row0 + row < M) gout[(size_t)(row0 + row)*PT_W + col] = y;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_policy_tail(const float* __restrict__ h1, int M, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ wm,
+                                                     const float* __restrict__ bm, const float* __restrict__ ws, const float* __restrict__ bs, int D,
+                                                     float mul, float min_scale, float* __restrict__ h2, float* __restrict__ h3,
+                                                     float* __restrict__ mean, float* __restrict__ std_) {
+  __shared__ float act[2][PT_ROWS][PT_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, s = lane >> 4, row0 = blockIdx.x*PT_ROWS;
+  for (int i = tid; i < PT_ROWS*PT_W/4; i += 256) {                  // the 16 x 256 input tile (rows past the batch: a valid row, never stored)
+    const int row = i/(PT_W/4), c4 = i % (PT_W/4), gr = min(row0 + row, M - 1);
+    const float4 v = *reinterpret_cast<const float4*>(h1 + (size_t)gr*PT_W + 4*c4);
+    *reinterpret_cast<float4*>(&act[0][row][4*c4]) = v;
+  }
+  __syncthreads();
+  pt_layer(act[0], act[1], w2, b2, h2, row0, M, wave, r, s);
+  __syncthreads();
+  pt_layer(act[1], act[0], w3, b3, h3, row0, M, wave, r, s);
+  __syncthreads();
+  // heads: 2 x 64 (padded) columns = 8 tiles, two per wave: tile t -> head t / 4, columns 16 (t % 4) + r
+  f32x4 acc[2];
+  const float* wp[2]; int colh[2], head[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int t = 2*wave + u; head[u] = t >> 2; colh[u] = 16*(t & 3) + r;
+    const float* W = head[u] ? ws : wm;
+    wp[u] = W + (size_t)min(colh[u], D - 1)*PT_W + 4*s;
+    acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 4
+  for (int kb = 0; kb < PT_W/16; kb++) {
+    const float4 a4 = *reinterpret_cast<const float4*>(&act[0][r][16*kb + 4*s]);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float4 b4 = *reinterpret_cast<const float4*>(wp[u] + 16*kb);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[u], 0, 0, 0);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[u], 0, 0, 0);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[u], 0, 0, 0);
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[u], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    if (colh[u] >= D) continue;
+    const float bias = head[u] ? bs[colh[u]] : bm[colh[u]];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = row0 + 4*s + q;
+      if (row >= M) continue;
+      const float z = acc[u][q] + bias;
+      if (head[u]) std_[(size_t)row*D + colh[u]] = softplus_f(z)*mul + min_scale;
+      else mean[(size_t)row*D + colh[u]] = z;
+    }
+  }
+}
+extern "C" int fbl_policy_tail(const float* h1, int M, int H, const float* w2, const float* b2, const float* w3, const float* b3, const float* wm, const float* bm,
+                               const float* ws, const float* bs, int D, float mul, float min_scale, float* h2, float* h3, float* mean, float* std_, void* stream) {
+  if (!h1 || !w2 || !b2 || !w3 || !b3 || !wm || !bm || !ws || !bs || !mean || !std_) return lfail("fbl_policy_tail: null argument");
+  if (M <= 0 || H != PT_W || D <= 0 || D > 64 || !(mul > 0.f)) return lfail("fbl_policy_tail: hidden width must be 256, action dimension <= 64");
+  hipLaunchKernelGGL(k_policy_tail, dim3((M + PT_ROWS - 1)/PT_ROWS), dim3(256), 0, (hipStream_t)stream, h1, M, w2, b2, w3, b3, wm, bm, ws, bs, D, mul, min_scale,
+                     h2, h3, mean, std_);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------ n-step adder (acme adders.NStepTransitionAdder semantics; flybody_amd/dmpo/replay.py)
 // One control step of E environments in two launches.  k_nstep_plan (one workgroup): advances the per-environment window length, writes
 // this step's reward / discount into the ring, and decides for every (emit, environment) -- emit 0 = the transition that ends at this

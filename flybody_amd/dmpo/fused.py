@@ -64,6 +64,7 @@ def lib():
         L.fbl_bias_elu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_bias_elu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fbl_replay_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fbl_policy_tail.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p]*8 + [C.c_int, C.c_float, C.c_float] + [C.c_void_p]*5
         L.fbl_nstep_add.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int64, C.c_int, C.c_int] + [C.c_void_p]*23
         L.fbl_sgemm_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fbl_gauss_head_bwd_std.argtypes = [C.c_void_p]*3 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
@@ -484,6 +485,74 @@ def replay_gather(u, size, capacity, fields):
     src = (C.c_void_p*n)(*[f.data_ptr() for f in fields]); dst = (C.c_void_p*n)(*[o.data_ptr() for o in outs]); wid = (C.c_int32*n)(*widths)
     _check(lib().fbl_replay_gather(u.data_ptr(), size.data_ptr(), int(capacity), B, n, src, dst, wid, _stream()))
     return outs
+
+
+# ------------------------------------------------------------------ the policy network behind its first layer: one launch
+_USE_POLICY_TAIL = os.environ.get('FB_LEARNER_POLICY_TAIL', '1') != '0'
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _PolicyTail(torch.autograd.Function):
+    """(mean, stddev) = heads(ELU(ELU(h1 W2^T + b2) W3^T + b3)) through fbl_policy_tail (activations in LDS from layer 2 to the heads);
+    backward: the same launches the layer-by-layer path issues (Gaussian head, bias-ELU, the d x | d W pairs), on the h2 / h3 the
+    forward kernel stored."""
+
+    @staticmethod
+    def forward(ctx, h1, w2, b2, w3, b3, wm, bm, ws, bs, mul, min_scale):
+        h1, w2, w3, wm, ws = (_f32c(t) for t in (h1, w2, w3, wm, ws))
+        M, H = h1.shape; D = wm.shape[0]; dev = h1.device
+        need = any(ctx.needs_input_grad[:9])
+        h2 = torch.empty(M, H, device=dev) if need else None; h3 = torch.empty(M, H, device=dev) if need else None
+        mean = torch.empty(M, D, device=dev); std = torch.empty(M, D, device=dev)
+        _check(lib().fbl_policy_tail(_ptr(h1), M, H, _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(wm), _ptr(bm), _ptr(ws), _ptr(bs), D, float(mul), float(min_scale),
+                                     _ptr(h2), _ptr(h3), _ptr(mean), _ptr(std), _stream()))
+        if need:
+            ctx.save_for_backward(h1, w2, h2, w3, h3, wm, ws, std)
+        ctx.mul = float(mul); ctx.min_scale = float(min_scale)
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, dmean, dstd):
+        h1, w2, h2, w3, h3, wm, ws, std = ctx.saved_tensors
+        dmean = _f32c(dmean); dstd = _f32c(dstd); M, H = h1.shape; D = wm.shape[0]; dev = h1.device; st = _stream()
+        # heads (as _GaussHeadLinear.backward)
+        dzs = torch.empty_like(std); db = zero_pool.take(2, D, device=dev)
+        _check(lib().fbl_gauss_head_bwd_std(dmean.data_ptr(), dstd.data_ptr(), std.data_ptr(), ctx.mul, ctx.min_scale, M, D, dzs.data_ptr(),
+                                            db[0].data_ptr(), db[1].data_ptr(), st))
+        dwm = torch.empty(D, H, device=dev); dws = torch.empty(D, H, device=dev)
+        o0 = _op(dmean, 1, D, h3, H, 1, dwm); o1 = _op(dzs, 1, D, h3, H, 1, dws)
+        _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, H, D, H, M, st))
+        dh = torch.empty(M, H, device=dev)
+        o0 = _op(dmean, D, 1, wm, H, 1, dh); o1 = _op(dzs, D, 1, ws, H, 1)
+        _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 1, H, M, H, D, st))
+        # the two ELU layers (as _Linear.backward): d z = d h ELU'(.), d bias = column sums, then d x | d W
+        grads = []
+        for hin, w, hout in ((h2, w3, h3), (h1, w2, h2)):
+            dz = torch.empty_like(dh); dbias = zero_pool.take(H, device=dev)
+            _check(lib().fbl_bias_elu_bwd(dh.data_ptr(), hout.data_ptr(), M, H, dz.data_ptr(), dbias.data_ptr(), st))
+            dx = torch.empty(M, H, device=dev); dw = torch.empty(H, H, device=dev)
+            if M == H:
+                o0 = _op(dz, H, 1, w, H, 1, dx); o1 = _op(dz, 1, H, hin, H, 1, dw)
+                _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, H, M, H, H, st))
+            else:
+                dx = _sgemm(dz, H, 1, w, H, 1, M, H, H); dw = _sgemm(dz, 1, H, hin, H, 1, H, H, M)
+            grads.append((dw, dbias)); dh = dx
+        (dw3, db3), (dw2, db2) = grads
+        return dh, dw2, db2, dw3, db3, dwm, db[0], dws, db[1], None, None
+
+
+def can_policy_tail(h1, torso_rest, head) -> bool:
+    """The fused tail applies to the reference's policy: two ELU layers of width 256 behind the LayerNorm layer, action dimension <= 64."""
+    return (_USE_POLICY_TAIL and _USE_SGEMM and h1.is_cuda and h1.dim() == 2 and h1.dtype == torch.float32 and len(torso_rest) == 2
+            and all(tuple(l.weight.shape) == (256, 256) for l in torso_rest) and h1.shape[1] == 256 and head.mean.weight.shape[0] <= 64)
+
+
+def policy_tail(h1, lin2, lin3, head, mul, min_scale):
+    return _PolicyTail.apply(h1, lin2.weight, lin2.bias, lin3.weight, lin3.bias, head.mean.weight, head.mean.bias, head.scale.weight, head.scale.bias,
+                             mul, min_scale)
 
 
 def nstep_add(rep, obs, action, reward, discount, next_obs, first, last):

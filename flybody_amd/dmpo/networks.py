@@ -75,6 +75,15 @@ class Policy(nn.Module):
         self.head = GaussianHead(sizes[-1], action_dim)
 
     def forward(self, obs):
+        t = self.torso
+        if obs.is_cuda and obs.dim() == 2 and t.activate_final:
+            h1 = fused.bias_ln_tanh(fused.linear(obs, t.first.weight), t.first.bias, t.norm)
+            if fused.can_policy_tail(h1, t.rest, self.head):
+                # layers 2, 3 and both heads in ONE launch (fbl_policy_tail): the activations never leave the LDS of the workgroup
+                return fused.policy_tail(h1, t.rest[0], t.rest[1], self.head, self.head.init_scale / math.log(2.0), self.head.min_scale)
+            for lin in t.rest:
+                h1 = fused.linear(h1, lin.weight, lin.bias, elu=True)
+            return self.head(h1)
         return self.head(self.torso(obs))
 
 

@@ -124,6 +124,13 @@ int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, const float* s
 int fbl_replay_gather(const float* u, const int64_t* size, int64_t capacity, int B, int narr, const float* const* src, float* const* dst,
                       const int32_t* width, void* stream);
 
+/* The policy network behind its first layer in ONE launch (network_factory.py:66-109 at the reference's sizes (256, 256, 256) +
+ * MultivariateNormalDiagHead :81-86): h2 = ELU(h1 W2' + b2), h3 = ELU(h2 W3' + b3), mean = h3 Wm' + bm, stddev = softplus(h3 Ws' + bs) mul +
+ * min_scale.  h1 [M][H] is the output of the LayerNorm-tanh layer; H must be 256, D <= 64.  h2 / h3 [M][H] are written when non-null (the
+ * learner's backward pass needs them; target networks and actors pass NULL). */
+int fbl_policy_tail(const float* h1, int M, int H, const float* w2, const float* b2, const float* w3, const float* b3, const float* wm, const float* bm,
+                    const float* ws, const float* bs, int D, float mul, float min_scale, float* h2, float* h3, float* mean, float* std_, void* stream);
+
 /* n-step transition adder (acme adders.NStepTransitionAdder as used by the reference's actors, agents/ray_distributed_dmpo.py:205-208;
  * host mirror: flybody_amd/dmpo/replay.py NStepReplay.add): one control step of E environments appended to the device-resident replay in two
  * launches.  t = control steps added INCLUDING this one (ring slot t mod n); first / last = dm_env step types of the reply (uint8);

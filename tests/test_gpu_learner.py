@@ -362,6 +362,41 @@ def test_small_mfma_gemm(M, K, N):
         _close(fused.linear(x, wide[:, :K]), ref(x) @ ref(wide[:, :K]).T, rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize('M', [256, 37, 4096])
+def test_policy_tail_kernel(M):
+    """fbl_policy_tail (layers 2 and 3 of the policy MLP and both Gaussian heads in one launch, activations in LDS, v_mfma_f32_16x16x4_f32)
+    against the same network on plain PyTorch operations in FP64: outputs, and for the learner's batch sizes every gradient the backward
+    pass returns (it re-uses the h2 / h3 the forward kernel stored)."""
+    from flybody_amd.dmpo import fused
+    from flybody_amd.dmpo.networks import Policy
+    torch.manual_seed(21)
+    dev = 'cuda'
+    pol = Policy(741, 59).to(dev)
+    with torch.no_grad():                      # (the reference initialises the heads near zero and the biases at zero: give every term some weight)
+        for p in pol.parameters():
+            if p.dim() == 1: p.normal_(0, 0.1)
+        pol.head.mean.weight.normal_(0, 0.05); pol.head.scale.weight.normal_(0, 0.05)
+    obs = torch.randn(M, 741, device=dev)
+    ref = Policy(741, 59).double().to(dev); ref.load_state_dict({k: v.double() for k, v in pol.state_dict().items()})
+    t = ref.torso
+    h = torch.tanh(t.norm(F.linear(obs.double(), t.first.weight, t.first.bias)))
+    for lin in t.rest: h = F.elu(F.linear(h, lin.weight, lin.bias))
+    mean_r = F.linear(h, ref.head.mean.weight, ref.head.mean.bias)
+    std_r = F.softplus(F.linear(h, ref.head.scale.weight, ref.head.scale.bias))*(ref.head.init_scale/math.log(2.0)) + ref.head.min_scale
+    assert fused.can_policy_tail(torch.empty(M, 256, device=dev), pol.torso.rest, pol.head)
+    mean, std = pol(obs)
+    _close(mean, mean_r, rtol=2e-5, atol=2e-5); _close(std, std_r, rtol=2e-5, atol=2e-5)
+    with torch.no_grad():                      # forward-only path (target networks, actors): nothing stored
+        m2, s2 = pol(obs)
+    assert torch.equal(m2, mean) and torch.equal(s2, std)
+    if M <= 256:
+        gm = torch.randn(M, 59, device=dev); gs = torch.randn(M, 59, device=dev)
+        (mean*gm).sum().add((std*gs).sum()).backward()
+        (mean_r*gm.double()).sum().add((std_r*gs.double()).sum()).backward()
+        for (n, p), (_, q) in zip(pol.named_parameters(), ref.named_parameters()):
+            _close(p.grad, q.grad, rtol=2e-4, atol=2e-4*float(q.grad.abs().max()) + 1e-7), n
+
+
 def test_gaussian_head_pair_launch():
     """fbl_sgemm_pair: both policy heads in one launch (independent products with their own epilogues), their weight gradients in one
     launch, and the summed input gradient d h = d mean Wm + d zs Ws in one launch -- against the plain PyTorch head."""
