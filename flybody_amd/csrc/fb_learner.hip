@@ -951,18 +951,33 @@ __device__ __forceinline__ void pt_layer(const float (*in)[PT_LD], float (*out)[
   for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int cb = wave*64;
   const float* wp = W + (size_t)(cb + r)*PT_W + 4*s;                 // B fragment: column = lane % 16 of the tile, k = 16 kb + 4 s + j
-#pragma unroll 4
-  for (int kb = 0; kb < PT_W/16; kb++) {
-    const float4 a4 = *reinterpret_cast<const float4*>(&in[r][16*kb + 4*s]);
-    float4 b4[4];
+  // software pipeline over the weights: the loads of k-blocks (2 t + 2, 2 t + 3) are in flight while the 32 MFMAs of blocks (2 t, 2 t + 1)
+  // run (~1 k cycles: more than an L2 round trip) -- the compiler's own schedule issued a stage's loads only after the previous stage's
+  // MFMAs, i.e. exposed the latency eight times per layer
+  float4 bw[2][2][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) b4[ct] = *reinterpret_cast<const float4*>(wp + (size_t)16*ct*PT_W + 16*kb);
+  for (int h = 0; h < 2; h++)
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) {
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[ct].x, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[ct].y, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[ct].z, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[ct].w, acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < 4; ct++) bw[0][h][ct] = *reinterpret_cast<const float4*>(wp + (size_t)16*ct*PT_W + 16*h);
+#pragma unroll
+  for (int t = 0; t < PT_W/32; t++) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    if (t + 1 < PT_W/32) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) bw[nxt][h][ct] = *reinterpret_cast<const float4*>(wp + (size_t)16*ct*PT_W + 16*(2*t + 2 + h));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&in[r][16*(2*t + h) + 4*s]);
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bw[cur][h][ct].x, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bw[cur][h][ct].y, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bw[cur][h][ct].z, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bw[cur][h][ct].w, acc[ct], 0, 0, 0);
+      }
     }
   }
   // D[i][j]: lane l holds column j = l % 16, rows i = 4 (l / 16) + q

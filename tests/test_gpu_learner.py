@@ -363,12 +363,13 @@ def test_small_mfma_gemm(M, K, N):
 
 
 @pytest.mark.parametrize('M', [256, 37, 4096])
-def test_policy_tail_kernel(M):
+def test_policy_tail_kernel(M, monkeypatch):
     """fbl_policy_tail (layers 2 and 3 of the policy MLP and both Gaussian heads in one launch, activations in LDS, v_mfma_f32_16x16x4_f32)
     against the same network on plain PyTorch operations in FP64: outputs, and for the learner's batch sizes every gradient the backward
     pass returns (it re-uses the h2 / h3 the forward kernel stored)."""
     from flybody_amd.dmpo import fused
     from flybody_amd.dmpo.networks import Policy
+    monkeypatch.setattr(fused, '_POLICY_TAIL_MODE', '1')          # (default 'auto': only batches of more than 1024 rows)
     torch.manual_seed(21)
     dev = 'cuda'
     pol = Policy(741, 59).to(dev)
