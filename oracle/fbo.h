@@ -6,7 +6,8 @@
  * specialised to the fruit-fly model class (free root + hinge tree, fixed tendons,
  * plane/sphere/capsule/ellipsoid/cylinder geoms, elliptic cones; constraint solver = the model's own: Newton on MuJoCo's
  * primal cost, the default the reference XML leaves in place (fruitfly.xml:4), restated in constraint space
- * (fbo_constraint.c: solve_newton); block PGS behind opt_solver = 0 and for systems wider than 64 rows; noslip post-pass).
+ * (fbo_constraint.c: solve_newton) at EVERY system size, as MuJoCo does; block PGS behind opt_solver = 0 -- and beyond `opt_newton_maxrows` rows when a
+ * test sets that cap to mirror the kernel's flagged fallback for systems wider than 64 rows; noslip post-pass).
  *
  * Third-party algorithm: MuJoCo (C engine) via dm_control; the reference requires dm_control WITHOUT a version pin
  * (pyproject.toml:10), mujoco is a transitive unpinned dependency.  Restated here: the published MuJoCo 3.x forward /

@@ -4,8 +4,9 @@ Tolerances (written here, as the task statement requires):
   * FP64 kernel vs FP64 oracle, single forward evaluation:  1e-9 relative on every smooth-dynamics
     stage output (different summation orders only) and 1e-6 on solver-dependent outputs (the Newton
     solver -- the model's default, fb_newton.hpp / fbo_constraint.c: solve_newton -- stops on a 1e-8
-    bound on the scaled cost decrement, so the last iteration may differ; block PGS, behind opt_solver = 0 and
-    for systems wider than 64 rows, stops on the same threshold);
+    bound on the scaled cost decrement, so the last iteration may differ; block PGS -- behind opt_solver = 0, and the
+    KERNEL's flagged fallback (FB_WARN_SOLVER_FALLBACK) for systems wider than 64 rows, which the oracle mirrors only when a
+    test caps its Newton with opt_newton_maxrows -- stops on the same threshold);
   * FP64 kernel vs oracle over 20 ... 100 control steps (contacts, Newton, noslip):  1e-6 relative
     on qpos / qvel (contact-rich dynamics amplify rounding differences; measured ~1e-11);
   * FP32 kernel vs oracle, single forward evaluation:  2e-3 relative on accelerations.
