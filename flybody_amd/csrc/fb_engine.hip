@@ -841,12 +841,12 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   {
     // kinematics level loop: bodies beyond the wavefront width ride along on lanes whose own body sits on a
-    // different level, so one trip down the levels covers every body (fb_smooth.hpp fk_pass)
+    // SHALLOWER level, so one trip down the levels covers every body (fb_smooth.hpp fk_pass)
     std::vector<int> second(FB_WAVE, -1);
     bool ok = m->nbody > FB_WAVE && m->nbody <= 2*FB_WAVE && getenv("FB_NO_FK_MERGE") == nullptr;      // (switch: tests run both paths)
     for (int bq = FB_WAVE; ok && bq < m->nbody; bq++) {
       int pick = -1;
-      for (int l = 0; l < FB_WAVE && pick < 0; l++) if (second[l] < 0 && (l == 0 || m->body_depth[l] != m->body_depth[bq])) pick = l;
+      for (int l = 0; l < FB_WAVE && pick < 0; l++) if (second[l] < 0 && (l == 0 || m->body_depth[l] < m->body_depth[bq])) pick = l;      // (deeper than the lane's own body: fk_pass reuses the record registers)
       if (pick < 0) ok = false; else second[pick] = bq;
     }
     M.fk_second = nullptr;

@@ -130,7 +130,7 @@ template <typename real> FBD int fk_off_a(const DevModel<real>& M) { return 7*M.
 
 template <typename real>
 FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, FB_LDS real* A, int b1, int b2, int dlo, int dhi, int lane) {
-  // a lane may own a second body (b2, on a different level than b1: fb_engine.hip pairs them) so that a model
+  // a lane may own a second body (b2, on a DEEPER level than b1: fb_engine.hip pairs them) so that a model
   // with a few bodies beyond the wavefront width still takes one trip down the levels
   bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
   int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
@@ -147,16 +147,15 @@ FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, con
   for (int d = dlo; d <= dhi; d++) {
     int b = (dep1 == d) ? b1 : b2;
     if (dep1 == d || dep2 == d) {
-      // the body's flattened record (fb_engine.hip) and the free-joint pose
-      real R[37];
-      if (dep1 == d) {
-#pragma unroll
-        for (int k = 0; k < 37; k++) R[k] = R1[k];
-      } else {
+      // the body's flattened record (fb_engine.hip) and the free-joint pose.  A second body always sits DEEPER than the lane's own
+      // (fb_engine.hip pairs them that way): by its level the own record is dead and the second one is loaded over it -- the level
+      // body works on R1 itself, not on a per-level copy of 37 reals (74 moves x 14 levels: a quarter of the stage's instructions)
+      if (dep1 != d) {
         const real* rec = M.body_rec + b*FB_BODYREC;
 #pragma unroll
-        for (int k = 0; k < 37; k++) R[k] = rec[k];
+        for (int k = 0; k < 37; k++) R1[k] = rec[k];
       }
+      const real* R = R1;
       int par = (int)R[0], ja = (int)R[1], jn = (int)R[2];
       bool free_jnt = R[3] != 0;
       real pos[3], quat[4];
