@@ -260,30 +260,31 @@ class DMPOLearner:
         training loop happened to get a good one).  Every rotation of the candidate list runs a short burst of real steps inside the
         warm-up (rolled back with it: parameters, moments, targets, step counter); the fastest stays.  FB_LEARNER_QUEUE_OFFSET pins it."""
         free = getattr(self, '_free_streams', [])
-        if len(free) < 2:
-            return
+        cands = list(free) if free else [torch.cuda.current_stream(self.device)]
+        NROT = 4            # bursts per rank: a CONSTANT -- every burst step all-reduces on a data-parallel job, so all ranks must run the same
+                            # number of them whatever their own probe found (3 free streams on one rank, 4 on another)
         def assign(off):
-            rot = free[off:] + free[:off]
-            while len(rot) < 3: rot.append(rot[len(rot) % len(free)])
+            rot = cands[off:] + cands[:off]
+            while len(rot) < 3: rot.append(rot[len(rot) % len(cands)])
             self._pipe_stream = rot[0]; self._br_streams = (rot[2], rot[1]); self._a_ready = False; self._cur = 0
         pinned = os.environ.get('FB_LEARNER_QUEUE_OFFSET')
         if pinned is not None:
-            assign(int(pinned) % len(free)); self.stream_rotation = int(pinned) % len(free); return
+            assign(int(pinned) % len(cands)); self.stream_rotation = int(pinned) % len(cands); return
         saved_t = [t.clone() for t in list(self.target.policy.state_dict().values()) + list(self.target.critic.state_dict().values())]
         saved_steps = self.num_steps
         rng = torch.cuda.get_rng_state(self.device)       # (the A graphs draw: the burst must not shift the random stream of the run)
         main = torch.cuda.current_stream(self.device)
         batch = None if self._sampler is not None else self._static
         times = []
-        for off in range(len(free)):
-            assign(off)
+        for off in range(NROT):
+            assign(off % len(cands))
             for _ in range(4): self._step_pipelined(batch, True)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(main)
             for _ in range(24): self._step_pipelined(batch, True)
             e1.record(main); torch.cuda.synchronize(self.device)
             times.append(e0.elapsed_time(e1))
-        best = min(range(len(free)), key=lambda o: times[o])
+        best = min(range(NROT), key=lambda o: times[o]) % len(cands)
         assign(best); self.stream_rotation = best; self.stream_rotation_ms = [t/24 for t in times]
         self.num_steps = saved_steps
         torch.cuda.set_rng_state(rng, self.device)
