@@ -69,6 +69,18 @@ def observation_layout(model: engine.Model, future_steps: int, ball: bool = Fals
     return layout, off
 
 
+def action_spec_from_arrays(a) -> BoundedArray:
+    """fruitfly.py:548-579: tab-joined actuator names in action order, per-actuator ctrl range, user actions in [-1, 1].
+    The values are pinned literally by the reference's notebook outputs (tests/golden/notebook_specs.json)."""
+    idx = a['action_to_ctrl']
+    rng = a['actuator_ctrlrange'][idx]
+    names = [str(a['names_actuator'][i]) for i in idx]
+    lo, hi = list(rng[:, 0]), list(rng[:, 1])
+    for k in range(int(a['num_user_actions'])):          # fruitfly.py:571-576
+        lo.append(-1.0); hi.append(1.0); names.append(f'user_{k}')
+    return BoundedArray((len(names),), float, lo, hi, name='\t'.join(names))
+
+
 class _TrajGenerator:
     """Stand-in for InferenceWalkingTrajectoryLoader (tasks/trajectory_loaders.py:267-309)."""
 
@@ -192,14 +204,7 @@ class BatchedFlyEnv:
 
     # ---- specs --------------------------------------------------------------------------------
     def action_spec(self) -> BoundedArray:
-        a = self.model.arrays
-        idx = a['action_to_ctrl']
-        rng = a['actuator_ctrlrange'][idx]
-        names = [str(a['names_actuator'][i]) for i in idx]
-        lo, hi = list(rng[:, 0]), list(rng[:, 1])
-        for k in range(int(a['num_user_actions'])):          # fruitfly.py:571-576
-            lo.append(-1.0); hi.append(1.0); names.append(f'user_{k}')
-        return BoundedArray((len(names),), float, lo, hi, name='\t'.join(names))
+        return action_spec_from_arrays(self.model.arrays)
 
     def observation_spec(self):
         return collections.OrderedDict(('walker/' + k, Array(self.layout[k][2], np.float32, 'walker/' + k)) for k in self._keys())

@@ -13,12 +13,36 @@ qpos = np.zeros((n_steps, 7)); qpos[:, 0] = np.arange(0, n_steps*0.002, 0.002); 
 qvel = np.zeros((n_steps, 6)); qvel[:, 0] = 1.
 
 
+def _notebook_specs():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'notebook_specs.json')))
+
+
+def test_observation_and_action_specs_match_the_reference_notebooks():
+    """observation_spec() keys / order / shapes and action names of the envs the reference's notebooks print
+    (docs/getting-started.ipynb cells 44, 46: walk_on_ball; docs/sensory-input-tracking.ipynb cells 8, 9: flight_imitation)."""
+    from flybody_amd.fly_envs import walk_on_ball, flight_imitation
+    specs = _notebook_specs()
+    for env, okey, akey in ((walk_on_ball(precision=64), 'walk_on_ball_observation_spec', 'walk_on_ball_action_spec'),
+                            (flight_imitation(precision=64), 'flight_observation_spec', 'flight_action_spec_canonical')):
+        obs = env.observation_spec()
+        assert list(obs) == specs[okey]['keys']
+        assert [list(v.shape) for v in obs.values()] == specs[okey]['shapes']
+        assert env.action_spec().name.split('\t') == specs[akey]['names']
+        ts = env.reset()
+        assert [list(np.shape(ts.observation[k])) for k in specs[okey]['keys']] == specs[okey]['shapes']
+
+
 def test_can_create_env_inference_mode():
     from flybody_amd.fly_envs import walk_imitation
     env = walk_imitation(terminal_com_dist=float('inf'), precision=64)
     assert list(env.observation_spec()) == expect_obs_names
     spec = env.action_spec()
     assert spec.shape == (59,) and (spec.minimum < spec.maximum).all() and len(spec.name.split('\t')) == 59
+    # literally the vector the reference's notebook prints (docs/getting-started.ipynb cell 46 -> tests/golden/notebook_specs.json)
+    ref = _notebook_specs()['walk_on_ball_action_spec']
+    assert spec.name.split('\t') == ref['names']
+    assert np.allclose(spec.minimum, ref['minimum'], rtol=0, atol=1e-12) and np.allclose(spec.maximum, ref['maximum'], rtol=0, atol=1e-12)
     env.task._traj_generator.set_next_trajectory(qpos, qvel)
     ts = env.reset()
     assert ts.first() and ts.reward is None
