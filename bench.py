@@ -120,7 +120,12 @@ def main():
     ap.add_argument('--no-parity-sample', action='store_true', help='skip the post-run replay of sampled environments on the CPU oracle')
     ap.add_argument('--no-flight-leg', action='store_true', help='skip the flight_imitation leg (configs[3]) only')
     ap.add_argument('--dmpo-envs', type=int, default=4096, help='environments per GPU of the DMPO leg (configs[2] on one rank, configs[4] on several)')
-    ap.add_argument('--dmpo-iters', type=int, default=12); ap.add_argument('--dmpo-warmup', type=int, default=4); ap.add_argument('--dmpo-min-replay', type=int, default=8192)
+    # DMPO leg at the REFERENCE's parameters (train_dmpo_ray.py:105-137, ray_distributed_dmpo.py:82-96): replay table of 4 000 000 items,
+    # min_replay_size 10 000, 15 samples per insert, batch 256, 20 sampled actions; >= 100 timed control steps
+    ap.add_argument('--dmpo-iters', type=int, default=100); ap.add_argument('--dmpo-warmup', type=int, default=6); ap.add_argument('--dmpo-min-replay', type=int, default=10_000)
+    ap.add_argument('--dmpo-replay-capacity', type=int, default=4_000_000)
+    ap.add_argument('--dmpo-timeout', type=float, default=240.0, help='seconds after which a DMPO job is killed (its leg is lost, the benchmark line is not)')
+    ap.add_argument('--no-dmpo-f32', action='store_true', help='skip the FP32-physics repeat of the DMPO leg (reported beside the FP64 figure on one rank)')
     ap.add_argument('--rccl-dry-run', action='store_true', help='with --gpus N > 1: use RCCL when N devices are visible; otherwise run the N ranks on the '
                     'one visible device over gloo (same code path up to the backend) and say `rccl: unexercised` in the JSON')
     args = ap.parse_args()
@@ -235,6 +240,15 @@ def main():
                                              'a long-running pool of 235-step episodes sits at 1/236'}
             wv = batch.get('WARN_EVER').ravel()
             extras['warn'] = {name: int(((wv & bit) != 0).sum()) for name, bit in engine.WARN_BITS.items()}
+            # how close the run came to the caps and to the Newton solver's one-row-per-lane limit (FB_SIZE_STATS: over EVERY substep of
+            # the pre-roll, the warm-up and the timed steps, all environments)
+            ss = batch.get('SIZE_STATS').reshape(-1, 4).astype(np.int64)
+            nsub_total = float(n_env)*(P + args.warmup + args.steps)*int(model.dim('nsubstep'))
+            extras['sizes'] = {'max_ncon': int(ss[:, 0].max()), 'max_nefc': int(ss[:, 1].max()),
+                               'substep_share_above_32_rows': float(ss[:, 2].sum()/nsub_total), 'substep_share_above_64_rows': float(ss[:, 3].sum()/nsub_total),
+                               'envs_that_ever_exceeded_64_rows': int((ss[:, 3] > 0).sum()),
+                               'caps': {'kernel_contacts': 64, 'kernel_rows': 192, 'newton_rows_per_lane_limit': 64, 'mujoco_nconmax': 100, 'mujoco_njmax': 300},
+                               'substeps_counted': nsub_total}
             extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
             extras['solver_iterations_mean'] = float(batch.get('SOLVER_NITER').mean())
             extras['scheduler'] = ('substep tickets: waves draw (environment, substep) units per XCD, the batch exceeds the %d resident slots' % batch.resident_slots) if batch.substep_scheduler else 'one environment per wave, longest first'
@@ -307,16 +321,19 @@ def main():
         del env
         return out
 
-    def run_dmpo_leg(n_ranks=1):
-        """BASELINE configs[2] (one rank) / configs[4] (n_ranks > 1): DMPO training, 4096 environments per GPU, the reference's rate
-        limiter (15 samples per insert = 240 learner steps per control step of a rank's shard).  Own process (it owns the torch RNG and
-        the HIP graphs) -- for several ranks its own JOB: `train_dmpo --gpus N` re-executes itself under torch.distributed.run with one
-        rank per GPU (per-rank shard + replay, one flat gradient all-reduce per learner step over RCCL, hidden behind the next step's
-        target-network forwards), while this benchmark's ranks wait at a barrier.  A failure or a hang of that job costs this leg, not
-        the benchmark line.  FP32 physics as in training."""
+    def run_dmpo_leg(n_ranks=1, precision=64):
+        """BASELINE configs[2] (one rank) / configs[4] (n_ranks > 1): DMPO training at the reference's parameters -- 4096 environments
+        per GPU, replay table of 4 000 000 items, min_replay_size 10 000, the reference's rate limiter (15 samples per insert = 240
+        learner steps per control step of a rank's shard), >= 100 timed control steps.  Own process (it owns the torch RNG and the HIP
+        graphs) -- for several ranks its own JOB: `train_dmpo --gpus N` re-executes itself under torch.distributed.run with one rank
+        per GPU (per-rank shard + replay, one flat gradient all-reduce per learner step over RCCL, hidden behind the next step's
+        target-network forwards), while this benchmark's ranks wait on the host.  A failure or a hang of that job costs this leg, not
+        the benchmark line.  precision = the physics arithmetic: 64 is the reported figure (the reference's MuJoCo is FP64), 32 is
+        reported beside it."""
         import subprocess
         cmd = [sys.executable, '-m', 'flybody_amd.train_dmpo', '--envs', str(args.dmpo_envs), '--iters', str(args.dmpo_iters), '--warmup', str(args.dmpo_warmup),
-               '--min-replay', str(args.dmpo_min_replay), '--precision', '32'] + (['--gpus', str(n_ranks)] if n_ranks > 1 else [])
+               '--min-replay', str(args.dmpo_min_replay), '--replay-capacity', str(args.dmpo_replay_capacity), '--precision', str(precision)] + \
+              (['--gpus', str(n_ranks)] if n_ranks > 1 else [])
         t0 = time.perf_counter()
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
                                                                  'ROLE_RANK', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT',
@@ -324,20 +341,23 @@ def main():
         import signal
         pr = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
         try:
-            so, se = pr.communicate(timeout=240)
+            so, se = pr.communicate(timeout=args.dmpo_timeout)
         except subprocess.TimeoutExpired:
             try:
                 os.killpg(pr.pid, signal.SIGKILL)          # the job's own process group: launcher and ranks (nothing else lives in it)
             except ProcessLookupError:
                 pass
-            pr.communicate()
+            try:
+                pr.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
             return {'error': 'timeout'}
         line = [l for l in so.splitlines() if l.startswith('{')]
         if not line:
             return {'error': se[-600:]}
         o = json.loads(line[-1])
-        keep = ('n_gpus', 'env_steps_per_sec', 'learner_steps_per_sec', 'envs_per_gpu', 'learner_steps_per_env_step', 'batch_size', 'samples_per_insert',
-                'gradient_allreduce', 'dtype', 'reward')
+        keep = ('n_gpus', 'env_steps_per_sec', 'learner_steps_per_sec', 'envs_per_gpu', 'timed_control_steps', 'wall_s_timed', 'learner_steps_per_env_step',
+                'batch_size', 'num_samples', 'replay_capacity', 'min_replay_size', 'samples_per_insert', 'roofline', 'gradient_allreduce', 'dtype', 'physics_build', 'reward')
         out = {k: o[k] for k in keep if k in o}
         out.update({'wall_s_incl_startup': time.perf_counter() - t0,
                     'note': '%d rank(s) x %d environments, physics and learner on the same device(s); %d timed control steps after %d warm-up steps'
@@ -403,14 +423,22 @@ def main():
         if not args.no_flight_leg:
             flight = {f'f{p}': run_flight_leg(p, max(10, args.steps), max(5, args.warmup)) for p in ((64, 32) if args.precision == 64 else (32,))}
         if rank == 0:
-            dmpo = run_dmpo_leg(world)                  # configs[2] on one rank, configs[4] (its own N-rank job) on several
+            dmpo = run_dmpo_leg(world, 64)              # configs[2] on one rank, configs[4] (its own N-rank job) on several; FP64 physics
+            if world == 1 and not args.no_dmpo_f32 and 'error' not in dmpo:
+                f = run_dmpo_leg(1, 32)                 # the same loop on the FP32 build of the physics kernel, reported beside it
+                dmpo['f32_physics'] = {k: f[k] for k in ('env_steps_per_sec', 'learner_steps_per_sec', 'samples_per_insert', 'roofline', 'dtype', 'error') if k in f}
         if world > 1:                                   # the other ranks wait on the HOST (rendezvous store), not in a device-side collective that would
             from datetime import timedelta              # keep a polling kernel on the GPUs the DMPO job is measured on
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
                 store.set('fb_dmpo_leg_done', '1')
             else:
-                store.wait(['fb_dmpo_leg_done'], timedelta(seconds=300))
+                # (the job is killed after --dmpo-timeout, the kill itself is bounded by 30 s: wait longer than both, and a rank whose wait
+                # still expires reports the leg as lost instead of taking the benchmark line down)
+                try:
+                    store.wait(['fb_dmpo_leg_done'], timedelta(seconds=args.dmpo_timeout + 180))
+                except Exception:
+                    pass
         barrier()
     parity = None
     if rank == 0 and args.precision == 64 and not args.no_parity_sample:
@@ -448,8 +476,7 @@ def main():
                          'traffic': (traffic or {}).get('bytes_per_launch'),
                          'traffic_source': (traffic or {}).get('source'),
                          'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
-                         # (staggered pre-roll: every timed launch carries ~n_env/236 resetting environments, none is reset-only)
-                         'kernel_ms_avg_excl_reset_only': per_launch_s * 1e3,
+                         # (staggered pre-roll: every timed launch carries ~n_env/236 resetting environments, none is a reset-only pass)
                          'algorithmic_flop_per_env_step': ALGO_FLOP_PER_ENV_STEP,
                          'algorithmic_bytes_per_env_step': algo_bytes,
                          'hbm': {'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved_gbs / HBM_PEAK_GBS},
@@ -459,7 +486,7 @@ def main():
                          'valu_achieved_tflops': valu_tflops, 'valu_peak_tflops': VALU_PEAK_TFLOPS[args.precision],
                          'valu_frac': valu_tflops / VALU_PEAK_TFLOPS[args.precision]},
             'parity_sample': parity,
-            'warn': {'envs_with_flag_since_reset': extras.get('warn'), 'note': 'FB_WARN_EVER population over the batch: contact cap (64), constraint-row cap (192), '
+            'warn': {'envs_with_flag_since_reset': extras.get('warn'), 'sizes': extras.get('sizes'), 'note': 'FB_WARN_EVER population over the batch: contact cap (64), constraint-row cap (192), '
                      'solver at opt.iterations, MPR at its iteration limit -- MuJoCo reports the first two as nconmax / njmax warnings (fruitfly.xml:6)'},
             'rccl': ('exercised: init_process_group(nccl) + all_reduce(MAX) + barrier over %d ranks%s' % (world, '; dmpo_mode: one flat gradient all-reduce per learner step' if dmpo is not None else '')) if (world > 1 and backend == 'nccl') else
                     ('unexercised (gloo substitute)' if world > 1 else 'unexercised (single rank: no collective on the data path)'),
@@ -485,7 +512,8 @@ def main():
         if flight is not None:
             out['flight_mode'] = {'config': 'configs[3]: flight_imitation, 8192 envs per GPU, U(-1,1)^12 actions, WBPG + ellipsoid wing fluid forces', **flight}
         if dmpo is not None:
-            cfg_name = ('configs[2]: walk_imitation DMPO training, %d envs, on-GPU rollout + learner + replay, SPI 15' % args.dmpo_envs) if world == 1 else \
+            cfg_name = ('configs[2]: walk_imitation DMPO training, %d envs, on-GPU rollout + learner + replay; reference parameters: replay 4 M, '
+                        'min_replay 10 k, SPI 15, batch 256, N 20' % args.dmpo_envs) if world == 1 else \
                        ('configs[4]: walk_imitation DMPO, %d envs sharded across %d GPUs (%d per GPU), gradient all-reduce over %s, SPI 15'
                         % (args.dmpo_envs*world, world, args.dmpo_envs, 'RCCL / xGMI' if backend == 'nccl' else 'gloo (one-GPU functional run)'))
             out['dmpo_mode'] = {'config': cfg_name, **dmpo}

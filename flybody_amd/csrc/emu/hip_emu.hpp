@@ -124,6 +124,7 @@ static inline unsigned long long __ballot(int pred) {
   return r;
 }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }   // fibers run one at a time
+static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }

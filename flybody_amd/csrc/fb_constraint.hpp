@@ -165,7 +165,13 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       }
     }
   }
-  if (lane == 0) { w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
+  if (lane == 0) {
+    // how close the batch comes to the solver's shapes and the caps (bench.py: warn.sizes): running maxima and the number of substeps
+    // whose system had more than 32 / 64 rows (64 = one row per lane, beyond which Newton falls back to PGS)
+    if (nefc > w.istate()[IS_MAX_NEFC]) w.istate()[IS_MAX_NEFC] = nefc;
+    if (nefc > 32) w.istate()[IS_N_GT32]++;
+    if (nefc > 64) w.istate()[IS_N_GT64]++;
+    w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
   SYNC();
 }
 

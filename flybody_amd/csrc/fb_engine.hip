@@ -575,12 +575,15 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
         // are skipped.  Never observed; a launch that can get here has lost a wave.
         if (lane == 0) {
           int* is_ = (int*)(B.iarena + (size_t)env*M.off.nint + M.off.istate);
-          is_[IS_WARN] |= WARN_SCHED_WAIT; is_[IS_WARN_EVER] |= WARN_SCHED_WAIT;
+          // (the holder of the row may be writing IS_WARN itself: atomic OR.  The abandon mark nsubm + 2 must survive the holder's own
+          // publication of `round + 1` when it finally finishes -- both sides publish with an atomic MAX -- so that every later
+          // ticket of this environment is skipped at once (d > round) instead of spinning to the cap again.)
+          atomicOr(is_ + IS_WARN, WARN_SCHED_WAIT); atomicOr(is_ + IS_WARN_EVER, WARN_SCHED_WAIT);
           atomicAdd(B.sched_err, 1);
 #ifndef FB_EMULATE
-          __hip_atomic_store(B.done + env, nsubm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(B.done + env, nsubm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-          B.done[env] = nsubm + 2;
+          B.done[env] = max(B.done[env], nsubm + 2);
 #endif
         }
         continue;
@@ -619,9 +622,9 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
 #endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_fetch_max(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (MAX: an abandon mark stays)
 #else
-      if (lane == 0) B.done[env] = was_reset ? nsubm + 1 : round + 1;
+      if (lane == 0) B.done[env] = max(B.done[env], was_reset ? nsubm + 1 : round + 1);
 #endif
     }
     return;
@@ -775,7 +778,7 @@ struct fb_batch {
   int* sched = nullptr;
   int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true;
   int *tick = nullptr, *done = nullptr, *sched_err = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
-  unsigned xcc_mask = 0; void* probed_stream = nullptr; bool probed = false;               // ... the streams it was validated on
+  unsigned xcc_mask = 0; std::vector<void*> probed_streams; unsigned* probe_word = nullptr;  // ... the streams it was validated on, the probe's device word
   void* park = nullptr;               // MODE_STAGE: LDS pools between single-stage launches (allocated on first use)
   std::vector<void*> allocs;          // model tables on the device
   DevModel<double> M64; DevModel<float> M32;
@@ -963,6 +966,7 @@ static int batch_create_impl(fb_batch* b) {
     HIPCHK(hipMalloc((void**)&b->done, n_env*sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->sched_err, sizeof(int)));
     HIPCHK(hipMemset(b->sched_err, 0, sizeof(int)));
+    HIPCHK(hipMalloc((void**)&b->probe_word, sizeof(unsigned)));
     // (round 3 kept flight_imitation -- equal-cost environments, short substeps -- on the per-wave path: tickets cost 3 % there.  With
     // the round-4 kernel they win for flight too: 8192 FP64 environments 2.21 -> 2.25 M env-steps/s on the default build, 2.52 -> 2.63 M
     // on the 12-per-CU build, profiles/r4/flight_variants.txt.  FB_NO_TICKETS=1 still forces the per-wave path.)
@@ -990,7 +994,7 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done, b->sched_err, b->park};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done, b->sched_err, b->park, b->probe_word};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1160,16 +1164,23 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
   // wave in longest-first order
   bool tickets = (mode == MODE_STEP) && !ids && n == b->n_env && b->tickets;
 #ifndef FB_EMULATE
-  if (tickets && (!b->probed || b->probed_stream != stream)) {
-    // A stream with a CU mask may not reach every XCD: the ticket queues of the unreachable ones would never be drawn.  Probe the
-    // stream once (again whenever the caller switches streams); unless it sees exactly the XCDs the batch was set up for, this
-    // batch keeps the per-wave path for good.
-    unsigned* dmask; unsigned hmask = 0;
-    HIPCHK(hipMalloc((void**)&dmask, sizeof(unsigned))); HIPCHK(hipMemsetAsync(dmask, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_probe_xcc, dim3(4096), dim3(FB_WAVE), 0, st, dmask);
-    HIPCHK(hipMemcpyAsync(&hmask, dmask, sizeof(unsigned), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipFree(dmask));
-    b->probed = true; b->probed_stream = stream;
-    if (hmask != b->xcc_mask) { b->tickets = false; tickets = false; }
+  if (tickets && std::find(b->probed_streams.begin(), b->probed_streams.end(), stream) == b->probed_streams.end()) {
+    // A stream with a CU mask may not reach every XCD: the ticket queues of the unreachable ones would never be drawn.  Every stream
+    // is probed ONCE (the validated ones are remembered: a caller that alternates streams pays no blocking synchronisation per
+    // step); a stream that does not see exactly the XCDs the batch was set up for puts this batch on the per-wave path for good.
+    // The probe synchronises, so it cannot run while the stream is being captured into a graph: such a launch takes the per-wave
+    // path (same results) and the stream stays unvalidated.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) tickets = false;
+    else {
+      unsigned hmask = 0;
+      HIPCHK(hipMemsetAsync(b->probe_word, 0, sizeof(unsigned), st));
+      hipLaunchKernelGGL(k_probe_xcc, dim3(4096), dim3(FB_WAVE), 0, st, b->probe_word);
+      HIPCHK(hipMemcpyAsync(&hmask, b->probe_word, sizeof(unsigned), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+      if (hmask != b->xcc_mask) { b->tickets = false; tickets = false; }
+      else { if (b->probed_streams.size() >= 64) b->probed_streams.clear(); b->probed_streams.push_back(stream); }
+    }
   }
 #endif
   const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder && !tickets;
@@ -1231,7 +1242,8 @@ static int check_sched_errors(fb_batch* b) {
   int n = 0;
   HIPCHK(hipMemcpy(&n, b->sched_err, sizeof(int), hipMemcpyDeviceToHost));
   if (n) return fail("substep scheduler: " + std::to_string(n) + " ticket(s) were abandoned because the wait for an environment's previous substep hit its cap; "
-                     "the flagged environments (FB_WARN_SCHED_WAIT) are not in a valid state -- reset them, or run with FB_NO_TICKETS=1");
+                     "the flagged environments (FB_WARN_SCHED_WAIT) are not in a valid state and this batch fails from now on (sticky, include/flybody_engine.h): "
+                     "destroy it and create a new one; FB_NO_TICKETS=1 selects the per-wave path");
   return 0;
 }
 
@@ -1293,6 +1305,7 @@ static int field_desc(fb_batch* b, int field, FieldDesc* f) {
     case FB_STEP_TYPE: *f = {3, 0, 1, b->step_type}; break;
     case FB_WARN: *f = {1, o.istate + IS_WARN, 1, nullptr}; break;
     case FB_WARN_EVER: *f = {1, o.istate + IS_WARN_EVER, 1, nullptr}; break;
+    case FB_SIZE_STATS: *f = {1, o.istate + IS_MAX_NCON, 4, nullptr}; break;
     case FB_STEP_TICKS: *f = {3, 0, 1, b->cost}; break;
     case FB_LAUNCH_ORDER: *f = {3, 0, 1, b->order}; break;
     default: return fail("unknown field");

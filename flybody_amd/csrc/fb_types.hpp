@@ -39,7 +39,9 @@ enum { DYN_NONE = 0, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 // istate slots
 enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
-       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_PRIO = 14, IS_WARN = 15, IS_WARN_EVER = 16, IS_N = 20 };
+       IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_PRIO = 14, IS_WARN = 15, IS_WARN_EVER = 16,
+       IS_MAX_NCON = 17, IS_MAX_NEFC = 18, IS_N_GT32 = 19, IS_N_GT64 = 20,      // FB_SIZE_STATS: maxima / counts over every substep since the batch was created (or the field was last set)
+       IS_N = 24 };
 // IS_WARN bits (include/flybody_engine.h FB_WARN_*): raised during a launch, cleared at the start of the next control step;
 // IS_WARN_EVER accumulates them since the last reset of the environment
 enum { WARN_CONTACT_CAP = 1, WARN_EFC_CAP = 2, WARN_SOLVER_MAXITER = 4, WARN_CCD_MAXITER = 8, WARN_SCHED_WAIT = 16, WARN_SOLVER_FALLBACK = 32 };

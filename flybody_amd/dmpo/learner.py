@@ -201,10 +201,15 @@ class DMPOLearner:
     def _apply_gradients(self):
         self.opt.step()              # global-norm clipping per group (policy, critic) + Adam for everything
 
-    def step(self, batch=None, prefetch: bool = True) -> Dict[str, torch.Tensor]:
-        """One update.  `batch` may be omitted when the graphs were captured with a sampler.  prefetch = False: the caller is about
-        to change what the next step's replay draw sees (the trainer appends to the replay between bursts of updates), so the
-        overlapped data-parallel step must not draw the next batch ahead."""
+    def step(self, batch=None, prefetch: bool = False) -> Dict[str, torch.Tensor]:
+        """One update.  `batch` may be omitted when the graphs were captured with a sampler.
+
+        prefetch = True (opt-in; the pipelined step only): the NEXT step's phase A -- replay draw + target-network forwards -- is
+        replayed on a side stream while this step's online branches run, and nothing waits for it until the next step().  The caller
+        thereby promises not to touch what that phase reads (the replay, the target networks) before the next step(): the trainer
+        passes prefetch=True for every update of a burst but the last (it appends to the replay between bursts).  With the default,
+        step() leaves no work in flight that a following NStepReplay.add / Checkpointer.save / load_state_dict on the compute stream
+        could race with; drain() makes the compute stream wait for a prefetched phase explicitly."""
         if self._sets is not None:
             return self._step_pipelined(batch, prefetch)
         self._sync_targets()
@@ -219,6 +224,13 @@ class DMPOLearner:
         self._allreduce()
         self._apply_gradients()
         return stats
+
+    def drain(self):
+        """Makes the compute stream wait for a phase A that a step(prefetch=True) left running on the side stream (no-op otherwise).
+        The prefetched batch stays valid -- the next step() consumes it -- but whatever the caller enqueues on the compute stream
+        after drain() is ordered behind the side stream's reads of the replay and of the target networks."""
+        if self._sets is not None and getattr(self, '_a_ready', False):
+            torch.cuda.current_stream(self.device).wait_event(self._ev_a)
 
     def _streams_on_own_queues(self, want: int):
         """`want` HIP streams that do NOT share a hardware queue with the compute (current) stream, nor with each other.
@@ -267,9 +279,9 @@ class DMPOLearner:
             rot = cands[off:] + cands[:off]
             while len(rot) < 3: rot.append(rot[len(rot) % len(cands)])
             self._pipe_stream = rot[0]; self._br_streams = (rot[2], rot[1]); self._a_ready = False; self._cur = 0
+        # FB_LEARNER_QUEUE_OFFSET pins the rotation -- AFTER the bursts: every burst step all-reduces on a data-parallel job, so a rank
+        # that skipped them (the variable set on some ranks only) would leave the others hanging in a collective
         pinned = os.environ.get('FB_LEARNER_QUEUE_OFFSET')
-        if pinned is not None:
-            assign(int(pinned) % len(cands)); self.stream_rotation = int(pinned) % len(cands); return
         saved_t = [t.clone() for t in list(self.target.policy.state_dict().values()) + list(self.target.critic.state_dict().values())]
         saved_steps = self.num_steps
         rng = torch.cuda.get_rng_state(self.device)       # (the A graphs draw: the burst must not shift the random stream of the run)
@@ -285,6 +297,8 @@ class DMPOLearner:
             e1.record(main); torch.cuda.synchronize(self.device)
             times.append(e0.elapsed_time(e1))
         best = min(range(NROT), key=lambda o: times[o]) % len(cands)
+        if pinned is not None:
+            best = int(pinned) % len(cands)
         assign(best); self.stream_rotation = best; self.stream_rotation_ms = [t/24 for t in times]
         self.num_steps = saved_steps
         torch.cuda.set_rng_state(rng, self.device)
@@ -495,5 +509,7 @@ class DMPOLearner:
                     adam=self.opt.state_dict(), num_steps=self.num_steps)
 
     def load_state_dict(self, sd):
+        self.drain()                                      # (a prefetched phase A may still be reading the target networks)
+        self._a_ready = False                             # ... and what it computed belongs to the weights that are being replaced
         self.online.load_state_dict(sd['online']); self.target.load_state_dict(sd['target']); self.loss.load_state_dict(sd['duals'])
         self.opt.load_state_dict(sd['adam']); self.num_steps = sd['num_steps']

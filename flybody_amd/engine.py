@@ -29,8 +29,8 @@ ASSETS = os.path.join(_HERE, 'assets')
 FIELDS = dict(QPOS=0, QVEL=1, ACT=2, CTRL=3, QACC=4, XPOS=5, XQUAT=6, SENSORDATA=7, OBS=8, REWARD=9,
               DISCOUNT=10, STEP_TYPE=11, NCON=12, NEFC=13, SOLVER_NITER=14, QFRC_BIAS=15, QFRC_PASSIVE=16,
               QACC_SMOOTH=17, QM=18, CONTACT=19, EFC_FORCE=20, QFRC_ACTUATOR=21, QFRC_CONSTRAINT=22,
-              STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26, GEOM_XPOS=27, GEOM_XMAT=28, CVEL=29, STEP_TICKS=30, LAUNCH_ORDER=31, WARN=32, WARN_EVER=33)
-_INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF', 'STEP_TICKS', 'LAUNCH_ORDER', 'WARN', 'WARN_EVER'}
+              STEP_COUNT=23, SUBTREE_COM=24, PROF=25, REWARD_FACTORS=26, GEOM_XPOS=27, GEOM_XMAT=28, CVEL=29, STEP_TICKS=30, LAUNCH_ORDER=31, WARN=32, WARN_EVER=33, SIZE_STATS=34)
+_INT_FIELDS = {'STEP_TYPE', 'NCON', 'NEFC', 'SOLVER_NITER', 'STEP_COUNT', 'PROF', 'STEP_TICKS', 'LAUNCH_ORDER', 'WARN', 'WARN_EVER', 'SIZE_STATS'}
 # bits of WARN / WARN_EVER (include/flybody_engine.h): the caps MuJoCo reports as nconmax / njmax warnings, and iteration limits
 WARN_BITS = dict(CONTACT_CAP=1, EFC_CAP=2, SOLVER_MAXITER=4, CCD_MAXITER=8, SCHED_WAIT=16, SOLVER_FALLBACK=32)
 _F32_FIELDS = {'OBS', 'REWARD', 'DISCOUNT'}
@@ -264,7 +264,7 @@ class Batch:
                     QFRC_PASSIVE=m.dim('nv'), QACC_SMOOTH=m.dim('nv'), QM=m.dim('nM'), CONTACT=MAXCON*8,
                     EFC_FORCE=MAXEFC, QFRC_ACTUATOR=m.dim('nv'), QFRC_CONSTRAINT=m.dim('nv'), STEP_COUNT=1,
                     SUBTREE_COM=3, PROF=112, REWARD_FACTORS=5, GEOM_XPOS=3*m.dim('ngeom'),
-                    GEOM_XMAT=9*m.dim('ngeom'), CVEL=6*m.dim('nbody'), STEP_TICKS=1, LAUNCH_ORDER=1, WARN=1, WARN_EVER=1)[name]
+                    GEOM_XMAT=9*m.dim('ngeom'), CVEL=6*m.dim('nbody'), STEP_TICKS=1, LAUNCH_ORDER=1, WARN=1, WARN_EVER=1, SIZE_STATS=4)[name]
 
     def get(self, name: str) -> np.ndarray:
         w = self._width(name)

@@ -31,9 +31,14 @@ class Trainer:
     reference's rate limiter, SampleToInsertRatio(config.samples_per_insert = 15, min_size_to_sample = config.min_replay_size,
     error_buffer = 10 % tolerance) -- with 4096 environments and batch 256 that is 240 updates per control step, i.e. the learner
     sets the pace exactly as in the reference.  An integer fixes the count instead (throughput runs); the gate on
-    min_replay_size stays.  config.samples_per_insert = None means "no ratio" (reverb MinSize): one update per control step."""
+    min_replay_size stays.  config.samples_per_insert = None means "no ratio" (reverb MinSize): one update per control step.
 
-    def __init__(self, n_env=4096, precision=32, replay_capacity=400_000, learner_steps_per_env_step=None, seed=0,
+    Defaults are the reference's: replay table of 4 000 000 items (train_dmpo_ray.py:105-116; 24.7 GB of the GPU's 288 GB),
+    min_replay_size 10 000, 15 samples per insert -- and FP64 physics, the arithmetic of the reference's MuJoCo (north_star asks
+    for qpos / qvel within 1e-4 of it over 100 steps, which the FP64 kernel holds for EVERY environment and the FP32 build only for
+    most: tests/test_gpu_parity.py).  The loop is learner-bound, so FP64 physics costs it nothing (bench.py: dmpo_mode)."""
+
+    def __init__(self, n_env=4096, precision=64, replay_capacity=4_000_000, learner_steps_per_env_step=None, seed=0,
                  config: DMPOConfig = DMPOConfig(), terminal_com_dist=0.3, ref_path=None, traj_indices=None,
                  directory=None, checkpoint_to_load=None, time_delta_minutes=30.0, checkpoint_max_to_keep=1):
         self.world = int(os.environ.get('WORLD_SIZE', '1')); self.rank = int(os.environ.get('RANK', '0'))
@@ -86,6 +91,7 @@ class Trainer:
         self._fin_n = torch.zeros((), device=self.device); self._fin_ret = torch.zeros((), device=self.device)
         self._fin_len = torch.zeros((), device=self.device)
         self._last_return = 0.0; self._last_length = 0.0; self._t_learn = None
+        self._burst_events = None       # measure(): (start, end) HIP events around every learner burst -> the learner's share of the wall time
         self._eval_kw = dict(ref_path=ref_path, traj_indices=traj_indices, terminal_com_dist=terminal_com_dist, seed=seed)
         if directory is not None:
             ck = Checkpointer(directory, self.learner, self.counter, time_delta_minutes, checkpoint_max_to_keep)
@@ -165,9 +171,13 @@ class Trainer:
             if self.use_graphs and self.learner._graph_fb is None and self.learner._sets is None:
                 self.learner.enable_graphs(self.replay.sample(B), sampler=lambda: self.replay.sample(B))
             sampled_in_graph = self.learner._sampler is not None
+            if self._burst_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
             for k in range(allowed):
                 # (the last update of the burst must not draw the next batch ahead: the replay is appended to before the next burst)
                 stats = self.learner.step(None if sampled_in_graph else self.replay.sample(B), prefetch=k + 1 < allowed)
+            if self._burst_events is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(); self._burst_events.append((e0, e1))
             self.learner_steps += allowed; self.limiter.sample(allowed * B)
             now = time.time()
             self.counter.increment(learner_steps=allowed, learner_walltime=(now - self._t_learn) if self._t_learn else 0.0)
@@ -200,6 +210,8 @@ def measure(tr: 'Trainer', warmup: int, iters: int):
     if tr.world > 1:
         dist.barrier()
     e0, l0 = tr.env_steps, tr.learner_steps
+    ins0, smp0 = tr.limiter.inserts, tr.limiter.samples
+    tr._burst_events = []
     t0 = time.perf_counter(); stats = None
     for _ in range(iters):
         stats = tr.iterate() or stats
@@ -207,14 +219,34 @@ def measure(tr: 'Trainer', warmup: int, iters: int):
     if tr.world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    burst_s = sum(a.elapsed_time(b) for a, b in tr._burst_events)/1e3; tr._burst_events = None
     if tr.world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=tr.device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     lr = tr.learner
-    return {'n_gpus': tr.world, 'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': (tr.learner_steps - l0) / dt,
-            'envs_per_gpu': tr.env.n_env, 'learner_steps_per_env_step': (tr.learner_steps - l0) / max(1, iters), 'batch_size': tr.cfg.batch_size,
-            'samples_per_insert': {'configured': tr.cfg.samples_per_insert if tr.lsteps_per is None else None, 'achieved': tr.limiter.achieved_samples_per_insert,
+    lsteps = tr.learner_steps - l0
+    # learner roofline: the GEMM flops of one update (dmpo.gemm_flop_per_step: every matrix product of the three forward and two
+    # backward passes at the reference's shapes) x updates / wall time against the exact-f32 MFMA peak (v_mfma_f32_32x32x2_f32,
+    # MI355X_MICROARCH.md: 157.3 TFLOP/s) -- the learner sets the pace of this loop, so this is the loop's binding roofline
+    from .dmpo import gemm_flop_per_step
+    nobs, nu = tr.env.nobs, tr.env.action_spec().shape[0]
+    fl = gemm_flop_per_step(tr.cfg.batch_size, tr.cfg.num_samples, nobs, nu)
+    tfl = fl*lsteps/dt/1e12
+    return {'n_gpus': tr.world, 'env_steps_per_sec': (tr.env_steps - e0) * tr.world / dt, 'learner_steps_per_sec': lsteps / dt,
+            'envs_per_gpu': tr.env.n_env, 'timed_control_steps': iters, 'wall_s_timed': dt,
+            'learner_steps_per_env_step': lsteps / max(1, iters), 'batch_size': tr.cfg.batch_size,
+            'replay_capacity': tr.replay.capacity, 'min_replay_size': tr.limiter.min_size, 'physics_build': tr.env.build,
+            'samples_per_insert': {'configured': tr.cfg.samples_per_insert if tr.lsteps_per is None else None,
+                                   # over the timed window (what the rate limiter holds in steady state) / since the start of the run (the
+                                   # first min_size_to_sample inserts are not sampled against: Reverb's offset)
+                                   'achieved': (tr.limiter.samples - smp0) / max(1, tr.limiter.inserts - ins0),
+                                   'achieved_since_start': tr.limiter.achieved_samples_per_insert,
                                    'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
+            'roofline': {'bound': 'mfma', 'achieved': tfl, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tfl/157.3,
+                         'gemm_gflop_per_learner_step': fl/1e9, 'dtype': 'f32 (exact: v_mfma_f32_32x32x2_f32 / rocBLAS sgemm)',
+                         'learner_time_share': burst_s/dt,
+                         'note': 'learner_time_share = HIP-event time of the learner bursts / wall time (rank 0); the physics kernel of the '
+                                 'same control step runs concurrently on its own stream'},
             'num_samples': tr.cfg.num_samples, 'replay_size': tr.replay.size, 'independent_queues_found': getattr(lr, 'independent_queues_found', None),
             'gradient_allreduce': ('none (single rank)' if tr.world == 1 else
                                    ('one flat buffer of %d floats per learner step over %s, %s' % (lr.flat_grad.numel(), dist.get_backend(),
@@ -225,7 +257,9 @@ def measure(tr: 'Trainer', warmup: int, iters: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--iters', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10); ap.add_argument('--precision', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--precision', type=int, default=64, help='physics arithmetic: 64 (default, the reference\'s) or 32')
+    ap.add_argument('--replay-capacity', type=int, default=4_000_000, help='reference: 4 000 000 (train_dmpo_ray.py:105-116)')
     ap.add_argument('--gpus', type=int, default=None, help='started bare with --gpus N > 1: re-execute under torch.distributed.run with N ranks')
     ap.add_argument('--learner-steps', type=int, default=None,
                     help='fixed number of learner steps per control step of the batch (default: set by the sample-to-insert limiter)')
@@ -243,7 +277,7 @@ def main():
                '--master-port', str(port), '-m', 'flybody_amd.train_dmpo'] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1')))
     spi = a.samples_per_insert if a.samples_per_insert > 0 else None
-    tr = Trainer(n_env=a.envs, precision=a.precision, learner_steps_per_env_step=a.learner_steps,
+    tr = Trainer(n_env=a.envs, precision=a.precision, replay_capacity=a.replay_capacity, learner_steps_per_env_step=a.learner_steps,
                  config=DMPOConfig(min_replay_size=a.min_replay, samples_per_insert=spi), terminal_com_dist=float('inf') if a.ref_path is None else 0.3,
                  ref_path=a.ref_path, directory=a.directory, checkpoint_to_load=a.checkpoint_to_load, time_delta_minutes=a.checkpoint_minutes)
     res = measure(tr, a.warmup, a.iters)

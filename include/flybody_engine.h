@@ -65,6 +65,10 @@ enum {
   FB_WARN = 32,       /* [n_env] int32: FB_WARN_* bits raised during the last launch (cleared when a control step / reset starts).
                          Mirrors MuJoCo's nconmax / njmax warnings (fruitfly.xml:6) and adds the iteration limits. */
   FB_WARN_EVER = 33,  /* [n_env] int32: the same bits accumulated since the environment's last reset */
+  FB_SIZE_STATS = 34, /* [n_env][4] int32: largest contact count, largest constraint-row count, number of substeps with more than 32 rows,
+                         number of substeps with more than 64 rows (= Newton fell back to PGS) -- over every substep since the batch was
+                         created; not cleared by resets; fb_batch_set(FB_SIZE_STATS, zeros) clears.  Against FB_MAXCON / FB_MAXEFC and
+                         MuJoCo's nconmax 100 / njmax 300 (fruitfly.xml:6) this says how close a run came to the caps. */
   FB_NFIELD
 };
 

@@ -86,7 +86,7 @@ def test_dmpo_leg_runs_under_several_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FB_BENCH_DEVICE', 'FB_BENCH_BACKEND')}
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rccl-dry-run', '--steps', '2', '--warmup', '1', '--preroll', '0', '--envs-per-gpu', '128',
            '--no-f32-leg', '--no-split-leg', '--no-cpu-baseline', '--no-parity-sample', '--no-flight-leg',
-           '--dmpo-envs', '256', '--dmpo-iters', '4', '--dmpo-warmup', '6', '--dmpo-min-replay', '512']
+           '--dmpo-envs', '256', '--dmpo-iters', '4', '--dmpo-warmup', '6', '--dmpo-min-replay', '512', '--dmpo-replay-capacity', '50000']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
@@ -94,3 +94,23 @@ def test_dmpo_leg_runs_under_several_ranks():
     assert d['config'].startswith('configs[4]') and d['n_gpus'] == 2 and d['envs_per_gpu'] == 256
     assert d['env_steps_per_sec'] > 0 and d['learner_steps_per_sec'] > 0 and d['learner_steps_per_env_step'] >= 1
     assert 'overlapped' in d['gradient_allreduce'] and '1' in str(d['samples_per_insert']['configured'])
+    # the leg says at which parameters it ran and carries its own roofline; the defaults are the reference's
+    # (replay 4 000 000, min_replay 10 000, 100 timed steps: asserted on the argument parser below, this run shrinks them)
+    assert d['replay_capacity'] == 50000 and d['min_replay_size'] == 512 and d['timed_control_steps'] == 4
+    assert d['dtype'].startswith('f64') and d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1 and 0 < d['roofline']['learner_time_share'] <= 1.0
+    assert abs(d['samples_per_insert']['achieved'] - 15) < 0.75          # within 5 % of the reference's ratio over the timed window
+
+
+def test_dmpo_leg_defaults_are_the_reference_parameters():
+    """train_dmpo_ray.py:105-137 / ray_distributed_dmpo.py:82-96: replay 4 000 000, min_replay_size 10 000, 15 samples per insert,
+    batch 256, 20 sampled actions -- and FP64 physics (the reference's MuJoCo arithmetic).  CPU-only: reads the argument defaults."""
+    import re
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert re.search(r"--dmpo-iters', type=int, default=100", src) and re.search(r"--dmpo-min-replay', type=int, default=10_000", src)
+    assert re.search(r"--dmpo-replay-capacity', type=int, default=4_000_000", src)
+    tsrc = open(os.path.join(ROOT, 'flybody_amd', 'train_dmpo.py')).read()
+    assert re.search(r"--precision', type=int, default=64", tsrc) and re.search(r"--replay-capacity', type=int, default=4_000_000", tsrc)
+    assert re.search(r"--samples-per-insert', type=float, default=15.0", tsrc) and re.search(r"--min-replay', type=int, default=10_000", tsrc)
+    from flybody_amd.dmpo import DMPOConfig
+    c = DMPOConfig()
+    assert (c.batch_size, c.num_samples, c.n_step, c.max_replay_size, c.min_replay_size, c.samples_per_insert) == (256, 20, 5, 4_000_000, 10_000, 15.0)

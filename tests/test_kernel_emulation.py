@@ -242,6 +242,17 @@ def test_solver_paths_by_system_size(emu_model, oracle_model, walk_arrays, preci
         assert _rel(B.get('QACC')[e], od.field('qacc')) < tol, (e, n)
         if precision == 64:
             assert _rel(B.get('EFC_FORCE')[e][:n], od.field('efc_force')[:n]) < 1e-6, (e, n)
+    if precision == 64:
+        # against the UNcapped oracle (Newton at every size, like MuJoCo): identical up to 64 rows, bounded beyond (the flagged fallback)
+        for e, (q, v) in enumerate(zip(Q, V)):
+            od = fbo.OracleData(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+            dev = _rel(B.get('QACC')[e], od.field('qacc'))
+            assert dev < (1e-6 if nefc[e] <= 64 else 5e-2), (e, nefc[e], dev)
+        # FB_SIZE_STATS (bench.py: warn.sizes): largest contact / row counts, substeps above 32 / 64 rows
+        ss = B.get('SIZE_STATS').reshape(-1, 4)
+        assert ss[:, 1].tolist() == nefc and ss[:, 3].tolist() == [int(n > 64) for n in nefc] and ss[:, 2].tolist() == [int(n > 32) for n in nefc]
+        assert (ss[:, 0] == B.get('NCON').ravel()).all()
+        B.set('SIZE_STATS', np.zeros((len(cases), 4), np.int32)); assert not B.get('SIZE_STATS').any()
 
 
 def test_maximum_system_size_is_capped_like_the_oracle(emu_model, oracle_model, walk_arrays):

@@ -40,16 +40,15 @@ torch.cuda.synchronize(); t_add = (time.perf_counter() - t0)/20
 sampler = lambda: rep.sample(a.batch)
 if not a.no_graphs:
     L.enable_graphs(sampler(), sampler=sampler)
-step = (lambda: L.step()) if not a.no_graphs else (lambda: L.step(sampler()))
+step = (lambda: L.step(prefetch=True)) if not a.no_graphs else (lambda: L.step(sampler()))
 for _ in range(a.warmup):
     stats = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     stats = step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-flop = 2*(a.batch*(nobs*256 + 256*256*2 + 256*2*nu)*4                                     # target + online policy fwd, online bwd (x2)
-          + a.samples*a.batch*(nu*512 + 512*512 + 512*256 + 256*51) + a.batch*nobs*512          # target critic on N*B samples
-          + 3*a.batch*((nobs + nu)*512 + 512*512 + 512*256 + 256*51))                           # online critic fwd + bwd
+from flybody_amd.dmpo import gemm_flop_per_step
+flop = gemm_flop_per_step(a.batch, a.samples, nobs, nu)
 print(json.dumps({'metric': 'DMPO learner steps/sec (learner alone, synthetic replay)', 'value': a.steps/dt, 'ms_per_step': dt/a.steps*1e3,
                   'graphs': not a.no_graphs, 'batch': a.batch, 'num_samples': a.samples, 'gemm_gflop_per_step': flop/1e9,
                   'gemm_tflops': flop/(dt/a.steps)/1e12, 'replay_add_ms_4096_envs': t_add*1e3,
