@@ -9,6 +9,15 @@
 #define MPR_TOL ((real)1e-6)
 #define MPR_ITER 50
 #define MPR_EPS ((real)1e-14)
+// (host-side statistics of the narrow phase: tools/collision_stats.py builds the emulation library with -DFB_STATS)
+#if defined(FB_EMULATE) && defined(FB_STATS)
+extern "C" { long long fb_stats[64]; }
+#define FB_STAT(k) (fb_stats[k]++)
+#define FB_STAT_ADD(k, v) (fb_stats[k] += (v))
+#else
+#define FB_STAT(k) do {} while (0)
+#define FB_STAT_ADD(k, v) do {} while (0)
+#endif
 
 template <typename real>
 struct CGeom { real pos[3], mat[9], size[3]; int type; real margin; };     // by value: pointers to the caller's arrays pin those arrays in scratch memory
@@ -155,7 +164,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
   md_support(a, b, d, s);
 #pragma unroll
   for (int k = 0; k < 3; k++) { P.v[1][k] = s.v[k]; P.a1[1][k] = s.v1[k]; P.a2[1][k] = s.v2[k]; P.v[2][k] = 0; P.v[3][k] = 0; }
-  if (dot3(P.v[1], d) < 0) return false;
+  if (dot3(P.v[1], d) < 0) { FB_STAT(10); return false; }
   cross3(d, P.v[0], P.v[1]);
   if (dot3(d, d) < MPR_EPS*MPR_EPS) {
     if (dot3(P.v[1], P.v[1]) < MPR_EPS*MPR_EPS) { *depth = 0; dir[0] = 1; dir[1] = 0; dir[2] = 0; }
@@ -167,7 +176,7 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
   md_support(a, b, d, s);
 #pragma unroll
   for (int k = 0; k < 3; k++) { P.v[2][k] = s.v[k]; P.a1[2][k] = s.v1[k]; P.a2[2][k] = s.v2[k]; }
-  if (dot3(P.v[2], d) < 0) return false;
+  if (dot3(P.v[2], d) < 0) { FB_STAT(11); return false; }
   sub3(va, P.v[1], P.v[0]); sub3(vb, P.v[2], P.v[0]);
   cross3(d, va, vb); normalize3(d);
   if (dot3(d, P.v[0]) > 0) {
@@ -184,7 +193,8 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
     md_support(a, b, d, s);
 #pragma unroll
     for (int k = 0; k < 3; k++) { P.v[3][k] = s.v[k]; P.a1[3][k] = s.v1[k]; P.a2[3][k] = s.v2[k]; }
-    if (dot3(P.v[3], d) < 0) return false;
+    FB_STAT(20);
+    if (dot3(P.v[3], d) < 0) { FB_STAT(12); return false; }
     int j = 0;
     cross3(va, P.v[1], P.v[3]);
     if (dot3(va, P.v[0]) < -MPR_EPS) j = 2;
@@ -201,14 +211,17 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
     portal_dir(P, d);
     if (dot3(d, P.v[1]) >= 0) break;
     md_support(a, b, d, v4);
+    FB_STAT(21);
     if (it > MPR_ITER) *hit_cap = 1;
-    if (dot3(v4.v, d) < 0 || reach_tol(P, v4, d) || it > MPR_ITER) return false;
+    if (dot3(v4.v, d) < 0 || reach_tol(P, v4, d) || it > MPR_ITER) { FB_STAT(13); return false; }
     expand_portal(P, v4);
   }
   for (int it = 0;; it++) {
     portal_dir(P, d);
     md_support(a, b, d, v4);
+    FB_STAT(22);
     if (reach_tol(P, v4, d) || it > MPR_ITER) {
+      FB_STAT(14);
       if (it > MPR_ITER && !reach_tol(P, v4, d)) *hit_cap = 1;
       real wit[3];
       real d2 = origin_tri_dist2(P.v[1], P.v[2], P.v[3], wit);
@@ -410,7 +423,9 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
   for (int k = 0; k < 3; k++) { p1[k] = w.gxpos()[3*g1 + k]; p2[k] = w.gxpos()[3*g2 + k]; s1[k] = M.geom_size[3*g1 + k]; s2[k] = M.geom_size[3*g2 + k]; }
 #pragma unroll
   for (int k = 0; k < 9; k++) { m1[k] = w.gxmat()[9*g1 + k]; m2[k] = w.gxmat()[9*g2 + k]; }
+  FB_STAT(0);
   if (t1 == GEOM_PLANE) {
+    FB_STAT(2);
     real n[3] = {m1[2], m1[5], m1[8]};
     if (t2 == GEOM_SPHERE) c_plane_sphere(lc, p1, n, p2, s2[0], margin);
     else if (t2 == GEOM_CAPSULE) {
@@ -447,6 +462,7 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
     for (int k = 0; k < 9; k++) { A.mat[k] = m1[k]; B.mat[k] = m2[k]; }
     A.type = t1; B.type = t2; A.margin = margin; B.margin = margin;
     real depth, dir[3], pos[3];
+    FB_STAT(1); FB_STAT(30 + t1*6 + t2 - 14);
     if (mpr_penetration(A, B, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
   }
   return lc.n | (lc.ccd_cap ? 256 : 0);
