@@ -12,7 +12,17 @@
 #include "fb_smooth.hpp"
 #include "fb_newton.hpp"
 
+#ifndef FB_J_ROWMAJOR
+#define FB_J_ROWMAJOR 1
+#endif
+#if FB_J_ROWMAJOR
+// row-major (round 5): the 2 x FB_MAXCH chain entries of a constraint row are contiguous (320 B in FP64), so the ~12 rows of a typical system
+// occupy ~4 KB of the environment's row instead of 40 x 2 pieces of 96 B at a stride of 1536 B -- and J^T f, which walks the rows
+// one by one with lane == dof, reads two cache lines per row instead of one per lane
+#define JIDX(side, s, r) (((r)*2 + (side))*FB_MAXCH + (s))
+#else
 #define JIDX(side, s, r) (((side)*FB_MAXCH + (s))*FB_MAXEFC_ + (r))
+#endif
 #define MINIMP ((real)0.0001)
 #define MAXIMP ((real)0.9999)
 

@@ -16,6 +16,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#if defined(FB_EMULATE) && defined(FB_STATS)
+extern "C" { long long fb_stats[64]; }
+#endif
 
 #include "../../include/flybody_engine.h"
 #include "fb_step.hpp"

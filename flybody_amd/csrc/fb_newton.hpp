@@ -210,6 +210,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     }
     real z = 0;
     if (tile) {
+      FB_STAT(40);
       // ---- K = I + F'AF in the tile layout, two passes over the block structure of F (column j of F = the three entries fc0..2 of lane j
       // at the rows base_j .. base_j + 2):  G = A F from three entries of AR per register, then K[i][j] = delta_ij + sum_a fc_a(i) G[base_i + a][j],
       // where G[base_i + a][j] is the SAME register of lane (base_i + a, tc).  Inactive columns have zero factors: K is the identity there
@@ -324,6 +325,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       }
       NW_PROF(2);
       if (n_act <= FB_NEWTON_NT) {
+        FB_STAT(41);
         // ---- tile factorisation (98.5 % of the iterations of the bench workload have <= 16 ACTIVE columns): the compacted K as a full
         // symmetric 16 x 16 tile over the wave -- lane (ti, tc) = (lane >> 2, lane & 3) holds K[ti][4 tc + 0..3] -- so that one elimination
         // step is ONE multiply-add per register for the whole trailing matrix instead of a v_readlane per remaining column: the pivot row
@@ -397,6 +399,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       //    own storage (slot c) -- the trailing update of an entry is two v_readlane, one compare, the multiply-adds and one masked store;
       //  * two pivots per pass over the trailing rows (rank-2 update: one LDS read and write per entry for two multiply-adds), eight
       //    entries of a row per LDS round trip; the next pivot's column entry stays in a register.
+      FB_STAT(43);
       const bool mine = on && ((m_act >> lane) & 1ull);
       if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;       // row of compact index my_ci, parked in the diagonal slot of packed row my_ci
       SYNC();

@@ -10,6 +10,14 @@
 #endif
 #include <stdint.h>
 
+// host-side event counters of the emulation build (tools/collision_stats.py, tests: -DFB_STATS); no-ops everywhere else
+#if defined(FB_EMULATE) && defined(FB_STATS)
+extern "C" { extern long long fb_stats[64]; }
+#define FB_STAT(k) (fb_stats[k]++)
+#else
+#define FB_STAT(k) do {} while (0)
+#endif
+
 #define FB_WAVE 64
 #define FB_EPB 4            // environments (wavefronts) per workgroup of the FP32 build (LdsCfg<real>::EPB); they share the LDS topology tables
 #define FB_MAXCH 20        // longest root->leaf dof chain (6 root + 14 abdomen dofs)

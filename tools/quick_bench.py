@@ -17,7 +17,7 @@ else:
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 a = torch.empty(n, M.dim('nact'), device='cuda')
 st = torch.cuda.current_stream().cuda_stream
-for _ in range(5):
+for _ in range(int(os.environ.get("FB_QB_WARM", "30"))):
     a.normal_(generator=g).clamp_(-1, 1); B.step_ptr(a.data_ptr(), st)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(K):
