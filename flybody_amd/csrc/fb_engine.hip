@@ -896,7 +896,10 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
 template <typename real>
 static void compute_offsets(const DevModel<real>& M, WSOff& o) {
   uint32_t r = 0, i = 0;
-  auto al = [](uint32_t v) { return (v + 3u) & ~3u; };   // keep every array 16/32-byte aligned
+#ifndef FB_WS_ALIGN
+#define FB_WS_ALIGN 16
+#endif
+  auto al = [](uint32_t v) { return (v + (uint32_t)(FB_WS_ALIGN - 1)) & ~(uint32_t)(FB_WS_ALIGN - 1); };   // 4: every array 16/32-byte aligned; 16: on a cache line of its own
 #define X(name, n) o.name = r; r = al(r + (uint32_t)(n));
   FB_WS_REAL(X)
 #undef X

@@ -90,12 +90,13 @@ template <typename T> struct GP {
   X(qfrc_bias, M.nv) X(qfrc_passive, M.nv) X(qfrc_actuator, M.nv) X(qfrc_smooth, M.nv) X(qacc_smooth, M.nv) \
   X(qfrc_constraint, M.nv) X(ten_length, M.ntendon + 1) X(act_force, M.nu) \
   X(con_dist, FB_MAXCON_) X(con_pos, 3*FB_MAXCON_) X(con_frame, 9*FB_MAXCON_) \
-  X(efc_J, 2*FB_MAXCH*FB_MAXEFC_) X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) \
+  X(efc_J, 2*FB_MAXCH*FB_MAXEFC_) \
   X(efc_pos, FB_MAXEFC_) X(efc_margin, FB_MAXEFC_) X(efc_R, FB_MAXEFC_) X(efc_D, FB_MAXEFC_) X(efc_K, FB_MAXEFC_) \
   X(efc_B, FB_MAXEFC_) X(efc_imp, FB_MAXEFC_) X(efc_aref, FB_MAXEFC_) X(efc_b, FB_MAXEFC_) X(efc_force, FB_MAXEFC_) \
   X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) \
-  X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2) /* packed lower triangle, only written for systems that do not fit the LDS copy */ \
-  X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody)
+  X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody) \
+  /* cold tail of the row: only systems that do not fit the LDS copies (wide-system Y, Delassus triangle + Newton work matrix) touch it */ \
+  X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2)
 
 #define FB_WS_INT(X) \
   X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
