@@ -44,6 +44,14 @@ WAVE_REDUCE(wmax, fmaxf, -INFINITY)
 WAVE_REDUCE(wmin, fminf, INFINITY)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f/(1.f + expf(-x)); }
+// ELU for the GEMM epilogues (x <= 0 branch: expm1).  The library expm1f costs ~100 instructions; a tile epilogue evaluates it 40 times per
+// lane (measured: 7 us of a 16 us launch).  Near zero, where exp(x) - 1 cancels, a degree-7 Taylor polynomial (truncation 1.6e-8
+// relative on [-0.35, 0]); below, exp(x) - 1 with exp(x) < 0.71 loses at most one bit.
+__device__ __forceinline__ float elu_f(float x) {
+  const float p = x*(1.f + x*(0.5f + x*(0.16666667f + x*(0.041666668f + x*(0.008333334f + x*(0.0013888889f + x*0.0001984127f))))));
+  const float e = __expf(x) - 1.f;
+  return x > 0.f ? x : (x > -0.35f ? p : e);
+}
 
 // ------------------------------------------------------------------ categorical TD loss
 // Four wavefronts per batch row (lane == atom), TD_ROWS rows per workgroup.  The row's work is a chain of dependent wave reductions and
@@ -788,6 +796,7 @@ extern "C" int fbl_bias_elu_bwd(const float* dy, const float* y, int M, int W, f
 // and leave through the epilogue (bias / bias + ELU).  C = A B with A(i, k) = a[i sai + k sak], B(k, j) = b[k sbk + j sbj]:
 // every transpose combination of the forward and backward passes is a choice of strides.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GB 8                                  // k-steps (of 8) prefetched per block: 64 k per wave in flight
 
 // Two operand sets per launch: mode 0 = one product; mode 1 = two independent products of the same shape (blockIdx.z picks the set:
@@ -899,6 +908,236 @@ extern "C" int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* 
 }
 extern "C" int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream) {
   return gemm_launch(op0, op1, sum ? 2 : 1, ldc, M, N, K, stream);
+}
+
+// ------------------------------------------------------------------ large f32 GEMM: LDS-tiled, for the [5120 x K] products of the target critic
+// C[M, N] = epilogue(A[M, K] W[N, K]^T) -- both operands k-contiguous, the form of every forward layer (y = x W^T).  Round 5: the
+// N x B = 5120-row products of the target critic (learning_dmpo.py:223-251: 20 sampled actions per observation through the 512-512-256
+// critic torso) were the last GEMMs of the step that went to the BLAS library, each followed by a bias + ELU launch of its own.
+//
+// Tile shape is chosen for THIS machine and THESE shapes: 256 CUs, 5120 rows.  A workgroup owns 80 x 128 (or 80 x 64) outputs -- five
+// row fragments of v_mfma_f32_16x16x4_f32 (exact f32) by eight (four) column fragments, split column-wise over its four wavefronts
+// -- so that [5120 x 512] is 64 x 4 = 256 tiles (and [5120 x 256] 64 x 4 = 256 tiles of 80 x 64): ONE per CU, every SIMD with the same
+// load.  (The textbook 128 x 128 tile gives 160 workgroups -- 96 CUs idle; a 64 x 64 tile was measured first: 640 workgroups, 38 us,
+// bound by the L2 -- 16 flops per byte fetched; 80 x 128 has 49 multiply-adds per float.)  K is walked in blocks of 32 through a
+// double-buffered LDS stage: the global loads of block t + 1 are in flight while the 80 MFMAs of block t run, one barrier per block.
+// LDS rows are padded to 36 floats: a lane reads the four consecutive k of its fragment row (the four MFMAs of a 16-k group: lane l
+// feeds k = 16 g + 4 (l >> 4) + q) as ONE ds_read_b128, conflict-free.  Tile order is XCD-aware (below).  Rows / columns past the edge
+// read a valid row (never stored), the K tail is zero-filled: any M, N, K (K = 59 action columns); row strides need not be multiples of
+// four (unaligned 16-byte loads).
+#define NT_BM 80
+#define NT_KB 32
+#define NT_LD (NT_KB + 4)
+// K-tail loads WITHOUT control flow: a divergent `if (k + 3 < K)` around a load makes the compiler wait (vmcnt(0)) at every join, which
+// serialised the seven loads of a K block -- seven L2 round trips per block instead of one (first version: 1.8 us per block against
+// 1.07 us of MFMA).  Blocks that lie inside K use plain 16-byte loads (wave-uniform choice); only the last, partial block takes this
+// path: four clamped 4-byte loads and selects.
+__device__ __forceinline__ float4 nt_load4(const float* __restrict__ p, int k) { return *reinterpret_cast<const float4*>(p + k); }
+__device__ __forceinline__ float4 nt_load4_tail(const float* __restrict__ p, int k, int K) {
+  const float x = p[min(k, K - 1)], y = p[min(k + 1, K - 1)], z = p[min(k + 2, K - 1)], w = p[min(k + 3, K - 1)];
+  float4 t;
+  t.x = k < K ? x : 0.f; t.y = k + 1 < K ? y : 0.f; t.z = k + 2 < K ? z : 0.f; t.w = k + 3 < K ? w : 0.f;
+  return t;
+}
+template <int CW>                             // 16-column fragments per wavefront: the tile is 80 x (64 CW)
+__global__ void __launch_bounds__(256) k_gemm_nt(const float* __restrict__ A, long long lda, const float* __restrict__ W, long long ldw, float* __restrict__ C,
+                                                 long long ldc, const float* __restrict__ bias, int epi, int M, int N, int K) {
+  constexpr int BN = 64*CW, PB = BN/32;
+  __shared__ float smem[2*NT_BM*NT_LD + 2*BN*NT_LD];
+  float (*As)[NT_BM][NT_LD] = reinterpret_cast<float (*)[NT_BM][NT_LD]>(smem);
+  float (*Bs)[BN][NT_LD] = reinterpret_cast<float (*)[BN][NT_LD]>(smem + 2*NT_BM*NT_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, g4 = lane >> 4;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (id mod 8), each with an L2 of its own.  With a plain
+  // (column tile, row tile) grid, XCD k would own the same column tile(s) of EVERY row tile: all 10 MB of A stream through each of the
+  // eight 4 MB L2s without a single reuse (measured on the first version: every K block an L2 miss).  Here the id is re-read as (XCD,
+  // index inside the XCD): an XCD owns a contiguous band of row tiles and walks its column tiles first, so the workgroups that share
+  // a row tile of A run on ONE XCD, next to each other in time; W (<= 1 MB) is resident in every L2.
+  const int CT = (N + BN - 1)/BN, RT = (M + NT_BM - 1)/NT_BM;
+  const int id = blockIdx.x, xcd = id & 7, ix = id >> 3;
+  const int rpx = (RT + 7) >> 3;                                          // row tiles per XCD
+  const int rt = xcd*rpx + ix/CT, ct = ix % CT;
+  if (rt >= RT || ix >= rpx*CT) return;                                   // (uniform per workgroup, before any barrier)
+  const int i0 = rt*NT_BM, j0 = ct*BN;
+  // loader: thread t brings the float4 at k = 4 (t & 7) of rows (t >> 3) + 32 p of both tiles (A: 80 rows = 2.5 passes)
+  const int lr = tid >> 3, lk = 4*(tid & 7);
+  const bool a2 = lr < NT_BM - 64;
+  const float* pa[3]; const float* pb[PB];
+#pragma unroll
+  for (int p = 0; p < 3; p++) pa[p] = A + (long long)min(i0 + min(lr + 32*p, NT_BM - 1), M - 1)*lda;
+#pragma unroll
+  for (int p = 0; p < PB; p++) pb[p] = W + (long long)min(j0 + lr + 32*p, N - 1)*ldw;
+  f32x4 acc[5][CW];
+#pragma unroll
+  for (int a = 0; a < 5; a++)
+#pragma unroll
+    for (int c = 0; c < CW; c++) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nkb = (K + NT_KB - 1)/NT_KB;
+  float4 ra[3], rb[PB];
+  // (the third A pass covers rows 64..79 only: the upper half of the threads re-reads row 79, harmlessly, instead of branching)
+  if (NT_KB <= K) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) ra[p] = nt_load4(pa[p], lk);
+#pragma unroll
+    for (int p = 0; p < PB; p++) rb[p] = nt_load4(pb[p], lk);
+  } else {
+#pragma unroll
+    for (int p = 0; p < 3; p++) ra[p] = nt_load4_tail(pa[p], lk, K);
+#pragma unroll
+    for (int p = 0; p < PB; p++) rb[p] = nt_load4_tail(pb[p], lk, K);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; p++) if (p < 2 || a2) *reinterpret_cast<float4*>(&As[0][lr + 32*p][lk]) = ra[p];
+#pragma unroll
+  for (int p = 0; p < PB; p++) *reinterpret_cast<float4*>(&Bs[0][lr + 32*p][lk]) = rb[p];
+  __syncthreads();
+  for (int kb = 0; kb < nkb; kb++) {
+    const int buf = kb & 1;
+    const bool more = kb + 1 < nkb;
+    if (more) {
+      const int k = (kb + 1)*NT_KB + lk;
+      if ((kb + 2)*NT_KB <= K) {                       // (wave-uniform) the whole next block lies inside K
+#pragma unroll
+        for (int p = 0; p < 3; p++) ra[p] = nt_load4(pa[p], k);
+#pragma unroll
+        for (int p = 0; p < PB; p++) rb[p] = nt_load4(pb[p], k);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 3; p++) ra[p] = nt_load4_tail(pa[p], k, K);
+#pragma unroll
+        for (int p = 0; p < PB; p++) rb[p] = nt_load4_tail(pb[p], k, K);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NT_KB/16; g++) {
+      float4 fa[5], fb[CW];
+#pragma unroll
+      for (int a = 0; a < 5; a++) fa[a] = *reinterpret_cast<const float4*>(&As[buf][16*a + r][16*g + 4*g4]);
+#pragma unroll
+      for (int c = 0; c < CW; c++) fb[c] = *reinterpret_cast<const float4*>(&Bs[buf][16*(CW*wv + c) + r][16*g + 4*g4]);
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+#pragma unroll
+        for (int c = 0; c < CW; c++) {
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].x, fb[c].x, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].y, fb[c].y, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].z, fb[c].z, acc[a][c], 0, 0, 0);
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a].w, fb[c].w, acc[a][c], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 3; p++) if (p < 2 || a2) *reinterpret_cast<float4*>(&As[buf ^ 1][lr + 32*p][lk]) = ra[p];
+#pragma unroll
+      for (int p = 0; p < PB; p++) *reinterpret_cast<float4*>(&Bs[buf ^ 1][lr + 32*p][lk]) = rb[p];
+    }
+    __syncthreads();
+  }
+  // ---- epilogue through LDS: the accumulator layout (C/D map of the 16x16 MFMA: register v of lane l is C[4 (l >> 4) + v][l & 15])
+  // would store 64-byte pieces, four rows per instruction; staged in the (now idle) operand buffers the tile leaves as full rows,
+  // 16 bytes per lane -- 512 contiguous bytes per row of a 128-column tile
+  constexpr int CLD = BN + 4;
+  float* Cs = &As[0][0][0];                   // 80 x (BN + 4) floats <= the two operand stages (contiguous: As then Bs)
+  static_assert(NT_BM*CLD <= 2*NT_BM*NT_LD + 2*BN*NT_LD, "epilogue staging does not fit the operand buffers");
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const int jl = 16*(CW*wv + c) + r, j = j0 + jl;
+    const float bj = (epi >= 1 && j < N) ? bias[j] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        float y = acc[a][c][v] + bj;
+        if (epi == 2) y = elu_f(y);
+        Cs[(16*a + 4*g4 + v)*CLD + jl] = y;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int TPR = BN/4, RPP = 256/TPR;          // threads per row (float4 each), rows per pass
+    const int cr = tid/TPR, cj = 4*(tid % TPR);
+    for (int row = cr; row < NT_BM; row += RPP) {
+      const int i = i0 + row, j = j0 + cj;
+      if (i >= M) break;
+      const float4 y = *reinterpret_cast<const float4*>(&Cs[row*CLD + cj]);
+      float* dst = C + (long long)i*ldc + j;
+      if (j + 3 < N && ((ldc & 3) == 0)) *reinterpret_cast<float4*>(dst) = y;
+      else { if (j < N) dst[0] = y.x; if (j + 1 < N) dst[1] = y.y; if (j + 2 < N) dst[2] = y.z; if (j + 3 < N) dst[3] = y.w; }
+    }
+  }
+}
+extern "C" int fbl_gemm_nt(const float* a, int64_t lda, const float* w, int64_t ldw, float* c, int64_t ldc, int M, int N, int K, int epilogue, const float* bias,
+                           void* stream) {
+  if (!a || !w || !c || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N || epilogue < 0 || epilogue > 2 || (epilogue && !bias))
+    return lfail("fbl_gemm_nt: bad argument");
+  const int RT = (M + NT_BM - 1)/NT_BM;
+  // 128-column tiles while they still give every CU a workgroup (N = 512 at 5120 rows: 256 tiles), 64-column tiles otherwise
+  const bool wide = (long long)RT*((N + 127)/128) >= 256 || N > 4096;
+  const int BN = wide ? 128 : 64, CT = (N + BN - 1)/BN;
+  const dim3 grid(8*((RT + 7)/8)*CT);
+  if (wide) hipLaunchKernelGGL((k_gemm_nt<2>), grid, dim3(256), 0, (hipStream_t)stream, a, (long long)lda, w, (long long)ldw, c, (long long)ldc, bias, epilogue, M, N, K);
+  else hipLaunchKernelGGL((k_gemm_nt<1>), grid, dim3(256), 0, (hipStream_t)stream, a, (long long)lda, w, (long long)ldw, c, (long long)ldc, bias, epilogue, M, N, K);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ long-K, few-rows GEMM: the 741 / 800-column first layers at B = 256
+// Same form (C = A W^T, both k-contiguous, no epilogue: a LayerNorm follows), but M is the learner's batch: a [256 x 256] output is 64
+// tiles of 32 x 32 -- a quarter of the GPU, each wave chewing through 185 k in three dependent load blocks (fbl_sgemm: 9-11 us, the
+// library 7.5 us).  Here a workgroup owns a 16 x 16 tile (v_mfma_f32_16x16x4_f32: lane l feeds A[l & 15][4 (l >> 4) + q] of a 16-k
+// group, one 16-byte load per group and operand), its four wavefronts split K, and ALL of a wave's loads (<= 13 groups x 2 operands)
+// are issued before the first MFMA: 256-512 workgroups, one memory round trip + ~50 MFMAs each.  Up to two weight matrices that
+// read the SAME rows (the target policy's first layer and the observation half of the target critic's: both consume o_t) share a launch.
+#define LK_GROUPS 13                         // 16-k groups per wave: K <= 4 * 16 * 13 = 832
+__global__ void __launch_bounds__(256) k_gemm_longk(const float* __restrict__ A, long long lda, const float* __restrict__ W0, long long ldw0, float* __restrict__ C0,
+                                                    int N0, const float* __restrict__ W1, long long ldw1, float* __restrict__ C1, int N1, int M, int K) {
+  __shared__ float red[4][4][WAVE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g4 = lane >> 4;
+  const int nt0 = (N0 + 15)/16;
+  const bool second = (int)blockIdx.x >= nt0;
+  const float* W = second ? W1 : W0; const long long ldw = second ? ldw1 : ldw0; float* C = second ? C1 : C0; const int N = second ? N1 : N0;
+  const int j0 = (second ? (int)blockIdx.x - nt0 : (int)blockIdx.x)*16, i0 = blockIdx.y*16;
+  const int ngroups = (K + 15)/16, per = (ngroups + 3)/4;                 // 16-k groups per wave
+  const int gb = wv*per, ge = min(ngroups, gb + per);
+  const float* pa = A + (long long)min(i0 + r, M - 1)*lda; const float* pb = W + (long long)min(j0 + r, N - 1)*ldw;
+  float4 av[LK_GROUPS], bv[LK_GROUPS];
+#pragma unroll
+  for (int g = 0; g < LK_GROUPS; g++) {
+    const int k = 16*(gb + g) + 4*g4;
+    if (16*(gb + g + 1) <= K) { av[g] = nt_load4(pa, k); bv[g] = nt_load4(pb, k); }                       // (wave-uniform: the group lies inside K)
+    else if (gb + g < ge) { av[g] = nt_load4_tail(pa, k, K); bv[g] = nt_load4_tail(pb, k, K); }
+    else { av[g] = make_float4(0.f, 0.f, 0.f, 0.f); bv[g] = av[g]; }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < LK_GROUPS; g++) {
+    if (gb + g < ge) {                                                     // (wave-uniform)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bv[g].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, bv[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].z, bv[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].w, bv[g].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) red[wv][v][lane] = acc[v];
+  __syncthreads();
+  // C/D map of the 16x16 MFMA: register v of lane l is C[4 (l >> 4) + v][l & 15]; wave w finishes register w
+  {
+    const int v = wv;
+    const float t = red[0][v][lane] + red[1][v][lane] + red[2][v][lane] + red[3][v][lane];
+    const int i = i0 + 4*g4 + v, j = j0 + r;
+    if (i < M && j < N) C[(long long)i*N + j] = t;
+  }
+}
+extern "C" int fbl_gemm_longk(const float* a, int64_t lda, const float* w0, int64_t ldw0, float* c0, int N0, const float* w1, int64_t ldw1, float* c1, int N1,
+                              int M, int K, void* stream) {
+  if (!a || !w0 || !c0 || M <= 0 || N0 <= 0 || K <= 0 || K > 64*LK_GROUPS || lda < K || ldw0 < K || (N1 > 0 && (!w1 || !c1 || ldw1 < K)) || N1 < 0)
+    return lfail("fbl_gemm_longk: bad argument (K <= 832)");
+  hipLaunchKernelGGL(k_gemm_longk, dim3((N0 + 15)/16 + (N1 + 15)/16, (M + 15)/16), dim3(256), 0, (hipStream_t)stream, a, (long long)lda, w0, (long long)ldw0, c0, N0,
+                     w1, (long long)ldw1, c1, N1, M, K);
+  LCHK(hipGetLastError());
+  return 0;
 }
 
 // Gaussian head backward when the head ran through fbl_sgemm_pair (its pre-activation was never stored): sigmoid(z) = 1 - exp(-softplus(z)),

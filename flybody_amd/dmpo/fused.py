@@ -68,6 +68,8 @@ def lib():
         L.fbl_nstep_add.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int64, C.c_int, C.c_int] + [C.c_void_p]*23
         L.fbl_sgemm_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fbl_gauss_head_bwd_std.argtypes = [C.c_void_p]*3 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
+        L.fbl_gemm_nt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fbl_gemm_longk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -368,10 +370,82 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+LONGK_MAX = 832                 # fbl_gemm_longk: reductions of up to 13 x 64 columns (the 741 / 800-column first layers)
+
+
+def _rows2d(x):
+    """[..., K] -> [rows, K] view with a unit inner stride (no copy for the tensors of the learner step)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.stride(1) == 1 else x2.contiguous()
+
+
+def gemm_nt(x, w, bias=None, epilogue=0):
+    """epilogue(x W^T) on the LDS-tiled MFMA kernel (fbl_gemm_nt): x [..., K], w [N, K] (a column slice of a wider matrix is fine: the row
+    stride is passed).  epilogue 0 none, 1 + bias, 2 ELU(. + bias).  Forward only (the target networks' 5120-row products)."""
+    x2 = _rows2d(x); M, K = x2.shape; N = w.shape[0]
+    assert w.shape[1] == K and w.stride(1) == 1 and x2.dtype == torch.float32 and w.dtype == torch.float32
+    y = torch.empty(M, N, device=x.device)
+    _check(lib().fbl_gemm_nt(x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), N, M, N, K, int(epilogue),
+                             bias.data_ptr() if bias is not None else None, _stream()))
+    return y.view(*x.shape[:-1], N)
+
+
+def can_longk(x) -> bool:
+    """The shapes fbl_gemm_longk is meant for: a 2-D float32 GPU batch of at most SMALL_GEMM_ROWS rows with SMALL_GEMM_K < K <= LONGK_MAX."""
+    return _USE_SGEMM and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] <= SMALL_GEMM_ROWS and SMALL_GEMM_K < x.shape[1] <= LONGK_MAX
+
+
+def gemm_longk(x, w0, w1=None):
+    """x W0^T (and x W1^T in the same launch) for few rows and a long reduction (fbl_gemm_longk: the 741 / 800-column first layers at the
+    learner's batch).  Forward only; returns one tensor or a pair."""
+    x2 = _rows2d(x); M, K = x2.shape
+    assert K <= LONGK_MAX and w0.shape[1] == K and w0.stride(1) == 1 and (w1 is None or (w1.shape[1] == K and w1.stride(1) == 1))
+    y0 = torch.empty(M, w0.shape[0], device=x.device); y1 = torch.empty(M, w1.shape[0], device=x.device) if w1 is not None else None
+    _check(lib().fbl_gemm_longk(x2.data_ptr(), x2.stride(0), w0.data_ptr(), w0.stride(0), y0.data_ptr(), w0.shape[0],
+                                w1.data_ptr() if w1 is not None else None, w1.stride(0) if w1 is not None else 0,
+                                y1.data_ptr() if w1 is not None else None, w1.shape[0] if w1 is not None else 0, M, K, _stream()))
+    return y0 if w1 is None else (y0, y1)
+
+
+class _LinearLongK(torch.autograd.Function):
+    """y = x W^T for the long-reduction first layers (K = 741 / 800 > SMALL_GEMM_K) of the ONLINE networks: forward on fbl_gemm_longk, the
+    weight gradient d W = d y^T x on fbl_sgemm (a reduction over the 256 rows of the batch: its home shape).  The input is an
+    observation batch -- no gradient flows into it."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _f32c(x); w = _f32c(w)
+        ctx.save_for_backward(x)
+        return gemm_longk(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy); M, K = x.shape; N = dy.shape[1]
+        assert not ctx.needs_input_grad[0], 'fbl_gemm_longk layers take observations: no input gradient'
+        return None, _sgemm(dy, 1, N, x, K, 1, N, K, M)                                        # [N, K] = d y^T [N, M] x [M, K]
+
+
 def linear(x, w, bias=None, elu=False):
-    """x W^T (bias None) or ELU(x W^T + bias).  2-D GPU inputs of up to SMALL_GEMM_ROWS rows run on the hand-written MFMA kernel
-    (fbl_sgemm) with the epilogue fused; anything else is the BLAS GEMM + the fused epilogue kernel (bias_elu)."""
+    """x W^T (bias None) or ELU(x W^T + bias).  Every GPU shape of the learner step runs on a hand-written MFMA kernel (round 5: no BLAS
+    library call is left in it): up to SMALL_GEMM_ROWS rows and SMALL_GEMM_K columns -> fbl_sgemm (32 x 32 tile per workgroup, K split
+    over its waves, epilogue fused); more rows, forward only (the target critic's N x B = 5120 rows) -> fbl_gemm_nt (LDS-tiled, epilogue
+    fused); longer reductions at the learner's batch (the 741 / 800-column first layers) -> fbl_gemm_longk.  Anything else (CPU
+    tensors, FB_LEARNER_GEMM=blas) is F.linear + the fused epilogue kernel."""
     assert bias is None or elu, 'bias without activation is not used by the networks (the loss kernels add the output biases)'
+    if _USE_SGEMM and x.is_cuda and x.dtype == torch.float32 and w.stride(1) == 1:
+        need = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad))
+        rows = x.numel() // x.shape[-1]
+        if rows > SMALL_GEMM_ROWS and not need:
+            if w.shape[0] <= 64 and x.shape[-1] <= SMALL_GEMM_K:
+                # few output columns (the 51 logits): one column tile would leave the LDS-tiled kernel with 64 workgroups walking K one
+                # after the other (11 us); the K-split kernel has 160 x 2 of them (8 us; the library: 5 us)
+                x2 = _rows2d(x)
+                return _sgemm(x2, x2.stride(0), 1, w, 1, w.stride(0), x2.shape[0], w.shape[0], x2.shape[1], 2 if elu else 0,
+                              bias if elu else None).view(*x.shape[:-1], w.shape[0])
+            return gemm_nt(x, w, bias if elu else None, 2 if elu else 0)
+        if x.dim() == 2 and rows <= SMALL_GEMM_ROWS and SMALL_GEMM_K < x.shape[1] <= LONGK_MAX and not elu and not (need and x.requires_grad):
+            return _LinearLongK.apply(x, w) if need else gemm_longk(x, w)
     if _USE_SGEMM and x.is_cuda and x.dim() == 2 and x.shape[0] <= SMALL_GEMM_ROWS and x.shape[1] <= SMALL_GEMM_K and x.dtype == torch.float32:
         if not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad))):
             # forward only (target networks, actors): nothing is saved, and W may be a column slice of a wider matrix (row stride)

@@ -419,10 +419,14 @@ class DMPOLearner:
         N, B = cfg.num_samples, o_t.shape[0]
         tc = self.target.critic
         with torch.no_grad():
-            t_mean, t_std = self.target.policy(o_t)
+            z1 = h_o = None
+            if o_t.is_cuda and fused.can_longk(o_t):
+                # both target networks start with a product of the same observations: one launch (fbl_gemm_longk, two weight matrices)
+                z1, h_o = fused.gemm_longk(o_t, self.target.policy.torso.first.weight, tc.torso.first.weight[:, :o_t.shape[1]])
+            t_mean, t_std = self.target.policy(o_t, z1=z1)
             noise = torch.randn(N, B, t_mean.shape[-1], device=self.device)
             sampled, clipped = fused.sample_actions(t_mean, t_std, noise)
-            q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True)       # [N, B, atoms], logits bias not added yet
+            q_t_raw = tc.forward_samples(o_t, sampled, clipped=clipped, raw=True, h_o=h_o)       # [N, B, atoms], logits bias not added yet
             if with_q:
                 return t_mean, t_std, sampled, q_t_raw, tc.mean_q(q_t_raw + tc.logits.bias)
         return t_mean, t_std, sampled, q_t_raw

@@ -74,10 +74,12 @@ class Policy(nn.Module):
         self.torso = LayerNormMLP(obs_dim, sizes, activate_final=True)
         self.head = GaussianHead(sizes[-1], action_dim)
 
-    def forward(self, obs):
+    def forward(self, obs, z1=None):
+        """z1: the first layer's product obs W1^T when the caller has it already (the learner's target phase computes it in one
+        launch with the target critic's observation half: both read o_t, fused.gemm_longk)."""
         t = self.torso
         if obs.is_cuda and obs.dim() == 2 and t.activate_final:
-            h1 = fused.bias_ln_tanh(fused.linear(obs, t.first.weight), t.first.bias, t.norm)
+            h1 = fused.bias_ln_tanh(fused.linear(obs, t.first.weight) if z1 is None else z1, t.first.bias, t.norm)
             if fused.can_policy_tail(h1, t.rest, self.head):
                 # layers 2, 3 and both heads in ONE launch (fbl_policy_tail): the activations never leave the LDS of the workgroup
                 return fused.policy_tail(h1, t.rest[0], t.rest[1], self.head, self.head.init_scale / math.log(2.0), self.head.min_scale)
@@ -107,18 +109,21 @@ class Critic(nn.Module):
             x = fused.concat_clamp(obs, action)
         return fused.linear(self.torso(x), self.logits.weight)
 
-    def forward_samples(self, obs, actions, clipped=None, raw=False):
+    def forward_samples(self, obs, actions, clipped=None, raw=False, h_o=None):
         """Logits [N, B, atoms] for N actions per observation (obs [B, O], actions [N, B, A]).  Same function as
         `forward` on the tiled inputs; the first layer is split into its observation and action halves so that the
         observation half (741 of the 800 input columns) is multiplied once per observation instead of once per pair.
-        clipped: clip(actions, -1, 1) when the caller has it already; raw: leave the logits bias out (see forward_raw)."""
+        clipped: clip(actions, -1, 1) when the caller has it already; raw: leave the logits bias out (see forward_raw); h_o: the
+        observation half obs W1[:, :O]^T when the caller has it already."""
         t = self.torso
         no = obs.shape[-1]
         if clipped is None:
             clipped = actions.clamp(-1.0, 1.0)
-        h_o = fused.linear(obs, t.first.weight[:, :no])                                  # [B, H]
-        h_a = F.linear(clipped, t.first.weight[:, no:])                                  # [N, B, H]
-        z = F.linear(t.tail(h_a, rowadd=h_o), self.logits.weight)
+        if h_o is None:
+            h_o = fused.linear(obs, t.first.weight[:, :no])                              # [B, H]
+        # (fused.linear routes the N x B-row products to the LDS-tiled MFMA kernel, bias + ELU in its epilogue: fbl_gemm_nt)
+        h_a = fused.linear(clipped, t.first.weight[:, no:])                              # [N, B, H]
+        z = fused.linear(t.tail(h_a, rowadd=h_o), self.logits.weight)
         return z if raw else z + self.logits.bias
 
     def mean_q(self, logits):

@@ -114,6 +114,16 @@ int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t 
  * heads.  Both sets must have the same k-contiguity (sak == 1 / sbk == 1). */
 typedef struct fbl_gemm_op { const float* a; const float* b; float* c; const float* bias; int64_t sai, sak, sbk, sbj; int32_t epilogue; float p0, p1; } fbl_gemm_op;
 int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream);
+/* Large forward GEMM, LDS-tiled (80 x 128 or 80 x 64 outputs per workgroup, K in double-buffered blocks of 32): c[M, N] = epilogue(a[M, K] w[N, K]^T), both
+ * operands k-contiguous with row strides lda / ldw (any value >= K: unaligned rows are fine), c row stride ldc.  epilogue 0: none, 1: + bias[j],
+ * 2: ELU(. + bias[j]).  The N x B = 5120-row products of the target critic (learning_dmpo.py:223-251) run here instead of a BLAS library
+ * call + a bias / ELU launch. */
+int fbl_gemm_nt(const float* a, int64_t lda, const float* w, int64_t ldw, float* c, int64_t ldc, int M, int N, int K, int epilogue, const float* bias, void* stream);
+/* Few rows, long reduction (the 741 / 800-column first layers at the learner's batch of 256): c0[M, N0] = a[M, K] w0[N0, K]^T and, when N1 > 0,
+ * c1[M, N1] = a w1[N1, K]^T in the same launch (two layers that read the same observations).  16 x 16 tiles, K <= 832 split over the
+ * four wavefronts of a workgroup; outputs are dense (row stride N0 / N1), no epilogue (a LayerNorm kernel follows). */
+int fbl_gemm_longk(const float* a, int64_t lda, const float* w0, int64_t ldw0, float* c0, int N0, const float* w1, int64_t ldw1, float* c1, int N1,
+                   int M, int K, void* stream);
 /* fbl_gauss_head_bwd for a head evaluated through fbl_sgemm_pair (epilogue 3): the pre-activation is recovered from the stddev. */
 int fbl_gauss_head_bwd_std(const float* dmean, const float* dstd, const float* std_, float mul, float min_scale, int M, int D, float* dzs,
                            float* dbm, float* dbs, void* stream);

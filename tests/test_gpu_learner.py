@@ -362,6 +362,51 @@ def test_small_mfma_gemm(M, K, N):
         _close(fused.linear(x, wide[:, :K]), ref(x) @ ref(wide[:, :K]).T, rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize('M,K,N,ep', [(5120, 512, 512, 2), (5120, 512, 256, 2), (5120, 59, 512, 0), (5120, 256, 51, 0), (4096, 741, 256, 0), (203, 45, 77, 1),
+                                      (81, 33, 130, 2), (1, 7, 1, 0)])
+def test_lds_tiled_gemm(M, K, N, ep):
+    """fbl_gemm_nt (round 5: 80 x 128 / 80 x 64 tiles of v_mfma_f32_16x16x4_f32 through a double-buffered LDS stage, bias / ELU in the
+    epilogue) against FP64 matmul at the target critic's 5120-row shapes -- including the action half, whose weight operand is a column
+    slice of the [512, 800] first-layer matrix at an UNALIGNED offset (741 floats), and the actors' [4096, 741] batch -- and at ragged
+    shapes that exercise every edge (rows / columns past the tile, K tail)."""
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(5)
+    x = torch.randn(M, K, device='cuda'); wide = torch.randn(N, K + 741, device='cuda')/math.sqrt(K); w = wide[:, 741:]; b = torch.randn(N, device='cuda')
+    ref = x.double() @ w.double().T
+    if ep >= 1: ref = ref + b.double()
+    if ep == 2: ref = F.elu(ref)
+    y = fused.gemm_nt(x, w, b if ep else None, ep)
+    assert y.shape == (M, N)
+    _close(y, ref, rtol=2e-5, atol=2e-5)
+    # 3-D input (the [N, B, K] sampled-action batch) and the routing of fused.linear for forward-only products of many rows
+    if M == 5120:
+        with torch.no_grad():
+            y3 = fused.linear(x.view(20, 256, K), w, b if ep == 2 else None, elu=(ep == 2))
+        assert y3.shape == (20, 256, N)
+        _close(y3.reshape(M, N), (F.elu(x.double() @ w.double().T + b.double()) if ep == 2 else x.double() @ w.double().T), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('M,K,N0,N1', [(256, 741, 256, 512), (256, 800, 512, 0), (256, 741, 256, 0), (37, 203, 45, 19), (5, 832, 16, 0), (300, 17, 3, 70)])
+def test_long_k_gemm(M, K, N0, N1):
+    """fbl_gemm_longk: the 741 / 800-column first layers at the learner's batch (16 x 16 tiles, K split over the four waves of a
+    workgroup, every load in flight before the first MFMA), one or two weight matrices per launch, against FP64 -- and its autograd
+    wrapper (weight gradient on fbl_sgemm)."""
+    from flybody_amd.dmpo import fused
+    torch.manual_seed(6)
+    x = torch.randn(M, K, device='cuda'); w0 = torch.randn(N0, K, device='cuda')/math.sqrt(K)
+    wide = torch.randn(max(N1, 1), K + 59, device='cuda')/math.sqrt(K); w1 = wide[:, :K] if N1 else None      # (the critic's observation half: row stride K + 59)
+    out = fused.gemm_longk(x, w0, w1)
+    y0, y1 = out if N1 else (out, None)
+    _close(y0, x.double() @ w0.double().T, rtol=2e-5, atol=2e-5)
+    if N1:
+        _close(y1, x.double() @ w1.double().T, rtol=2e-5, atol=2e-5)
+    if K > fused.SMALL_GEMM_K:
+        w = w0.clone().requires_grad_(True); up = torch.randn(M, N0, device='cuda')
+        y = fused.linear(x, w); y.backward(up)                       # -> _LinearLongK
+        _close(y, x.double() @ w0.double().T, rtol=2e-5, atol=2e-5)
+        _close(w.grad, up.double().T @ x.double(), rtol=2e-5, atol=2e-4)
+
+
 @pytest.mark.parametrize('M', [256, 37, 4096])
 def test_policy_tail_kernel(M, monkeypatch):
     """fbl_policy_tail (layers 2 and 3 of the policy MLP and both Gaussian heads in one launch, activations in LDS, v_mfma_f32_16x16x4_f32)
@@ -389,7 +434,12 @@ def test_policy_tail_kernel(M, monkeypatch):
     _close(mean, mean_r, rtol=2e-5, atol=2e-5); _close(std, std_r, rtol=2e-5, atol=2e-5)
     with torch.no_grad():                      # forward-only path (target networks, actors): nothing stored
         m2, s2 = pol(obs)
-    assert torch.equal(m2, mean) and torch.equal(s2, std)
+    # (above 1024 rows the forward-only first layer runs on fbl_gemm_nt while the grad-enabled path keeps the library GEMM: equal to
+    #  rounding there, bit-equal at the learner's batch sizes)
+    if M <= 1024:
+        assert torch.equal(m2, mean) and torch.equal(s2, std)
+    else:
+        _close(m2, mean, rtol=1e-5, atol=1e-6); _close(s2, std, rtol=1e-5, atol=1e-6)
     if M <= 256:
         gm = torch.randn(M, 59, device=dev); gs = torch.randn(M, 59, device=dev)
         (mean*gm).sum().add((std*gs).sum()).backward()
