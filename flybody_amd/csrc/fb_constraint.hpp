@@ -80,6 +80,9 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
       int len = M.dof_depth[dof] + 1;
       w.efc_type()[r] = CN_LIMIT; w.efc_id()[r] = j;
       w.efc_bA()[r] = M.jnt_bodyid[j]; w.efc_lA()[r] = len; w.efc_bB()[r] = 0; w.efc_lB()[r] = 0;
+      // (round 5: what the solver stages used to chase through efc_id -> con_efc / con_pair -> pair_friction is written per ROW here, so
+      //  that their set-up is one round of lane == row loads: position inside the contact block, friction coefficients, chain ends)
+      w.efc_k()[r] = 0; w.efc_eA()[r] = dof; w.efc_eB()[r] = -1; w.efc_s1()[r] = 1; w.efc_s2()[r] = 1;
       w.efc_pos()[r] = dist; w.efc_margin()[r] = M.jnt_margin[j];
       // (only the slots a reader looks at: every consumer of a row masks its chain slots with the row's chain lengths, lA = len, lB = 0)
       for (int s = 0; s < len; s++) w.efc_J()[JIDX(0, s, r)] = (s == len - 1) ? (real)(-side) : (real)0;
@@ -128,16 +131,20 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
     real R1 = R0 / fmax(FB_MINV, M.impratio);
     real mu = fr[0]*sqrt(R1/R0);
     real R2 = R1*fr[0]*fr[0]/(fr[1]*fr[1]);
+    const int l1 = M.body_chlen[b1], l2 = M.body_chlen[b2];
+    const int eA = l1 > 0 ? M.body_chain[b1*FB_MAXCH + l1 - 1] : -1, eB = l2 > 0 ? M.body_chain[b2*FB_MAXCH + l2 - 1] : -1;
     for (int k = 0; k < dim; k++) {
       int r = adr + k;
       w.efc_type()[r] = (dim == 1) ? CN_FRICTIONLESS : CN_ELLIPTIC; w.efc_id()[r] = lane;
       w.efc_bA()[r] = b1; w.efc_bB()[r] = b2;
-      w.efc_lA()[r] = M.body_chlen[b1]; w.efc_lB()[r] = M.body_chlen[b2];
+      w.efc_lA()[r] = l1; w.efc_lB()[r] = l2;
       w.efc_pos()[r] = dist; w.efc_margin()[r] = incl;
       w.efc_K()[r] = (k == 0) ? K : (real)0; w.efc_B()[r] = B; w.efc_imp()[r] = imp;
       const real Rk = (k == 0) ? R0 : (k == 1 ? R1 : R2);
       w.efc_R()[r] = Rk; w.efc_D()[r] = (real)1 / Rk;          // (1 / R here, not in a pass of its own behind a fence: one global round trip less)
       w.efc_mu()[r] = mu;
+      w.efc_k()[r] = k; w.efc_s1()[r] = (dim == 1) ? (real)1 : fr[0]; w.efc_s2()[r] = (dim == 1) ? (real)1 : fr[1];
+      w.efc_eA()[r] = eA; w.efc_eB()[r] = eB;
     }
   }
   // ---- contact Jacobians, one lane per (contact, side, chain slot): 40 entries per contact, 64 per pass.  Every entry needs
@@ -598,7 +605,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
       a0[q] = 1; a1[q] = 1;
-      if (r < nefc && w.efc_type()[r] == CN_ELLIPTIC) { const real* fr = M.pair_friction + 5*w.con_pair()[w.efc_id()[r]]; a0[q] = fr[0]; a1[q] = fr[1]; }
+      if (r < nefc) { a0[q] = w.efc_s1()[r]; a1[q] = w.efc_s2()[r]; }          // (per row since round 5: 1 for scalar rows; no walk through efc_id -> con_pair -> pair_friction)
     }
     rfr0.v0 = a0[0]; rfr0.v1 = a0[1]; rfr0.v2 = a0[2]; rfr1.v0 = a1[0]; rfr1.v1 = a1[1]; rfr1.v2 = a1[2];
   }
@@ -627,7 +634,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
     for (int q = 0; q < (S ? 1 : 3); q++) {
       int r = lane + 64*q;
       for (int u = 0; u < 13; u++) t[u][q] = 0;
-      bool first = r < nefc && w.efc_type()[r] == CN_ELLIPTIC && w.con_efc()[w.efc_id()[r]] == r;
+      bool first = r < nefc && w.efc_type()[r] == CN_ELLIPTIC && w.efc_k()[r] == 0;
       if (first) {
         real a00 = AR[ARIDX(r, r)], a01 = AR[ARIDX(r + 1, r)], a02 = AR[ARIDX(r + 2, r)];
         real a11 = AR[ARIDX(r + 1, r + 1)], a12 = AR[ARIDX(r + 2, r + 1)], a22 = AR[ARIDX(r + 2, r + 2)];
@@ -678,7 +685,7 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   // differ in the last Newton pass of a non-converged multiplier (u is recomputed after the 19th update here).
   unsigned long long m_first;        // bit i: row i is the first row of an elliptic contact
   {
-    bool fst = lane < nefc && w.efc_type()[lane] == CN_ELLIPTIC && w.con_efc()[w.efc_id()[lane]] == lane;
+    bool fst = lane < nefc && w.efc_type()[lane] == CN_ELLIPTIC && w.efc_k()[lane] == 0;
     m_first = __ballot(fst);
   }
   for (int it = 0; it < max_it; it++) {
@@ -906,7 +913,8 @@ FB_PGS_ATTR int d_pgs(const DevModel<real>& M, const WS<real>& w, ARP AR, int ne
   PROF(P_PGS);
   // ---- noslip: friction dims only, regularisation removed; lane == contact keeps its row address
   int ncon = w.istate()[IS_NCON];
-  int my_efc = (lane < ncon && w.con_dim()[lane] > 1) ? w.con_efc()[lane] : -1;
+  int my_efc;
+  { const int cl_ = lane < ncon ? lane : 0; const int cd_ = w.con_dim()[cl_], ce_ = w.con_efc()[cl_]; my_efc = (lane < ncon && cd_ > 1) ? ce_ : -1; }      // (both loads in one round)
   for (int it = 0; it < max_noslip; it++) {
     real improvement = 0;
     for (int c = 0; c < ncon; c++) {
@@ -993,7 +1001,12 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     }
   }
   SYNC();
-  // ---- warm start: force implied by the previous acceleration (primal map)
+  // Solver: the model's choice (opt_solver; the reference XML sets none = Newton) for systems of up to one row per lane, PGS otherwise.
+  const bool newton = uniform_int(M.solver) == FB_SOLVER_NEWTON && nefc <= FB_NEWTON_MAXROWS;
+  // ---- warm start: force implied by the previous acceleration (primal map).  (Round 5: the Newton solver derives it from efc_jar in
+  // its own registers -- the same zone logic is its constraint update -- so this pass, a chain of five dependent global round trips
+  // through efc_id / con_efc / con_pair / pair_friction, and the store + reload of efc_force only run for PGS.)
+  if (!newton)
   for (int r = lane; r < nefc; r += FB_WAVE) {
     int type = w.efc_type()[r];
     if (type != CN_ELLIPTIC) { real jar = w.efc_jar()[r]; w.efc_force()[r] = jar < 0 ? -w.efc_D()[r]*jar : (real)0; }
@@ -1018,10 +1031,8 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
       w.efc_force()[r] = f0; w.efc_force()[r+1] = f1; w.efc_force()[r+2] = f2;
     }
   }
-  SYNC();
+  if (!newton) SYNC();
   int niter;
-  // Solver: the model's choice (opt_solver; the reference XML sets none = Newton) for systems of up to one row per lane, PGS otherwise.
-  const bool newton = uniform_int(M.solver) == FB_SOLVER_NEWTON && nefc <= FB_NEWTON_MAXROWS;
   const int tri = nefc*(nefc + 1)/2;
   if (nefc <= LdsCfg<real>::WIDE_ROWS) {
     // Delassus matrix in LDS.  A system that does not fit the matrix slot alone borrows the factor row in front of it (the
@@ -1082,27 +1093,36 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     // ---- qfrc_constraint = J^T f, one lane per dof: lane == row keeps (force, last dof of each chain) in registers and
     // broadcasts them with v_readlane; dof i collects J[side][depth(i)][r] f_r from every row whose chain runs through it
     // (the chain's last dof lies in i's DFS subtree).  Same summation order as the row-major loop, no global read-modify-write.
+    // (round 5: the chain ends come per row from make_constraint -- they used to be looked up here through efc_bA / efc_lA -> body_chain,
+    //  two dependent round trips -- and the Jacobian entries of EIGHT rows are in flight together: the row-by-row loop waited for a
+    //  global round trip per row, 12-24 per substep)
     real fr = (lane < nefc) ? w.efc_force()[lane] : (real)0;
-    int eA = -1, eB = -1;
-    if (lane < nefc) {
-      int lA = w.efc_lA()[lane], lB = w.efc_lB()[lane];
-      if (lA > 0) eA = M.body_chain[w.efc_bA()[lane]*FB_MAXCH + lA - 1];
-      if (lB > 0) eB = M.body_chain[w.efc_bB()[lane]*FB_MAXCH + lB - 1];
-    }
+    int eA = (lane < nefc) ? w.efc_eA()[lane] : -1, eB = (lane < nefc) ? w.efc_eB()[lane] : -1;
     int dep[2], nd[2]; real acc[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; bool has = i < nv; dep[q] = has ? M.dof_depth[i] : 0; nd[q] = has ? M.dof_ndesc[i] : -1; }
-    for (int r = 0; r < nefc; r++) {
-      real f = rdlane(fr, r);
-      if (f == 0) continue;
-      int ea = rdlane(eA, r), eb = rdlane(eB, r);
+    for (int r0 = 0; r0 < nefc; r0 += 8) {
+      real ja[8][2], jb[8][2];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        int i = lane + q*FB_WAVE;
-        bool onA = nd[q] >= 0 && ea >= i && ea <= i + nd[q], onB = nd[q] >= 0 && eb >= i && eb <= i + nd[q];
-        real ja = w.efc_J()[JIDX(0, dep[q], r)], jb = w.efc_J()[JIDX(1, dep[q], r)];
-        if (onA) acc[q] += ja*f;
-        if (onB) acc[q] += jb*f;
+      for (int u = 0; u < 8; u++) {
+        const int r = min(r0 + u, nefc - 1);
+#pragma unroll
+        for (int q = 0; q < 2; q++) { ja[u][q] = w.efc_J()[JIDX(0, dep[q], r)]; jb[u][q] = w.efc_J()[JIDX(1, dep[q], r)]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (r0 + u < nefc) {
+          const int r = r0 + u;
+          const real f = rdlane(fr, r);
+          const int ea = rdlane(eA, r), eb = rdlane(eB, r);
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int i = lane + q*FB_WAVE;
+            const bool onA = nd[q] >= 0 && ea >= i && ea <= i + nd[q], onB = nd[q] >= 0 && eb >= i && eb <= i + nd[q];
+            if (onA) acc[q] += ja[u][q]*f;
+            if (onB) acc[q] += jb[u][q]*f;
+          }
+        }
       }
     }
 #pragma unroll

@@ -103,23 +103,32 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
 #define NW_PROF(k) do {} while (0)
 #define NW_COUNT(k) do {} while (0)
 #endif
-  // ---- per-row constants
+  // ---- per-row constants.  Round 5: ONE round of lane == row loads.  make_constraint leaves the row's position inside its contact block
+  // and the contact's friction coefficients per row; the block's other rows are reached by shuffles.  (Before: efc_type -> efc_id ->
+  // con_efc / con_pair -> pair_friction, efc_mu[base], efc_D[base], efc_R[block rows] -- five dependent global round trips at ~2 k
+  // cycles each on every solve -- plus a warm-start pass of its own in front of the solver that did the same walk and handed the force
+  // over through efc_force.)
   const int type = on ? w.efc_type()[lane] : CN_LIMIT;
+  const int kblk = on ? w.efc_k()[lane] : 0;
+  const real R = on ? w.efc_R()[lane] : (real)1;
+  const real Dl = on ? w.efc_D()[lane] : (real)0;
+  const real b = on ? w.efc_b()[lane] : (real)0;
+  const real jarw = on ? w.efc_jar()[lane] : (real)0;              // J qacc_warmstart - aref: the warm start's argument
+  const real mul = on ? w.efc_mu()[lane] : (real)0;
+  const real s1l = on ? w.efc_s1()[lane] : (real)1, s2l = on ? w.efc_s2()[lane] : (real)1;
   NwConst<real> c;
   c.ell = type == CN_ELLIPTIC;
-  const int con = c.ell ? w.efc_id()[lane] : 0;
-  const int base = c.ell ? w.con_efc()[con] : lane;
-  c.k = lane - base;
-  const real R = on ? w.efc_R()[lane] : (real)1;
-  c.D = on ? w.efc_D()[lane] : (real)0;
+  c.k = c.ell ? kblk : 0;
+  const int base = lane - c.k;
+  c.D = Dl;
   c.sqD = sqrt(c.D);
-  const real b = on ? w.efc_b()[lane] : (real)0;
-  real lam = on ? w.efc_force()[lane] : (real)0;
   c.s0 = 1; c.s1 = 1; c.s2 = 1; c.mu = 0; c.Dm = 0;
-  if (c.ell) {
-    const real* fr = M.pair_friction + 5*w.con_pair()[con];
-    c.mu = w.efc_mu()[base]; c.s0 = c.mu; c.s1 = fr[0]; c.s2 = fr[1];
-    c.Dm = fb_div(w.efc_D()[base], (real)fmax(FB_MINV, c.mu*c.mu*((real)1 + c.mu*c.mu)));
+  {
+    const real Dbase = nw_lane(Dl, base);
+    if (c.ell) {
+      c.mu = mul; c.s0 = mul; c.s1 = s1l; c.s2 = s2l;
+      c.Dm = fb_div(Dbase, (real)fmax(FB_MINV, c.mu*c.mu*((real)1 + c.mu*c.mu)));
+    }
   }
   c.g1 = sqrt(c.Dm);
   const unsigned long long m_first = __ballot(c.ell && c.k == 0);       // bit i: row i opens a 3-row contact block
@@ -127,7 +136,8 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   const int rl = on ? lane : n - 1, tri_l = rl*(rl + 1)/2;
   const int ra0 = min(base, n - 1), ra1 = min(base + 1, n - 1), ra2 = min(base + 2, n - 1);
   const int ta0 = ra0*(ra0 + 1)/2, ta1 = ra1*(ra1 + 1)/2, ta2 = ra2*(ra2 + 1)/2;
-  const real Rb0 = w.efc_R()[ra0], Rb1 = w.efc_R()[ra1], Rb2 = w.efc_R()[ra2];
+  const real Rb0 = nw_lane(R, ra0), Rb1 = nw_lane(R, ra1), Rb2 = nw_lane(R, ra2);
+  real lam = 0;
   // Systems of up to FB_NEWTON_NT = 16 rows (93 % of the solves of the bench workload) run on a 16 x 16 TILE over the wave: lane (ti, tc) =
   // (lane >> 2, lane & 3) holds the entries [ti][4 tc + 0..3] of a matrix in four registers.  A = AR - diag R is loaded into that layout
   // once per solve; a product A x is four multiply-adds on shuffled x plus a sum over the quad, the work matrix K and its factorisation
@@ -175,6 +185,9 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   // ---- warm start: the force implied by the previous acceleration, unless the zero force is cheaper
   real jb0, jb1, jb2;
   {
+    // the force implied by the previous acceleration (primal map): the constraint update at jar = J qacc_warmstart - aref
+    nw_update(c, nw_lane(jarw, base), nw_lane(jarw, base + 1), nw_lane(jarw, base + 2), o);
+    lam = on ? o.f : (real)0;
     const real Al = amul(lam);
     const real jar = b + Al;
     jb0 = nw_lane(jar, base); jb1 = nw_lane(jar, base + 1); jb2 = nw_lane(jar, base + 2);

@@ -93,14 +93,15 @@ template <typename T> struct GP {
   X(efc_J, 2*FB_MAXCH*FB_MAXEFC_) \
   X(efc_pos, FB_MAXEFC_) X(efc_margin, FB_MAXEFC_) X(efc_R, FB_MAXEFC_) X(efc_D, FB_MAXEFC_) X(efc_K, FB_MAXEFC_) \
   X(efc_B, FB_MAXEFC_) X(efc_imp, FB_MAXEFC_) X(efc_aref, FB_MAXEFC_) X(efc_b, FB_MAXEFC_) X(efc_force, FB_MAXEFC_) \
-  X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) \
+  X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) X(efc_s1, FB_MAXEFC_) X(efc_s2, FB_MAXEFC_) /* friction coefficients of the row's contact (1: other rows) */ \
   X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody) \
   /* cold tail of the row: only systems that do not fit the LDS copies (wide-system Y, Delassus triangle + Newton work matrix) touch it */ \
   X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2)
 
 #define FB_WS_INT(X) \
   X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
-  X(efc_type, FB_MAXEFC_) X(efc_id, FB_MAXEFC_) X(efc_bA, FB_MAXEFC_) X(efc_bB, FB_MAXEFC_) X(efc_lA, FB_MAXEFC_) X(efc_lB, FB_MAXEFC_)
+  X(efc_type, FB_MAXEFC_) X(efc_id, FB_MAXEFC_) X(efc_bA, FB_MAXEFC_) X(efc_bB, FB_MAXEFC_) X(efc_lA, FB_MAXEFC_) X(efc_lB, FB_MAXEFC_) \
+  X(efc_k, FB_MAXEFC_) /* position of the row inside its contact block (0 for scalar rows) */ X(efc_eA, FB_MAXEFC_) X(efc_eB, FB_MAXEFC_) /* last dof of the row's two chains (-1: empty chain) */
 
 struct WSOff {
 #define X(name, n) uint32_t name;
