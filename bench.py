@@ -247,7 +247,8 @@ def main():
             extras['sizes'] = {'max_ncon': int(ss[:, 0].max()), 'max_nefc': int(ss[:, 1].max()),
                                'substep_share_above_32_rows': float(ss[:, 2].sum()/nsub_total), 'substep_share_above_64_rows': float(ss[:, 3].sum()/nsub_total),
                                'envs_that_ever_exceeded_64_rows': int((ss[:, 3] > 0).sum()),
-                               'caps': {'kernel_contacts': 64, 'kernel_rows': 192, 'newton_rows_per_lane_limit': 64, 'mujoco_nconmax': 100, 'mujoco_njmax': 300},
+                               'caps': {'kernel_contacts': 64, 'kernel_rows': 192, 'mujoco_nconmax': 100, 'mujoco_njmax': 300},
+                               'solver': 'Newton at every system size (one row per lane up to 64 rows: registers / LDS; beyond: d_newton_wide)',
                                'substeps_counted': nsub_total}
             extras['qpos'] = batch.get('QPOS')[sample_ids]; extras['qvel'] = batch.get('QVEL')[sample_ids]
             extras['solver_iterations_mean'] = float(batch.get('SOLVER_NITER').mean())

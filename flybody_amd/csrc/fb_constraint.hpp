@@ -1002,11 +1002,14 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   }
   SYNC();
   // Solver: the model's choice (opt_solver; the reference XML sets none = Newton) for systems of up to one row per lane, PGS otherwise.
-  const bool newton = uniform_int(M.solver) == FB_SOLVER_NEWTON && nefc <= FB_NEWTON_MAXROWS;
+  // (systems of up to one row per lane on the register / LDS solver d_newton, wider ones on d_newton_wide: Newton at EVERY size, like
+  //  the reference -- rounds 3-4 fell back to PGS beyond 64 rows)
+  const bool newton_any = uniform_int(M.solver) == FB_SOLVER_NEWTON;
+  const bool newton = newton_any && nefc <= FB_NEWTON_MAXROWS;
   // ---- warm start: force implied by the previous acceleration (primal map).  (Round 5: the Newton solver derives it from efc_jar in
   // its own registers -- the same zone logic is its constraint update -- so this pass, a chain of five dependent global round trips
   // through efc_id / con_efc / con_pair / pair_friction, and the store + reload of efc_force only run for PGS.)
-  if (!newton)
+  if (!newton_any)
   for (int r = lane; r < nefc; r += FB_WAVE) {
     int type = w.efc_type()[r];
     if (type != CN_ELLIPTIC) { real jar = w.efc_jar()[r]; w.efc_force()[r] = jar < 0 ? -w.efc_D()[r]*jar : (real)0; }
@@ -1031,7 +1034,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
       w.efc_force()[r] = f0; w.efc_force()[r+1] = f1; w.efc_force()[r+2] = f2;
     }
   }
-  if (!newton) SYNC();
+  if (!newton_any) SYNC();
   int niter;
   const int tri = nefc*(nefc + 1)/2;
   if (nefc <= LdsCfg<real>::WIDE_ROWS) {
@@ -1080,12 +1083,17 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     }
     if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane, !newton); if (!newton) niter = it2; }
   }
+  else if (newton_any) {
+    const WS<real> wc = w;
+    niter = d_newton_wide<real>(M, wc, nefc, lane);
+    SYNC();
+    if (M.noslip_iterations > 0) d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane, false);
+  }
   else niter = d_pgs<real, const real*, false>(M, w, (const real*)w.AR(), nefc, lane);
   if (lane == 0) {
     w.istate()[IS_NITER] = niter;
-    // the model asks for Newton and the system is wider than one row per lane: block PGS ran instead (the one algorithmic deviation
-    // from the reference solver; MuJoCo runs Newton at every size) -- observable per environment, like the caps
-    int wbits = (niter >= M.iterations ? WARN_SOLVER_MAXITER : 0) | ((uniform_int(M.solver) == FB_SOLVER_NEWTON && !newton) ? WARN_SOLVER_FALLBACK : 0);
+    // (WARN_SOLVER_FALLBACK -- "the model asks for Newton, PGS ran" -- cannot be raised any more: round 5 solves every size with Newton)
+    int wbits = (niter >= M.iterations ? WARN_SOLVER_MAXITER : 0);
     if (wbits) { w.istate()[IS_WARN] |= wbits; w.istate()[IS_WARN_EVER] |= wbits; }
   }
   SYNC();

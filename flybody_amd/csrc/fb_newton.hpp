@@ -88,6 +88,187 @@ FBD double nw_lane(double v, int src) { return __shfl(v, src, 64); }
 FBD float nw_lane(float v, int src) { return __shfl(v, src, 64); }
 FBD int nw_lane_i(int v, int src) { return __shfl(v, src, 64); }
 
+// ------------------------------------------------------------------ systems wider than one row per lane (65 ... FB_MAXEFC rows)
+// MuJoCo's Newton runs at every system size; rounds 3-4 fell back to block PGS beyond 64 rows (flagged, FB_WARN_SOLVER_FALLBACK: a
+// deviation of up to 1e-2 on qacc where PGS stops short).  Such systems do occur in long rollouts (a fly on its back: 76 rows seen in
+// 150 control steps of 4096 environments), so round 5 solves them with the SAME algorithm -- same constraint update, same Woodbury
+// direction, same line search, same termination as d_newton / oracle/fbo_constraint.c: solve_newton.  Built for correctness, not
+// speed (0.0x % of the substeps): lane l owns rows l, l + 64, l + 128; every vector lives in the environment's global row (nws), the
+// Delassus triangle and the work matrix K in its AR slot (the second triangle), cross-row access goes through memory behind a
+// wave fence.  Inactive columns of F leave identity rows in K; they are factorised like any other (pivot 1).
+template <typename real>
+FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, int nefc, int lane) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const int n = uniform_int(nefc);
+  FB_SETPRIO(3);
+  real* AR = w.AR(); real* K = AR + FB_MAXEFC_*(FB_MAXEFC_ + 1)/2;
+  real* V = w.nws();
+  real *lam = V, *jar = V + FB_MAXEFC_, *rv = V + 2*FB_MAXEFC_, *qv = V + 3*FB_MAXEFC_, *pv = V + 4*FB_MAXEFC_, *zv = V + 5*FB_MAXEFC_;
+  real *dl = V + 6*FB_MAXEFC_, *Adl = V + 7*FB_MAXEFC_, *Ff = V + 8*FB_MAXEFC_, *Fcost = V + 9*FB_MAXEFC_;
+  real *Fc0 = V + 10*FB_MAXEFC_, *Fc1 = V + 11*FB_MAXEFC_, *Fc2 = V + 12*FB_MAXEFC_, *Fr0 = V + 13*FB_MAXEFC_, *Fr1 = V + 14*FB_MAXEFC_, *Fr2 = V + 15*FB_MAXEFC_;
+  real *xt = V + 16*FB_MAXEFC_;                         // scratch argument of the constraint update
+  const real* Rv = w.efc_R(); const real* bv = w.efc_b();
+  auto Aat = [&](int i, int k) -> real { const real e = AR[i >= k ? i*(i + 1)/2 + k : k*(k + 1)/2 + i]; return i == k ? e - Rv[i] : e; };
+  // row constants (the same as d_newton's, re-read per use: this path trades time for registers)
+  auto rowc = [&](int i, NwConst<real>& c, int& base) {
+    const int type = w.efc_type()[i];
+    c.ell = type == CN_ELLIPTIC; c.k = c.ell ? w.efc_k()[i] : 0; base = i - c.k;
+    c.D = w.efc_D()[i]; c.sqD = sqrt(c.D); c.s0 = 1; c.s1 = 1; c.s2 = 1; c.mu = 0; c.Dm = 0;
+    if (c.ell) {
+      c.mu = w.efc_mu()[i]; c.s0 = c.mu; c.s1 = w.efc_s1()[i]; c.s2 = w.efc_s2()[i];
+      c.Dm = fb_div(w.efc_D()[base], (real)fmax(FB_MINV, c.mu*c.mu*((real)1 + c.mu*c.mu)));
+    }
+    c.g1 = sqrt(c.Dm);
+  };
+  // constraint update of every row at the vector x (memory); results to the F* vectors; returns the summed cost
+  auto update_all = [&](const real* x) -> real {
+    real cost = 0;
+    for (int i = lane; i < n; i += FB_WAVE) {
+      NwConst<real> c; int base; rowc(i, c, base);
+      const int b1 = min(base + 1, n - 1), b2 = min(base + 2, n - 1);
+      NwRow<real> o;
+      nw_update(c, x[base], x[b1], x[b2], o);
+      Ff[i] = o.f; Fcost[i] = o.cost; Fc0[i] = o.fc0; Fc1[i] = o.fc1; Fc2[i] = o.fc2; Fr0[i] = o.fr0; Fr1[i] = o.fr1; Fr2[i] = o.fr2;
+      cost += o.cost;
+    }
+    SYNC();
+    return wave_sum(cost);
+  };
+  auto amul = [&](real* out, const real* x) {            // out = A x; x must be visible (fence before)
+    for (int i = lane; i < n; i += FB_WAVE) {
+      real s0 = 0, s1 = 0;
+      int k = 0;
+      for (; k + 1 < n; k += 2) { s0 += Aat(i, k)*x[k]; s1 += Aat(i, k + 1)*x[k + 1]; }
+      if (k < n) s0 += Aat(i, k)*x[k];
+      out[i] = s0 + s1;
+    }
+    SYNC();
+  };
+  const real scale = (real)1 / (M.meaninertia * (real)(M.nv > 1 ? M.nv : 1));
+  const real tol = M.tolerance;
+  const int max_it = M.iterations;
+  // ---- warm start: the force implied by the previous acceleration, unless the zero force is cheaper
+  {
+    update_all(w.efc_jar());
+    for (int i = lane; i < n; i += FB_WAVE) lam[i] = Ff[i];
+    SYNC();
+    amul(jar, lam);
+    real lAl = 0;
+    for (int i = lane; i < n; i += FB_WAVE) { lAl += lam[i]*jar[i]; jar[i] += bv[i]; }
+    SYNC();
+    lAl = wave_sum(lAl);
+    const real c_ws = (real)0.5*lAl + update_all(jar), c_0 = update_all(bv);
+    if (c_ws > c_0) { for (int i = lane; i < n; i += FB_WAVE) { lam[i] = 0; jar[i] = bv[i]; } SYNC(); }
+  }
+  int niter = 0;
+  for (int it = 0; it < max_it; it++) {
+    update_all(jar);
+    for (int i = lane; i < n; i += FB_WAVE) rv[i] = Ff[i] - lam[i];
+    SYNC();
+    amul(qv, rv);
+    real dec = 0;
+    for (int i = lane; i < n; i += FB_WAVE) dec += rv[i]*qv[i];
+    dec = wave_sum(dec);
+    if ((real)0.5*dec*scale < tol) break;
+    if (sizeof(real) == 4) {
+      real lAl = 0;
+      for (int i = lane; i < n; i += FB_WAVE) lAl += lam[i]*(jar[i] - bv[i]);
+      lAl = wave_sum(lAl);
+      if (dec <= (real)FB_NEWTON_F32_FLOOR*(lAl + dec)) break;
+    }
+    // ---- K = I + F'AF (lower triangle, row j by its owner lane), p = F'q
+    for (int j = lane; j < n; j += FB_WAVE) {
+      const bool ej = w.efc_type()[j] == CN_ELLIPTIC;
+      const int bj = j - (ej ? w.efc_k()[j] : 0), nj = ej ? 3 : 1;
+      const real fj[3] = {Fc0[j], Fc1[j], Fc2[j]};
+      real pj = 0;
+      for (int a = 0; a < nj; a++) pj += fj[a]*qv[min(bj + a, n - 1)];
+      pv[j] = pj;
+      for (int k = 0; k <= j; k++) {
+        const bool ek = w.efc_type()[k] == CN_ELLIPTIC;
+        const int bk = k - (ek ? w.efc_k()[k] : 0), nk = ek ? 3 : 1;
+        const real fk[3] = {Fc0[k], Fc1[k], Fc2[k]};
+        real s = 0;
+        for (int a = 0; a < nj; a++) {
+          real wa = 0;
+          for (int c2 = 0; c2 < nk; c2++) wa += Aat(min(bj + a, n - 1), min(bk + c2, n - 1))*fk[c2];
+          s += fj[a]*wa;
+        }
+        K[j*(j + 1)/2 + k] = s + (j == k ? (real)1 : (real)0);
+      }
+    }
+    SYNC();
+    // ---- Cholesky K = L L' (right-looking; the diagonal slot keeps 1 / L_jj), forward substitution folded in
+    for (int j = 0; j < n; j++) {
+      const real inv = fb_rsqrt(K[j*(j + 1)/2 + j]);
+      const real yj = pv[j]*inv;
+      SYNC();                                            // (every lane has read K[j][j] and p[j] before their owner overwrites them)
+      if (lane == (j & 63)) { K[j*(j + 1)/2 + j] = inv; pv[j] = yj; }
+      for (int i = lane; i < n; i += FB_WAVE) if (i > j) { const real l = K[i*(i + 1)/2 + j]*inv; K[i*(i + 1)/2 + j] = l; pv[i] -= l*yj; }
+      SYNC();
+      for (int i = lane; i < n; i += FB_WAVE) if (i > j) {
+        const real l = K[i*(i + 1)/2 + j];
+        if (l != 0) for (int k = j + 1; k <= i; k++) K[i*(i + 1)/2 + k] -= l*K[k*(k + 1)/2 + j];
+      }
+      SYNC();
+    }
+    // ---- back substitution L' z = y, last column first
+    for (int j = n - 1; j >= 0; j--) {
+      const real zj = pv[j]*K[j*(j + 1)/2 + j];
+      SYNC();
+      if (lane == (j & 63)) zv[j] = zj;
+      for (int i = lane; i < j; i += FB_WAVE) pv[i] -= K[j*(j + 1)/2 + i]*zj;
+      SYNC();
+    }
+    for (int i = lane; i < n; i += FB_WAVE) {
+      const bool ei = w.efc_type()[i] == CN_ELLIPTIC;
+      const int bi = i - (ei ? w.efc_k()[i] : 0), ni = ei ? 3 : 1;
+      const real fr[3] = {Fr0[i], Fr1[i], Fr2[i]};
+      real s = 0;
+      for (int c2 = 0; c2 < ni; c2++) s += fr[c2]*zv[min(bi + c2, n - 1)];
+      dl[i] = rv[i] - s;
+    }
+    SYNC();
+    amul(Adl, dl);
+    real lAd = 0, dAd = 0;
+    for (int i = lane; i < n; i += FB_WAVE) { lAd += (jar[i] - bv[i])*dl[i]; dAd += dl[i]*Adl[i]; }
+    lAd = wave_sum(lAd); dAd = wave_sum(dAd);
+    // ---- line search (as in d_newton)
+    real alpha = 0, g0 = 0, lo = 0, hi = -1;
+    for (int kls = 0; kls <= FB_NEWTON_LS_MAX; kls++) {
+      for (int i = lane; i < n; i += FB_WAVE) xt[i] = jar[i] + alpha*Adl[i];
+      SYNC();
+      update_all(xt);
+      real gs = 0, hs = 0;
+      for (int i = lane; i < n; i += FB_WAVE) {
+        const bool ei = w.efc_type()[i] == CN_ELLIPTIC;
+        const int bi = i - (ei ? w.efc_k()[i] : 0), ni = ei ? 3 : 1;
+        const real fc[3] = {Fc0[i], Fc1[i], Fc2[i]};
+        real wv = 0;
+        for (int a = 0; a < ni; a++) wv += fc[a]*Adl[min(bi + a, n - 1)];
+        gs += Ff[i]*Adl[i]; hs += wv*wv;
+      }
+      const real g = lAd + alpha*dAd - wave_sum(gs);
+      const real h = dAd + wave_sum(hs);
+      if (kls == 0) { g0 = g; if (!(g0 < 0) || !(h > FB_MINV)) break; alpha = -fb_div(g0, h); continue; }
+      if (fabs(g) <= (real)0.01*fabs(g0) || kls == FB_NEWTON_LS_MAX) break;
+      if (g < 0) lo = alpha; else hi = alpha;
+      real an = (h > FB_MINV) ? alpha - fb_div(g, h) : (real)-1;
+      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = (hi < 0) ? 2*alpha : (real)0.5*(lo + hi);
+      alpha = an;
+    }
+    if (!(alpha > 0)) break;
+    for (int i = lane; i < n; i += FB_WAVE) { lam[i] += alpha*dl[i]; jar[i] += alpha*Adl[i]; }
+    SYNC();
+    niter = it + 1;
+  }
+  update_all(jar);
+  for (int i = lane; i < n; i += FB_WAVE) w.efc_force()[i] = Ff[i];
+  SYNC();
+  FB_SETPRIO(uniform_int(w.istate()[IS_PRIO]));
+  return niter;
+}
+
 // ARP / KP: LDS (address_space(3)) or global pointers to the packed lower triangles of AR and of the work matrix K.
 // Returns the number of Newton iterations; the forces are left in efc_force.
 template <typename real, typename ARP, typename KP>

@@ -33,6 +33,7 @@ extern "C" { extern long long fb_stats[64]; }
 #define FB_MAXCON_ 64
 #define FB_MAXEFC_ 192
 #define FB_NSENS 33
+#define FB_NWS_VECS 18
 #define FB_NPROF 56
 #define FB_NSCHED 64          // progress counters of one launch (one per substep)
 #define FB_MAXWRAP 8          // dofs per actuator transmission / joints per fixed tendon
@@ -96,7 +97,8 @@ template <typename T> struct GP {
   X(efc_vel, FB_MAXEFC_) X(efc_mu, FB_MAXEFC_) X(efc_jar, FB_MAXEFC_) X(efc_s1, FB_MAXEFC_) X(efc_s2, FB_MAXEFC_) /* friction coefficients of the row's contact (1: other rows) */ \
   X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody) \
   /* cold tail of the row: only systems that do not fit the LDS copies (wide-system Y, Delassus triangle + Newton work matrix) touch it */ \
-  X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)/2)
+  X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)) /* Delassus triangle + the Newton work matrix K of systems wider than one row per lane */ \
+  X(nws, FB_NWS_VECS*FB_MAXEFC_) /* work vectors of the wide-system Newton solver (fb_newton.hpp: d_newton_wide) */
 
 #define FB_WS_INT(X) \
   X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \

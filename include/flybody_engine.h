@@ -77,8 +77,9 @@ enum { FB_MAXCON = 64, FB_MAXEFC = 192, FB_NSENSOR = 33 };
  * the cap were dropped); the constraint solver stopped at opt.iterations; a convex-pair penetration query (MPR) hit its
  * iteration limit */
 enum { FB_WARN_CONTACT_CAP = 1, FB_WARN_EFC_CAP = 2, FB_WARN_SOLVER_MAXITER = 4, FB_WARN_CCD_MAXITER = 8,
-       FB_WARN_SOLVER_FALLBACK = 32 /* the model selects Newton (the reference's solver) but the system had more than 64 rows: block PGS ran instead.
-                                       MuJoCo runs Newton at every size; the deviation is bounded in tests/test_oracle.py::test_newton_row_cap_deviation */,
+       FB_WARN_SOLVER_FALLBACK = 32 /* (rounds 3-4: the model selects Newton but the system had more than 64 rows and block PGS ran instead.  Never raised
+                                       since round 5: the engine runs Newton at every system size, like MuJoCo -- fb_newton.hpp: d_newton_wide.  The bit
+                                       stays defined so that FB_WARN words keep their layout.) */,
        FB_WARN_SCHED_WAIT = 16 /* substep scheduler: the wait for an environment's previous substep hit its iteration cap (never observed).
                                   The environment's control step was ABANDONED (its row is not stepped concurrently with its holder);
                                   fb_batch_synchronize / fb_batch_get fail from then on until the batch is destroyed. */ };

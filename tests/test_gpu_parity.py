@@ -4,9 +4,8 @@ Tolerances (written here, as the task statement requires):
   * FP64 kernel vs FP64 oracle, single forward evaluation:  1e-9 relative on every smooth-dynamics
     stage output (different summation orders only) and 1e-6 on solver-dependent outputs (the Newton
     solver -- the model's default, fb_newton.hpp / fbo_constraint.c: solve_newton -- stops on a 1e-8
-    bound on the scaled cost decrement, so the last iteration may differ; block PGS -- behind opt_solver = 0, and the
-    KERNEL's flagged fallback (FB_WARN_SOLVER_FALLBACK) for systems wider than 64 rows, which the oracle mirrors only when a
-    test caps its Newton with opt_newton_maxrows -- stops on the same threshold);
+    bound on the scaled cost decrement, so the last iteration may differ; Newton runs at EVERY system size on both sides since
+    round 5 -- d_newton_wide beyond one row per lane -- and block PGS, behind opt_solver = 0, stops on the same threshold);
   * FP64 kernel vs oracle over 20 ... 100 control steps (contacts, Newton, noslip):  1e-6 relative
     on qpos / qvel (contact-rich dynamics amplify rounding differences; measured ~1e-11);
   * FP32 kernel vs oracle, single forward evaluation:  2e-3 relative on accelerations.
@@ -494,38 +493,31 @@ def test_solver_paths_by_system_size_gpu(gpu_model, oracle_model, walk_arrays, p
     from flybody_amd.model_blob import pack_model
     from oracle import fbo
     from conftest import random_state
-    cases = [(1, 0.14), (1, 0.135), (1, 0.13), (1, 0.125), (3, 0.12)]     # nefc 24, 36, 54, 66, 114
-    capped = fbo.OracleModel(pack_model(dict(walk_arrays, opt_newton_maxrows=np.array(64, np.int32))))     # (mirrors the kernel's fallback: see the host test)
+    cases = [(1, 0.14), (1, 0.135), (1, 0.13), (1, 0.125), (3, 0.12), (1, 0.05)]     # nefc 24, 36, 54, 66, 114, 192 (the row cap)
+    # Round 5: Newton at every size (d_newton_wide beyond one row per lane) against the UNcapped oracle -- rounds 3-4 ran block PGS
+    # beyond 64 rows and were compared with an oracle capped the same way; VERDICT r4 item 5 asked for exactly this comparison at 1e-6.
     B = engine.Batch(gpu_model, len(cases), precision=precision)
     ods, Q, V = [], [], []
     for seed, z in cases:
         q, v = random_state(walk_arrays, np.random.default_rng(seed), z=z)
         if precision == 32:
             q = q.astype(np.float32).astype(float); v = v.astype(np.float32).astype(float)
-        od = _oracle(capped); od._keep = capped; od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
+        od = _oracle(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
         ods.append(od); Q.append(q); V.append(v)
     B.set('QPOS', np.array(Q)); B.set('QVEL', np.array(V))
     B.forward()
     nefc = [int(od.scalar('nefc')) for od in ods]
-    assert min(nefc) <= 29 and any(36 < n <= 64 for n in nefc) and max(nefc) > 64
-    fb = (B.get('WARN').ravel() & engine.WARN_BITS['SOLVER_FALLBACK']) != 0          # the PGS fallback beyond 64 rows is flagged
-    assert fb.tolist() == [n > 64 for n in nefc], (fb, nefc)
+    assert min(nefc) <= 29 and any(36 < n <= 64 for n in nefc) and any(64 < n < 192 for n in nefc) and max(nefc) == 192
+    assert not (B.get('WARN').ravel() & engine.WARN_BITS['SOLVER_FALLBACK']).any()          # cannot be raised any more
     if precision == 64:
         assert B.get('NEFC').ravel().tolist() == nefc
+        assert B.get('SOLVER_NITER').ravel().tolist() == [int(od.scalar('solver_niter')) for od in ods]
     for e, od in enumerate(ods):
         n = nefc[e]
         assert _rel(B.get('QACC')[e], od.field('qacc')) < (1e-6 if precision == 64 else 3e-2), (e, n)
         if precision == 64:
             assert _rel(B.get('EFC_FORCE')[e][:n], od.field('efc_force')[:n]) < 1e-6, (e, n)
-    # ... and against the UNcapped oracle (Newton at every size, like MuJoCo: VERDICT r4 item 5): identical up to 64 rows, and the
-    # deviation of the flagged PGS fallback beyond is bounded HERE, on the GPU's own numbers (measured: 1e-11 where PGS converges, up to
-    # 1e-2 where its sweep-to-sweep improvement drops under opt.tolerance first; tests/test_oracle.py::test_newton_row_cap_deviation)
     if precision == 64:
-        for e, (q, v) in enumerate(zip(Q, V)):
-            od = _oracle(oracle_model); od.field('qpos')[:] = q; od.field('qvel')[:] = v; od.call('forward')
-            assert int(od.scalar('nefc')) == nefc[e]
-            dev = _rel(B.get('QACC')[e], od.field('qacc'))
-            assert dev < (1e-6 if nefc[e] <= 64 else 5e-2), (e, nefc[e], dev)
         # the size statistics the bench reports (FB_SIZE_STATS) saw these systems
         ss = B.get('SIZE_STATS').reshape(-1, 4)
         assert ss[:, 1].tolist() == nefc and ss[:, 3].tolist() == [int(n > 64) for n in nefc] and ss[:, 2].tolist() == [int(n > 32) for n in nefc]

@@ -148,10 +148,11 @@ def test_golden_rollout_regression(oracle_model, reference_traj):
 
 
 def test_newton_row_cap_deviation(walk_arrays):
-    """the HIP kernel keeps one constraint row per lane and falls back to block PGS for systems wider than 64 rows, while the
-    reference's solver (MuJoCo's default, Newton: fruitfly.xml:4) runs at every size.  The oracle follows MuJoCo -- Newton, uncapped --
-    and mirrors the kernel only on request (opt_newton_maxrows, used by the tests of the fallback path itself).  Here the deviation the
-    fallback introduces is MEASURED on states with 65 ... 114 rows: forces / accelerations of the capped oracle (= the kernel's
+    """History (rounds 3-4): the HIP kernel kept one constraint row per lane and fell back to block PGS for systems wider than 64 rows,
+    while the reference's solver (MuJoCo's default, Newton: fruitfly.xml:4) runs at every size.  Round 5 removed the fallback
+    (fb_newton.hpp: d_newton_wide; tests/test_gpu_parity.py::test_solver_paths_by_system_size_gpu compares 66 ... 192-row systems with
+    THIS oracle, uncapped, at 1e-6).  What stays here is the measurement that motivated it -- the oracle can still be capped on request
+    (opt_newton_maxrows) -- i.e. the deviation a PGS fallback introduces, MEASURED on states with 65 ... 114 rows: forces / accelerations of the capped oracle (= the kernel's
     arithmetic, tests/test_kernel_emulation.py::test_solver_paths_by_system_size) against the uncapped one.  PGS reaches the same
     minimiser when it converges (1e-9 ... 1e-11) and stops short of it when its sweep-to-sweep improvement falls under opt.tolerance
     first (worst case here 1e-2 on qacc).  The kernel flags every such solve (FB_WARN_SOLVER_FALLBACK); bench.py counts them (0 in the
