@@ -134,12 +134,24 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
     SYNC();
     return wave_sum(cost);
   };
+  // (memory-level parallelism by hand, here and in the loops below: nothing of these matrices is cache-resident, a dependent load costs
+  //  ~2 k cycles, and the compiler does not hoist loads out of a runtime-bounded loop -- so every inner loop first issues the loads of
+  //  EIGHT elements (clamped addresses, masked results), then consumes them)
   auto amul = [&](real* out, const real* x) {            // out = A x; x must be visible (fence before)
     for (int i = lane; i < n; i += FB_WAVE) {
       real s0 = 0, s1 = 0;
-      int k = 0;
-      for (; k + 1 < n; k += 2) { s0 += Aat(i, k)*x[k]; s1 += Aat(i, k + 1)*x[k + 1]; }
-      if (k < n) s0 += Aat(i, k)*x[k];
+      const real Ri = Rv[i];
+      for (int k0 = 0; k0 < n; k0 += 8) {
+        real a[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int k = min(k0 + u, n - 1); a[u] = AR[i >= k ? i*(i + 1)/2 + k : k*(k + 1)/2 + i]; xv[u] = x[k]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int k = k0 + u;
+          const real e = (k == i) ? a[u] - Ri : a[u];
+          if (k < n) { if (u & 1) s1 += e*xv[u]; else s0 += e*xv[u]; }
+        }
+      }
       out[i] = s0 + s1;
     }
     SYNC();
@@ -184,40 +196,164 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
       real pj = 0;
       for (int a = 0; a < nj; a++) pj += fj[a]*qv[min(bj + a, n - 1)];
       pv[j] = pj;
-      for (int k = 0; k <= j; k++) {
-        const bool ek = w.efc_type()[k] == CN_ELLIPTIC;
-        const int bk = k - (ek ? w.efc_k()[k] : 0), nk = ek ? 3 : 1;
-        const real fk[3] = {Fc0[k], Fc1[k], Fc2[k]};
-        real s = 0;
-        for (int a = 0; a < nj; a++) {
-          real wa = 0;
-          for (int c2 = 0; c2 < nk; c2++) wa += Aat(min(bj + a, n - 1), min(bk + c2, n - 1))*fk[c2];
-          s += fj[a]*wa;
+      for (int k0 = 0; k0 <= j; k0 += 4) {
+        // round 1: what describes columns k0 .. k0 + 3; round 2: the 3 x 3 x 4 entries of A they select
+        int bk[4], nk[4]; real fk[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = min(k0 + u, j);
+          const bool ek = w.efc_type()[k] == CN_ELLIPTIC;
+          bk[u] = k - (ek ? w.efc_k()[k] : 0); nk[u] = ek ? 3 : 1;
+          fk[u][0] = Fc0[k]; fk[u][1] = Fc1[k]; fk[u][2] = Fc2[k];
         }
-        K[j*(j + 1)/2 + k] = s + (j == k ? (real)1 : (real)0);
+        real av[4][3][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) av[u][a][c2] = Aat(min(bj + min(a, nj - 1), n - 1), min(bk[u] + min(c2, nk[u] - 1), n - 1));
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = k0 + u;
+          if (k <= j) {
+            real sacc = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              if (a < nj) {
+                real wa = 0;
+#pragma unroll
+                for (int c2 = 0; c2 < 3; c2++) if (c2 < nk[u]) wa += av[u][a][c2]*fk[u][c2];
+                sacc += fj[a]*wa;
+              }
+            }
+            K[j*(j + 1)/2 + k] = sacc + (j == k ? (real)1 : (real)0);
+          }
+        }
       }
     }
     SYNC();
-    // ---- Cholesky K = L L' (right-looking; the diagonal slot keeps 1 / L_jj), forward substitution folded in
-    for (int j = 0; j < n; j++) {
-      const real inv = fb_rsqrt(K[j*(j + 1)/2 + j]);
-      const real yj = pv[j]*inv;
-      SYNC();                                            // (every lane has read K[j][j] and p[j] before their owner overwrites them)
-      if (lane == (j & 63)) { K[j*(j + 1)/2 + j] = inv; pv[j] = yj; }
-      for (int i = lane; i < n; i += FB_WAVE) if (i > j) { const real l = K[i*(i + 1)/2 + j]*inv; K[i*(i + 1)/2 + j] = l; pv[i] -= l*yj; }
+    // ---- Cholesky K = L L', BLOCKED by NB = 8 pivots (the diagonal slot keeps 1 / L_jj), forward substitution folded in.  The exchange
+    // medium is global memory, and a wave fence on it costs ~1-2 k cycles (store acknowledgements): pivot by pivot that was three fences
+    // per column -- 0.14 ms per factorisation of a 76-row system, ~13 ms per control step for the one environment everybody waits for.
+    // Here EVERY lane factorises the 8 x 8 diagonal block redundantly in registers (36 loads, 8 reciprocal square roots), solves its
+    // own rows' panel entries against it without talking to anybody, and the trailing update reads the finished panel: two fences per
+    // eight pivots.
+    constexpr int NB = 8;
+    for (int j0 = 0; j0 < n; j0 += NB) {
+      const int nb = min(NB, n - j0);
+      real Dg[NB][NB], yb[NB];                                   // diagonal block (lower triangle, becoming L with 1 / L_qq on the diagonal), its right-hand side
+#pragma unroll
+      for (int q = 0; q < NB; q++) {
+        const int jq = min(j0 + q, n - 1);
+        yb[q] = pv[jq];
+#pragma unroll
+        for (int t = 0; t < NB; t++) Dg[q][t] = (t <= q && q < nb) ? K[jq*(jq + 1)/2 + min(j0 + t, jq)] : (real)0;
+      }
+#pragma unroll
+      for (int q = 0; q < NB; q++) {
+        if (q < nb) {
+          const real inv = fb_rsqrt(Dg[q][q]);
+          Dg[q][q] = inv; yb[q] *= inv;
+#pragma unroll
+          for (int t = q + 1; t < NB; t++) {
+            if (t < nb) {
+              const real l = Dg[t][q]*inv;
+              Dg[t][q] = l; yb[t] -= l*yb[q];
+#pragma unroll
+              for (int u = q + 1; u <= t; u++) Dg[t][u] -= l*Dg[u][q];
+            }
+          }
+        }
+      }
+      SYNC();                                              // (every lane has read the block and p before their owners overwrite them)
+      for (int i = lane; i < n; i += FB_WAVE) {
+        if (i >= j0 && i < j0 + nb) {
+          const int q0 = i - j0;                               // a row of the diagonal block: publish its finished entries
+#pragma unroll
+          for (int q = 0; q < NB; q++) if (q == q0) {
+            pv[i] = yb[q];
+#pragma unroll
+            for (int t = 0; t < NB; t++) if (t <= q) K[i*(i + 1)/2 + j0 + t] = Dg[q][t];
+          }
+        } else if (i >= j0 + nb) {
+          real li[NB]; real pi = pv[i];                          // panel row i: L[i][j0 + t] = (K[i][j0 + t] - sum_{u < t} L[i][u] L[t][u]) / L[t][t]
+#pragma unroll
+          for (int t = 0; t < NB; t++) li[t] = t < nb ? K[i*(i + 1)/2 + j0 + t] : (real)0;
+#pragma unroll
+          for (int t = 0; t < NB; t++) {
+            if (t < nb) {
+              real v = li[t];
+#pragma unroll
+              for (int u = 0; u < t; u++) v -= li[u]*Dg[t][u];
+              v *= Dg[t][t];
+              li[t] = v; pi -= v*yb[t];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NB; t++) if (t < nb) K[i*(i + 1)/2 + j0 + t] = li[t];
+          pv[i] = pi;
+        }
+      }
       SYNC();
-      for (int i = lane; i < n; i += FB_WAVE) if (i > j) {
-        const real l = K[i*(i + 1)/2 + j];
-        if (l != 0) for (int k = j + 1; k <= i; k++) K[i*(i + 1)/2 + k] -= l*K[k*(k + 1)/2 + j];
+      // trailing update: K[i][k] -= sum_t L[i][j0 + t] L[k][j0 + t] for j0 + nb <= k <= i
+      for (int i = lane; i < n; i += FB_WAVE) {
+        if (i >= j0 + nb) {
+          real li[NB]; bool any = false;
+#pragma unroll
+          for (int t = 0; t < NB; t++) { li[t] = t < nb ? K[i*(i + 1)/2 + j0 + t] : (real)0; any = any || li[t] != 0; }
+          if (any) {
+            for (int k0 = j0 + nb; k0 <= i; k0 += 4) {
+              real lk[4][NB], kik[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int k = min(k0 + u, i);
+                kik[u] = K[i*(i + 1)/2 + k];
+#pragma unroll
+                for (int t = 0; t < NB; t++) lk[u][t] = K[k*(k + 1)/2 + j0 + min(t, nb - 1)];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                if (k0 + u <= i) {
+                  real acc = 0;
+#pragma unroll
+                  for (int t = 0; t < NB; t++) if (t < nb) acc += li[t]*lk[u][t];
+                  K[i*(i + 1)/2 + k0 + u] = kik[u] - acc;
+                }
+              }
+            }
+          }
+        }
       }
       SYNC();
     }
-    // ---- back substitution L' z = y, last column first
-    for (int j = n - 1; j >= 0; j--) {
-      const real zj = pv[j]*K[j*(j + 1)/2 + j];
+    // ---- back substitution L' z = y, last block first: every lane solves the block's 8 x 8 triangle redundantly
+    for (int j0 = ((n - 1)/NB)*NB; j0 >= 0; j0 -= NB) {
+      const int nb = min(NB, n - j0);
+      real zb[NB];
+#pragma unroll
+      for (int q = NB - 1; q >= 0; q--) {
+        zb[q] = 0;
+        if (q < nb) {
+          const int jq = j0 + q;
+          real v = pv[jq];
+#pragma unroll
+          for (int t = q + 1; t < NB; t++) if (t < nb) v -= K[(j0 + t)*(j0 + t + 1)/2 + jq]*zb[t];
+          zb[q] = v*K[jq*(jq + 1)/2 + jq];
+        }
+      }
       SYNC();
-      if (lane == (j & 63)) zv[j] = zj;
-      for (int i = lane; i < j; i += FB_WAVE) pv[i] -= K[j*(j + 1)/2 + i]*zj;
+      for (int i = lane; i < n; i += FB_WAVE) {
+        if (i >= j0 && i < j0 + nb) {
+#pragma unroll
+          for (int q = 0; q < NB; q++) if (q == i - j0) zv[i] = zb[q];
+        } else if (i < j0) {
+          real pi = pv[i];
+#pragma unroll
+          for (int q = 0; q < NB; q++) if (q < nb) pi -= K[(j0 + q)*(j0 + q + 1)/2 + i]*zb[q];
+          pv[i] = pi;
+        }
+      }
       SYNC();
     }
     for (int i = lane; i < n; i += FB_WAVE) {
