@@ -1397,6 +1397,20 @@ extern "C" void* fb_batch_device_ptr(fb_batch* b, int field) {
   }
 }
 
+extern "C" int fb_batch_row(fb_batch* b, int which, int env, void* host, size_t bytes, int write, size_t* row_bytes) {
+  if (!b || which < 0 || which > 1 || env < 0 || env >= b->n_env) return fail("fb_batch_row: bad argument");
+  const size_t rs = which == 0 ? (b->precision == 64 ? 8 : 4) : 4;
+  const size_t rb = (which == 0 ? (size_t)b->off.nreal : (size_t)b->off.nint)*rs;
+  if (row_bytes) *row_bytes = rb;
+  if (bytes == 0) return 0;
+  if (!host || bytes != rb) return fail("fb_batch_row: size mismatch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  char* dev = (which == 0 ? (char*)b->rarena : (char*)b->iarena) + (size_t)env*rb;
+  if (write) HIPCHK(hipMemcpy(dev, host, rb, hipMemcpyHostToDevice)); else HIPCHK(hipMemcpy(host, dev, rb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" int fb_batch_scheduler(const fb_batch* b, int* slots) {
   if (!b) return fail("fb_batch_scheduler: null batch");
   if (slots) *slots = b->slots;

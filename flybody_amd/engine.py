@@ -93,6 +93,7 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_forward.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.fb_batch_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
     L.fb_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p
@@ -255,6 +256,18 @@ class Batch:
 
     def synchronize(self, stream=None):
         _check(self.L, self.L.fb_batch_synchronize(self.h, stream))
+
+    def row(self, which: int, env: int, data: Optional[np.ndarray] = None) -> np.ndarray:
+        """Profiling: the raw workspace row of one environment as bytes (which = 0 real arena, 1 int arena); data: write it back."""
+        n = C.c_size_t(0)
+        _check(self.L, self.L.fb_batch_row(self.h, which, env, None, 0, 0, C.byref(n)))
+        if data is not None:
+            buf = np.ascontiguousarray(data, np.uint8); assert buf.size == n.value
+            _check(self.L, self.L.fb_batch_row(self.h, which, env, buf.ctypes.data, n.value, 1, None))
+            return buf
+        buf = np.empty(n.value, np.uint8)
+        _check(self.L, self.L.fb_batch_row(self.h, which, env, buf.ctypes.data, n.value, 0, None))
+        return buf
 
     def _width(self, name):
         m = self.model

@@ -170,6 +170,11 @@ int fb_batch_forward(fb_batch* b, void* stream);
  * MODE_STAGE); the caller walks the stage sequence of a control step itself (tools/stage_profile.py), `action` is only read by
  * the first stage (the task's before_step hook).  Same results as fb_batch_step while no environment ends its episode. */
 int fb_batch_stage(fb_batch* b, int stage_word, const float* action, void* stream);
+/* Profiling entry point: the raw workspace row of ONE environment (which = 0: the physics-real arena row, 1: the int32 arena row), copied
+ * to (write = 0) or from (write = 1) host memory after a device synchronisation.  bytes = 0 with a non-null `row_bytes` only reports the
+ * row size.  The layout is internal (fb_types.hpp: FB_WS_REAL / FB_WS_INT); tools/footprint.py uses this to measure which cache lines of a
+ * row a substep reads and writes.  Not a parity or product interface. */
+int fb_batch_row(fb_batch* b, int which, int env, void* host, size_t bytes, int write, size_t* row_bytes);
 
 /* Synchronous host copies (physics-real fields are converted to/from FP64; FB_OBS/REWARD/
  * DISCOUNT are float32, the int fields int32).  `bytes` must match exactly. */

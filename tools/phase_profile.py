@@ -11,7 +11,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 task = sys.argv[4] if len(sys.argv) > 4 else 'walk'
 if task == 'flight':
     # BASELINE configs[3]: the flight environment (WBPG + wing fluid forces) on the profiling build of the library
-    engine.HIP_LIB = lib
+    engine.HIP_LIB = lib; engine.HIP_LIB_DENSE = lib
     from flybody_amd.fly_envs import flight_imitation
     env = flight_imitation(n_env=n, precision=prec); B = env.batch; M = B.model; env.reset_all()
 else:
@@ -34,7 +34,8 @@ p = B.get('PROF').view(np.int64).astype(np.float64)   # [n][32]
 names = ['kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'csetup', 'pgs', 'noslip', 'cfin', 'sens', 'euler', 'f_publish', 'f_setup(row loads)', 'f_sync', 'f_tail', 'sol_fwd', 'sol_bwd', 'f_pull_dof_lo', 'f_pull_dof_hi', 'f_loop_overhead+small_loops', 'kin_fk', 'kin_geoms', 'env_pre', 'env_post', 'TOTAL_clock64', 'TOTAL_wall100MHz', 'pgs_blocks_evaluated',
          'nw_setup', 'nw_residual', 'nw_kbuild', 'nw_chol', 'nw_backsub', 'nw_direction', 'nw_linesearch', 'nw_iterations(count)', 'nw_ls_evals(count)', 'nw_solves(count)', 'co_stage_spheres', 'co_mid_phase', 'co_box_filter', 'co_narrow', 'co_write', '-',
          'ki_joint_rot', 'ki_fk_levels', 'ki_geoms_sites', 'ki_com', 've_com_vel', 've_passive', 've_rne', '-']
-tot = p[:, names.index('TOTAL_clock64')].mean()          # denominator: the wave's own clock64 lifetime (col 28 holds a start tick, not a duration)
+tot = p[:, names.index('TOTAL_clock64')].mean()
+if not tot > 0: tot = sum(p[:, names.index(k)].mean() for k in ('kin', 'compos', 'crb', 'factor', 'coll', 'makec', 'proj', 'vel', 'act', 'acc', 'cfin', 'sens', 'euler'))      # (substep scheduler: no per-wave lifetime; the stages' sum)          # denominator: the wave's own clock64 lifetime (col 28 holds a start tick, not a duration)
 print(f'task {task} precision {prec} n_env {n}: {dt/K*1e3:.2f} ms/step (profiling build); wave lifetime {tot/K:.0f} cycles per env-step; nefc mean {B.get("NEFC").mean():.1f} ncon mean {B.get("NCON").mean():.1f} niter mean {B.get("SOLVER_NITER").mean():.1f}')
 for i, nm in enumerate(names):
     if nm == 'env_post': continue
