@@ -397,13 +397,19 @@ __device__ __forceinline__ bool boxes_may_touch(const real* pa, const real* ma, 
 template <typename real>
 FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
-  int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-  int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
-  if (t1 == GEOM_PLANE) return true;
-  real e1[3], e2[3];
-  box_extents(t1, (const real*)(M.geom_size + 3*g1), e1); box_extents(t2, (const real*)(M.geom_size + 3*g2), e2);
-  return boxes_may_touch((const real*)(w.gxpos() + 3*g1), (const real*)(w.gxmat() + 9*g1), e1, (const real*)(w.gxpos() + 3*g2), (const real*)(w.gxmat() + 9*g2), e2,
-                         (real)M.pair_margin[p]);
+  // Two rounds of loads (round 5; before: pair -> geoms -> types -> sizes -> poses, fourteen dependent waits per call, two calls per
+  // substep): the pair's packed word and margin, then everything they address at once -- the boxes' half extents come from a
+  // per-geom model table, the centres from the bounding spheres the mid phase staged in LDS.
+  const int pw = M.pair_word[p]; const real margin = M.pair_margin[p];
+  const int g1 = pw & 1023, g2 = (pw >> 10) & 1023;
+  if (pw >> 20) return true;                                     // plane pairs go straight to the narrow phase
+  real e1[3], e2[3], c1[3], c2[3], m1[9], m2[9];
+  const FB_LDS real* G = w.lAR;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { e1[k] = M.geom_box[3*g1 + k]; e2[k] = M.geom_box[3*g2 + k]; c1[k] = G[4*g1 + k]; c2[k] = G[4*g2 + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m1[k] = w.gxmat()[9*g1 + k]; m2[k] = w.gxmat()[9*g2 + k]; }
+  return boxes_may_touch(c1, m1, e1, c2, m2, e2, margin);
 }
 
 // returns the number of contacts | (penetration query at its iteration limit) << 8
@@ -412,9 +418,9 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   LaneContacts<real> lc;
   lc.first = w.lLD + 6*M.nv; lc.more = (FB_GLOBAL real*)w.efc_Y(); lc.lane = lane; lc.n = 0; lc.ccd_cap = 0;
-  int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+  const int pw_ = M.pair_word[p]; real margin = M.pair_margin[p];          // (round 1: the pair; round 2: everything its two geoms address)
+  int g1 = pw_ & 1023, g2 = (pw_ >> 10) & 1023;
   int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
-  real margin = M.pair_margin[p];
   // Both geoms' pose and size into registers ONCE, through the typed (global address space) accessors.  Handing the routines
   // below generic pointers into the workspace made every use a flat_load that the compiler could not hoist out of the MPR loops
   // (a flat access may alias the scratch-resident contact list): ~30 reloads per support-function pair, 96 flat loads in all.

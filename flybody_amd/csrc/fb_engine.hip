@@ -40,6 +40,7 @@ struct fb_model {
   std::vector<int> body_nsub, body_depth, body_chlen, body_chain, body_common, dof_depth, dof_ndesc, lvl_dof, lvl_start, adh_act;
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, pair_body, plane_geoms;
+  std::vector<double> geom_box;          // [ngeom][3] oriented-box half extents by geom type (constant: one lookup instead of type -> size -> switch)
   std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
@@ -359,6 +360,15 @@ static int model_load_impl(fb_model* m, size_t n) {
       m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20);
     }
     if (m->plane_geoms.empty()) m->plane_geoms.push_back(0);
+    const double* gs = m->d("geom_size");
+    m->geom_box.assign(3*std::max(m->ngeom, 1), 0.0);
+    for (int g = 0; g < m->ngeom; g++) {
+      double* e = &m->geom_box[3*g]; const double* sz = gs + 3*g;
+      if (gt[g] == GEOM_CAPSULE) { e[0] = e[1] = sz[0]; e[2] = sz[1] + sz[0]; }
+      else if (gt[g] == GEOM_CYLINDER) { e[0] = e[1] = sz[0]; e[2] = sz[1]; }
+      else if (gt[g] == GEOM_ELLIPSOID) { e[0] = sz[0]; e[1] = sz[1]; e[2] = sz[2]; }
+      else { e[0] = e[1] = e[2] = sz[0]; }
+    }
   }
   // flattened actuator transmissions and tendon wraps: one padded record per actuator / wrap, so that the kernel fetches
   // them with a fixed number of independent loads instead of walking tendon_adr -> wrap_dofid -> dof_jntid -> jnt_qposadr
@@ -879,6 +889,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UD(body_mass, "body_mass")
   UD(body_inertia, "body_inertia") UD(body_invweight0, "body_invweight0")
   if (upload<real>(b, m->body_box.data(), m->body_box.size(), &M.body_box)) return -1;
+  if (upload<real>(b, m->geom_box.data(), m->geom_box.size(), &M.geom_box)) return -1;
   if (upload<real>(b, m->body_rec.data(), m->body_rec.size(), &M.body_rec)) return -1;
   UD(jnt_axis, "jnt_axis") UD(jnt_stiffness, "jnt_stiffness") UD(jnt_range, "jnt_range") UD(jnt_solref, "jnt_solref")
   UD(jnt_solimp, "jnt_solimp") UD(jnt_margin, "jnt_margin") UD(qpos0, "qpos0") UD(qpos_spring, "qpos_spring")

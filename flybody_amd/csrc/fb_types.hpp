@@ -163,6 +163,7 @@ struct DevModel {
   GP<const real> jnt_axis, jnt_stiffness, jnt_range, jnt_solref, jnt_solimp, jnt_margin;
   GP<const real> qpos0, qpos_spring, dof_armature, dof_damping, dof_invweight0;
   GP<const real> geom_pos, geom_quat, geom_size, geom_rbound, geom_fluid;
+  GP<const real> geom_box;      // [ngeom][3] half extents of the geom's oriented bounding box (fb_collide.hpp: box_filter)
   GP<const real> site_pos, site_quat, site_size;
   GP<const real> wrap_coef;
   GP<const real> act_dynprm, act_gainprm, act_biasprm, act_ctrlrange, act_forcerange;
