@@ -67,11 +67,18 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   for (int base = 0; base < M.njnt; base += FB_WAVE) {
     int j = base + lane;
     int side = 0; real dist = 0;
-    if (j < M.njnt && M.jnt_limited[j] && M.jnt_type[j] == JNT_HINGE) {
-      real value = w.qpos()[M.jnt_qposadr[j]];
-      real dlo = value - M.jnt_range[2*j], dhi = M.jnt_range[2*j+1] - value;
-      if (dlo < M.jnt_margin[j]) { side = -1; dist = dlo; }
-      else if (dhi < M.jnt_margin[j]) { side = 1; dist = dhi; }
+    {
+      // (loads in two rounds, unconditional: [limited, type, address, range, margin] of the lane's joint, then its position -- the
+      //  nested tests made them four dependent waits per pass)
+      const int js = j < M.njnt ? j : 0;
+      const int lim = M.jnt_limited[js], jty = M.jnt_type[js], qad = M.jnt_qposadr[js];
+      const real rlo = M.jnt_range[2*js], rhi = M.jnt_range[2*js + 1], mg = M.jnt_margin[js];
+      const real value = w.qpos()[qad];
+      if (j < M.njnt && lim && jty == JNT_HINGE) {
+        real dlo = value - rlo, dhi = rhi - value;
+        if (dlo < mg) { side = -1; dist = dlo; }
+        else if (dhi < mg) { side = 1; dist = dhi; }
+      }
     }
     int has = side != 0;
     int r = nlimit + wave_excl_scan(has, lane);

@@ -227,12 +227,35 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   FB_LDS real* S = w.lLD;                          // body frames: 7*nbody
   FB_LDS real* JQ = w.lLD + fk_off_jq(M);          // joint rotations: 4*njnt
   FB_LDS real* A = w.lLD + fk_off_a(M);            // joint anchors / axes: 6*njnt (runs on into the matrix slot: the pool is contiguous)
-  for (int j = lane; j < M.njnt; j += FB_WAVE) {
-    real q[4] = {1, 0, 0, 0};
-    int jt = M.jnt_type[j], qa = M.jnt_qposadr[j];
-    if (jt == JNT_HINGE) axisangle2quat(q, M.jnt_axis + 3*j, w.qpos()[qa] - M.qpos0[qa]);
-    else if (jt == JNT_BALL) { for (int k = 0; k < 4; k++) q[k] = w.qpos()[qa + k]; normquat(q); }
-    for (int k = 0; k < 4; k++) JQ[4*j + k] = q[k];
+  // joint rotations, in two rounds of loads for BOTH joints of a lane (round 5; the branchy per-joint form -- type, then address, then
+  // value behind a test -- was eight dependent waits): [type, address, axis] of joints l and l + 64, then the four position words
+  // either kind of joint may need, unconditionally (a hinge uses the first, a ball all four, a free joint none: clamped, ignored)
+  {
+    int jt[2], qa[2]; real ax[2][3], qv[2][4], q0[2]; bool jok[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = lane + u*FB_WAVE; jok[u] = j < M.njnt; const int js = jok[u] ? j : 0;
+      jt[u] = M.jnt_type[js]; qa[u] = M.jnt_qposadr[js];
+#pragma unroll
+      for (int k = 0; k < 3; k++) ax[u][k] = M.jnt_axis[3*js + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int nq = M.nq;
+#pragma unroll
+      for (int k = 0; k < 4; k++) qv[u][k] = w.qpos()[min(qa[u] + k, nq - 1)];
+      q0[u] = M.qpos0[qa[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = lane + u*FB_WAVE;
+      if (jok[u]) {
+        real q[4] = {1, 0, 0, 0};
+        if (jt[u] == JNT_HINGE) axisangle2quat(q, ax[u], qv[u][0] - q0[u]);
+        else if (jt[u] == JNT_BALL) { for (int k = 0; k < 4; k++) q[k] = qv[u][k]; normquat(q); }
+        for (int k = 0; k < 4; k++) JQ[4*j + k] = q[k];
+      }
+    }
   }
   if (lane == 0) {
     // world body: identity frame
