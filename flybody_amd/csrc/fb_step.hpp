@@ -266,38 +266,63 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
 template <typename real>
 __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<real>& w, int lane) {
   real h = M.timestep;
-  for (int i = lane; i < M.nu; i += FB_WAVE) {
-    int aa = M.act_actadr[i];
-    if (aa < 0) continue;
-    if (M.act_dyntype[i] == DYN_FILTEREXACT) {
-      real tau = fmax(FB_MINV, M.act_dynprm[i]);
-      w.act()[aa] += w.act_dot()[aa]*tau*(1 - exp(-h/tau));
-    } else w.act()[aa] += h*w.act_dot()[aa];
+  // Round 5: in load rounds, and without the store -> fence -> reload of qvel between the velocity and the position update (the new
+  // velocities reach the joints through the solve vector in LDS, which is dead after this stage).
+  for (int i0 = 0; i0 < M.nu; i0 += FB_WAVE) {
+    const int i = i0 + lane; const bool ok = i < M.nu; const int is = ok ? i : 0;
+    const int aa = M.act_actadr[is], dt = M.act_dyntype[is]; const real prm = M.act_dynprm[is];
+    const int as_ = (ok && aa >= 0) ? aa : 0;
+    const real a0 = w.act()[as_], ad = w.act_dot()[as_];
+    if (ok && aa >= 0) {
+      real an;
+      if (dt == DYN_FILTEREXACT) { real tau = fmax(FB_MINV, prm); an = a0 + ad*tau*(1 - exp(-h/tau)); }
+      else an = a0 + h*ad;
+      w.act()[aa] = an;
+    }
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) w.qvel()[i] += h*w.lx[i];
-  SYNC();
-  for (int j = lane; j < M.njnt; j += FB_WAVE) {
-    int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
-    if (M.jnt_type[j] == JNT_FREE) {
-      for (int k = 0; k < 3; k++) w.qpos()[qa+k] += h*w.qvel()[da+k];
-      real ax[3] = {w.qvel()[da+3], w.qvel()[da+4], w.qvel()[da+5]};
-      real n = normalize3(ax);
-      real q[4] = {w.qpos()[qa+3], w.qpos()[qa+4], w.qpos()[qa+5], w.qpos()[qa+6]}, qr[4], res[4];
-      axisangle2quat(qr, ax, n*h);
-      normquat(q);
-      mulquat(res, q, qr);
-      normquat(res);
-      for (int k = 0; k < 4; k++) w.qpos()[qa+3+k] = res[k];
-    } else if (M.jnt_type[j] == JNT_BALL) {
-      real ax[3] = {w.qvel()[da], w.qvel()[da+1], w.qvel()[da+2]};
-      real n = normalize3(ax);
-      real q[4] = {w.qpos()[qa], w.qpos()[qa+1], w.qpos()[qa+2], w.qpos()[qa+3]}, qr[4], res[4];
-      axisangle2quat(qr, ax, n*h);
-      normquat(q);
-      mulquat(res, q, qr);
-      normquat(res);
-      for (int k = 0; k < 4; k++) w.qpos()[qa+k] = res[k];
-    } else w.qpos()[qa] += h*w.qvel()[da];
+  for (int i = lane; i < M.nv; i += FB_WAVE) { const real v = w.qvel()[i] + h*w.lx[i]; w.qvel()[i] = v; w.lx[i] = v; }
+  SYNC_LDS();
+  {
+    int jt[2], qa[2], da[2]; bool jok[2]; real qv[2][7], vv[2][6];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = lane + u*FB_WAVE; jok[u] = j < M.njnt; const int js = jok[u] ? j : 0;
+      jt[u] = M.jnt_type[js]; qa[u] = M.jnt_qposadr[js]; da[u] = M.jnt_dofadr[js];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int nq = M.nq, nv = M.nv;
+      const int nqw = jt[u] == JNT_FREE ? 7 : (jt[u] == JNT_BALL ? 4 : 1), nvw = jt[u] == JNT_FREE ? 6 : (jt[u] == JNT_BALL ? 3 : 1);
+#pragma unroll
+      for (int k = 0; k < 7; k++) qv[u][k] = w.qpos()[min(qa[u] + min(k, nqw - 1), nq - 1)];
+#pragma unroll
+      for (int k = 0; k < 6; k++) vv[u][k] = w.lx[min(da[u] + min(k, nvw - 1), nv - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!jok[u]) continue;
+      const int qa_ = qa[u];
+      if (jt[u] == JNT_FREE) {
+        for (int k = 0; k < 3; k++) w.qpos()[qa_ + k] = qv[u][k] + h*vv[u][k];
+        real ax[3] = {vv[u][3], vv[u][4], vv[u][5]};
+        real n = normalize3(ax);
+        real q[4] = {qv[u][3], qv[u][4], qv[u][5], qv[u][6]}, qr[4], res[4];
+        axisangle2quat(qr, ax, n*h);
+        normquat(q);
+        mulquat(res, q, qr);
+        normquat(res);
+        for (int k = 0; k < 4; k++) w.qpos()[qa_ + 3 + k] = res[k];
+      } else if (jt[u] == JNT_BALL) {
+        real ax[3] = {vv[u][0], vv[u][1], vv[u][2]};
+        real n = normalize3(ax);
+        real q[4] = {qv[u][0], qv[u][1], qv[u][2], qv[u][3]}, qr[4], res[4];
+        axisangle2quat(qr, ax, n*h);
+        normquat(q);
+        mulquat(res, q, qr);
+        normquat(res);
+        for (int k = 0; k < 4; k++) w.qpos()[qa_ + k] = res[k];
+      } else w.qpos()[qa_] = qv[u][0] + h*vv[u][0];
+    }
   }
   if (lane == 0) w.simtime()[0] += h;
   SYNC();
