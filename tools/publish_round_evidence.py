@@ -4,7 +4,7 @@
 Per-launch PMC tables are reduced to the step kernel's rows; `pmc_traffic_f{64,32}.json` (read by bench.py) go to profiles/."""
 import csv, json, os, shutil, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r5'
 src, fin, dst = (os.path.join(ROOT, p) for p in ('gpurun_out/profiles_final', 'gpurun_out/final', f'profiles/{tag}'))
 os.makedirs(dst, exist_ok=True)
 clean = lambda p: ('\n'.join(l for l in open(p).read().splitlines() if 'amdgpu.ids' not in l) + '\n') if os.path.exists(p) else ''
@@ -41,7 +41,9 @@ for sub, pre, name in (('pmc_fetch', 'f', 'fetch'), ('pmc_write', 'w', 'write'),
         per_launch(f'{src}/{sub}/{pre}_counter_collection.csv', f'{dst}/pmc_{name}_per_launch.csv')
 for extra, name in ((f'{src}/pmc_calibration.json', 'pmc_calibration.json'), (f'{fin}/bench_1000_steps.json', 'bench_1000_steps.json'), (f'{fin}/bench_steps20.json', 'bench_steps20.json'), (f'{fin}/solver_bench.txt', 'solver_newton_vs_pgs.txt'),
                     (f'{fin}/ticket_trace_dense.txt', 'ticket_trace_dense.txt'), (f'{fin}/ticket_check.txt', 'substep_scheduler.txt'),
-                    (os.path.join(ROOT, 'gpurun_out/stage_final/stage_lanes.txt'), 'stage_lanes_dense_final.txt')):
+                    (os.path.join(ROOT, 'gpurun_out/stage_final/stage_lanes.txt'), 'stage_lanes_dense_final.txt'),
+                    (f'{fin}/launch_times.txt', 'launch_times.txt'), (f'{fin}/gemm_shapes_probe.txt', 'learner_gemm_shapes.txt'),
+                    (f'{fin}/phase64_dense_tickets.txt', 'phase_cycles_dense_tickets.txt'), (f'{fin}/phase64_flight_dense.txt', 'phase_cycles_flight.txt')):
     if os.path.exists(extra):
         open(f'{dst}/{name}', 'w').write(clean(extra))
 shutil.copy(f'{fin}/bench_default.json', f'{dst}/bench_default.json')
