@@ -247,7 +247,6 @@ template <typename real> FBD real wave_sum(real v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_r(v, m);
   return v;
 }
-template <typename real> FBD real row0_sum(real v) { return wave_sum(v); }      // (callers guarantee zeros outside lanes 0..15)
 #else
 // broadcast from a wave-uniform source lane: v_readlane, no LDS crossbar round trip
 FBD int rdlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
@@ -270,12 +269,6 @@ template <typename real> FBD real wave_sum(real v) {
   v += dpp_mov<0x141>(v);   // row_half_mirror
   v += dpp_mov<0x140>(v);   // row_mirror
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
-}
-// sum of a vector whose lanes 16..63 hold zeros (the per-row quantities of a system of <= 16 rows): the butterflies of row 0 and ONE
-// broadcast -- 14 instructions instead of 23 (six v_readlane and three adds less); all 64 lanes active, result wave-uniform
-template <typename real> FBD real row0_sum(real v) {
-  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
-  return rdlane(v, 0);
 }
 #endif
 // sum over the four lanes of a quad (lanes 4k .. 4k+3), result in all four; every lane must call

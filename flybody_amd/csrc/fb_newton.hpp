@@ -495,8 +495,6 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     }
     return on ? (acc0 + acc1) - R*x : (real)0;
   };
-  // sums over the rows: systems on the tile (<= 16 rows) carry zeros beyond lane 15 in every per-row quantity
-  auto wsum = [&](real v) -> real { return tile ? row0_sum(v) : wave_sum(v); };
   const real scale = (real)1 / (M.meaninertia * (real)(M.nv > 1 ? M.nv : 1));
   const real tol = M.tolerance;
   const int max_it = M.iterations;
@@ -511,10 +509,10 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     const real jar = b + Al;
     jb0 = nw_lane(jar, base); jb1 = nw_lane(jar, base + 1); jb2 = nw_lane(jar, base + 2);
     nw_update(c, jb0, jb1, jb2, o);
-    const real c_ws = wsum((real)0.5*lam*Al + o.cost);
+    const real c_ws = wave_sum((real)0.5*lam*Al + o.cost);
     const real bb0 = nw_lane(b, base), bb1 = nw_lane(b, base + 1), bb2 = nw_lane(b, base + 2);
     nw_update(c, bb0, bb1, bb2, o);
-    const real c_0 = wsum(o.cost);
+    const real c_0 = wave_sum(o.cost);
     if (c_ws > c_0) { lam = 0; jb0 = bb0; jb1 = bb1; jb2 = bb2; }
   }
   int niter = 0;
@@ -523,14 +521,14 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     nw_update(c, jb0, jb1, jb2, o);
     const real r = o.f - lam;
     const real q = amul(r);
-    const real dec = wsum(r*q);
+    const real dec = wave_sum(r*q);
     NW_PROF(1);
     if ((real)0.5*dec*scale < tol) break;           // bound on the attainable improvement (MuJoCo's `improvement` scaling)
     if (sizeof(real) == 4) {
       // single precision cannot resolve the absolute tolerance: r = f - lam carries a rounding error of ~1e-7 |f|, so the
       // decrement bottoms out at ~1e-14 |lam|_A^2 times the conditioning.  Stop at that floor (the FP64 build never gets here).
       const real jo_ = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
-      const real lAl = wsum(lam*(jo_ - b));
+      const real lAl = wave_sum(lam*(jo_ - b));
       if (dec <= (real)FB_NEWTON_F32_FLOOR*(lAl + dec)) break;
     }
     const unsigned long long m_act = __ballot(o.fc0 != 0 || o.fc1 != 0 || o.fc2 != 0);     // non-zero columns of F
@@ -817,7 +815,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     const real Adl = amul(dl);
     const real Ab0 = nw_lane(Adl, base), Ab1 = nw_lane(Adl, base + 1), Ab2 = nw_lane(Adl, base + 2);
     const real jo = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
-    const real lAd = wsum((jo - b)*dl), dAd = wsum(dl*Adl);
+    const real lAd = wave_sum((jo - b)*dl), dAd = wave_sum(dl*Adl);
     NW_PROF(5);
     // ---- line search: phi'(alpha) = lAd + alpha dAd - f(jar + alpha Adl).Adl,  phi'' = dAd + |F'Adl|^2
     real alpha = 0, g0 = 0, lo = 0, hi = -1;
@@ -826,8 +824,8 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       NW_COUNT(1);
       if (kls > 0) nw_update(c, jb0 + alpha*Ab0, jb1 + alpha*Ab1, jb2 + alpha*Ab2, o2);
       const real wv = o2.fc0*Ab0 + o2.fc1*Ab1 + o2.fc2*Ab2;
-      const real g = lAd + alpha*dAd - wsum(o2.f*Adl);
-      const real h = dAd + wsum(wv*wv);
+      const real g = lAd + alpha*dAd - wave_sum(o2.f*Adl);
+      const real h = dAd + wave_sum(wv*wv);
       if (kls == 0) { g0 = g; if (!(g0 < 0) || !(h > FB_MINV)) break; alpha = -fb_div(g0, h); continue; }
       if (fabs(g) <= (real)0.01*fabs(g0) || kls == FB_NEWTON_LS_MAX) break;
       if (g < 0) lo = alpha; else hi = alpha;
