@@ -22,10 +22,31 @@ extern "C" { long long fb_stats[64]; }
 template <typename real>
 struct CGeom { real pos[3], mat[9], size[3]; int type; real margin; };     // by value: pointers to the caller's arrays pin those arrays in scratch memory
 
+#ifndef FB_SUPPORT_SELECT
+#define FB_SUPPORT_SELECT 1
+#endif
 template <typename real>
 FBD void support(const CGeom<real>& g, const real* dir, real* out) {
   real l[3], p[3];
   mulmatT3(l, g.mat, dir);
+#if FB_SUPPORT_SELECT
+  // Round 5: all four shapes by SELECTS.  The lanes of a narrow-phase pass hold different geom types, so a branch per type made the
+  // wave run every branch anyway -- plus a saveexec / branch / restore around each, twice per support pair and ~25 times per pass.
+  // Same arithmetic per shape (the unused shapes' square roots are computed and dropped).
+  const bool caps = g.type == GEOM_CAPSULE, ell = g.type == GEOM_ELLIPSOID, cyl = g.type == GEOM_CYLINDER, sph = g.type == GEOM_SPHERE;
+  const real s0 = g.size[0]*l[0], s1 = g.size[1]*l[1], s2 = g.size[2]*l[2];
+  const real se_[3] = {s0, s1, s2};
+  const real ne = norm3(se_);                                          // ellipsoid: |S l|
+  const real nc = fb_sqrt(l[0]*l[0] + l[1]*l[1]);                      // cylinder: |l_xy|
+  const real nie = fb_inv(ne < FB_MINV ? (real)1 : ne), nic = fb_inv(nc < FB_MINV ? (real)1 : nc);
+  const real hz = (l[2] >= 0 ? g.size[1] : -g.size[1]);
+  // sphere / capsule: r l (+ the capsule's half length along z)
+  real px = g.size[0]*l[0], py = g.size[0]*l[1], pz = g.size[0]*l[2] + (caps ? hz : (real)0);
+  if (ell) { px = ne < FB_MINV ? g.size[0] : g.size[0]*s0*nie; py = ne < FB_MINV ? (real)0 : g.size[1]*s1*nie; pz = ne < FB_MINV ? (real)0 : g.size[2]*s2*nie; }
+  if (cyl) { px = nc < FB_MINV ? (real)0 : g.size[0]*l[0]*nic; py = nc < FB_MINV ? (real)0 : g.size[0]*l[1]*nic; pz = hz; }
+  if (!(caps || ell || cyl || sph)) { px = 0; py = 0; pz = 0; }
+  p[0] = px; p[1] = py; p[2] = pz;
+#else
   if (g.type == GEOM_SPHERE) { scl3(p, l, g.size[0]); }
   else if (g.type == GEOM_CAPSULE) {
     scl3(p, l, g.size[0]);
@@ -41,6 +62,7 @@ FBD void support(const CGeom<real>& g, const real* dir, real* out) {
     else { real ni = fb_inv(n); p[0] = g.size[0]*l[0]*ni; p[1] = g.size[0]*l[1]*ni; }
     p[2] = (l[2] >= 0 ? g.size[1] : -g.size[1]);
   } else { p[0] = p[1] = p[2] = 0; }
+#endif
   addscl3(p, l, (real)0.5*g.margin);
   mulmat3(out, g.mat, p);
   add3(out, out, g.pos);
