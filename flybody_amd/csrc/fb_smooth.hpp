@@ -940,8 +940,11 @@ template <typename real>
 FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
   const int nv = M.nv;
   int ja[FB_NJUMP], jb[FB_NJUMP];
+  // (unconditional loads at clamped indices + selects: a load behind a lane-varying test is a branch of its own, and the compiler
+  //  waits at every join -- ten serialised table look-ups per call, three calls per substep)
+  const int la = min(lane, nv - 1), lb = min(lane + FB_WAVE, nv - 1);
 #pragma unroll
-  for (int k = 0; k < FB_NJUMP; k++) { ja[k] = lane < nv ? M.dof_jump[k*nv + lane] : -1; jb[k] = lane + FB_WAVE < nv ? M.dof_jump[k*nv + lane + FB_WAVE] : -1; }
+  for (int k = 0; k < FB_NJUMP; k++) { const int va = M.dof_jump[k*nv + la], vb = M.dof_jump[k*nv + lb]; ja[k] = lane < nv ? va : -1; jb[k] = lane + FB_WAVE < nv ? vb : -1; }
 #pragma unroll
   for (int k = 0; k < FB_NJUMP; k++) {
     real ga[6], gb[6];
@@ -967,7 +970,8 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
   const int ia = lane, ib = lane + FB_WAVE;
   const bool ha = ia < nv, hb = ib < nv;
   real ca[6], cb[6];
-  const real qa = ha ? w.qvel()[ia] : (real)0, qb = hb ? w.qvel()[ib] : (real)0;
+  const real qa_ = w.qvel()[min(ia, nv - 1)], qb_ = w.qvel()[min(ib, nv - 1)];
+  const real qa = ha ? qa_ : (real)0, qb = hb ? qb_ : (real)0;
   DofPair<real> V;
 #pragma unroll
   for (int c = 0; c < 6; c++) { ca[c] = ha ? Lc[6*ia + c] : (real)0; cb[c] = hb ? Lc[6*ib + c] : (real)0; V.a[c] = ca[c]*qa; V.b[c] = cb[c]*qb; }

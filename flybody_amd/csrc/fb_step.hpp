@@ -99,9 +99,14 @@ __device__ __forceinline__ void d_sensor_acc(const DevModel<real>& M, const WS<r
   {
     const int ia = lane, ib = lane + FB_WAVE;
     const bool ha = ia < M.nv, hb = ib < M.nv;
-    const real qa = ha ? w.qacc()[ia] : (real)0, qb = hb ? w.qacc()[ib] : (real)0;
+    // (all twelve loads unconditional at clamped indices, then selects: one round trip instead of a branch per test)
+    const int sa = min(ia, M.nv - 1), sb = min(ib, M.nv - 1);
+    const real qa = w.qacc()[sa], qb = w.qacc()[sb];
+    real da[6], db[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) { Q.a[c] = ha ? w.cdof()[6*ia + c]*qa : (real)0; Q.b[c] = hb ? w.cdof()[6*ib + c]*qb : (real)0; }
+    for (int c = 0; c < 6; c++) { da[c] = w.cdof()[6*sa + c]; db[c] = w.cdof()[6*sb + c]; }
+#pragma unroll
+    for (int c = 0; c < 6; c++) { Q.a[c] = ha ? da[c]*qa : (real)0; Q.b[c] = hb ? db[c]*qb : (real)0; }
     tree_prefix6(M, Q, lane);
   }
   if (nsb > 0) {
