@@ -740,16 +740,26 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
   }
 #pragma unroll
   for (int a = 0; a < FB_MAXTRUNK; a++) xt[a] = (a < nT) ? x[a] - wave_sum(xt[a]) : (real)0;
+  // (round 5: the 21 + 6 trunk loads of M in ONE round, issued before the reductions that consume them.  Written entry by entry --
+  //  load, reduce, subtract -- each load's latency was covered by one wave_sum only: 21 exposed round trips per factorisation)
+  {
+    real m0[FB_NTT], dadd[FB_MAXTRUNK];
 #pragma unroll
-  for (int a = 0; a < FB_MAXTRUNK; a++)
+    for (int a = 0; a < FB_MAXTRUNK; a++) {
+      dadd[a] = diag_add ? hscale*diag_add[a < nT ? a : 0] : (real)0;
 #pragma unroll
-    for (int b2 = 0; b2 <= a; b2++) {
-      int e = a*(a + 1)/2 + b2;
-      // trunk dof a sits at depth a: its row of M starts at a(a+1)/2 (unconditional load, masked afterwards)
-      real m0 = qM[a < nT ? a*(a + 1)/2 + (a - b2) : 0];
-      if (a == b2 && diag_add) m0 += hscale*diag_add[a < nT ? a : 0];
-      S[e] = (a < nT) ? m0 - wave_sum(S[e]) : (real)0;
+      for (int b2 = 0; b2 <= a; b2++) m0[a*(a + 1)/2 + b2] = qM[a < nT ? a*(a + 1)/2 + (a - b2) : 0];      // trunk dof a sits at depth a: its row of M starts at a(a+1)/2
     }
+#pragma unroll
+    for (int a = 0; a < FB_MAXTRUNK; a++)
+#pragma unroll
+      for (int b2 = 0; b2 <= a; b2++) {
+        const int e = a*(a + 1)/2 + b2;
+        real m = m0[e];
+        if (a == b2) m += dadd[a];
+        S[e] = (a < nT) ? m - wave_sum(S[e]) : (real)0;
+      }
+  }
   SYNC();
   // normalise the published rows: L[i,j] = M~[i,j] / D[i]
   // (branch-free: all reads in flight together, an empty slot reads row 0 and writes the dummy word behind the factor)
