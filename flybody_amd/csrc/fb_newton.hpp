@@ -397,6 +397,7 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
     for (int i = lane; i < n; i += FB_WAVE) { lam[i] += alpha*dl[i]; jar[i] += alpha*Adl[i]; }
     SYNC();
     niter = it + 1;
+    if (-g0*alpha*scale < tol) break;                  // (the step's improvement is below the tolerance: see d_newton)
   }
   update_all(jar);
   for (int i = lane; i < n; i += FB_WAVE) w.efc_force()[i] = Ff[i];
@@ -837,6 +838,12 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     if (!(alpha > 0)) break;
     lam += alpha*dl; jb0 += alpha*Ab0; jb1 += alpha*Ab1; jb2 += alpha*Ab2;
     niter = it + 1;
+    // MuJoCo's own stopping test: the IMPROVEMENT of the iteration, scaled, below opt.tolerance.  phi is convex with phi'(0) = g0 < 0, so
+    // the cost fell by at most -g0 alpha: when even that bound is under the tolerance the solver is done.  (The decrement bound at the
+    // top of the loop ends a converging solve one iteration earlier; this test ends a STAGNATING one -- an ill-conditioned system whose
+    // decrement sits at its rounding floor just above the tolerance used to run to opt.iterations = 100 with vanishing steps:
+    // seen once in 160 environment-steps of the wing-collision variant, FB_WARN_SOLVER_MAXITER.)
+    if (-g0*alpha*scale < tol) break;
   }
   nw_update(c, jb0, jb1, jb2, o);
   if (on) w.efc_force()[lane] = o.f;

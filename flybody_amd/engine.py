@@ -93,7 +93,8 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_substep.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.fb_batch_forward.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-    L.fb_batch_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    if hasattr(L, 'fb_batch_row'):          # (profiling entry point, round 5; A/B builds of older sources lack it)
+        L.fb_batch_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
     L.fb_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p

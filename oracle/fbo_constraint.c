@@ -503,6 +503,9 @@ static void solve_newton(fbo_data* d) {
     if (!(alpha > 0)) break;
     for (int i = 0; i < n; i++) { lam[i] += alpha*dl[i]; jar[i] += alpha*Adl[i]; }
     d->solver_niter = it + 1;
+    /* MuJoCo's own stopping test: the improvement of the iteration (scaled) below opt.tolerance.  phi is convex with phi'(0) = g0 < 0:
+     * the cost fell by at most -g0 alpha.  Ends a solve that stagnates at the rounding floor of the decrement just above the tolerance. */
+    if (-g0*alpha*scale < m->tolerance) break;
   }
   newton_update(d, jar, rw);
   for (int i = 0; i < n; i++) d->efc_force[i] = rw[i].f;
