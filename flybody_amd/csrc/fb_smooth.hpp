@@ -982,6 +982,13 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
   real ca[6], cb[6];
   const real qa_ = w.qvel()[min(ia, nv - 1)], qb_ = w.qvel()[min(ib, nv - 1)];
   const real qa = ha ? qa_ : (real)0, qb = hb ? qb_ : (real)0;
+  // (every table look-up of the stage up front, unconditional at clamped indices: behind the stores of the first half a load's wait
+  //  would include the stores' acknowledgements -- vmcnt counts them -- and a load behind a lane-varying test is a branch of its own)
+  const int nb = M.nbody;
+  int bvd[2], vbef[2];
+  { const int t0 = M.body_veldof[min(lane, nb - 1)], t1 = M.body_veldof[min(lane + FB_WAVE, nb - 1)];
+    const int u0 = M.dof_vbef[min(ia, nv - 1)], u1 = M.dof_vbef[min(ib, nv - 1)];
+    bvd[0] = lane < nb ? t0 : -1; bvd[1] = lane + FB_WAVE < nb ? t1 : -1; vbef[0] = ha ? u0 : -1; vbef[1] = hb ? u1 : -1; }
   DofPair<real> V;
 #pragma unroll
   for (int c = 0; c < 6; c++) { ca[c] = ha ? Lc[6*ia + c] : (real)0; cb[c] = hb ? Lc[6*ib + c] : (real)0; V.a[c] = ca[c]*qa; V.b[c] = cb[c]*qb; }
@@ -991,13 +998,13 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
   for (int q = 0; q < 2; q++) {
     const int b = q*FB_WAVE + lane;
     real v[6];
-    dof_fetch6(V, b < M.nbody ? M.body_veldof[b] : -1, v);
+    dof_fetch6(V, bvd[q], v);
     if (b < M.nbody) for (int c = 0; c < 6; c++) { w.cvel()[6*b + c] = v[c]; Lv[6*b + c] = v[c]; }
   }
   // cdof_dot_i = v x cdof_i with v = the velocity "before" dof i (dof_vbef, fb_engine.hip)
   DofPair<real> A;
   {
-    const int va = ha ? M.dof_vbef[ia] : -1, vb = hb ? M.dof_vbef[ib] : -1;
+    const int va = vbef[0], vb = vbef[1];
     real ua[6], ub[6], da[6], db[6];
     dof_fetch6(V, va, ua); dof_fetch6(V, vb, ub);
     crossmotion(da, ua, ca); crossmotion(db, ub, cb);
@@ -1008,7 +1015,7 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int b = q*FB_WAVE + lane;
-    dof_fetch6(A, b < M.nbody ? M.body_veldof[b] : -1, ab[q]);
+    dof_fetch6(A, bvd[q], ab[q]);
     if (b < M.nbody) for (int c = 0; c < 6; c++) w.cabias()[6*b + c] = ab[q][c];
   }
   SYNC_LDS();
