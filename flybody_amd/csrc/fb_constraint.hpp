@@ -1068,10 +1068,18 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     const FB_LDS real* arp = wide ? (const FB_LDS real*)w.lLD : (const FB_LDS real*)w.lAR;
     if (newton) {
       const WS<real> wc = w;               // (the callee is not inlined: hand it a copy, the caller's descriptor stays in registers)
-      if (k_in_slot) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lAR + tri, nefc, lane);
-      else if (!wide) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lLD, nefc, lane);
-      else if (2*tri <= FB_LDS_SCRATCH + LdsCfg<real>::AR_ELEMS) niter = d_newton<real, const FB_LDS real*, FB_LDS real*>(M, wc, arp, w.lLD + tri, nefc, lane);
-      else niter = d_newton<real, const FB_LDS real*, real*>(M, wc, arp, w.AR() + tri, nefc, lane);
+      // (two instantiations by system size: <= FB_NEWTON_NT rows -- 93 % of the solves -- runs the register-tile code alone, the rest the
+      //  lane == row code alone; FB_NW_SPLIT = 0: one function that decides at run time)
+#if FB_NW_SPLIT
+      constexpr int MT = 1, MR = 2;
+#else
+      constexpr int MT = 0, MR = 0;
+#endif
+      if (k_in_slot && nefc <= FB_NEWTON_NT) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MT>(M, wc, arp, w.lAR + tri, nefc, lane);
+      else if (k_in_slot) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lAR + tri, nefc, lane);
+      else if (!wide) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lLD, nefc, lane);
+      else if (2*tri <= FB_LDS_SCRATCH + LdsCfg<real>::AR_ELEMS) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lLD + tri, nefc, lane);
+      else niter = d_newton<real, const FB_LDS real*, real*, MR>(M, wc, arp, w.AR() + tri, nefc, lane);
       SYNC();
     }
     // PGS sweeps (when PGS is the solver) and the noslip passes (after either solver)
@@ -1085,7 +1093,11 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   else if (nefc <= 64) {
     if (newton) {
       const WS<real> wc = w;
+#if FB_NW_SPLIT
+      niter = d_newton<real, const real*, real*, 2>(M, wc, (const real*)w.AR(), w.AR() + tri, nefc, lane);       // (beyond the LDS slot: > 16 rows)
+#else
       niter = d_newton<real, const real*, real*>(M, wc, (const real*)w.AR(), w.AR() + tri, nefc, lane);
+#endif
       SYNC();
     }
     if (!newton || M.noslip_iterations > 0) { const int it2 = d_pgs<real, const real*, true>(M, w, (const real*)w.AR(), nefc, lane, !newton); if (!newton) niter = it2; }

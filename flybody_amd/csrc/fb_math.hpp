@@ -271,6 +271,18 @@ template <typename real> FBD real wave_sum(real v) {
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 #endif
+// wave_sum of a value that is ZERO outside the first 16 lanes when `row0` (wave-uniform) says so: the three other row sums are exact
+// zeros, so their six v_readlane and three additions are skipped -- same bits as wave_sum.  All 64 lanes must call.
+#ifdef FB_EMULATE
+template <typename real> FBD real wave_sum_lo(real v, bool) { return wave_sum(v); }
+#else
+template <typename real> FBD real wave_sum_lo(real v, bool row0) {
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+  real r = rdlane(v, 0);
+  if (!row0) r = (r + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+  return r;
+}
+#endif
 // sum over the four lanes of a quad (lanes 4k .. 4k+3), result in all four; every lane must call
 #ifdef FB_EMULATE
 template <typename real> FBD real quad_sum(real v) { v += shfl_xor_r(v, 1); v += shfl_xor_r(v, 2); return v; }

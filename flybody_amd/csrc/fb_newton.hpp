@@ -46,6 +46,12 @@ enum { FB_SOLVER_PGS = 0, FB_SOLVER_CG = 1, FB_SOLVER_NEWTON = 2 };      // mjtS
 #define FB_NEWTON_ATTR __device__ __forceinline__
 #endif
 
+#ifndef FB_NW_SPLIT
+#define FB_NW_SPLIT 1
+#endif
+#ifndef FB_NW_RSQ
+#define FB_NW_RSQ 1
+#endif
 // constants of a row (lane): position inside its contact block, scaling of the block's three rows, regulariser
 template <typename real> struct NwConst { int k; bool ell; real D, sqD, s0, s1, s2, mu, Dm, g1; };
 // force, cost share, and this lane's row / column of the block factor F (H = F F')
@@ -57,12 +63,23 @@ template <typename real>
 FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<real>& o) {
   const real jo = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
   const real U0 = jb0*c.s0, U1 = jb1*c.s1, U2 = jb2*c.s2;
+#if FB_NW_RSQ && !defined(FB_EMULATE) && !defined(FB_EXACT_DIV64)
+  // |tangential part| and its reciprocal from ONE reciprocal square root (fb_sqrt is a * rsqrt(a) anyway): no division on the chain
+  const real TT = U1*U1 + U2*U2;
+  const real Tr = TT > 0 ? fb_rsqrt(TT) : (real)0;
+  const real N = U0, T = TT*Tr;
+#else
   const real N = U0, T = fb_sqrt(U1*U1 + U2*U2);
+#endif
   const bool top = (N >= c.mu*T) || (T <= 0 && N >= 0);
   const bool bot = !top && ((c.mu*N + T <= 0) || (T <= 0 && N < 0));
   const bool mid = c.ell && !top && !bot;
   const bool quad = c.ell ? bot : (jo < 0);
+#if FB_NW_RSQ && !defined(FB_EMULATE) && !defined(FB_EXACT_DIV64)
+  const real Ti = mid ? Tr : (real)1;
+#else
   const real Ti = fb_div((real)1, mid ? T : (real)1);
+#endif
   const real t1 = mid ? U1*Ti : (real)0, t2 = mid ? U2*Ti : (real)0;
   const real NT = N - c.mu*T;
   const real f0 = -c.Dm*NT*c.mu;
@@ -406,9 +423,74 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
   return niter;
 }
 
+// One elimination step of the 16 x 16 register tile (lane (ti, tc) holds K[ti][4 tc + 0..3]): trailing update, the scaled pivot ROW kept
+// in place (the back substitution reads U[ti][p] from it), forward substitution.  Round 5: two masks and one multiply-add per register
+// instead of a three-way choice per register -- the scaled pivot COLUMN is not written back (nothing reads a finished column: the next
+// pivots read trailing entries, the back substitution the row images), and the rows above the pivot pass through the multiply-add with a
+// zero multiplier.
+#ifndef FB_NW_CHOLMASK
+#define FB_NW_CHOLMASK 1
+#endif
+#if FB_NW_CHOLMASK
+#define NW_ELIM(pv, Kr, Lip, Lpj, inv, invd, yp, yv)                                        \
+  do {                                                                                      \
+    const bool prow_ = ti == (pv);                                                          \
+    const real Lm_ = ti > (pv) ? (Lip) : (real)0;                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) {                                         \
+      const bool right_ = 4*tc + s > (pv);                                                  \
+      const real l_ = right_ ? Lpj[s] : (real)0;                                            \
+      const real t_ = Kr[s] - Lm_*l_;                                                       \
+      Kr[s] = (prow_ && right_) ? l_ : t_;                                                  \
+    }                                                                                       \
+    invd = prow_ ? (inv) : invd;                                                            \
+    yv = prow_ ? (yp) : yv - Lm_*(yp);                                                      \
+  } while (0)
+#else
+#define NW_ELIM(pv, Kr, Lip, Lpj, inv, invd, yp, yv)                                        \
+  do {                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) {                                         \
+      const int tj = 4*tc + s;                                                              \
+      if (ti > (pv) && tj > (pv)) Kr[s] -= (Lip)*Lpj[s];                                    \
+      else if (ti == (pv) && tj > (pv)) Kr[s] = Lpj[s];                                     \
+      else if (tj == (pv) && ti > (pv)) Kr[s] = (Lip);                                      \
+    }                                                                                       \
+    if (ti == (pv)) { invd = (inv); yv = (yp); }                                            \
+    else if (ti > (pv)) yv -= (Lip)*(yp);                                                   \
+  } while (0)
+#endif
+// Gauss-Jordan step on the register tile (round 5): the pivot row is scaled by 1 / K[p][p] and EVERY other row -- above and below --
+// eliminates its entry of the pivot column, the right-hand side riding along: after the last pivot the right-hand side IS the solution,
+// there is no back substitution (a second serial chain of one LDS-crossbar round trip per pivot), no triangular mask (a finished column
+// of the pivot row holds exact zeros or rounding residue that nothing reads), no square root.  In the tile layout the whole matrix is
+// one multiply-add per register anyway, so touching the rows above the pivot is free.  K = I + F'AF is symmetric positive definite with
+// pivots >= 1: elimination without pivoting is stable; the direction it yields differs from the Cholesky one (oracle) by rounding.
+#ifndef FB_NW_GJ
+#define FB_NW_GJ 1
+#endif
+#define NW_GJ_STEP(pv, P, q, Kr, yv)                                                        \
+  do {                                                                                      \
+    const real invp_ = fb_inv(rdlane(Kr[q], 4*(pv) + (P)));                                 \
+    const real Lip_ = nw_lane(Kr[q], 4*ti + (P));                                           \
+    real rp_[4];                                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) rp_[s] = nw_lane(Kr[s], 4*(pv) + tc)*invp_; \
+    const real yp_ = rdlane(yv, 4*(pv))*invp_;                                              \
+    const bool prow_ = ti == (pv);                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) Kr[s] = prow_ ? rp_[s] : Kr[s] - Lip_*rp_[s]; \
+    yv = prow_ ? yp_ : yv - Lip_*yp_;                                                       \
+  } while (0)
+#ifndef FB_NW_ROWSUM
+#define FB_NW_ROWSUM 1
+#endif
+#if FB_NW_ROWSUM
+#define NW_SUM(x) wave_sum_lo((x), tile)          // tile systems (<= 16 rows): every summand is zero outside lanes 0-15
+#else
+#define NW_SUM(x) wave_sum(x)
+#endif
 // ARP / KP: LDS (address_space(3)) or global pointers to the packed lower triangles of AR and of the work matrix K.
 // Returns the number of Newton iterations; the forces are left in efc_force.
-template <typename real, typename ARP, typename KP>
+// MODE: 1 = the caller guarantees nefc <= FB_NEWTON_NT (tile layout only: the lane == row code is not compiled in), 2 = nefc > FB_NEWTON_NT
+// (no tile-layout code), 0 = decided at run time.
+template <typename real, typename ARP, typename KP, int MODE = 0>
 FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR, KP K, int nefc, int lane) {
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   const int n = nefc;
@@ -460,7 +542,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   // (lane >> 2, lane & 3) holds the entries [ti][4 tc + 0..3] of a matrix in four registers.  A = AR - diag R is loaded into that layout
   // once per solve; a product A x is four multiply-adds on shuffled x plus a sum over the quad, the work matrix K and its factorisation
   // never leave the registers (below).  Larger systems keep lane == row and the packed triangles in LDS.
-  const bool tile = n <= FB_NEWTON_NT;
+  const bool tile = MODE == 1 ? true : (MODE == 2 ? false : n <= FB_NEWTON_NT);
   if (n > FB_NEWTON_NT) FB_SETPRIO(3);              // the large systems are what a lock-step launch ends on: let them win issue arbitration (restored by the caller)
   const int ti = lane >> 2, tc = lane & 3;
   const int tir = min(ti, n - 1);                   // (rows beyond the system: clamped addresses, zero factors)
@@ -510,10 +592,10 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     const real jar = b + Al;
     jb0 = nw_lane(jar, base); jb1 = nw_lane(jar, base + 1); jb2 = nw_lane(jar, base + 2);
     nw_update(c, jb0, jb1, jb2, o);
-    const real c_ws = wave_sum((real)0.5*lam*Al + o.cost);
+    const real c_ws = NW_SUM((real)0.5*lam*Al + o.cost);
     const real bb0 = nw_lane(b, base), bb1 = nw_lane(b, base + 1), bb2 = nw_lane(b, base + 2);
     nw_update(c, bb0, bb1, bb2, o);
-    const real c_0 = wave_sum(o.cost);
+    const real c_0 = NW_SUM(o.cost);
     if (c_ws > c_0) { lam = 0; jb0 = bb0; jb1 = bb1; jb2 = bb2; }
   }
   int niter = 0;
@@ -522,14 +604,14 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     nw_update(c, jb0, jb1, jb2, o);
     const real r = o.f - lam;
     const real q = amul(r);
-    const real dec = wave_sum(r*q);
+    const real dec = NW_SUM(r*q);
     NW_PROF(1);
     if ((real)0.5*dec*scale < tol) break;           // bound on the attainable improvement (MuJoCo's `improvement` scaling)
     if (sizeof(real) == 4) {
       // single precision cannot resolve the absolute tolerance: r = f - lam carries a rounding error of ~1e-7 |f|, so the
       // decrement bottoms out at ~1e-14 |lam|_A^2 times the conditioning.  Stop at that floor (the FP64 build never gets here).
       const real jo_ = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
-      const real lAl = wave_sum(lam*(jo_ - b));
+      const real lAl = NW_SUM(lam*(jo_ - b));
       if (dec <= (real)FB_NEWTON_F32_FLOOR*(lAl + dec)) break;
     }
     const unsigned long long m_act = __ballot(o.fc0 != 0 || o.fc1 != 0 || o.fc2 != 0);     // non-zero columns of F
@@ -577,6 +659,17 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       // U[ti][p] from a lane of its own row.
       real yv = nw_lane(y, ti), invd = 1;
       const int PN = (n - 1) >> 2;
+#if FB_NW_GJ
+      (void)invd;
+      for (int P = 0; P <= PN; P++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int pv = 4*P + q;
+          if ((m_act >> pv) & 1ull) NW_GJ_STEP(pv, P, q, Kr, yv);
+        }
+      }
+      NW_PROF(3);
+#else
       for (int P = 0; P <= PN; P++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -588,15 +681,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
 #pragma unroll
             for (int s = 0; s < 4; s++) Lpj[s] = nw_lane(Kr[s], 4*pv + tc)*inv;
             const real yp = rdlane(yv, 4*pv)*inv;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-              const int tj = 4*tc + s;
-              if (ti > pv && tj > pv) Kr[s] -= Lip*Lpj[s];
-              else if (ti == pv && tj > pv) Kr[s] = Lpj[s];
-              else if (tj == pv && ti > pv) Kr[s] = Lip;
-            }
-            if (ti == pv) { invd = inv; yv = yp; }
-            else if (ti > pv) yv -= Lip*yp;
+            NW_ELIM(pv, Kr, Lip, Lpj, inv, invd, yp, yv);
           }
         }
       }
@@ -614,6 +699,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
           }
         }
       }
+#endif
       const real zr = nw_lane(yv, 4*(lane & 15));
       z = (on && ((m_act >> lane) & 1ull)) ? zr : (real)0;
       NW_PROF(4);
@@ -681,6 +767,17 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
         }
         if (!iv) yv = 0;
         real invd = 1;
+#if FB_NW_GJ
+        (void)invd;
+        for (int P = 0; 4*P < n_act; P++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int pv = 4*P + q;
+            if (pv < n_act) NW_GJ_STEP(pv, P, q, Kr, yv);
+          }
+        }
+        NW_PROF(3);
+#else
         for (int P = 0; 4*P < n_act; P++) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -692,15 +789,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
 #pragma unroll
               for (int s = 0; s < 4; s++) Lpj[s] = nw_lane(Kr[s], 4*pv + tc)*inv;
               const real yp = rdlane(yv, 4*pv)*inv;
-#pragma unroll
-              for (int s = 0; s < 4; s++) {
-                const int tj = 4*tc + s;
-                if (ti > pv && tj > pv) Kr[s] -= Lip*Lpj[s];
-                else if (ti == pv && tj > pv) Kr[s] = Lpj[s];
-                else if (tj == pv && ti > pv) Kr[s] = Lip;
-              }
-              if (ti == pv) { invd = inv; yv = yp; }
-              else if (ti > pv) yv -= Lip*yp;
+              NW_ELIM(pv, Kr, Lip, Lpj, inv, invd, yp, yv);
             }
           }
         }
@@ -718,6 +807,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
             }
           }
         }
+#endif
         const real zr = nw_lane(yv, mine ? 4*my_ci : 0);
         z = mine ? zr : (real)0;
         SYNC();                                       // (K is rewritten by the next iteration)
@@ -816,7 +906,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     const real Adl = amul(dl);
     const real Ab0 = nw_lane(Adl, base), Ab1 = nw_lane(Adl, base + 1), Ab2 = nw_lane(Adl, base + 2);
     const real jo = c.k == 0 ? jb0 : (c.k == 1 ? jb1 : jb2);
-    const real lAd = wave_sum((jo - b)*dl), dAd = wave_sum(dl*Adl);
+    const real lAd = NW_SUM((jo - b)*dl), dAd = NW_SUM(dl*Adl);
     NW_PROF(5);
     // ---- line search: phi'(alpha) = lAd + alpha dAd - f(jar + alpha Adl).Adl,  phi'' = dAd + |F'Adl|^2
     real alpha = 0, g0 = 0, lo = 0, hi = -1;
@@ -825,8 +915,8 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       NW_COUNT(1);
       if (kls > 0) nw_update(c, jb0 + alpha*Ab0, jb1 + alpha*Ab1, jb2 + alpha*Ab2, o2);
       const real wv = o2.fc0*Ab0 + o2.fc1*Ab1 + o2.fc2*Ab2;
-      const real g = lAd + alpha*dAd - wave_sum(o2.f*Adl);
-      const real h = dAd + wave_sum(wv*wv);
+      const real g = lAd + alpha*dAd - NW_SUM(o2.f*Adl);
+      const real h = dAd + NW_SUM(wv*wv);
       if (kls == 0) { g0 = g; if (!(g0 < 0) || !(h > FB_MINV)) break; alpha = -fb_div(g0, h); continue; }
       if (fabs(g) <= (real)0.01*fabs(g0) || kls == FB_NEWTON_LS_MAX) break;
       if (g < 0) lo = alpha; else hi = alpha;
