@@ -46,6 +46,9 @@ enum { FB_SOLVER_PGS = 0, FB_SOLVER_CG = 1, FB_SOLVER_NEWTON = 2 };      // mjtS
 #define FB_NEWTON_ATTR __device__ __forceinline__
 #endif
 
+#ifndef FB_NW_HOIST
+#define FB_NW_HOIST 1
+#endif
 #ifndef FB_NW_SPLIT
 #define FB_NW_SPLIT 1
 #endif
@@ -100,6 +103,8 @@ FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<r
   o.fc2 = mid ? (c.k == 0 ? a2 : (c.k == 1 ? b2 : (real)0)) : (c.k == 2 ? qd : (real)0);
 }
 
+template <typename P> struct NwMut { typedef P type; };
+template <typename T> struct NwMut<const T*> { typedef T* type; };      // (the address space is part of T)
 // values of lanes base, base+1, base+2 (ds_bpermute; every lane must call)
 FBD double nw_lane(double v, int src) { return __shfl(v, src, 64); }
 FBD float nw_lane(float v, int src) { return __shfl(v, src, 64); }
@@ -521,7 +526,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   c.k = c.ell ? kblk : 0;
   const int base = lane - c.k;
   c.D = Dl;
-  c.sqD = sqrt(c.D);
+  c.sqD = fb_sqrt(c.D);
   c.s0 = 1; c.s1 = 1; c.s2 = 1; c.mu = 0; c.Dm = 0;
   {
     const real Dbase = nw_lane(Dl, base);
@@ -530,7 +535,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       c.Dm = fb_div(Dbase, (real)fmax(FB_MINV, c.mu*c.mu*((real)1 + c.mu*c.mu)));
     }
   }
-  c.g1 = sqrt(c.Dm);
+  c.g1 = fb_sqrt(c.Dm);
   const unsigned long long m_first = __ballot(c.ell && c.k == 0);       // bit i: row i opens a 3-row contact block
   // the rows of this lane's block (scalar rows: the two extra rows carry zero factor entries; clamped to stay in range)
   const int rl = on ? lane : n - 1, tri_l = rl*(rl + 1)/2;
@@ -547,7 +552,30 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   const int ti = lane >> 2, tc = lane & 3;
   const int tir = min(ti, n - 1);                   // (rows beyond the system: clamped addresses, zero factors)
   real At[4] = {0, 0, 0, 0};
+#if FB_NW_HOIST
+  // Round 5: what the K build of EVERY iteration needs from the matrix is iteration-invariant -- for this lane's four tile columns
+  // tj = 4 tc + s the packed-triangle positions of A[tir][base(tj) + 0..2] (three 8-bit indices per register: a 16-row triangle has 136
+  // entries) -- and the regulariser leaves the diagonal ONCE: the solve works on A = AR - diag R in place (the owner lane keeps the
+  // original diagonal entry and puts it back, bit for bit, behind the last iteration: the noslip pass reads AR).
+  typename NwMut<ARP>::type ARw = (typename NwMut<ARP>::type)AR;
+  real ar_diag = 0; unsigned kadr[4] = {0, 0, 0, 0};
+#endif
   if (tile) {
+#if FB_NW_HOIST
+    if (on) { const int dd = lane*(lane + 1)/2 + lane; ar_diag = ARw[dd]; ARw[dd] = ar_diag - R; }
+    SYNC_LDS();
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int tj = 4*tc + s, tjr = min(tj, n - 1);
+      const real e = AR[tir >= tjr ? tir*(tir + 1)/2 + tjr : tjr*(tjr + 1)/2 + tir];
+      At[s] = (ti < n && tj < n) ? e : (real)0;
+      const int bj = nw_lane_i(base, tj);
+      const int c0 = min(bj, n - 1), c1 = min(bj + 1, n - 1), c2 = min(bj + 2, n - 1);
+      const int a0 = tir >= c0 ? tir*(tir + 1)/2 + c0 : c0*(c0 + 1)/2 + tir, a1 = tir >= c1 ? tir*(tir + 1)/2 + c1 : c1*(c1 + 1)/2 + tir;
+      const int a2 = tir >= c2 ? tir*(tir + 1)/2 + c2 : c2*(c2 + 1)/2 + tir;
+      kadr[s] = (unsigned)a0 | ((unsigned)a1 << 8) | ((unsigned)a2 << 16);
+    }
+#else
     const real Rt = nw_lane(R, tir);
 #pragma unroll
     for (int s = 0; s < 4; s++) {
@@ -555,6 +583,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       const real e = AR[tir >= tjr ? tir*(tir + 1)/2 + tjr : tjr*(tjr + 1)/2 + tir];
       At[s] = (ti < n && tj < n) ? (ti == tj ? e - Rt : e) : (real)0;
     }
+#endif
   }
   // y = A x  (A = AR - diag R).  lane == row: column k of the packed triangle per step, x_k by v_readlane
   auto amul = [&](real x) -> real {
@@ -637,8 +666,15 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
 #pragma unroll
         for (int s = 0; s < 4; s++) {
           const int tj = 4*tc + s;
-          const int bj = nw_lane_i(base, tj);
           const real fj0 = nw_lane(o.fc0, tj), fj1 = nw_lane(o.fc1, tj), fj2 = nw_lane(o.fc2, tj);
+#if FB_NW_HOIST
+          // (rows beyond the system compute garbage here that nothing reads: the second pass below addresses rows base_i + a < n only,
+          //  and an off row's own factors are zero)
+          const unsigned pk = kadr[s];
+          G[s] = fj0*AR[pk & 255u] + fj1*AR[(pk >> 8) & 255u] + fj2*AR[(pk >> 16) & 255u];
+          continue;
+#endif
+          const int bj = nw_lane_i(base, tj);
           const int c0 = min(bj, n - 1), c1 = min(bj + 1, n - 1), c2 = min(bj + 2, n - 1);
           real e0 = AR[tir >= c0 ? tir*(tir + 1)/2 + c0 : c0*(c0 + 1)/2 + tir];
           real e1 = AR[tir >= c1 ? tir*(tir + 1)/2 + c1 : c1*(c1 + 1)/2 + tir];
@@ -937,6 +973,9 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   }
   nw_update(c, jb0, jb1, jb2, o);
   if (on) w.efc_force()[lane] = o.f;
+#if FB_NW_HOIST
+  if (tile) { if (on) ARw[lane*(lane + 1)/2 + lane] = ar_diag; SYNC_LDS(); }
+#endif
   if (n > FB_NEWTON_NT) FB_SETPRIO(uniform_int(w.istate()[IS_PRIO]));
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 7; k_++) pp_[32 + k_] += nwp_[k_]; pp_[39] += nwc_[0]; pp_[40] += nwc_[1]; pp_[41] += 1; }
