@@ -35,10 +35,9 @@ FBD void support(const CGeom<real>& g, const real* dir, real* out) {
   // Same arithmetic per shape (the unused shapes' square roots are computed and dropped).
   const bool caps = g.type == GEOM_CAPSULE, ell = g.type == GEOM_ELLIPSOID, cyl = g.type == GEOM_CYLINDER, sph = g.type == GEOM_SPHERE;
   const real s0 = g.size[0]*l[0], s1 = g.size[1]*l[1], s2 = g.size[2]*l[2];
-  const real se_[3] = {s0, s1, s2};
-  const real ne = norm3(se_);                                          // ellipsoid: |S l|
-  const real nc = fb_sqrt(l[0]*l[0] + l[1]*l[1]);                      // cylinder: |l_xy|
-  const real nie = fb_inv(ne < FB_MINV ? (real)1 : ne), nic = fb_inv(nc < FB_MINV ? (real)1 : nc);
+  real nie, nic;                                                       // (reciprocals: used only where the norm is >= FB_MINV)
+  const real ne = norm_rnorm(s0*s0 + s1*s1 + s2*s2, nie);              // ellipsoid: |S l|
+  const real nc = norm_rnorm(l[0]*l[0] + l[1]*l[1], nic);              // cylinder: |l_xy|
   const real hz = (l[2] >= 0 ? g.size[1] : -g.size[1]);
   // sphere / capsule: r l (+ the capsule's half length along z)
   real px = g.size[0]*l[0], py = g.size[0]*l[1], pz = g.size[0]*l[2] + (caps ? hz : (real)0);
@@ -283,10 +282,11 @@ FBD void lc_add(LaneContacts<real>& lc, real dist, const real* pos, const real* 
 template <typename real>
 FBD void c_sphere_sphere(LaneContacts<real>& lc, const real* p1, real r1, const real* p2, real r2, real margin) {
   real n[3]; sub3(n, p2, p1);
-  real len = norm3(n);
+  real rlen;
+  real len = norm_rnorm(dot3(n, n), rlen);
   real dist = len - r1 - r2;
   if (dist > margin) return;
-  if (len < FB_MINV) { n[0] = 1; n[1] = 0; n[2] = 0; } else scl3(n, n, (real)1/len);
+  if (len < FB_MINV) { n[0] = 1; n[1] = 0; n[2] = 0; } else scl3(n, n, rlen);
   real pos[3]; copy3(pos, p1); addscl3(pos, n, r1 + (real)0.5*dist);
   lc_add(lc, dist, pos, n);
 }

@@ -100,10 +100,20 @@ template <typename real> FBD void add3(real* r, const real* a, const real* b) { 
 template <typename real> FBD void scl3(real* r, const real* a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
 template <typename real> FBD void addscl3(real* r, const real* a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
 template <typename real> FBD real norm3(const real* a) { return fb_sqrt(dot3(a, a)); }
+#ifndef FB_RSQ_NORM
+#define FB_RSQ_NORM 1
+#endif
+// norm and its reciprocal from ONE reciprocal square root (device builds: fb_sqrt is a * rsqrt(a) there anyway; the division that
+// followed it was 8 more instructions on the chain of every normalisation and support-function call)
+#if FB_RSQ_NORM && !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+template <typename real> FBD real norm_rnorm(real n2, real& rn) { rn = n2 > 0 ? fb_rsqrt(n2) : (real)0; return n2*rn; }
+#else
+template <typename real> FBD real norm_rnorm(real n2, real& rn) { const real n = fb_sqrt(n2); rn = fb_inv(n > 0 ? n : (real)1); return n; }
+#endif
 template <typename real> FBD real normalize3(real* a) {
-  real n = norm3(a);
+  real inv;
+  const real n = norm_rnorm(dot3(a, a), inv);
   if (n < FB_MINV) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
-  real inv = fb_inv(n);
   a[0] *= inv; a[1] *= inv; a[2] *= inv;
   return n;
 }
