@@ -46,6 +46,9 @@ enum { FB_SOLVER_PGS = 0, FB_SOLVER_CG = 1, FB_SOLVER_NEWTON = 2 };      // mjtS
 #define FB_NEWTON_ATTR __device__ __forceinline__
 #endif
 
+#ifndef FB_NW_REUSE
+#define FB_NW_REUSE 1
+#endif
 #ifndef FB_NW_HOIST
 #define FB_NW_HOIST 1
 #endif
@@ -629,8 +632,15 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
   }
   int niter = 0;
   NW_PROF(0);
+#if FB_NW_REUSE
+  nw_update(c, jb0, jb1, jb2, o);
+#endif
   for (int it = 0; it < max_it; it++) {
+#if !FB_NW_REUSE
     nw_update(c, jb0, jb1, jb2, o);
+#endif
+    // (FB_NW_REUSE: `o` is the constraint update at the current iterate on entry -- the line search's last evaluation is AT the accepted
+    //  step, so the update it computed is handed over instead of being recomputed here and once more behind the loop)
     const real r = o.f - lam;
     const real q = amul(r);
     const real dec = NW_SUM(r*q);
@@ -947,9 +957,10 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     // ---- line search: phi'(alpha) = lAd + alpha dAd - f(jar + alpha Adl).Adl,  phi'' = dAd + |F'Adl|^2
     real alpha = 0, g0 = 0, lo = 0, hi = -1;
     NwRow<real> o2 = o;
+    real tb0 = jb0, tb1 = jb1, tb2 = jb2;               // the trial point of the last evaluation
     for (int kls = 0; kls <= FB_NEWTON_LS_MAX; kls++) {
       NW_COUNT(1);
-      if (kls > 0) nw_update(c, jb0 + alpha*Ab0, jb1 + alpha*Ab1, jb2 + alpha*Ab2, o2);
+      if (kls > 0) { tb0 = jb0 + alpha*Ab0; tb1 = jb1 + alpha*Ab1; tb2 = jb2 + alpha*Ab2; nw_update(c, tb0, tb1, tb2, o2); }
       const real wv = o2.fc0*Ab0 + o2.fc1*Ab1 + o2.fc2*Ab2;
       const real g = lAd + alpha*dAd - NW_SUM(o2.f*Adl);
       const real h = dAd + NW_SUM(wv*wv);
@@ -962,7 +973,10 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     }
     NW_PROF(6); NW_COUNT(0);
     if (!(alpha > 0)) break;
-    lam += alpha*dl; jb0 += alpha*Ab0; jb1 += alpha*Ab1; jb2 += alpha*Ab2;
+    lam += alpha*dl; jb0 = tb0; jb1 = tb1; jb2 = tb2;
+#if FB_NW_REUSE
+    o = o2;
+#endif
     niter = it + 1;
     // MuJoCo's own stopping test: the IMPROVEMENT of the iteration, scaled, below opt.tolerance.  phi is convex with phi'(0) = g0 < 0, so
     // the cost fell by at most -g0 alpha: when even that bound is under the tolerance the solver is done.  (The decrement bound at the
@@ -971,7 +985,9 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
     // seen once in 160 environment-steps of the wing-collision variant, FB_WARN_SOLVER_MAXITER.)
     if (-g0*alpha*scale < tol) break;
   }
+#if !FB_NW_REUSE
   nw_update(c, jb0, jb1, jb2, o);
+#endif
   if (on) w.efc_force()[lane] = o.f;
 #if FB_NW_HOIST
   if (tile) { if (on) ARw[lane*(lane + 1)/2 + lane] = ar_diag; SYNC_LDS(); }
