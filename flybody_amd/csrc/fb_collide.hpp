@@ -9,15 +9,7 @@
 #define MPR_TOL ((real)1e-6)
 #define MPR_ITER 50
 #define MPR_EPS ((real)1e-14)
-// (host-side statistics of the narrow phase: tools/collision_stats.py builds the emulation library with -DFB_STATS)
-#if defined(FB_EMULATE) && defined(FB_STATS)
-extern "C" { long long fb_stats[64]; }
-#define FB_STAT(k) (fb_stats[k]++)
-#define FB_STAT_ADD(k, v) (fb_stats[k] += (v))
-#else
-#define FB_STAT(k) do {} while (0)
-#define FB_STAT_ADD(k, v) do {} while (0)
-#endif
+// (host-side statistics of the narrow phase: tools/collision_stats.py builds the emulation library with -DFB_STATS; FB_STAT: fb_types.hpp)
 
 template <typename real>
 struct CGeom { real pos[3], mat[9], size[3]; int type; real margin; };     // by value: pointers to the caller's arrays pin those arrays in scratch memory

@@ -24,3 +24,7 @@ print(f'per env-substep: narrow-phase pairs {s[0]/sub:.2f}  plane pairs {s[2]/su
 print(f'MPR exits per env-substep: first support {s[10]/sub:.2f}  second {s[11]/sub:.2f}  portal discovery {s[12]/sub:.2f}  refinement-miss {s[13]/sub:.2f}  penetration {s[14]/sub:.2f}')
 print(f'support evaluations per env-substep: discovery loop {s[20]/sub:.2f}  phase-2 loop {s[21]/sub:.2f}  phase-3 loop {s[22]/sub:.2f}')
 print('nefc mean', B.get('NEFC').mean(), 'ncon mean', B.get('NCON').mean())
+names = {2: 'sphere', 3: 'capsule', 4: 'ellipsoid', 5: 'cylinder'}
+tp = {(t1, t2): s[30 + 6*t1 + t2 - 14]/sub for t1 in range(2, 6) for t2 in range(t1, 6) if 30 + 6*t1 + t2 - 14 not in (40, 41, 43)}
+print('MPR pairs per env-substep by shapes: ' + '  '.join(f'{names[a]}-{names[b]} {v:.2f}' for (a, b), v in tp.items() if v > 0))
+print(f'Newton solves by path: register tile {s[40]:.0f}  compacted tile {s[41]:.0f}  rows in LDS {s[43]:.0f} (iterations)')
