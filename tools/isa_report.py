@@ -13,7 +13,10 @@ SRC = os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')
 prec = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in 'fd' else 'f'
 lines_arg = sys.argv[sys.argv.index('--lines') + 1] if '--lines' in sys.argv else None
 out = os.path.join(tempfile.gettempdir(), 'fb_engine_gfx950.s')
-subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from __graft_entry__ import hip_flags
+HIP_FLAGS = hip_flags()          # the package's own extra compiler flags (csrc/fb_build_flags.h)
+subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', *HIP_FLAGS, '-S', '--cuda-device-only',
                        '-gline-tables-only', '-o', out, SRC], stderr=subprocess.DEVNULL)
 files, cur, fn = {}, None, None
 st = collections.defaultdict(collections.Counter); info = collections.defaultdict(dict); byline = collections.Counter()

@@ -13,7 +13,10 @@ prec = sys.argv[1] if len(sys.argv) > 1 else 'd'
 flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else ''
 flags = [a for a in sys.argv[2:] if a.startswith('-')]        # extra hipcc flags, e.g. -DFB_F64_DENSE=1
 out = os.path.join(tempfile.gettempdir(), 'fb_engine_isa.s')
-subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from __graft_entry__ import hip_flags
+HIP_FLAGS = hip_flags()          # the package's own extra compiler flags (csrc/fb_build_flags.h)
+subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', *HIP_FLAGS, '--cuda-device-only', '-S',
                        '-o', out] + flags + [os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')], stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
 heads = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r'^(_Z\w+):', l)] if m]

@@ -7,7 +7,10 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 prec = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ('d', 'f') else 'd'
 flags = [a for a in sys.argv[1:] if a not in ('d', 'f')]
 out = os.path.join(tempfile.gettempdir(), 'fb_engine_res_%d.s' % os.getpid())
-subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from __graft_entry__ import hip_flags
+HIP_FLAGS = hip_flags()          # the package's own extra compiler flags (csrc/fb_build_flags.h)
+subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', *HIP_FLAGS, '--cuda-device-only', '-S',
                        '-o', out] + flags + [os.path.join(ROOT, 'flybody_amd', 'csrc', 'fb_engine.hip')], stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines(); os.unlink(out)
 tag = 'I%sE' % prec
