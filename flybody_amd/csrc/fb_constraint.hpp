@@ -230,15 +230,25 @@ FBD void project_row(const DevModel<real>& M, const WS<real>& w, int side, int r
 }
 
 // AR of a system of at most 64 rows from the rows' Y held in the registers of lane == row: the row loop broadcasts them with
-// v_readlane; the shared-prefix lengths of the NEXT row are fetched while the current row is accumulated
-template <typename real, typename ARP>
-FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane, const real* yA, const real* yB, int bA, int bB, int lA, int lB) {
+// v_readlane; the shared-prefix lengths of the NEXT row are fetched while the current row is accumulated.
+// Round 5: the TRUNK slots -- the unbranched dof chain at the root (the free joint's six dofs), which every non-empty chain starts with --
+// are common to any two chains by construction: their contribution is (yA + yB)_r (yA + yB)_c, ONE v_readlane pair and ONE multiply-add
+// per slot and row instead of two pairs and four products each behind a lane-varying prefix test (~20 instructions per slot and row;
+// the masked form remains for the slots below the trunk, and for models without a trunk -- a forest of dof trees: TRUNK = 0).
+#ifndef FB_AR_TRUNK
+#define FB_AR_TRUNK 1
+#endif
+template <int TRUNK, typename real, typename ARP>
+FBD void ar_from_registers_t(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane, const real* yA, const real* yB, int bA, int bB, int lA, int lB) {
   const bool valid = lane < nefc;
   const int c = lane;
   const int* common = M.body_common; const int nb = M.nbody;
   int rbA = rdlane(bA, 0), rbB = rdlane(bB, 0);
   int cAA = common[rbA*nb + bA], cAB = common[rbA*nb + bB], cBA = common[rbB*nb + bA], cBB = common[rbB*nb + bB];
   const real Rc = valid ? w.efc_R()[c] : (real)0;
+  real tr[TRUNK > 0 ? TRUNK : 1];
+#pragma unroll
+  for (int s = 0; s < TRUNK; s++) tr[s] = yA[s] + yB[s];
   for (int r = 0; r < nefc; r++) {
     int rlA = rdlane(lA, r), rlB = rdlane(lB, r);
     int cmAA = min(min(cAA, lA), rlA), cmAB = min(min(cAB, lB), rlA), cmBA = min(min(cBA, lA), rlB), cmBB = min(min(cBB, lB), rlB);
@@ -247,19 +257,21 @@ FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, i
       cAA = common[rbA*nb + bA]; cAB = common[rbA*nb + bB]; cBA = common[rbB*nb + bA]; cBB = common[rbB*nb + bB];
     }
     real acc = 0;
+#pragma unroll
+    for (int s = 0; s < TRUNK; s++) acc += rdlane(tr[s], r)*tr[s];
     // (the chain-length bounds of row r are wave-uniform: tested once per four slots -- Y is exactly zero beyond a chain's end)
 #pragma unroll
     for (int s0 = 0; s0 < FB_MAXCH; s0 += 4) {
-      if (s0 < rlA) {
+      if (s0 + 4 > TRUNK && s0 < rlA) {
 #pragma unroll
-        for (int s = s0; s < s0 + 4; s++) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
+        for (int s = s0; s < s0 + 4; s++) if (s >= TRUNK) { real yr = rdlane(yA[s], r); if (s < cmAA) acc += yr*yA[s]; if (s < cmAB) acc += yr*yB[s]; }
       }
     }
 #pragma unroll
     for (int s0 = 0; s0 < FB_MAXCH; s0 += 4) {
-      if (s0 < rlB) {
+      if (s0 + 4 > TRUNK && s0 < rlB) {
 #pragma unroll
-        for (int s = s0; s < s0 + 4; s++) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
+        for (int s = s0; s < s0 + 4; s++) if (s >= TRUNK) { real yr = rdlane(yB[s], r); if (s < cmBA) acc += yr*yA[s]; if (s < cmBB) acc += yr*yB[s]; }
       }
     }
     if (valid && c <= r) {                  // symmetric: only the lower triangle is stored (packed)
@@ -268,6 +280,14 @@ FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, i
     }
   }
   SYNC();
+}
+template <typename real, typename ARP>
+FBD void ar_from_registers(const DevModel<real>& M, const WS<real>& w, ARP AR, int nefc, int lane, const real* yA, const real* yB, int bA, int bB, int lA, int lB) {
+#if FB_AR_TRUNK
+  if (uniform_int(M.ntrunk) == FB_MAXTRUNK) ar_from_registers_t<FB_MAXTRUNK>(M, w, AR, nefc, lane, yA, yB, bA, bB, lA, lB);
+  else
+#endif
+  ar_from_registers_t<0>(M, w, AR, nefc, lane, yA, yB, bA, bB, lA, lB);
 }
 
 template <typename real>
