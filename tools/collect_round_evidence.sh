@@ -12,6 +12,7 @@ python tools/publish_round_evidence.py ${ROUND_TAG:-r5} --traffic-only > $O/traf
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary-configs > $O/bench_steps20.json 2> $O/bench_steps20.err
 timeout 900 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_1000_steps.json 2> $O/bench_1000_steps.err
+timeout 900 python bench.py --steps 3000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_3000_steps.json 2> $O/bench_3000_steps.err      # long horizon: warn counters, system sizes, parity of sampled environments after ~3300 control steps
 timeout 900 bash tools/collect_stage_profile.sh final --dense > $O/stage.log 2>&1
 timeout 300 python tools/launch_times.py - 300 > $O/launch_times.txt 2>&1                      # per-launch durations vs the largest constraint system of the step
 timeout 300 python tools/gemm_shapes_probe.py > $O/gemm_shapes_probe.txt 2>&1              # the learner's former library GEMM shapes: rocBLAS vs the hand-written kernels

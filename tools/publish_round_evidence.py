@@ -39,7 +39,7 @@ def per_launch(path, out):
 for sub, pre, name in (('pmc_fetch', 'f', 'fetch'), ('pmc_write', 'w', 'write'), ('pmc_sq1', 's', 'sq1'), ('pmc_sq2', 's', 'sq2'), ('pmc_sq3', 's', 'sq3'), ('pmc_sq4', 's', 'sq4')):
     if os.path.exists(f'{src}/{sub}/{pre}_counter_collection.csv'):
         per_launch(f'{src}/{sub}/{pre}_counter_collection.csv', f'{dst}/pmc_{name}_per_launch.csv')
-for extra, name in ((f'{src}/pmc_calibration.json', 'pmc_calibration.json'), (f'{fin}/bench_1000_steps.json', 'bench_1000_steps.json'), (f'{fin}/bench_steps20.json', 'bench_steps20.json'), (f'{fin}/solver_bench.txt', 'solver_newton_vs_pgs.txt'),
+for extra, name in ((f'{src}/pmc_calibration.json', 'pmc_calibration.json'), (f'{fin}/bench_1000_steps.json', 'bench_1000_steps.json'), (f'{fin}/bench_steps20.json', 'bench_steps20.json'), (f'{fin}/bench_3000_steps.json', 'bench_3000_steps.json'), (f'{fin}/solver_bench.txt', 'solver_newton_vs_pgs.txt'),
                     (f'{fin}/ticket_trace_dense.txt', 'ticket_trace_dense.txt'), (f'{fin}/ticket_check.txt', 'substep_scheduler.txt'),
                     (os.path.join(ROOT, 'gpurun_out/stage_final/stage_lanes.txt'), 'stage_lanes_dense_final.txt'),
                     (f'{fin}/launch_times.txt', 'launch_times.txt'), (f'{fin}/gemm_shapes_probe.txt', 'learner_gemm_shapes.txt'),
