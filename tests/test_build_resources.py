@@ -46,3 +46,19 @@ def test_fp64_kernel_residency(usage):
 def test_order_kernel_is_tiny(usage):
     ks = [k for k in usage if 'k_order' in k]
     assert len(ks) == 1 and usage[ks[0]]['LDS Size'] <= 4096 and usage[ks[0]]['ScratchSize'] == 0
+
+
+def test_build_flags_are_part_of_the_source_hash():
+    """The engine's extra compiler flags live in csrc/fb_build_flags.h: every build recipe reads them from there, and the file is
+    hashed with the sources, so a library built with other flags is rebuilt (its embedded hash no longer matches)."""
+    import os
+    import __graft_entry__ as g
+    from flybody_amd import engine
+    flags = g.hip_flags()
+    assert flags and all(isinstance(f, str) for f in flags)
+    path = os.path.join(g.ROOT, 'flybody_amd', 'csrc', 'fb_build_flags.h')
+    assert ' '.join(flags) in open(path).read()
+    assert path in g._csrc()                                              # hashed by engine.source_hash()
+    for script in ('tools/build_variant.sh', 'tools/build_profile_lib.sh'):
+        assert 'fb_build_flags.h' in open(os.path.join(g.ROOT, script)).read()
+    assert len(engine.source_hash()) == 12
