@@ -172,6 +172,15 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+        # the collective path is CHECKED before it is reported: a SUM all-reduce of the rank ids on the device (N (N - 1) / 2 on every
+        # rank) and an all-gather that must return 0 .. N-1 in order -- `rccl: exercised` below is printed only behind this
+        dev_t = 'cuda' if backend == 'nccl' else 'cpu'
+        t = torch.tensor([float(rank)], device=dev_t, dtype=torch.float32)
+        dist.all_reduce(t)
+        g = [torch.zeros(1, device=dev_t, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([float(rank)], device=dev_t, dtype=torch.float32))
+        if float(t.item()) != world*(world - 1)/2 or [int(x.item()) for x in g] != list(range(world)):
+            raise SystemExit(f'bench.py: collective check failed on rank {rank}: all_reduce(SUM) of rank ids = {float(t.item())}, all_gather = {[int(x.item()) for x in g]}')
     n_env = args.envs_per_gpu
     model = engine.Model.from_asset('walk_imitation')
     # FP64 batches beyond the 2048 resident slots of the default build run on the 12-environments-per-CU build of the same kernel
@@ -201,6 +210,8 @@ def main():
         batch = engine.Batch(model_headline if precision == args.precision else model, n_env, device=local_rank, precision=precision)
         batch.set_reference(qp, qv, terminal_com_dist=float('inf'))
         batch.reset(stream=stream)
+        batch.set('SIZE_STATS', 0)                 # (the reset's forward evaluation counted one constraint set-up per environment: substeps only from here on;
+                                                   #  the auto-resets inside the run, one launch in 236 per environment, still add one each)
         action = torch.empty(n_env, nu, device='cuda', dtype=torch.float32)
         aptr = action.data_ptr()
 
@@ -219,6 +230,8 @@ def main():
         for k in range(args.steps):
             one_step(P + args.warmup + k)
         kernel_ms, nlaunch = batch.timing_end(stream)      # HIP events on the launch stream
+        if extras is not None:
+            extras['launch_ms'] = batch.timing_launches()  # ... and around every single launch of the timed region
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -453,6 +466,11 @@ def main():
         total_env_steps = n_env * world * args.steps
         value = total_env_steps / dt
         per_launch_s = (kernel_ms / 1e3) / max(nlaunch, 1)
+        lm = np.sort(np.asarray(extras.get('launch_ms', []), np.float64))
+        # every timed launch on its own (HIP events around each): one long control step -- the environment with the largest constraint
+        # system ends the launch -- shows here instead of silently moving a 20-step mean
+        launch_stats = None if lm.size == 0 else {'n': int(lm.size), 'min': float(lm[0]), 'median': float(np.median(lm)), 'mean': float(lm.mean()),
+                                                  'p90': float(lm[min(lm.size - 1, int(np.ceil(0.9*lm.size)) - 1)]), 'max': float(lm[-1])}
         algo_bytes = ALGO_BYTES_PER_ENV_STEP[args.precision]
         achieved_gbs = algo_bytes * n_env / per_launch_s / 1e9
         valu_tflops = ALGO_FLOP_PER_ENV_STEP * n_env / per_launch_s / 1e12
@@ -468,7 +486,8 @@ def main():
                        'solver': 'Newton (the reference XML sets no solver = MuJoCo default), constraint-space restatement; noslip 3',
                        'solver_iterations_mean': extras.get('solver_iterations_mean'),
                        'auto_resets': extras.get('auto_resets'), 'scheduler': extras.get('scheduler'),
-                       'build': ('libflybody_hip_dense.so: FP64, 12 environments per CU (3072 resident)' if dense_headline else 'libflybody_hip.so: default build (FP64: 8 environments per CU, 2048 resident)')},
+                       'build': ('libflybody_hip_dense.so: FP64, 12 environments per CU (3072 resident)' if dense_headline else 'libflybody_hip.so: default build (FP64: 8 environments per CU, 2048 resident)'),
+                       'build_version': engine.version(engine.HIP_LIB_DENSE if dense_headline else None), 'sources_in_tree': engine.source_hash()},
             # the binding roofline of this path is the vector ALU (neither HBM nor MFMA bounds it), so the primary
             # achieved/peak/frac are algorithmic FLOP/s against the vector peak of the arithmetic type; the HBM view the
             # contract also asks for (algorithmic bytes / launch time against 8 TB/s, and the PMC traffic) sits in `hbm`
@@ -477,6 +496,7 @@ def main():
                          'traffic': (traffic or {}).get('bytes_per_launch'),
                          'traffic_source': (traffic or {}).get('source'),
                          'kernel': 'k_fly (one control step of all envs)', 'kernel_ms_avg': per_launch_s * 1e3,
+                         'kernel_ms': launch_stats,
                          # (staggered pre-roll: every timed launch carries ~n_env/236 resetting environments, none is a reset-only pass)
                          'algorithmic_flop_per_env_step': ALGO_FLOP_PER_ENV_STEP,
                          'algorithmic_bytes_per_env_step': algo_bytes,
@@ -489,7 +509,7 @@ def main():
             'parity_sample': parity,
             'warn': {'envs_with_flag_since_reset': extras.get('warn'), 'sizes': extras.get('sizes'), 'note': 'FB_WARN_EVER population over the batch: contact cap (64), constraint-row cap (192), '
                      'solver at opt.iterations, MPR at its iteration limit -- MuJoCo reports the first two as nconmax / njmax warnings (fruitfly.xml:6)'},
-            'rccl': ('exercised: init_process_group(nccl) + all_reduce(MAX) + barrier over %d ranks%s' % (world, '; dmpo_mode: one flat gradient all-reduce per learner step' if dmpo is not None else '')) if (world > 1 and backend == 'nccl') else
+            'rccl': ('exercised, ranks: %d (checked: all_reduce(SUM) of the rank ids = N(N-1)/2 and all_gather = 0..N-1 on every rank; then all_reduce(MAX) of the timings + barriers)%s' % (world, '; dmpo_mode: one flat gradient all-reduce per learner step' if dmpo is not None else '')) if (world > 1 and backend == 'nccl') else
                     ('unexercised (gloo substitute)' if world > 1 else 'unexercised (single rank: no collective on the data path)'),
             'parity': 'FP64 kernel vs in-repo FP64 C oracle (1e-6 over 100 control steps, tests/test_gpu_parity.py); '
                       'parity vs CPU MuJoCo is UNPINNED (no MuJoCo here; tools/dump_mujoco_golden.py + tests/test_mujoco_golden.py)',

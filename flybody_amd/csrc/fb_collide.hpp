@@ -612,7 +612,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   }
   C_PROF(4);
   if (ncon > FB_MAXCON_) { ncon = FB_MAXCON_; warn |= WARN_CONTACT_CAP; }
-  if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; if (ncon > w.istate()[IS_MAX_NCON]) w.istate()[IS_MAX_NCON] = ncon; if (warn) { w.istate()[IS_WARN] |= warn; w.istate()[IS_WARN_EVER] |= warn; } }
+  if (lane == 0) { w.istate()[IS_NCON] = ncon; w.istate()[IS_NCAND] = ncand; if (ncon > w.istate()[IS_MAX_NCON]) w.istate()[IS_MAX_NCON] = ncon; if (warn) { atomicOr(w.istate() + IS_WARN, warn); atomicOr(w.istate() + IS_WARN_EVER, warn); } /* atomic: an abandoning wave of the substep scheduler may OR WARN_SCHED_WAIT into the same words (fb_engine.hip) */ }
   SYNC();
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   if (lane == 0) { long long* pp_ = (long long*)w.prof(); for (int k_ = 0; k_ < 5; k_++) pp_[42 + k_] += cp_[k_]; }

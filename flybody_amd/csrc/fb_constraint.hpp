@@ -191,11 +191,11 @@ __device__ __forceinline__ void d_make_constraint(const DevModel<real>& M, const
   }
   if (lane == 0) {
     // how close the batch comes to the solver's shapes and the caps (bench.py: warn.sizes): running maxima and the number of substeps
-    // whose system had more than 32 / 64 rows (64 = one row per lane, beyond which Newton falls back to PGS)
+    // whose system had more than 32 / 64 rows (64 = one row per lane, beyond which the wide Newton solver runs: fb_newton.hpp d_newton_wide)
     if (nefc > w.istate()[IS_MAX_NEFC]) w.istate()[IS_MAX_NEFC] = nefc;
     if (nefc > 32) w.istate()[IS_N_GT32]++;
     if (nefc > 64) w.istate()[IS_N_GT64]++;
-    w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { w.istate()[IS_WARN] |= WARN_EFC_CAP; w.istate()[IS_WARN_EVER] |= WARN_EFC_CAP; } }
+    w.istate()[IS_NEFC] = nefc; w.istate()[IS_NLIMIT] = nlimit; if (ob || nlimit > FB_MAXEFC_) { atomicOr(w.istate() + IS_WARN, (int)WARN_EFC_CAP); atomicOr(w.istate() + IS_WARN_EVER, (int)WARN_EFC_CAP); } }
   SYNC();
 }
 
@@ -1133,7 +1133,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     w.istate()[IS_NITER] = niter;
     // (WARN_SOLVER_FALLBACK -- "the model asks for Newton, PGS ran" -- cannot be raised any more: round 5 solves every size with Newton)
     int wbits = (niter >= M.iterations ? WARN_SOLVER_MAXITER : 0);
-    if (wbits) { w.istate()[IS_WARN] |= wbits; w.istate()[IS_WARN_EVER] |= wbits; }
+    if (wbits) { atomicOr(w.istate() + IS_WARN, wbits); atomicOr(w.istate() + IS_WARN_EVER, wbits); }
   }
   SYNC();
   if (nefc <= FB_WAVE) {

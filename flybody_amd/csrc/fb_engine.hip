@@ -491,9 +491,23 @@ struct Batch {
   int* done;                  // ... [n_env] substeps of the running control step completed, zeroed before every launch
   int nq;                     // ... number of XCDs (ticket queues)
   int* sched_err;             // ... [1] tickets abandoned because the wait for the predecessor substep hit its cap (sticky; fb_batch_synchronize / fb_batch_get fail)
+  const int* torder;          // ... [nq][ceil(n_env / nq)] environments of every XCD's share in the order their tickets are handed out (k_ticket_order:
+                              //     largest constraint system of the previous step first); null = by id
   real* park;                 // MODE_STAGE (profiling): [n_env][POOL] the LDS pool between two single-stage launches
 };
 
+#ifndef FB_TICKET_SPLIT
+#define FB_TICKET_SPLIT 1                 // final substeps of a control step handed out as two half tickets (0: whole substeps only)
+#endif
+#ifndef FB_HEAVY_PRIO_ROWS
+#define FB_HEAVY_PRIO_ROWS 0              // constraint rows (previous substep) from which a ticket runs at issue priority FB_HEAVY_PRIO (0: off)
+#endif
+#ifndef FB_HEAVY_PRIO
+#define FB_HEAVY_PRIO 2
+#endif
+#ifndef FB_TICKET_ORDER
+#define FB_TICKET_ORDER 1                 // hand an XCD's environments out by decreasing size of their last constraint system (k_ticket_order)
+#endif
 #ifndef FB_SCHED_SPIN_CAP
 #define FB_SCHED_SPIN_CAP (1 << 22)       // x s_sleep(32): seconds.  (Test builds lower it to provoke the abandon path.)
 #endif
@@ -553,13 +567,25 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
     // (acquire fence).  Protocol measured stand-alone in tools/microbench/ticket_proto.hip.
     const int nq = B.nq, xcc = fb_xcc_id() % nq, nsubm = uniform_int(M.nsubstep);
     const int cnt = (B.n_env - xcc + nq - 1)/nq;
-    const int total = cnt*nsubm;
+    // Round 6: the LAST FB_TICKET_SPLIT substeps of the control step are handed out as two tickets each -- [actuation .. sensors] and
+    // [integration .. velocity stage of the next substep's mj_step1], the boundary at which nothing LDS-resident is alive (the factor of M
+    // is dead, M + h D is factorised behind it: fb_step.hpp) -- because the launch ends with a quantisation tail: 10 x 4096 tickets over
+    // 3072 resident waves are 13.33 rounds, so a third of the waves run a 14th ticket while the rest idle, and the waves are out of phase
+    // by then (mean idle = half a ticket).  Half-size units at the end halve both.  A unit index u = t / cnt counts them:
+    // u < nsubm - split: whole substep u; beyond: halves.  `done` counts completed units.
+    const int nsplit = uniform_int(FB_TICKET_SPLIT < nsubm ? FB_TICKET_SPLIT : nsubm), nfull = nsubm - nsplit, nunit = nsubm + nsplit;
+    const int total = cnt*nunit;
+    const int ostride = (B.n_env + nq - 1)/nq;
     for (int guard = 0; guard < (1 << 20); guard++) {
       int t = 0;
       if (lane == 0) t = atomicAdd(B.tick + 16*xcc, 1);
       t = uniform_int(__shfl(t, 0, FB_WAVE));
       if (t >= total || cnt <= 0) return;
-      const int round = t / cnt, env = (t % cnt)*nq + xcc;
+      const int round = t / cnt;                      // unit index of this ticket
+      int env = (t % cnt)*nq + xcc;
+      if (B.torder) env = uniform_int(B.torder[xcc*ostride + (t % cnt)]);
+      const int hk = round - nfull;                   // >= 0: a half ticket
+      const int tkhalf = hk < 0 ? 0 : 1 + (hk & 1);   // 1: [actuation .. sensors], 2: [integration .. velocity]
       // wait for the predecessor substep (normally long done: it was drawn `cnt` tickets ago).  An environment whose predecessor is still
       // running when its next ticket comes up is BEHIND the round-robin: its ten substeps in sequence are what the launch will wait for
       // at the end (tools/ticket_trace.py), so that ticket runs at the highest issue priority.
@@ -594,9 +620,9 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
           atomicOr(is_ + IS_WARN, WARN_SCHED_WAIT); atomicOr(is_ + IS_WARN_EVER, WARN_SCHED_WAIT);
           atomicAdd(B.sched_err, 1);
 #ifndef FB_EMULATE
-          __hip_atomic_fetch_max(B.done + env, nsubm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(B.done + env, nunit + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-          B.done[env] = max(B.done[env], nsubm + 2);
+          B.done[env] = max(B.done[env], nunit + 2);
 #endif
         }
         continue;
@@ -611,13 +637,24 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
       w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
       w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
       float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
+#ifdef FB_EMULATE
+      // (host emulation, test infrastructure: every ticket starts from a POISONED LDS pool -- whatever a stage left there for a later ticket,
+      //  against the claim that nothing LDS-resident crosses a ticket boundary, turns the state into NaN and fails the parity tests)
+      for (int i = lane; i < LdsCfg<real>::POOL; i += FB_WAVE) w.lLD[i] = (real)NAN;
+      SYNC();
+#endif
+#if FB_HEAVY_PRIO_ROWS > 0
+      // an environment whose last constraint system was large is the likely end of the launch (its ten substeps are a serial chain:
+      // profiles/r5/launch_times.txt): issue priority from its first ticket, not only once it has fallen a round behind
+      if (late < FB_HEAVY_PRIO && uniform_int(w.istate()[IS_NEFC]) >= FB_HEAVY_PRIO_ROWS) late = FB_HEAVY_PRIO;
+#endif
       if (lane == 0) { w.istate()[IS_PRIO] = late; if (round == 0) w.istate()[IS_WARN] = 0; }
       FB_SETPRIO(late);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
       const long long tw1_ = wall_clock64();       // (tools/ticket_trace.py) per environment: wait for the predecessor, first start, last end, busy ticks
 #endif
       const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
-                                   B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nsubm - 1 ? 2 : 0));
+                                   B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nunit - 1 ? 2 : 0) | (tkhalf == 1 ? 4 : 0) | (tkhalf == 2 ? 8 : 0));
 #ifndef FB_EMULATE
       // Release.  What the next holder of this environment (a wave of the SAME XCD: environments are bound to XCDs) must see is this
       // wave's global stores.  On gfx942 / gfx950 the vector L1 is write-through and an XCD has ONE L2, so "visible to the XCD" =
@@ -635,9 +672,9 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
 #endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_max(B.done + env, was_reset ? nsubm + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (MAX: an abandon mark stays)
+      if (lane == 0) __hip_atomic_fetch_max(B.done + env, was_reset ? nunit + 1 : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (MAX: an abandon mark stays)
 #else
-      if (lane == 0) B.done[env] = max(B.done[env], was_reset ? nsubm + 1 : round + 1);
+      if (lane == 0) B.done[env] = max(B.done[env], was_reset ? nunit + 1 : round + 1);
 #endif
     }
     return;
@@ -733,6 +770,30 @@ __global__ void __launch_bounds__(FB_ORDER_THREADS) k_order(const int* cost, int
   }
 }
 
+// Ticket order of the substep scheduler: per XCD, the environments of its share (env % nq == xcc) by DECREASING size of the constraint
+// system their last substep solved (counting sort, one workgroup per XCD).  The cost of a substep grows with that size (Newton: cubic),
+// contact configurations persist from step to step, and the launch ends with the last tickets drawn: longest first means the stragglers
+// of the final round are the cheap environments.  Scheduling only -- environments are independent, results do not depend on it.
+__global__ void __launch_bounds__(FB_ORDER_THREADS) k_ticket_order(const int* iarena, int nint, int off_nefc, int* order, int n_env, int nq) {
+  __shared__ int s_hist[256];
+  const int tid = threadIdx.x, xcc = blockIdx.x;
+  const int cnt = (n_env - xcc + nq - 1)/nq, stride = (n_env + nq - 1)/nq;
+  s_hist[tid & 255] = 0;
+  __syncthreads();
+  for (int j = tid; j < cnt; j += FB_ORDER_THREADS) {
+    int key = iarena[(size_t)(j*nq + xcc)*nint + off_nefc]; key = key < 0 ? 0 : (key > 255 ? 255 : key);
+    atomicAdd(&s_hist[255 - key], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { int h = s_hist[k]; s_hist[k] = acc; acc += h; } }
+  __syncthreads();
+  for (int j = tid; j < cnt; j += FB_ORDER_THREADS) {
+    const int e = j*nq + xcc;
+    int key = iarena[(size_t)e*nint + off_nefc]; key = key < 0 ? 0 : (key > 255 ? 255 : key);
+    order[xcc*stride + atomicAdd(&s_hist[255 - key], 1)] = e;
+  }
+}
+
 // ------------------------------------------------------------------ synthetic actions
 // Random-action rollouts ("per-env RNG = Philox(seed, stream = env_id)"): one counter-based stream per
 // GLOBAL environment id, so what an environment is fed does not depend on the number of GPUs the batch is sharded over or on its
@@ -789,8 +850,8 @@ struct fb_batch {
   float *obs = nullptr, *reward = nullptr, *discount = nullptr; int* step_type = nullptr;
   int* d_ids = nullptr;
   int* sched = nullptr;
-  int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true;
-  int *tick = nullptr, *done = nullptr, *sched_err = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
+  int *cost = nullptr, *order = nullptr; bool order_valid = false, reorder = true, use_prio = true, ticket_order = true;
+  int *tick = nullptr, *done = nullptr, *sched_err = nullptr, *torder = nullptr; int nq = 0, slots = 0; bool tickets = false;      // substep scheduler (k_fly)
   unsigned xcc_mask = 0; std::vector<void*> probed_streams; unsigned* probe_word = nullptr;  // ... the streams it was validated on, the probe's device word
   void* park = nullptr;               // MODE_STAGE: LDS pools between single-stage launches (allocated on first use)
   std::vector<void*> allocs;          // model tables on the device
@@ -800,6 +861,7 @@ struct fb_batch {
   void *ref_qpos = nullptr, *ref_qvel = nullptr;
   bool have_ref = false, have_wbpg = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; int timed_launches = 0; bool timing = false;
+  std::vector<hipEvent_t> lev;        // per-launch event pairs of the timed region (fb_batch_timing_launches), created on first use
 };
 
 template <typename real, typename T, typename P>
@@ -957,7 +1019,7 @@ static int batch_create_impl(fb_batch* b) {
   HIPCHK(hipMalloc((void**)&b->cost, n_env*sizeof(int)));
   HIPCHK(hipMemset(b->cost, 0, n_env*sizeof(int)));
   HIPCHK(hipMalloc((void**)&b->order, n_env*sizeof(int)));
-  { const char* e_ = getenv("FB_NO_REORDER"); b->reorder = !(e_ && e_[0] == '1'); }
+  { const char* e_ = getenv("FB_NO_REORDER"); b->reorder = !(e_ && e_[0] == '1'); b->ticket_order = b->reorder; }
   // substep scheduler: for batches larger than the resident wave slots (k_fly)
   {
 #ifdef FB_EMULATE
@@ -981,6 +1043,7 @@ static int batch_create_impl(fb_batch* b) {
 #endif
     HIPCHK(hipMalloc((void**)&b->tick, 16*16*sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->done, n_env*sizeof(int)));
+    HIPCHK(hipMalloc((void**)&b->torder, (size_t)(n_env + 16)*sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->sched_err, sizeof(int)));
     HIPCHK(hipMemset(b->sched_err, 0, sizeof(int)));
     HIPCHK(hipMalloc((void**)&b->probe_word, sizeof(unsigned)));
@@ -1011,11 +1074,12 @@ extern "C" void fb_batch_destroy(fb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
-  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done, b->sched_err, b->park, b->probe_word};
+  void* frees_[] = {b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->d_ids, b->sched, b->cost, b->order, b->ref_qpos, b->ref_qvel, b->dM, b->tick, b->done, b->sched_err, b->park, b->probe_word, b->torder};
   for (void* p : frees_) (void)hipFree(p);
 
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  for (hipEvent_t e_ : b->lev) (void)hipEventDestroy(e_);
   delete b;
 }
 
@@ -1188,7 +1252,7 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
     // The probe synchronises, so it cannot run while the stream is being captured into a graph: such a launch takes the per-wave
     // path (same results) and the stream stays unvalidated.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }      // (the legacy stream under another stream's global-mode capture: the query fails -- treat as capturing, never synchronise)
     if (cap != hipStreamCaptureStatusNone) tickets = false;
     else {
       unsigned hmask = 0;
@@ -1202,18 +1266,31 @@ static int launch(fb_batch* b, int mode, const float* action, const int* ids, in
 #endif
   const bool full_step = (mode == MODE_STEP) && !ids && n == b->n_env && b->reorder && !tickets;
   if (full_step && b->order_valid) ids = b->order;       // slowest environments of the previous step first
-  if (tickets) { HIPCHK(hipMemsetAsync(b->tick, 0, 16*16*sizeof(int), st)); HIPCHK(hipMemsetAsync(b->done, 0, (size_t)n*sizeof(int), st)); }
+  if (tickets) {
+    HIPCHK(hipMemsetAsync(b->tick, 0, 16*16*sizeof(int), st)); HIPCHK(hipMemsetAsync(b->done, 0, (size_t)n*sizeof(int), st));
+#if FB_TICKET_ORDER
+    if (b->ticket_order) hipLaunchKernelGGL(k_ticket_order, dim3(b->nq), dim3(FB_ORDER_THREADS), 0, st, (const int*)b->iarena, (int)b->off.nint, (int)(b->off.istate + IS_NEFC), b->torder, n, b->nq);
+#endif
+  }
+  const int* tord = (tickets && FB_TICKET_ORDER && b->ticket_order) ? b->torder : nullptr;
+  const int FB_TIMED_MAX = 2048;
+  const bool per_launch = b->timing && mode == MODE_STEP && b->timed_launches < FB_TIMED_MAX;
+  if (per_launch) {
+    while ((int)b->lev.size() < 2*(b->timed_launches + 1)) { hipEvent_t nev; HIPCHK(hipEventCreate(&nev)); b->lev.push_back(nev); }
+    HIPCHK(hipEventRecord(b->lev[2*b->timed_launches], st));
+  }
   if (b->precision == 64) {
     Batch<double> B = {(double*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
-                       tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (double*)b->park};
+                       tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, tord, (double*)b->park};
     if (mode == MODE_RESET) hipLaunchKernelGGL((k_fly_reset<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, ids, nsub, n);
     else hipLaunchKernelGGL((k_fly<double>), dim3((n + LdsCfg<double>::EPB - 1)/LdsCfg<double>::EPB), dim3(FB_WAVE*LdsCfg<double>::EPB), 0, st, (const DevModel<double>*)b->dM, B, action, ids, mode, nsub, n);
   } else {
     Batch<float> B = {(float*)b->rarena, b->iarena, b->obs, b->reward, b->discount, b->step_type, b->n_env, b->nobs, b->use_prio ? b->sched : nullptr, b->cost,
-                      tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, (float*)b->park};
+                      tickets ? b->tick : nullptr, b->done, b->nq, b->sched_err, tord, (float*)b->park};
     if (mode == MODE_RESET) hipLaunchKernelGGL((k_fly_reset<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, ids, nsub, n);
     else hipLaunchKernelGGL((k_fly<float>), dim3((n + LdsCfg<float>::EPB - 1)/LdsCfg<float>::EPB), dim3(FB_WAVE*LdsCfg<float>::EPB), 0, st, (const DevModel<float>*)b->dM, B, action, ids, mode, nsub, n);
   }
+  if (per_launch) HIPCHK(hipEventRecord(b->lev[2*b->timed_launches + 1], st));
   if (full_step) { hipLaunchKernelGGL(k_order, dim3(1), dim3(FB_ORDER_THREADS), 0, st, b->cost, b->order, n); b->order_valid = true; }
   HIPCHK(hipGetLastError());
   if (b->timing) b->timed_launches++;
@@ -1448,4 +1525,12 @@ extern "C" int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, i
   if (n_launches) *n_launches = b->timed_launches;
   b->timing = false;
   return 0;
+}
+
+extern "C" int fb_batch_timing_launches(fb_batch* b, float* ms, int cap) {
+  if (!b || b->timing) return fail("fb_batch_timing_launches: call after fb_batch_timing_end");
+  HIPCHK(hipSetDevice(b->device));
+  const int n = std::min((int)b->lev.size()/2, std::min(b->timed_launches, cap));
+  for (int k = 0; k < n && ms; k++) HIPCHK(hipEventElapsedTime(ms + k, b->lev[2*k], b->lev[2*k + 1]));
+  return n;
 }

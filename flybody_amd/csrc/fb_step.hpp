@@ -838,14 +838,18 @@ template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const 
 
 // tk < 0: the whole call (all substeps of a control step, or what `mode` says).  tk >= 0: ONE substep of a control step handed out by
 // the substep scheduler of k_fly (MODE_STEP only): bit 0 = first substep of the step (the action scatter, or the auto-reset, happens
-// here), bit 1 = last (the task epilogue happens here).  Returns true when the call was an auto-reset (the step is complete then).
+// here), bit 1 = last (the task epilogue happens here); bit 2 = the FIRST HALF of a substep only (actuation .. acceleration sensors: stop where
+// the integration would start), bit 3 = the SECOND HALF only (start at the integration: M + h D, Euler, mj_step1 of the next substep).  Nothing
+// LDS-resident is alive at that boundary -- the factor of M is dead, the right-hand side of the Euler solve is assembled from the global row --
+// so the two halves may run on different waves (k_fly hands the last substeps of a step out in halves).
+// Returns true when the call was an auto-reset (the step is complete then).
 template <typename real>
 __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w, int env, int mode, int nsub_arg, int nslot, int* sched, const float* action,
                       float* obs, float* reward, float* discount, int* step_type, int lane, int tk = -1, int only = -1) {
   // every selector of the stage machine is wave-uniform: say so (v_readfirstlane), otherwise the interpreter's state lives in
   // VGPRs + saved exec masks across every stage call and counts against the register budget of all stages
   mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg); tk = uniform_int(tk); only = uniform_int(only);
-  const bool tk_first = tk < 0 || (tk & 1), tk_last = tk < 0 || (tk & 2);
+  const bool tk_first = tk < 0 || (tk & 1), tk_last = tk < 0 || (tk & 2), tk_half_a = tk >= 0 && (tk & 4), tk_half_b = tk >= 0 && (tk & 8);
   int parts = 15;
   bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && tk_first && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
@@ -870,7 +874,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
     PROF_BEGIN();
     if (mode == MODE_STEP && tk_first) s_pre(M, wc, action, lane);
     PROF(27);
-    pc = (nsub > 0) ? ST_ACT : ST_DONE;
+    pc = (nsub > 0) ? (tk_half_b ? ST_EULER_PRE : ST_ACT) : ST_DONE;
   }
   bool single_pass = resetting || (mode == MODE_FORWARD);     // KIN..COLL then ACT..SENS once, no integration
   if (only >= 0) single_pass = false;
@@ -929,7 +933,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         PROF_BEGIN();
         s_sensor_acc(M, wc, lane);
         PROF(P_SENS);
-        pc = single_pass ? ST_DONE : ST_EULER_PRE; break; }
+        pc = (single_pass || tk_half_a) ? ST_DONE : ST_EULER_PRE; break; }
       case ST_EULER_PRE: {
         // the factor of M is dead after the constraint solve: its LDS slot is reused for M + h*D
         PROF_BEGIN();

@@ -74,6 +74,18 @@ def lib():
     return _lib
 
 
+def library_version() -> str:
+    """Build identity of the loaded learner library (fbl_version): carries the hash of the sources it was built from."""
+    return lib().fbl_version().decode()
+
+
+def source_hash() -> str:
+    """Hash of the learner kernel source + its C-ABI header in this tree (what __graft_entry__.build_learner embeds as FB_BUILD_ID)."""
+    import hashlib
+    src = os.path.join(_HERE, 'csrc', 'fb_learner.hip'); hdr = os.path.join(os.path.dirname(_HERE), 'include', 'flybody_learner.h')
+    return hashlib.sha1(open(src, 'rb').read() + open(hdr, 'rb').read()).hexdigest()[:12]
+
+
 def _check(rc):
     if rc != 0:
         raise LearnerLibError(lib().fbl_last_error().decode())
@@ -326,9 +338,9 @@ def bias_elu(x, bias):
 
 
 # ------------------------------------------------------------------ the B = 256 layers: small MFMA GEMM (+ bias + ELU epilogue)
-SMALL_GEMM_ROWS = 1024          # layers with more rows than this (the [5120 x 512] target-critic products) go to the BLAS library
-SMALL_GEMM_K = 512              # ... and so do longer reductions (741 / 800 input columns): measured 14.8 us here against 7.6 us there
-_USE_SGEMM = os.environ.get('FB_LEARNER_GEMM', 'mfma') != 'blas'
+SMALL_GEMM_ROWS = 1024          # layers with more rows than this (the [5120 x 512] target-critic products) go to fbl_gemm_nt (LDS-tiled)
+SMALL_GEMM_K = 512              # ... longer reductions (741 / 800 input columns) to fbl_gemm_longk
+_USE_SGEMM = True               # (rounds 3-5 kept an FB_LEARNER_GEMM=blas switch for A/B runs against rocBLAS; removed: no BLAS call on the GPU path)
 
 
 def _sgemm(a, sai, sak, b, sbk, sbj, M, N, K, epilogue=0, bias=None):
@@ -430,8 +442,8 @@ def linear(x, w, bias=None, elu=False):
     """x W^T (bias None) or ELU(x W^T + bias).  Every GPU shape of the learner step runs on a hand-written MFMA kernel (round 5: no BLAS
     library call is left in it): up to SMALL_GEMM_ROWS rows and SMALL_GEMM_K columns -> fbl_sgemm (32 x 32 tile per workgroup, K split
     over its waves, epilogue fused); more rows, forward only (the target critic's N x B = 5120 rows) -> fbl_gemm_nt (LDS-tiled, epilogue
-    fused); longer reductions at the learner's batch (the 741 / 800-column first layers) -> fbl_gemm_longk.  Anything else (CPU
-    tensors, FB_LEARNER_GEMM=blas) is F.linear + the fused epilogue kernel."""
+    fused); longer reductions at the learner's batch (the 741 / 800-column first layers) -> fbl_gemm_longk.  CPU tensors (the test-suite's
+    reference) are F.linear + the plain epilogue; a GPU shape none of the kernels covers RAISES -- there is no BLAS fall-through."""
     assert bias is None or elu, 'bias without activation is not used by the networks (the loss kernels add the output biases)'
     if _USE_SGEMM and x.is_cuda and x.dtype == torch.float32 and w.stride(1) == 1:
         need = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad))
@@ -452,6 +464,9 @@ def linear(x, w, bias=None, elu=False):
             if x.stride(1) == 1 and w.stride(1) == 1:
                 return _sgemm(x, x.stride(0), 1, w, 1, w.stride(0), x.shape[0], w.shape[0], x.shape[1], 2 if elu else 0, bias if elu else None)
         return _Linear.apply(x, w, bias, elu)
+    if x.is_cuda:
+        raise LearnerLibError('fused.linear: no hand-written kernel covers x %s (%s, requires_grad=%s) @ w %s^T on the GPU; the learner never '
+                              'falls back to a BLAS library (shapes: DESIGN.md 5)' % (tuple(x.shape), x.dtype, x.requires_grad, tuple(w.shape)))
     z = F.linear(x, w)
     return bias_elu(z, bias) if elu else z
 

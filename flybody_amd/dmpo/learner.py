@@ -84,12 +84,6 @@ class DMPOLearner:
         self._net_params = [p for p in self.policy_params + self.critic_params if p is not self.online.critic.logits.bias]
         if self.fused:
             fused.lib()
-            # The learner's GEMMs are plain (no bias epilogue) [256 | 5120] x K x [51 .. 512] products.  hipBLASLt's heuristics pick
-            # a 256x256 macro tile for the M = 256, N = 256 ones (one or two workgroups on a 256-CU device: 63-170 us each,
-            # profiles/r2/learner_gemm_probe.txt); rocBLAS runs every shape of this step in 4-40 us.  Process-wide switch.
-            blas = os.environ.get('FB_LEARNER_BLAS', 'hipblas')
-            if blas != 'default':
-                torch.backends.cuda.preferred_blas_library(blas)
 
     def broadcast_parameters(self):
         """Make every rank start from rank 0's weights (replicas then stay identical deterministically)."""

@@ -103,6 +103,8 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_timing_begin.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    if hasattr(L, 'fb_batch_timing_launches'):
+        L.fb_batch_timing_launches.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     _libs[path] = L
     return L
 
@@ -315,6 +317,14 @@ class Batch:
         ms = C.c_float(); n = C.c_int()
         _check(self.L, self.L.fb_batch_timing_end(self.h, stream, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_launches(self, cap: int = 2048) -> np.ndarray:
+        """Duration (ms) of every fb_batch_step kernel of the last timed region (fb_batch_timing_launches)."""
+        out = np.zeros(cap, np.float32)
+        n = self.L.fb_batch_timing_launches(self.h, out.ctypes.data, cap)
+        if n < 0:
+            raise EngineError(self.L.fb_last_error().decode())
+        return out[:n].copy()
 
     def __del__(self):
         try:

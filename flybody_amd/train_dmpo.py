@@ -243,7 +243,7 @@ def measure(tr: 'Trainer', warmup: int, iters: int):
                                    'achieved_since_start': tr.limiter.achieved_samples_per_insert,
                                    'min_size_to_sample': tr.limiter.min_size, 'error_buffer': tr.limiter.error_buffer},
             'roofline': {'bound': 'mfma', 'achieved': tfl, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tfl/157.3,
-                         'gemm_gflop_per_learner_step': fl/1e9, 'dtype': 'f32 (exact: v_mfma_f32_32x32x2_f32 / rocBLAS sgemm)',
+                         'gemm_gflop_per_learner_step': fl/1e9, 'dtype': 'f32 (exact: v_mfma_f32_32x32x2_f32, hand-written kernels: no BLAS library call in the step)',
                          'learner_time_share': burst_s/dt,
                          'note': 'learner_time_share = HIP-event time of the learner bursts / wall time (rank 0); the physics kernel of the '
                                  'same control step runs concurrently on its own stream'},

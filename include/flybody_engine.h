@@ -66,8 +66,9 @@ enum {
                          Mirrors MuJoCo's nconmax / njmax warnings (fruitfly.xml:6) and adds the iteration limits. */
   FB_WARN_EVER = 33,  /* [n_env] int32: the same bits accumulated since the environment's last reset */
   FB_SIZE_STATS = 34, /* [n_env][4] int32: largest contact count, largest constraint-row count, number of substeps with more than 32 rows,
-                         number of substeps with more than 64 rows (= Newton fell back to PGS) -- over every substep since the batch was
-                         created; not cleared by resets; fb_batch_set(FB_SIZE_STATS, zeros) clears.  Against FB_MAXCON / FB_MAXEFC and
+                         number of substeps with more than 64 rows (= beyond one row per lane: d_newton_wide) -- over every constraint
+                         set-up since the batch was created, i.e. every substep AND every forward evaluation (fb_batch_forward, the
+                         forward pass of a reset); not cleared by resets; fb_batch_set(FB_SIZE_STATS, zeros) clears.  Against FB_MAXCON / FB_MAXEFC and
                          MuJoCo's nconmax 100 / njmax 300 (fruitfly.xml:6) this says how close a run came to the caps. */
   FB_NFIELD
 };
@@ -189,6 +190,10 @@ int fb_batch_synchronize(fb_batch* b, void* stream);
  * launch stream between fb_batch_timing_begin / fb_batch_timing_end. */
 int fb_batch_timing_begin(fb_batch* b, void* stream);
 int fb_batch_timing_end(fb_batch* b, void* stream, float* total_ms, int* n_launches);
+/* Duration (ms) of EVERY fb_batch_step kernel of the last timed region (HIP events around each launch, up to 2048 of them): returns
+ * how many were written to ms[0 .. cap).  Call after fb_batch_timing_end.  bench.py reports their min / median / p90 / max, so that a
+ * single long control step (one environment with a very large constraint system ends the launch) shows in a 20-step window. */
+int fb_batch_timing_launches(fb_batch* b, float* ms, int cap);
 
 /* How fb_batch_step schedules a control step of this batch: 1 = substep scheduler (the batch exceeds the GPU's resident wave slots:
  * waves draw (environment, substep) tickets per XCD until the step is complete), 0 = one environment per wave, longest first.

@@ -282,6 +282,53 @@ def test_two_rank_gradient_allreduce(tmp_path):
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-7)
 
 
+WORKER_LONG = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from flybody_amd.dmpo import DMPOConfig, DMPOLearner, MPOLoss, make_networks
+dist.init_process_group('gloo'); rank = dist.get_rank(); world = dist.get_world_size()
+torch.manual_seed(1234)
+cfg = DMPOConfig(batch_size=8, num_samples=4, target_policy_update_period=13, target_critic_update_period=17)
+L = DMPOLearner(make_networks(12, 3, policy_sizes=(16, 16), critic_sizes=(16, 16)), MPOLoss(3), cfg)
+L.broadcast_parameters()
+g = torch.Generator().manual_seed(100 + rank)            # every rank draws its OWN batches (its environment shard / replay)
+synced = 0
+for k in range(60):
+    batch = (torch.randn(8, 12, generator=g), torch.rand(8, 3, generator=g) * 2 - 1, torch.rand(8, generator=g), torch.ones(8), torch.randn(8, 12, generator=g))
+    torch.manual_seed(1000 + k)                          # same action-sampling noise on both ranks
+    before = [t.clone() for t in L.target.policy.state_dict().values()]
+    L.step(batch)
+    synced += any(not torch.equal(a, b) for a, b in zip(before, L.target.policy.state_dict().values()))
+assert synced >= 4, synced                               # the window holds several target-policy syncs (period 13) and critic syncs (17)
+def flat(mods):
+    return torch.cat([t.detach().flatten().float() for m in mods for t in m.state_dict().values()])
+mine = torch.cat([flat([L.online, L.loss]), flat([L.target])])
+out = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(out, mine)
+assert torch.equal(out[0], out[1]), 'replicas (online, duals or TARGET networks) diverged: %%g' %% float((out[0] - out[1]).abs().max())
+assert L.num_steps == 60
+dist.barrier(); dist.destroy_process_group()
+if rank == 0: print('LONG_OK')
+"""
+
+
+def test_two_ranks_bit_identical_over_60_steps_across_target_syncs(tmp_path):
+    """Data-parallel learner on two gloo ranks, own data per rank, 60 updates with the target networks copied on their periods INSIDE the
+    window (reference: one learner, ray_distributed_dmpo.py:355-380; here every rank is a learner and ONE flat all-reduce per update keeps
+    them identical): online networks, dual variables and target networks must be bit-equal on both ranks afterwards.  (The overlapped
+    variant of the same step -- the all-reduce on a side stream between two HIP graphs -- needs a GPU: tests/test_gpu_fly_envs.py
+    test_dmpo_two_ranks_identical_across_a_target_sync.)"""
+    import socket
+    script = tmp_path / 'wl.py'
+    script.write_text(WORKER_LONG % dict(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], env=dict(os.environ, MASTER_ADDR='127.0.0.1'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'LONG_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_checkpoint_snapshot_and_metrics(tmp_path):
     """Checkpointer / Snapshotter / Counter / MetricsLogger (agents/learning_dmpo.py:107-162, 319-355; loggers.py:37-104)."""
     import json

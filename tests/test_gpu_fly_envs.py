@@ -328,3 +328,23 @@ def test_two_half_batches_on_two_streams_equal_one_batch():
         torch.cuda.synchronize()
         assert torch.equal(torch.cat([o['obs'] for o in outs]), v1['obs']), step
         assert torch.equal(torch.cat([o['reward'].view(-1) for o in outs]), v1['reward'].view(-1))
+
+
+@pytest.mark.gpu
+def test_dmpo_two_ranks_identical_across_a_target_sync():
+    """The overlapped data-parallel step (learner.py _step_pipelined: next step's target-network forwards on a side stream, the flat
+    gradient all-reduce between the backward graph and the optimizer graph) over >= 120 learner steps, i.e. ACROSS the target-network
+    copies at steps 101 (policy) and 107 (critic) -- the one place where phase A of the next step must NOT run ahead.  Two ranks on
+    one GPU over gloo; online parameters, duals and target networks bit-equal on both ranks afterwards."""
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    env = dict(os.environ, FB_BENCH_DEVICE='0', FB_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', FB_LEARNER_GRAPHS='1', FB_TEST_LSTEPS='8', FB_TEST_ITERS='26')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', '_dmpo_two_ranks.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'TWO_RANKS_OK' in r.stdout and 'pipelined=True' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    import re
+    steps = int(re.search(r'steps=(\d+)', r.stdout).group(1))
+    assert steps >= 120, steps
