@@ -65,19 +65,62 @@ FBD void support(const CGeom<real>& g, const real* dir, real* out) {
 // the witnesses are only read once, at the end, so a runtime-indexed store (the compiler keeps such an array in scratch memory:
 // stores nobody waits for) is fine for them.  With all three in one array of structs the whole portal lived in scratch and every
 // iteration started by reloading it through vector memory.
-template <typename real> struct MprPt { real v[3], v1[3], v2[3]; };
-template <typename real> struct Portal { real v[4][3], a1[4][3], a2[4][3]; };
+// Round 6: the refinement is written once over a SUPPORT POLICY with NW witness arrays per portal point:
+//   * MprBoth (NW = 2): one lane holds both shapes and evaluates both support maps (rounds 1-5; the host emulation build);
+//   * MprPaired (NW = 1): a pair is worked by TWO ADJACENT LANES, one per shape.  Each lane evaluates the support map of ITS shape only and
+//     keeps ITS witness points only; the Minkowski-difference point v = s_A - s_B is formed on both lanes from the own point and the
+//     partner's (quad_perm DPP moves, no LDS), so both lanes hold the same portal bit for bit and take the same decisions.  The support
+//     maps are ~2/3 of an iteration's arithmetic: the instructions a wave issues per pass drop by about a third, the mean number of
+//     enabled lanes doubles, and the per-lane state shrinks by one shape (15 reals) and one witness array (12 reals) -- the 168-register
+//     budget no longer spills the portal (d_collision hands the convex pairs of a pass out to lane pairs).
+#ifndef FB_MPR_PAIRED
+#ifdef FB_EMULATE
+#define FB_MPR_PAIRED 0            // (the fibers of the host emulation exchange values at wave-uniform yield points only: the pair exchange sits inside the
+                                   //  divergent refinement loops, so the emulation build runs the one-lane policy -- same portal code, same arithmetic)
+#else
+#define FB_MPR_PAIRED 1
+#endif
+#endif
+template <typename real, int NW> struct MprPt { real v[3], w[NW][3]; };
+template <typename real, int NW> struct Portal { real v[4][3], w[NW][4][3]; };
 
-template <typename real>
-FBD void md_support(const CGeom<real>& a, const CGeom<real>& b, const real* dir, MprPt<real>& s) {
-  real nd[3] = {-dir[0], -dir[1], -dir[2]};
-  support(a, dir, s.v1);
-  support(b, nd, s.v2);
-  sub3(s.v, s.v1, s.v2);
-}
+template <typename real> struct MprBoth {
+  static constexpr int NW = 2;
+  const CGeom<real>& a; const CGeom<real>& b;
+  FBD void centre(real* v0, real (*w0)[4][3]) const {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { w0[0][0][k] = a.pos[k]; w0[1][0][k] = b.pos[k]; v0[k] = a.pos[k] - b.pos[k]; }
+  }
+  FBD void support_md(const real* dir, MprPt<real, 2>& s) const {
+    real nd[3] = {-dir[0], -dir[1], -dir[2]};
+    support(a, dir, s.w[0]);
+    support(b, nd, s.w[1]);
+    sub3(s.v, s.w[0], s.w[1]);
+  }
+  // sum of the two shapes' weighted witness sums (contact position)
+  FBD real both(const real (*p)[3], int k) const { return p[0][k] + p[1][k]; }
+};
+#if FB_MPR_PAIRED
+template <typename real> struct MprPaired {
+  static constexpr int NW = 1;
+  const CGeom<real>& own; const bool second;        // second: this lane holds shape B (its support direction is -d, v = partner - own)
+  FBD void centre(real* v0, real (*w0)[4][3]) const {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const real o = dpp_mov<0xB1>(own.pos[k]); w0[0][0][k] = own.pos[k]; v0[k] = second ? o - own.pos[k] : own.pos[k] - o; }
+  }
+  FBD void support_md(const real* dir, MprPt<real, 1>& s) const {
+    const real sd[3] = {second ? -dir[0] : dir[0], second ? -dir[1] : dir[1], second ? -dir[2] : dir[2]};
+    support(own, sd, s.w[0]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const real o = dpp_mov<0xB1>(s.w[0][k]); s.v[k] = second ? o - s.w[0][k] : s.w[0][k] - o; }
+  }
+  FBD real both(const real (*p)[3], int k) const { const real o = dpp_mov<0xB1>(p[0][k]); return second ? o + p[0][k] : p[0][k] + o; }      // (A + B on both lanes: same rounding)
+};
+#endif
+
 // point j (1..3, runtime) <- s
-template <typename real>
-FBD void portal_set(Portal<real>& P, int j, const MprPt<real>& s) {
+template <typename real, int NW>
+FBD void portal_set(Portal<real, NW>& P, int j, const MprPt<real, NW>& s) {
 #pragma unroll
   for (int q = 1; q < 4; q++) {
     const bool sel = (j == q);
@@ -85,31 +128,25 @@ FBD void portal_set(Portal<real>& P, int j, const MprPt<real>& s) {
     for (int k = 0; k < 3; k++) P.v[q][k] = sel ? s.v[k] : P.v[q][k];
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) { P.a1[j][k] = s.v1[k]; P.a2[j][k] = s.v2[k]; }
-}
-// point j <- point 3 (j = 1 or 2, runtime)
-template <typename real>
-FBD void portal_from3(Portal<real>& P, int j) {
-  MprPt<real> s;
+  for (int n = 0; n < NW; n++)
 #pragma unroll
-  for (int k = 0; k < 3; k++) { s.v[k] = P.v[3][k]; s.v1[k] = P.a1[3][k]; s.v2[k] = P.a2[3][k]; }
-  portal_set(P, j, s);
+    for (int k = 0; k < 3; k++) P.w[n][j][k] = s.w[n][k];
 }
-template <typename real>
-FBD void portal_dir(const Portal<real>& P, real* dir) {
+template <typename PT, typename real>
+FBD void portal_dir(const PT& P, real* dir) {
   real a[3], b[3];
   sub3(a, P.v[2], P.v[1]); sub3(b, P.v[3], P.v[1]);
   cross3(dir, a, b); normalize3(dir);
 }
-template <typename real>
-FBD bool reach_tol(const Portal<real>& P, const MprPt<real>& v4, const real* dir) {
-  real dv4 = dot3(v4.v, dir);
+template <typename PT, typename real>
+FBD bool reach_tol(const PT& P, const real* v4, const real* dir) {
+  real dv4 = dot3(v4, dir);
   real d1 = dv4 - dot3(P.v[1], dir), d2 = dv4 - dot3(P.v[2], dir), d3 = dv4 - dot3(P.v[3], dir);
   real dm = fmin(d1, fmin(d2, d3));
   return dm <= MPR_TOL;
 }
-template <typename real>
-FBD void expand_portal(Portal<real>& P, const MprPt<real>& v4) {
+template <typename real, int NW>
+FBD void expand_portal(Portal<real, NW>& P, const MprPt<real, NW>& v4) {
   real v4v0[3];
   cross3(v4v0, v4.v, P.v[0]);
   int j;
@@ -143,8 +180,8 @@ FBD real origin_tri_dist2(const real* a, const real* b, const real* c, real* wit
   copy3(wit, a); addscl3(wit, ab, v); addscl3(wit, ac, w_);
   return dot3(wit, wit);
 }
-template <typename real>
-FBD void find_pos(const Portal<real>& P, real* pos) {
+template <typename real, class S>
+FBD void find_pos(const S& sup, const Portal<real, S::NW>& P, real* pos) {
   real dir[3], t[3], b[4];
   portal_dir(P, dir);
   cross3(t, P.v[1], P.v[2]); b[0] = dot3(t, P.v[3]);
@@ -159,36 +196,49 @@ FBD void find_pos(const Portal<real>& P, real* pos) {
     cross3(t, P.v[1], P.v[2]); b[3] = dot3(t, dir);
     sum = b[1] + b[2] + b[3];
   }
-  real inv = (real)1/sum, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+  real inv = (real)1/sum, pw[S::NW][3];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { addscl3(p1, P.a1[i], b[i]); addscl3(p2, P.a2[i], b[i]); }
+  for (int n = 0; n < S::NW; n++) {
+    pw[n][0] = pw[n][1] = pw[n][2] = 0;
 #pragma unroll
-  for (int k = 0; k < 3; k++) pos[k] = (real)0.5*inv*(p1[k] + p2[k]);
+    for (int i = 0; i < 4; i++) addscl3(pw[n], P.w[n][i], b[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) pos[k] = (real)0.5*inv*sup.both(pw, k);
 }
 
 // Minkowski portal refinement on the margin-inflated shapes; returns penetration depth >= 0
-template <typename real>
-__device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeom<real>& b, real* depth, real* dir, real* pos, int* hit_cap) {
-  Portal<real> P; MprPt<real> s, v4;
+template <typename real, class S>
+__device__ __forceinline__ bool mpr_penetration(const S& sup, real* depth, real* dir, real* pos, int* hit_cap) {
+  constexpr int NW = S::NW;
+  Portal<real, NW> P; MprPt<real, NW> s, v4;
   real d[3], va[3], vb[3];
-  copy3(P.a1[0], a.pos); copy3(P.a2[0], b.pos); sub3(P.v[0], a.pos, b.pos);
+  sup.centre(P.v[0], P.w);
   if (dot3(P.v[0], P.v[0]) < MPR_EPS*MPR_EPS) P.v[0][0] += (real)1e-9;
   scl3(d, P.v[0], (real)-1); normalize3(d);
-  md_support(a, b, d, s);
+  sup.support_md(d, s);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { P.v[1][k] = s.v[k]; P.a1[1][k] = s.v1[k]; P.a2[1][k] = s.v2[k]; P.v[2][k] = 0; P.v[3][k] = 0; }
+  for (int k = 0; k < 3; k++) {
+    P.v[1][k] = s.v[k]; P.v[2][k] = 0; P.v[3][k] = 0;
+#pragma unroll
+    for (int n = 0; n < NW; n++) P.w[n][1][k] = s.w[n][k];
+  }
   if (dot3(P.v[1], d) < 0) { FB_STAT(10); return false; }
   cross3(d, P.v[0], P.v[1]);
   if (dot3(d, d) < MPR_EPS*MPR_EPS) {
     if (dot3(P.v[1], P.v[1]) < MPR_EPS*MPR_EPS) { *depth = 0; dir[0] = 1; dir[1] = 0; dir[2] = 0; }
     else { *depth = norm3(P.v[1]); copy3(dir, P.v[1]); normalize3(dir); }
-    for (int k = 0; k < 3; k++) pos[k] = (real)0.5*(s.v1[k] + s.v2[k]);
+    for (int k = 0; k < 3; k++) pos[k] = (real)0.5*sup.both(s.w, k);
     return true;
   }
   normalize3(d);
-  md_support(a, b, d, s);
+  sup.support_md(d, s);
 #pragma unroll
-  for (int k = 0; k < 3; k++) { P.v[2][k] = s.v[k]; P.a1[2][k] = s.v1[k]; P.a2[2][k] = s.v2[k]; }
+  for (int k = 0; k < 3; k++) {
+    P.v[2][k] = s.v[k];
+#pragma unroll
+    for (int n = 0; n < NW; n++) P.w[n][2][k] = s.w[n][k];
+  }
   if (dot3(P.v[2], d) < 0) { FB_STAT(11); return false; }
   sub3(va, P.v[1], P.v[0]); sub3(vb, P.v[2], P.v[0]);
   cross3(d, va, vb); normalize3(d);
@@ -196,16 +246,20 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       real t = P.v[1][k]; P.v[1][k] = P.v[2][k]; P.v[2][k] = t;
-      t = P.a1[1][k]; P.a1[1][k] = P.a1[2][k]; P.a1[2][k] = t;
-      t = P.a2[1][k]; P.a2[1][k] = P.a2[2][k]; P.a2[2][k] = t;
+#pragma unroll
+      for (int n = 0; n < NW; n++) { t = P.w[n][1][k]; P.w[n][1][k] = P.w[n][2][k]; P.w[n][2][k] = t; }
     }
     scl3(d, d, (real)-1);
   }
   for (int it = 0;; it++) {
     if (it > 4*MPR_ITER) { *hit_cap = 1; return false; }
-    md_support(a, b, d, s);
+    sup.support_md(d, s);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { P.v[3][k] = s.v[k]; P.a1[3][k] = s.v1[k]; P.a2[3][k] = s.v2[k]; }
+    for (int k = 0; k < 3; k++) {
+      P.v[3][k] = s.v[k];
+#pragma unroll
+      for (int n = 0; n < NW; n++) P.w[n][3][k] = s.w[n][k];
+    }
     FB_STAT(20);
     if (dot3(P.v[3], d) < 0) { FB_STAT(12); return false; }
     int j = 0;
@@ -223,24 +277,24 @@ __device__ __forceinline__ bool mpr_penetration(const CGeom<real>& a, const CGeo
   for (int it = 0;; it++) {
     portal_dir(P, d);
     if (dot3(d, P.v[1]) >= 0) break;
-    md_support(a, b, d, v4);
+    sup.support_md(d, v4);
     FB_STAT(21);
     if (it > MPR_ITER) *hit_cap = 1;
-    if (dot3(v4.v, d) < 0 || reach_tol(P, v4, d) || it > MPR_ITER) { FB_STAT(13); return false; }
+    if (dot3(v4.v, d) < 0 || reach_tol(P, v4.v, d) || it > MPR_ITER) { FB_STAT(13); return false; }
     expand_portal(P, v4);
   }
   for (int it = 0;; it++) {
     portal_dir(P, d);
-    md_support(a, b, d, v4);
+    sup.support_md(d, v4);
     FB_STAT(22);
-    if (reach_tol(P, v4, d) || it > MPR_ITER) {
+    if (reach_tol(P, v4.v, d) || it > MPR_ITER) {
       FB_STAT(14);
-      if (it > MPR_ITER && !reach_tol(P, v4, d)) *hit_cap = 1;
+      if (it > MPR_ITER && !reach_tol(P, v4.v, d)) *hit_cap = 1;
       real wit[3];
       real d2 = origin_tri_dist2(P.v[1], P.v[2], P.v[3], wit);
       *depth = fb_sqrt(d2);
       if (*depth < MPR_EPS) copy3(dir, d); else { copy3(dir, wit); normalize3(dir); }
-      find_pos(P, pos);
+      find_pos<real, S>(sup, P, pos);
       return true;
     }
     expand_portal(P, v4);
@@ -416,7 +470,7 @@ FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) 
   // per-geom model table, the centres from the bounding spheres the mid phase staged in LDS.
   const int pw = M.pair_word[p]; const real margin = M.pair_margin[p];
   const int g1 = pw & 1023, g2 = (pw >> 10) & 1023;
-  if (pw >> 20) return true;                                     // plane pairs go straight to the narrow phase
+  if ((pw >> 20) & 1023) return true;                            // plane pairs go straight to the narrow phase
   real e1[3], e2[3], c1[3], c2[3], m1[9], m2[9];
   const FB_LDS real* G = w.lAR;
 #pragma unroll
@@ -475,6 +529,7 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
     c_sphere_sphere(lc, p1, s1[0], v, s2[0], margin);
   } else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) c_capsule_capsule(lc, p1, m1, s1, p2, m2, s2, margin);
   else {
+#if !FB_MPR_PAIRED
     CGeom<real> A, B;
 #pragma unroll
     for (int k = 0; k < 3; k++) { A.pos[k] = p1[k]; B.pos[k] = p2[k]; A.size[k] = s1[k]; B.size[k] = s2[k]; }
@@ -483,10 +538,44 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
     A.type = t1; B.type = t2; A.margin = margin; B.margin = margin;
     real depth, dir[3], pos[3];
     FB_STAT(1); FB_STAT(30 + t1*6 + t2 - 14);
-    if (mpr_penetration(A, B, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
+    const MprBoth<real> sup = {A, B};
+    if (mpr_penetration<real, MprBoth<real>>(sup, &depth, dir, pos, &lc.ccd_cap)) lc_add(lc, margin - depth, pos, dir);
+#endif
+    // (FB_MPR_PAIRED: the convex pairs never get here -- d_collision hands them to lane pairs, narrow_mpr_pair)
   }
   return lc.n | (lc.ccd_cap ? 256 : 0);
 }
+
+#if FB_MPR_PAIRED
+// One side of a convex pair (lane pair 2j, 2j+1: shape A on the even lane, B on the odd one).  Both lanes compute the same depth, normal
+// and position; the even lane stores the contact in the LDS slot of the lane that owns the candidate.  Returns contacts | cap << 8.
+template <typename real>
+FB_STAGE_B int narrow_mpr_pair(const DevModel<real>& M_, const WS<real>& w_, int p, int slot, int lane) {
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const bool second = (lane & 1) != 0;
+  const int pw_ = M.pair_word[p]; const real margin = M.pair_margin[p];
+  const int g = second ? (pw_ >> 10) & 1023 : pw_ & 1023;
+  CGeom<real> G;
+  G.type = M.geom_type[g]; G.margin = margin;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { G.pos[k] = w.gxpos()[3*g + k]; G.size[k] = M.geom_size[3*g + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) G.mat[k] = w.gxmat()[9*g + k];
+  real depth, dir[3], pos[3]; int cap = 0;
+  const MprPaired<real> sup = {G, second};
+  int n = 0;
+  if (mpr_penetration<real, MprPaired<real>>(sup, &depth, dir, pos, &cap)) {
+    n = 1;
+    if (!second) {
+      FB_LDS real* first = w.lLD + 6*M.nv;
+      const real v[7] = {margin - depth, pos[0], pos[1], pos[2], dir[0], dir[1], dir[2]};
+#pragma unroll
+      for (int k = 0; k < 7; k++) first[k*FB_WAVE + slot] = v[k];
+    }
+  }
+  return n | (cap ? 256 : 0);
+}
+#endif
 
 template <typename real>
 __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<real>& w, int lane) {
@@ -536,7 +625,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
     for (int u = 0; u < 4; u++) {
       int p = base + u*FB_WAVE + lane;
       if (base + u*FB_WAVE >= M.npair) break;
-      int g1 = pw[u] & 1023, g2 = (pw[u] >> 10) & 1023, ns = pw[u] >> 20;
+      int g1 = pw[u] & 1023, g2 = (pw[u] >> 10) & 1023, ns = (pw[u] >> 20) & 1023;
       const FB_LDS real* c1 = G + 4*g1; const FB_LDS real* c2 = G + 4*g2;
       real dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
       bool hit;
@@ -581,7 +670,28 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   const FB_LDS real* first = w.lLD + 6*M.nv; const FB_GLOBAL real* more = (const FB_GLOBAL real*)w.efc_Y();
   for (int base = 0; base < ncand; base += FB_WAVE) {
     int c = base + lane, p = -1, res = 0;
+#if FB_MPR_PAIRED
+    // closed-form pairs: one lane each, as before.  Convex pairs (bit 30 of the pair word): compacted and handed to LANE PAIRS, 32 per trip
+    bool is_mpr = false;
+    if (c < ncand) { p = w.cand()[c]; is_mpr = ((M.pair_word[p] >> 30) & 1) != 0; if (!is_mpr) res = narrow_phase(M, wc, p, lane); }
+    {
+      const unsigned long long mbal = __ballot(is_mpr);
+      const int nm = __popcll(mbal), rk = __popcll(mbal & lt_mask);
+      FB_LDS int* jobs = (FB_LDS int*)(w.lLD + 6*M.nv + 7*FB_WAVE);       // [32] pair | [32] owner lane: behind the lanes' first contacts
+      for (int j0 = 0; j0 < nm; j0 += 32) {
+        const bool mine = is_mpr && rk >= j0 && rk < j0 + 32;
+        if (mine) { jobs[rk - j0] = p; jobs[32 + rk - j0] = lane; }
+        SYNC_LDS();
+        int rm = 0;
+        if ((lane >> 1) < nm - j0) rm = narrow_mpr_pair(M, wc, jobs[lane >> 1], jobs[32 + (lane >> 1)], lane);
+        const int got = __shfl(rm, mine ? 2*(rk - j0) : lane, FB_WAVE);
+        if (mine) res = got;
+        SYNC_LDS();
+      }
+    }
+#else
     if (c < ncand) { p = w.cand()[c]; res = narrow_phase(M, wc, p, lane); }
+#endif
     const int n = res & 255;
     SYNC();                                        // the lanes' first contacts are in LDS, further ones in the overflow area
     C_PROF(3);

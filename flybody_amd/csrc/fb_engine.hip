@@ -357,7 +357,11 @@ static int model_load_impl(fb_model* m, size_t n) {
     { const int* gb = m->i("geom_bodyid"); for (int q = 0; q < m->npair; q++) m->pair_body[q] = gb[g1[q]] | (gb[g2[q]] << 16); }
     for (int q = 0; q < m->npair; q++) {
       if (gt[g2[q]] == GEOM_PLANE) { return fail("fb_model_load: a plane must be the first geom of a pair"); }
-      m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20);
+      // bit 30: the pair goes through the convex narrow phase (MPR) -- everything but plane-x, sphere-sphere, sphere-capsule and
+      // capsule-capsule, which have closed forms (fb_collide.hpp: narrow_phase)
+      const int t1 = gt[g1[q]], t2 = gt[g2[q]];
+      const bool analytic = t1 == GEOM_PLANE || (t1 == GEOM_SPHERE && (t2 == GEOM_SPHERE || t2 == GEOM_CAPSULE)) || (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE);
+      m->pair_word[q] = g1[q] | (g2[q] << 10) | (slot[g1[q]] << 20) | (analytic ? 0 : (1 << 30));
     }
     if (m->plane_geoms.empty()) m->plane_geoms.push_back(0);
     const double* gs = m->d("geom_size");
@@ -497,7 +501,7 @@ struct Batch {
 };
 
 #ifndef FB_TICKET_SPLIT
-#define FB_TICKET_SPLIT 1                 // final substeps of a control step handed out as two half tickets (0: whole substeps only)
+#define FB_TICKET_SPLIT 0                 // final substeps of a control step handed out as two half tickets (0: whole substeps only; measured: profiles/r6/ab_tickets.txt)
 #endif
 #ifndef FB_HEAVY_PRIO_ROWS
 #define FB_HEAVY_PRIO_ROWS 0              // constraint rows (previous substep) from which a ticket runs at issue priority FB_HEAVY_PRIO (0: off)

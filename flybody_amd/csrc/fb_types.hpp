@@ -150,7 +150,7 @@ struct DevModel {
   GP<const int> action_to_ctrl;
   GP<const int> pair_geom1, pair_geom2, pair_condim;
   GP<const int> pair_body;      // [npair] b1 | b2 << 16
-  GP<const int> pair_word;   // [npair] geom1 | geom2 << 10 | (slot of the plane normal in the LDS staging area, 0: no plane) << 20
+  GP<const int> pair_word;   // [npair] geom1 | geom2 << 10 | (slot of the plane normal in the LDS staging area, 0: no plane) << 20 | (convex narrow phase: MPR) << 30
   GP<const int> plane_geoms; int nplane;   // geoms of type plane (their normals are staged behind the bounding spheres)
   GP<const int> obs_jnt, app_sites, force_sites, touch_sites, wing_jnt;
   GP<const int> dof_jump;       // [FB_NJUMP][nv] the 2^k-th ancestor of a dof (-1: none): tree prefix sums by pointer jumping (fb_smooth.hpp)
