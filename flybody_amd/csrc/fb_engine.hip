@@ -416,6 +416,7 @@ static int model_load_impl(fb_model* m, size_t n) {
       int jn = bjn[b], ja = bja[b];
       if (jn > 3) { return fail("fb_model_load: more than 3 joints on one body"); }
       bool fr = jn > 0 && jt[ja] == JNT_FREE;
+      if (fr && jn != 1) { return fail("fb_model_load: a free joint must be the only joint of its body"); }
       R[0] = parent[b]; R[1] = ja; R[2] = jn; R[3] = fr ? 1 : 0;
       for (int k = 0; k < 3; k++) { R[4 + k] = bp[3*b + k]; R[11 + k] = bip[3*b + k]; }
       for (int k = 0; k < 4; k++) { R[7 + k] = bq[4*b + k]; R[14 + k] = biq[4*b + k]; }

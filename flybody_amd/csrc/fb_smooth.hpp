@@ -128,79 +128,129 @@ FBD void chain_axpy6x2(const int* ch, int n, int nmax, const real* X1, const rea
 template <typename real> FBD int fk_off_jq(const DevModel<real>& M) { return 7*M.nbody; }
 template <typename real> FBD int fk_off_a(const DevModel<real>& M) { return 7*M.nbody + 4*M.njnt; }
 
+// Round 6: LOCAL TRANSFORMS FIRST.  Rounds 1-5 composed a body's joints inside the level loop: every level executed the code of as many
+// joints as its widest body has (3, 3, 2, 2, 2, 2, 2, 1 over the fly's levels 2..9 -- the abdomen's two-joint segments keep the second
+// joint's code alive on five levels where every other body has one), ~150 instructions per joint slot on a dozen lanes.  The joints of a
+// body only need the PARENT frame as a left factor: with pos = P + Q p, quat = Q r,
+//     p <- body_pos, r <- body_quat;   per joint k:  a_k = r jp_k + p,  x_k = r ja_k,  r <- r q_k,  p <- a_k - r jp_k
+// is the same recursion relative to the parent frame (P, Q), and the world anchors / axes are P + Q a_k, Q x_k.  So (p, r, a_k, x_k) of
+// EVERY body are computed at once, lane-parallel, before the level loop; a level is then one composition (P + Q p, normalise(Q r)), and
+// the anchors / axes are moved to the world lane-parallel over the joints afterwards.  Same products in a different association: the
+// frames agree with the sequential order to rounding (a few ulp; tests/test_kernel_emulation.py holds 1e-9 against the oracle's order).
+template <typename real>
+FBD void fk_local(const real* R, const FB_LDS real* JQ, FB_LDS real* A, real* p, real* r) {
+  const int ja = (int)R[1], jn = (int)R[2];
+  const bool free_jnt = R[3] != 0;                 // (a free joint is the only joint of its body: checked at model load)
+  p[0] = free_jnt ? (real)0 : R[4]; p[1] = free_jnt ? (real)0 : R[5]; p[2] = free_jnt ? (real)0 : R[6];
+  r[0] = free_jnt ? (real)1 : R[7]; r[1] = free_jnt ? (real)0 : R[8]; r[2] = free_jnt ? (real)0 : R[9]; r[3] = free_jnt ? (real)0 : R[10];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < jn && !free_jnt) {
+      const int j = ja + k;
+      const real qloc[4] = {JQ[4*j], JQ[4*j + 1], JQ[4*j + 2], JQ[4*j + 3]};
+      real anc[3], t[3], qn[4], ax[3];
+      rotvecquat(t, R + 18 + 6*k, r);
+      add3(anc, t, p);
+      rotvecquat(ax, R + 21 + 6*k, r);
+#pragma unroll
+      for (int c = 0; c < 3; c++) { A[6*j + c] = anc[c]; A[6*j + 3 + c] = ax[c]; }
+      mulquat(qn, r, qloc);
+      r[0] = qn[0]; r[1] = qn[1]; r[2] = qn[2]; r[3] = qn[3];
+      rotvecquat(t, R + 18 + 6*k, r);
+      sub3(p, anc, t);
+    }
+  }
+}
+// frame of body b from its parent's (LDS) and its local transform; a free-joint body takes its pose from qpos
+template <typename real>
+FBD void fk_compose(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, FB_LDS real* A, int b, int par, bool free_jnt, int ja, int qadr,
+                    const real* p, const real* r, bool keep_axes) {
+  real pos[3], quat[4];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pos[k] = S[7*par + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) quat[k] = S[7*par + 3 + k];
+  if (free_jnt) {
+    const real* q = w.qpos() + qadr;
+    pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
+    quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
+    normquat(quat);
+    real ax[3] = {0, 0, 1}, axw[3];
+    rotvecquat(axw, ax, quat);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A[6*ja + k] = pos[k]; A[6*ja + 3 + k] = axw[k]; }
+    if (keep_axes) copy3(w.xaxis() + 3*ja, axw);
+  } else {
+    real t[3], qn[4];
+    rotvecquat(t, p, quat);
+    add3(pos, pos, t);
+    mulquat(qn, quat, r);
+    quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+    normquat(quat);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) S[7*b + k] = pos[k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) S[7*b + 3 + k] = quat[k];
+  copy3(w.xpos() + 3*b, pos);
+#pragma unroll
+  for (int k = 0; k < 4; k++) w.xquat()[4*b + k] = quat[k];
+}
+
 template <typename real>
 FBD void fk_pass(const DevModel<real>& M, const WS<real>& w, FB_LDS real* S, const FB_LDS real* JQ, FB_LDS real* A, int b1, int b2, int dlo, int dhi, int lane) {
   // a lane may own a second body (b2, on a DEEPER level than b1: fb_engine.hip pairs them) so that a model
   // with a few bodies beyond the wavefront width still takes one trip down the levels
-  bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
-  int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
-  int dep2 = has2 ? M.body_depth[has2 ? b2 : 0] : -1;
+  const bool has1 = b1 < M.nbody && b1 > 0, has2 = b2 < M.nbody && b2 > 0;
+  const int dep1 = has1 ? M.body_depth[has1 ? b1 : 0] : -1;
+  const int dep2 = has2 ? M.body_depth[has2 ? b2 : 0] : -1;
   const bool keep_axes = M.ds_qpos.p != nullptr;          // walk_imitation training mode: the reward reads the joint axes (fb_step.hpp)
-  // the record of the lane's own body is fetched before the level loop (every lane at once, one latency for the whole pass instead
-  // of one per level); only the few second bodies load theirs on their level
-  real R1[37];
+  // ---- local transforms of the lane's bodies (every lane at once; the second bodies -- a handful of lanes, one joint each on the fly --
+  // in a pass of their own that only runs the joint slots they have)
+  real p1[3], r1[4], p2[3] = {0, 0, 0}, r2[4] = {1, 0, 0, 0};
+  int par1, ja1, qa1, par2 = 0, ja2 = 0, qa2 = 0; bool fr1, fr2 = false;
   {
+    real R1[37];
     const real* rec = M.body_rec + (has1 ? b1 : 0)*FB_BODYREC;
 #pragma unroll
     for (int k = 0; k < 37; k++) R1[k] = rec[k];
+    par1 = (int)R1[0]; ja1 = (int)R1[1]; fr1 = R1[3] != 0; qa1 = (int)R1[36];
+    if (has1) fk_local(R1, JQ, A, p1, r1);
   }
+  if (has2) {
+    real R2[37];
+    const real* rec = M.body_rec + b2*FB_BODYREC;
+#pragma unroll
+    for (int k = 0; k < 37; k++) R2[k] = rec[k];
+    par2 = (int)R2[0]; ja2 = (int)R2[1]; fr2 = R2[3] != 0; qa2 = (int)R2[36];
+    fk_local(R2, JQ, A, p2, r2);
+  }
+  // ---- level loop: one composition per body
   for (int d = dlo; d <= dhi; d++) {
-    int b = (dep1 == d) ? b1 : b2;
-    if (dep1 == d || dep2 == d) {
-      // the body's flattened record (fb_engine.hip) and the free-joint pose.  A second body always sits DEEPER than the lane's own
-      // (fb_engine.hip pairs them that way): by its level the own record is dead and the second one is loaded over it -- the level
-      // body works on R1 itself, not on a per-level copy of 37 reals (74 moves x 14 levels: a quarter of the stage's instructions)
-      if (dep1 != d) {
-        const real* rec = M.body_rec + b*FB_BODYREC;
-#pragma unroll
-        for (int k = 0; k < 37; k++) R1[k] = rec[k];
-      }
-      const real* R = R1;
-      int par = (int)R[0], ja = (int)R[1], jn = (int)R[2];
-      bool free_jnt = R[3] != 0;
-      real pos[3], quat[4];
-      for (int k = 0; k < 3; k++) pos[k] = S[7*par + k];
-      for (int k = 0; k < 4; k++) quat[k] = S[7*par + 3 + k];
-      if (free_jnt) {
-        const real* q = w.qpos() + (int)R[36];
-        pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
-        quat[0] = q[3]; quat[1] = q[4]; quat[2] = q[5]; quat[3] = q[6];
-        normquat(quat);
-        real ax[3] = {0, 0, 1}, axw[3];
-        rotvecquat(axw, ax, quat);
-        for (int k = 0; k < 3; k++) { A[6*ja + k] = pos[k]; A[6*ja + 3 + k] = axw[k]; }
-        if (keep_axes) copy3(w.xaxis() + 3*ja, axw);
-      } else {
-        real t[3], qn[4];
-        rotvecquat(t, R + 4, quat);
-        add3(pos, pos, t);
-        mulquat(qn, quat, R + 7);
-        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        if (k < jn && !(free_jnt && k == 0)) {
-          int j = ja + k;
-          real qloc[4] = {JQ[4*j], JQ[4*j + 1], JQ[4*j + 2], JQ[4*j + 3]};
-          real anc[3], t[3], qn[4], axw[3];
-          rotvecquat(t, R + 18 + 6*k, quat);
-          add3(anc, t, pos);
-          rotvecquat(axw, R + 21 + 6*k, quat);
-          for (int c = 0; c < 3; c++) { A[6*j + c] = anc[c]; A[6*j + 3 + c] = axw[c]; }
-          if (keep_axes) copy3(w.xaxis() + 3*j, axw);
-          mulquat(qn, quat, qloc);
-          quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-          rotvecquat(t, R + 18 + 6*k, quat);
-          sub3(pos, anc, t);
-        }
-      }
-      normquat(quat);
-      for (int k = 0; k < 3; k++) S[7*b + k] = pos[k];
-      for (int k = 0; k < 4; k++) S[7*b + 3 + k] = quat[k];
-      copy3(w.xpos() + 3*b, pos);
-      for (int k = 0; k < 4; k++) w.xquat()[4*b + k] = quat[k];
-    }
+    if (dep1 == d) fk_compose(M, w, S, A, b1, par1, fr1, ja1, qa1, p1, r1, keep_axes);
+    if (dep2 == d) fk_compose(M, w, S, A, b2, par2, fr2, ja2, qa2, p2, r2, keep_axes);
     SYNC_LDS();                      // the next level reads the frames from LDS; the global copies are read after the pass
+  }
+}
+// joint anchors and axes from the parent frame of their body to the world (lane-parallel over the joints, after the level loop).
+// jpar[u]: parent body of the body joint lane + 64 u sits on (< 0: a free joint -- its anchor / axis are in the world already -- or none)
+template <typename real>
+FBD void fk_joints_to_world(const DevModel<real>& M, const WS<real>& w, const FB_LDS real* S, FB_LDS real* A, const int* jpar, int lane) {
+  const bool keep_axes = M.ds_qpos.p != nullptr;
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int j = lane + u*FB_WAVE;
+    if (jpar[u] >= 0) {
+      const int par = jpar[u];
+      const real P[3] = {S[7*par], S[7*par + 1], S[7*par + 2]}, Q[4] = {S[7*par + 3], S[7*par + 4], S[7*par + 5], S[7*par + 6]};
+      const real a[3] = {A[6*j], A[6*j + 1], A[6*j + 2]}, x[3] = {A[6*j + 3], A[6*j + 4], A[6*j + 5]};
+      real t[3], anc[3], axw[3];
+      rotvecquat(t, a, Q); add3(anc, P, t);
+      rotvecquat(axw, x, Q);
+#pragma unroll
+      for (int c = 0; c < 3; c++) { A[6*j + c] = anc[c]; A[6*j + 3 + c] = axw[c]; }
+      if (keep_axes) copy3(w.xaxis() + 3*j, axw);
+    }
   }
 }
 
@@ -230,12 +280,13 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
   // joint rotations, in two rounds of loads for BOTH joints of a lane (round 5; the branchy per-joint form -- type, then address, then
   // value behind a test -- was eight dependent waits): [type, address, axis] of joints l and l + 64, then the four position words
   // either kind of joint may need, unconditionally (a hinge uses the first, a ball all four, a free joint none: clamped, ignored)
+  int jpar[2];
   {
-    int jt[2], qa[2]; real ax[2][3], qv[2][4], q0[2]; bool jok[2];
+    int jt[2], qa[2], jb[2]; real ax[2][3], qv[2][4], q0[2]; bool jok[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int j = lane + u*FB_WAVE; jok[u] = j < M.njnt; const int js = jok[u] ? j : 0;
-      jt[u] = M.jnt_type[js]; qa[u] = M.jnt_qposadr[js];
+      jt[u] = M.jnt_type[js]; qa[u] = M.jnt_qposadr[js]; jb[u] = M.jnt_bodyid[js];
 #pragma unroll
       for (int k = 0; k < 3; k++) ax[u][k] = M.jnt_axis[3*js + k];
     }
@@ -245,7 +296,10 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
 #pragma unroll
       for (int k = 0; k < 4; k++) qv[u][k] = w.qpos()[min(qa[u] + k, nq - 1)];
       q0[u] = M.qpos0[qa[u]];
+      jpar[u] = M.body_parent[jb[u]];               // (for fk_joints_to_world: in flight with the joint positions)
     }
+#pragma unroll
+    for (int u = 0; u < 2; u++) if (!jok[u] || jt[u] == JNT_FREE) jpar[u] = -1;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int j = lane + u*FB_WAVE;
@@ -270,6 +324,7 @@ __device__ __forceinline__ void d_kinematics(const DevModel<real>& M, const WS<r
     fk_pass(M, w, S, JQ, A, lane, -1, 1, M.fk_dmax, lane);
     for (int b0 = FB_WAVE; b0 < M.nbody; b0 += FB_WAVE) fk_pass(M, w, S, JQ, A, lane + b0, -1, M.fk2_dlo, M.fk_dmax, lane);
   }
+  fk_joints_to_world(M, w, S, A, jpar, lane);
   PROF(25);
   SYNC_LDS();
   K_PROF(1);
