@@ -802,12 +802,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Two operand sets per launch: mode 0 = one product; mode 1 = two independent products of the same shape (blockIdx.z picks the set:
 // the two heads of the Gaussian policy, their two weight gradients); mode 2 = ONE output that is the sum of two products
 // C = A0 B0 + A1 B1 (waves 0-1 take set 0, waves 2-3 set 1: the gradient wrt the torso output that feeds both heads).
-struct GemmOp { const float* a; const float* b; float* c; const float* bias; long long sai, sak, sbk, sbj; int epi; float p0, p1; };
+struct GemmOp { const float* a; const float* b; float* c; const float* bias; long long sai, sak, sbk, sbj; int epi; float p0, p1;
+                const float* am; float* asum; };
+// Round 6: am != null -- operand A is multiplied, as it is loaded, by ELU'(.) of the layer OUTPUT am (same indexing as a): A(i, k) <- a ELU'
+// with ELU' = 1 (y > 0) / y + 1, i.e. the backward pass's d z = d y ELU'(y) never exists in memory; asum != null -- the row sums of that
+// operand (sum over k, the launch's first column of tiles writes them) leave with the product: for d W = d z^T x they are d bias.  Both
+// together replace the bias-ELU backward launch in front of every d x | d W pair (4 launches per learner step).
 
 template <bool AV, bool BV>                   // operand is k-contiguous (stride 1 along k): 16-byte loads
 #define GW 4                                  // wavefronts per workgroup (K is split GW ways)
 __global__ void __launch_bounds__(64*GW) k_sgemm(GemmOp o0, GemmOp o1, int mode, long long ldc, int M, int N, int K) {
   __shared__ float red[GW][16][WAVE];
+  __shared__ float rs[GW][WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.y*32, j0 = blockIdx.x*32;
   const bool in1 = (mode == 1 && blockIdx.z == 1) || (mode == 2 && wv >= 2);          // which operand set this wave reads
@@ -820,6 +826,9 @@ __global__ void __launch_bounds__(64*GW) k_sgemm(GemmOp o0, GemmOp o1, int mode,
   const int ia = min(i0 + r, M - 1), jb = min(j0 + r, N - 1);           // (rows / columns past the edge read a valid one; their results are not stored)
   const float* pa = a + (long long)ia*sai;
   const float* pb = b + (long long)jb*sbj;
+  const float* am = in1 ? o1.am : o0.am;
+  const float* pm = am ? am + (long long)ia*sai : nullptr;
+  float rsum = 0.f;
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k0 = kb; k0 < ke; k0 += 8*GB) {
     float av[GB][4], bv[GB][4];
@@ -849,6 +858,22 @@ __global__ void __launch_bounds__(64*GW) k_sgemm(GemmOp o0, GemmOp o1, int mode,
         }
       }
     }
+    if (pm) {                                                            // (wave-uniform) ELU' of the layer output on operand A, row sums on the side
+#pragma unroll
+      for (int s = 0; s < GB; s++) {
+        const int k = k0 + 8*s + 4*h;
+        if (k0 + 8*s < ke) {
+          float yv[4];
+          if (AV && k + 3 < ke) { const float4 t = *reinterpret_cast<const float4*>(pm + k); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const bool ok = k + q < ke; yv[q] = ok ? pm[(long long)(ok ? k + q : kb)*sak] : 0.f; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) { av[s][q] *= (yv[q] > 0.f ? 1.f : yv[q] + 1.f); rsum += av[s][q]; }
+        }
+      }
+    }
 #pragma unroll
     for (int s = 0; s < GB; s++) {
       if (k0 + 8*s < ke) {
@@ -859,7 +884,18 @@ __global__ void __launch_bounds__(64*GW) k_sgemm(GemmOp o0, GemmOp o1, int mode,
   }
 #pragma unroll
   for (int v = 0; v < 16; v++) red[wv][v][lane] = acc[v];
+  rs[wv][lane] = rsum;
   __syncthreads();
+  {
+    // row sums of operand A (d bias of the d W product): the first column of tiles writes them, K-split waves and lane halves summed in a fixed order
+    float* asum = out1 ? o1.asum : o0.asum;
+    if (asum && blockIdx.x == 0 && wv == 0 && lane < 32 && i0 + lane < M && mode != 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < GW; w++) t += rs[w][lane] + rs[w][lane + 32];
+      asum[i0 + lane] = t;
+    }
+  }
   float* c = out1 ? o1.c : o0.c; const float* bias = out1 ? o1.bias : o0.bias;
   const int epi = out1 ? o1.epi : o0.epi; const float p0 = out1 ? o1.p0 : o0.p0, p1 = out1 ? o1.p1 : o0.p1;
   // C/D map of the 32x32 MFMA: register v of lane l is C[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31]
@@ -887,7 +923,9 @@ static int gemm_launch(const fbl_gemm_op* q0, const fbl_gemm_op* q1, int mode, i
     if (!q[z] || !q[z]->a || !q[z]->b) return lfail("fbl_sgemm: null operand");
     if (q[z]->epilogue < 0 || q[z]->epilogue > 3 || (q[z]->epilogue && !q[z]->bias)) return lfail("fbl_sgemm: bad epilogue");
     o[z].a = q[z]->a; o[z].b = q[z]->b; o[z].c = q[z]->c; o[z].bias = q[z]->bias; o[z].sai = q[z]->sai; o[z].sak = q[z]->sak; o[z].sbk = q[z]->sbk; o[z].sbj = q[z]->sbj;
-    o[z].epi = q[z]->epilogue; o[z].p0 = q[z]->p0; o[z].p1 = q[z]->p1;
+    o[z].epi = q[z]->epilogue; o[z].p0 = q[z]->p0; o[z].p1 = q[z]->p1; o[z].am = q[z]->a_elu_of; o[z].asum = q[z]->a_rowsum;
+    if (mode == 2 && (o[z].am || o[z].asum)) return lfail("fbl_sgemm_pair: the operand transform is not available for summed products");
+    if (o[z].asum && !o[z].am) return lfail("fbl_sgemm: a_rowsum needs a_elu_of (the row sums are those of the transformed operand)");
   }
   if (!o[0].c || (mode == 1 && !o[1].c) || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return lfail("fbl_sgemm: bad argument");
   const dim3 grid((N + 31)/32, (M + 31)/32, mode == 1 ? 2 : 1);
@@ -903,8 +941,11 @@ static int gemm_launch(const fbl_gemm_op* q0, const fbl_gemm_op* q1, int mode, i
 extern "C" int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t sbk, int64_t sbj, float* c, int64_t ldc, int M, int N, int K,
                          int epilogue, const float* bias, void* stream) {
   if (epilogue > 2) return lfail("fbl_sgemm: bad argument");
-  fbl_gemm_op o = {a, b, c, bias, sai, sak, sbk, sbj, epilogue, 0.f, 0.f};
+  fbl_gemm_op o = {a, b, c, bias, sai, sak, sbk, sbj, epilogue, 0.f, 0.f, nullptr, nullptr};
   return gemm_launch(&o, nullptr, 0, ldc, M, N, K, stream);
+}
+extern "C" int fbl_sgemm_op(const fbl_gemm_op* op, int64_t ldc, int M, int N, int K, void* stream) {
+  return gemm_launch(op, nullptr, 0, ldc, M, N, K, stream);
 }
 extern "C" int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream) {
   return gemm_launch(op0, op1, sum ? 2 : 1, ldc, M, N, K, stream);

@@ -25,7 +25,8 @@ class LearnerLibError(RuntimeError):
 
 class _GemmOp(C.Structure):
     _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('bias', C.c_void_p), ('sai', C.c_int64), ('sak', C.c_int64),
-                ('sbk', C.c_int64), ('sbj', C.c_int64), ('epilogue', C.c_int32), ('p0', C.c_float), ('p1', C.c_float)]
+                ('sbk', C.c_int64), ('sbj', C.c_int64), ('epilogue', C.c_int32), ('p0', C.c_float), ('p1', C.c_float),
+                ('a_elu_of', C.c_void_p), ('a_rowsum', C.c_void_p)]
 
 
 class _MpoArgs(C.Structure):
@@ -67,6 +68,7 @@ def lib():
         L.fbl_policy_tail.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p]*8 + [C.c_int, C.c_float, C.c_float] + [C.c_void_p]*5
         L.fbl_nstep_add.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int64, C.c_int, C.c_int] + [C.c_void_p]*23
         L.fbl_sgemm_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.fbl_sgemm_op.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.fbl_gauss_head_bwd_std.argtypes = [C.c_void_p]*3 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p]*4
         L.fbl_gemm_nt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.fbl_gemm_longk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -350,6 +352,13 @@ def _sgemm(a, sai, sak, b, sbk, sbj, M, N, K, epilogue=0, bias=None):
     return c
 
 
+# Round 6 experiment, measured and left OFF: d z = d y ELU'(y) formed inside the d x | d W products (operand transform of fbl_sgemm) and
+# d bias taken from the d W product's row sums -- 4 launches fewer per learner step, but the products read a second operand stream and the
+# step got SLOWER: 4 100 against 4 280 learner steps/s (three runs each, profiles/r6/learner_fused_elu_bwd.txt).  The chains of the step
+# are bound by the duration of their ~6 us kernels, not by the number of launches.  FB_LEARNER_FUSED_ELU_BWD=1 switches it on.
+_FUSED_ELU_BWD = os.environ.get('FB_LEARNER_FUSED_ELU_BWD', '0') == '1'
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (act None) or ELU(x W^T + bias) (act 'elu') through fbl_sgemm; backward d x = d z W, d W = d z^T x on the same kernel."""
 
@@ -363,22 +372,28 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dy = _f32c(dy); M, K = x.shape; N = w.shape[0]
-        db = None
-        if ctx.elu:                                               # d z = d y ELU'(.), d bias = column sums of d z: one launch
-            dz = torch.empty_like(dy); db = zero_pool.take(N, device=dy.device)
+        dy = _f32c(dy); M, K = x.shape; N = w.shape[0]; dev = dy.device
+        nx, nw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ye = y if ctx.elu else None                                # d z = d y ELU'(y) is formed INSIDE the products (operand transform of
+        db = torch.empty(N, device=dev) if (ctx.elu and nw) else None   # fbl_sgemm), d bias = the row sums of d z^T leaves with d W: no launch of its own
+        if ctx.elu and (not nw or not _FUSED_ELU_BWD):            # (bias gradient without a weight gradient: not a case of the learner; keep the plain kernel)
+            dz = torch.empty_like(dy); db = zero_pool.take(N, device=dev)
             _check(lib().fbl_bias_elu_bwd(dy.data_ptr(), y.data_ptr(), M, N, dz.data_ptr(), db.data_ptr(), _stream()))
-        else:
-            dz = dy
-        if M == N and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dy = dz; ye = None
+        if M == N and nx and nw:
             # batch = layer width (the 256-wide layers at B = 256): d x [M, K] = d z W and d W [N, K] = d z^T x have the SAME shape and
             # reduction length -- one launch with the two products side by side in the grid instead of two launches one after the other
-            dx = torch.empty(M, K, device=dy.device); dw = torch.empty(N, K, device=dy.device)
-            o0 = _op(dz, N, 1, w, K, 1, dx); o1 = _op(dz, 1, N, x, K, 1, dw)
+            dx = torch.empty(M, K, device=dev); dw = torch.empty(N, K, device=dev)
+            o0 = _op(dy, N, 1, w, K, 1, dx, a_elu_of=ye); o1 = _op(dy, 1, N, x, K, 1, dw, a_elu_of=ye, a_rowsum=db if ye is not None else None)
             _check(lib().fbl_sgemm_pair(C.byref(o0), C.byref(o1), 0, K, M, K, N, _stream()))
             return dx, dw, db, None
-        dx = _sgemm(dz, N, 1, w, K, 1, M, K, N) if ctx.needs_input_grad[0] else None          # [M, K] = d z [M, N] W [N, K]
-        dw = _sgemm(dz, 1, N, x, K, 1, N, K, M) if ctx.needs_input_grad[1] else None          # [N, K] = d z^T [N, M] x [M, K]
+        dx = dw = None
+        if nx:                                                    # [M, K] = d z [M, N] W [N, K]
+            dx = torch.empty(M, K, device=dev); o0 = _op(dy, N, 1, w, K, 1, dx, a_elu_of=ye)
+            _check(lib().fbl_sgemm_op(C.byref(o0), K, M, K, N, _stream()))
+        if nw:                                                    # [N, K] = d z^T [N, M] x [M, K]
+            dw = torch.empty(N, K, device=dev); o1 = _op(dy, 1, N, x, K, 1, dw, a_elu_of=ye, a_rowsum=db if ye is not None else None)
+            _check(lib().fbl_sgemm_op(C.byref(o1), K, N, K, M, _stream()))
         return dx, dw, db, None
 
 
@@ -498,9 +513,12 @@ class _GaussHead(torch.autograd.Function):
         return dmean, dzs, db[0], db[1], None, None
 
 
-def _op(a, sai, sak, b, sbk, sbj, c=None, bias=None, epilogue=0, p0=0.0, p1=0.0):
+def _op(a, sai, sak, b, sbk, sbj, c=None, bias=None, epilogue=0, p0=0.0, p1=0.0, a_elu_of=None, a_rowsum=None):
+    """a_elu_of: the ELU layer's output, indexed like `a` -- operand A is a ELU'(output) (the backward pass's d z, never stored);
+    a_rowsum: receives the row sums of that operand (d bias of a d W product)."""
     return _GemmOp(a.data_ptr(), b.data_ptr(), c.data_ptr() if c is not None else None, bias.data_ptr() if bias is not None else None,
-                   sai, sak, sbk, sbj, epilogue, p0, p1)
+                   sai, sak, sbk, sbj, epilogue, p0, p1, a_elu_of.data_ptr() if a_elu_of is not None else None,
+                   a_rowsum.data_ptr() if a_rowsum is not None else None)
 
 
 class _GaussHeadLinear(torch.autograd.Function):

@@ -112,8 +112,15 @@ int fbl_sgemm(const float* a, int64_t sai, int64_t sak, const float* b, int64_t 
  * epilogue (0 none, 1 + bias, 2 ELU(. + bias), 3 softplus(. + bias) p0 + p1) -- the two heads of the Gaussian policy and their two
  * weight gradients.  sum != 0: op0->c = A0 B0 + A1 B1 (op1->c unused; op0's epilogue) -- the gradient wrt the torso output feeding both
  * heads.  Both sets must have the same k-contiguity (sak == 1 / sbk == 1). */
-typedef struct fbl_gemm_op { const float* a; const float* b; float* c; const float* bias; int64_t sai, sak, sbk, sbj; int32_t epilogue; float p0, p1; } fbl_gemm_op;
+typedef struct fbl_gemm_op { const float* a; const float* b; float* c; const float* bias; int64_t sai, sak, sbk, sbj; int32_t epilogue; float p0, p1;
+                             /* backward pass of an ELU layer without a launch of its own (round 6; NULL: off).  a_elu_of: the layer's OUTPUT y, indexed like a --
+                              * operand A becomes a ELU'(y) (ELU' = 1 for y > 0, y + 1 otherwise) as it is loaded, i.e. d z = d y ELU'(y) is never stored;
+                              * a_rowsum[M]: receives sum_k A(i, k) of that operand -- for d W = d z^T x this is d bias (agents/learning_dmpo.py:266-288: the
+                              * gradients tape.gradient returns for the Dense layers of network_factory.py:82-103).  Not with sum != 0. */
+                             const float* a_elu_of; float* a_rowsum; } fbl_gemm_op;
 int fbl_sgemm_pair(const fbl_gemm_op* op0, const fbl_gemm_op* op1, int sum, int64_t ldc, int M, int N, int K, void* stream);
+/* ONE product described by an operand set (fbl_sgemm with the set's epilogue parameters and operand transform). */
+int fbl_sgemm_op(const fbl_gemm_op* op, int64_t ldc, int M, int N, int K, void* stream);
 /* Large forward GEMM, LDS-tiled (80 x 128 or 80 x 64 outputs per workgroup, K in double-buffered blocks of 32): c[M, N] = epilogue(a[M, K] w[N, K]^T), both
  * operands k-contiguous with row strides lda / ldw (any value >= K: unaligned rows are fine), c row stride ldc.  epilogue 0: none, 1: + bias[j],
  * 2: ELU(. + bias[j]).  The N x B = 5120-row products of the target critic (learning_dmpo.py:223-251) run here instead of a BLAS library

@@ -337,12 +337,14 @@ def test_glue_kernels():
 
 
 @pytest.mark.parametrize('M,K,N', [(256, 741, 256), (256, 256, 256), (256, 800, 512), (256, 512, 512), (256, 256, 59), (256, 256, 51), (37, 203, 45), (64, 5, 33)])
-def test_small_mfma_gemm(M, K, N):
+def test_small_mfma_gemm(M, K, N, monkeypatch):
     """fbl_sgemm (v_mfma_f32_32x32x2_f32, one 32 x 32 tile per workgroup, K split over four waves) against torch.matmul in FP64 --
     forward with both epilogues, and the two backward products -- at the network's shapes and at ragged ones."""
     from flybody_amd.dmpo import fused
     torch.manual_seed(11)
     dev = 'cuda'
+    # (half of the shapes with the ELU backward formed inside the products -- the operand transform + row sums of fbl_sgemm, off by default)
+    monkeypatch.setattr(fused, '_FUSED_ELU_BWD', (M + K + N) % 2 == 1 or K == 512)
     x = torch.randn(M, K, device=dev, requires_grad=True); w = (torch.randn(N, K, device=dev)/math.sqrt(K)).requires_grad_(True)
     b = torch.randn(N, device=dev, requires_grad=True); up = torch.randn(M, N, device=dev)
     ref = lambda t: t.detach().double()
