@@ -10,6 +10,7 @@ task = os.environ.get('FB_TASK', 'walk_imitation'); M = engine.Model.from_asset(
 B = engine.Batch(M, n, precision=prec)
 if task == 'flight_imitation':
     from flybody_amd.fly_envs import BatchedFlyEnv
+    engine.HIP_LIB_DENSE = lib; engine.HIP_LIB = lib          # (the environment picks its build by these: time the library that was asked for)
     env = BatchedFlyEnv(n_env=n, precision=prec, terminal_com_dist=2.0, joint_filter=0.0, future_steps=5, time_limit=0.6, task=task)
     B = env.batch; B.reset()
 else:
