@@ -26,6 +26,21 @@ def test_library_exports_header_symbols(which):
         assert hasattr(lib, s), f'{s} declared in flybody_engine.h but not exported'
 
 
+def test_learner_library_exports_header_symbols():
+    """libflybody_learner.so exports every entry point include/flybody_learner.h declares (no compute calls without a GPU)."""
+    import __graft_entry__ as g
+    hdr = open(os.path.join(ROOT, 'include', 'flybody_learner.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    syms = sorted(set(re.findall(r'\b(fbl_[a-z_0-9]+)\s*\(', hdr)))
+    lib = C.CDLL(g.build_learner())
+    assert len(syms) >= 20 and 'fbl_sgemm_op' in syms and 'fbl_mpo_loss' in syms
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in flybody_learner.h but not exported'
+    lib.fbl_version.restype = C.c_char_p
+    from flybody_amd.dmpo import fused
+    assert fused.source_hash().encode() in lib.fbl_version()          # the binary names the sources it was built from
+
+
 def test_model_load_and_argument_validation(walk_arrays):
     from flybody_amd import engine
     M = engine.Model(walk_arrays)
