@@ -8,7 +8,7 @@ python -c "import flybody_amd.engine as e; print(e.version())" > $O/version.txt 
 timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_tests_full.txt 2>&1; tail -5 $O/gpu_tests_full.txt > $O/gpu_tests.txt
 timeout 1500 bash tools/collect_profiles.sh final > $O/collect.log 2>&1
 timeout 600 bash tools/calibrate_traffic.sh final > $O/calibrate.log 2>&1
-python tools/publish_round_evidence.py ${ROUND_TAG:-r5} --traffic-only > $O/traffic_publish.log 2>&1
+python tools/publish_round_evidence.py ${ROUND_TAG:-r6} --traffic-only > $O/traffic_publish.log 2>&1
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary-configs > $O/bench_steps20.json 2> $O/bench_steps20.err
 timeout 900 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary-configs > $O/bench_1000_steps.json 2> $O/bench_1000_steps.err
