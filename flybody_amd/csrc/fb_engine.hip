@@ -1336,6 +1336,14 @@ extern "C" int fb_batch_forward(fb_batch* b, void* stream) {
   return launch(b, MODE_FORWARD, nullptr, nullptr, b->n_env, 0, stream);
 }
 
+// The streams a batch was validated on are remembered by handle.  A caller that DESTROYS a stream must say so: a new stream (possibly with a
+// CU mask that hides an XCD) may reuse the handle and would skip the probe -- its unreachable ticket queues would never be drawn.
+extern "C" int fb_batch_forget_stream(fb_batch* b, void* stream) {
+  if (!b) return fail("fb_batch_forget_stream: null batch");
+  b->probed_streams.erase(std::remove(b->probed_streams.begin(), b->probed_streams.end(), stream), b->probed_streams.end());
+  return 0;
+}
+
 // substep scheduler: a control step that abandoned tickets (capped wait, k_fly) left environments half-stepped -- sticky failure
 static int check_sched_errors(fb_batch* b) {
   int n = 0;

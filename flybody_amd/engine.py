@@ -100,6 +100,8 @@ def load_library(lib_path: Optional[str] = None) -> C.CDLL:
     L.fb_batch_device_ptr.argtypes = [C.c_void_p, C.c_int]; L.fb_batch_device_ptr.restype = C.c_void_p
     L.fb_batch_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_scheduler.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.fb_batch_scheduler.restype = C.c_int
+    if hasattr(L, 'fb_batch_forget_stream'):
+        L.fb_batch_forget_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_batch_timing_begin.argtypes = [C.c_void_p, C.c_void_p]
     L.fb_random_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.fb_batch_timing_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -309,6 +311,10 @@ class Batch:
     @property
     def resident_slots(self) -> int:
         n = C.c_int(); self.L.fb_batch_scheduler(self.h, C.byref(n)); return n.value
+
+    def forget_stream(self, stream):
+        """Before destroying a HIP stream the batch was stepped on (the validated streams are remembered by handle: fb_batch_forget_stream)."""
+        _check(self.L, self.L.fb_batch_forget_stream(self.h, stream))
 
     def timing_begin(self, stream=None):
         _check(self.L, self.L.fb_batch_timing_begin(self.h, stream))

@@ -199,6 +199,10 @@ int fb_batch_timing_launches(fb_batch* b, float* ms, int cap);
  * waves draw (environment, substep) tickets per XCD until the step is complete), 0 = one environment per wave, longest first.
  * Scheduling only: results are identical.  `slots` (may be NULL) receives the number of resident environments of this build. */
 int fb_batch_scheduler(const fb_batch* b, int* slots);
+/* fb_batch_step validates every stream ONCE (a probe kernel checks that the stream reaches every XCD: a CU-masked stream would leave ticket
+ * queues undrawn) and remembers the handle.  Call this before destroying a stream the batch was stepped on: a later stream that reuses the
+ * handle is then probed again.  (NULL / unknown streams: no-op.) */
+int fb_batch_forget_stream(fb_batch* b, void* stream);
 
 /* Synthetic random actions for throughput rollouts (per-environment RNG = Philox(seed, stream = env id)):
  * fills the DEVICE array action[n_env][nact] (float32) for control step `step`.  One Philox4x32-10 stream per GLOBAL environment id

@@ -396,3 +396,14 @@ def test_capped_scheduler_wait_abandons_the_ticket_and_fails_loudly(walk_arrays,
         B.get('QPOS')
     w = B.get('WARN_EVER').ravel()                          # the flags stay readable: they say which environments
     assert ((w & engine.WARN_BITS['SCHED_WAIT']) != 0).all()
+
+
+def test_forget_stream_is_accepted(emu_model, reference_traj):
+    """fb_batch_forget_stream (validated streams are cached by handle): unknown / NULL handles are a no-op, stepping goes on."""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    B = engine.Batch(emu_model, 3, precision=64)
+    B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+    a = np.zeros((3, 59), np.float32)
+    B.step_ptr(a.ctypes.data); B.forget_stream(None); B.forget_stream(12345); B.step_ptr(a.ctypes.data)
+    assert np.isfinite(B.get('QPOS')).all()
