@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Is the learner's pipelined step bound by the HOST (graph launches, events)?  Time for the Python loop to return against time until the
+GPU is done, per step (profiles/r6/learner_leave_one_out.txt: 145 us against 237 us -- no)."""
 import os, sys, time, runpy
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch

@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""What would fusing / removing a kernel of the learner step be worth AT MOST?  Runs tools/learner_bench.py with selected kernels LEFT OUT
+(their outputs replaced by cached tensors: the results are WRONG, only the timing is meaningful):
+    SKIP=ha            the action-half GEMM of the target critic (5120 x 59 x 512, 24 us)
+    SKIP=ha,l2,l3      all three 5120-row products of the target critic (74 us)
+    SKIP=adam          the optimizer launch (13.6 us)
+    python tools/learner_leave_one_out.py          (SKIP in the environment; profiles/r6/learner_leave_one_out.txt)"""
 import os, sys, runpy
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
