@@ -472,7 +472,7 @@ FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) 
   const int g1 = pw & 1023, g2 = (pw >> 10) & 1023;
   if ((pw >> 20) & 1023) return true;                            // plane pairs go straight to the narrow phase
   real e1[3], e2[3], c1[3], c2[3], m1[9], m2[9];
-  const FB_LDS real* G = w.lAR;
+  const FB_LDS real* G = w.lAR();
 #pragma unroll
   for (int k = 0; k < 3; k++) { e1[k] = M.geom_box[3*g1 + k]; e2[k] = M.geom_box[3*g2 + k]; c1[k] = G[4*g1 + k]; c2[k] = G[4*g2 + k]; }
 #pragma unroll
@@ -590,7 +590,7 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   // ---- mid phase: bounding spheres.  The spheres {centre, radius} of all geoms and the normals of the planes are staged
   // in LDS first (slot of the Delassus matrix, not live yet), the pair list is a packed word per pair fetched four wave
   // passes at a time: ~10 global round trips per substep instead of two dependent ones for each of the 34 passes.
-  FB_LDS real* G = w.lAR;
+  FB_LDS real* G = w.lAR();
   for (int g = lane; g < M.ngeom; g += FB_WAVE) {
     const real* c = w.gxpos() + 3*g;
     real x = c[0], y = c[1], z = c[2], rb = M.geom_rbound[g];

@@ -212,7 +212,7 @@ FBD void project_row(const DevModel<real>& M, const WS<real>& w, int side, int r
   int chain[FB_MAXCH], rowadr[FB_MAXCH];
   load_chain(M, body, chain);
 #pragma unroll
-  for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr[chain[s]] + s; }
+  for (int s = 0; s < FB_MAXCH; s++) { y[s] = (s < len) ? w.efc_J()[JIDX(side, s, r)] : (real)0; rowadr[s] = (int)w.lmadr()[chain[s]] + s; }
   // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t.  The bound is the wave-uniform longest chain: a slot beyond
   // the lane's own chain carries y[s] = 0 and reads a trunk row (chain[] is padded with dof 0: finite factor entries), so it subtracts
   // exact zeros -- cheaper than an exec-mask round trip per slot for the lane-varying `s < len`
@@ -301,8 +301,8 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
   //   2. here: sqrt(1/D), dead when the projection returns;
   //   3. d_constraint_a: the tail of Newton's work matrix K when K runs on behind the Delassus matrix (k_in_slot);
   //   4. d_constraint_a: J^T f, the right-hand side of the solve that follows.
-  FB_LDS real* sd = w.lx;
-  for (int i = lane; i < M.nv; i += FB_WAVE) sd[i] = sqrt(w.lLD[w.lmadr[i]]);          // 1/D of the dof: diagonal slot = start of its row
+  FB_LDS real* sd = w.lx();
+  for (int i = lane; i < M.nv; i += FB_WAVE) sd[i] = sqrt(w.lLD[w.lmadr()[i]]);          // 1/D of the dof: diagonal slot = start of its row
   SYNC();
   if (nefc <= FB_WAVE) {
     // lane == row == column: the rows' Y never leave the registers (no efc_Y round trip through the environment's global row)
@@ -311,7 +311,7 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
     if (lane < nefc) { bA = w.efc_bA()[lane]; bB = w.efc_bB()[lane]; lA = w.efc_lA()[lane]; lB = w.efc_lB()[lane]; }
     project_row(M, w, 0, lane < nefc ? lane : 0, bA, lA, sd, yA);
     project_row(M, w, 1, lane < nefc ? lane : 0, bB, lB, sd, yB);
-    if (nefc <= LdsCfg<real>::AR_ROWS) ar_from_registers(M, w, w.lAR, nefc, lane, yA, yB, bA, bB, lA, lB);
+    if (nefc <= LdsCfg<real>::AR_ROWS) ar_from_registers(M, w, w.lAR(), nefc, lane, yA, yB, bA, bB, lA, lB);
     else ar_from_registers(M, w, w.AR(), nefc, lane, yA, yB, bA, bB, lA, lB);
     return;
   }
@@ -413,7 +413,7 @@ FB_STAGE_B void d_build_AR(const DevModel<real>& M_, const WS<real>& w_, ARP AR,
 // (the solve vector, free until the smooth right-hand side is formed from it) and stored to the global row once, behind the last use.
 template <typename real>
 __device__ __forceinline__ void d_actuation(const DevModel<real>& M, const WS<real>& w, int lane) {
-  FB_LDS real* qf = w.lx;                     // qfrc_actuator while it is being assembled (ST_ACC_PRE reads it from here)
+  FB_LDS real* qf = w.lx();                     // qfrc_actuator while it is being assembled (ST_ACC_PRE reads it from here)
   FB_LDS real* Lc = w.lLD;                    // [6 nv] motion axes (cdof), re-staged for the adhesion moment arms
   for (int i = lane; i < M.nv; i += FB_WAVE) qf[i] = 0;
   SYNC_LDS();                                 // (the zeroes before the transmissions' stores below; no memory operation is in flight yet)
@@ -988,7 +988,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
   int nefc = w.istate()[IS_NEFC];
   int nv = M.nv;
   if (nefc == 0) {
-    for (int i = lane; i < nv; i += FB_WAVE) { w.lx[i] = 0; w.qfrc_constraint()[i] = 0; }
+    for (int i = lane; i < nv; i += FB_WAVE) { w.lx()[i] = 0; w.qfrc_constraint()[i] = 0; }
     if (lane == 0) w.istate()[IS_NITER] = 0;
     SYNC();
     return false;
@@ -1085,7 +1085,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
       for (int i = lane; i < tri; i += FB_WAVE) w.lLD[i] = src[i];
       SYNC();
     }
-    const FB_LDS real* arp = wide ? (const FB_LDS real*)w.lLD : (const FB_LDS real*)w.lAR;
+    const FB_LDS real* arp = wide ? (const FB_LDS real*)w.lLD : (const FB_LDS real*)w.lAR();
     if (newton) {
       const WS<real> wc = w;               // (the callee is not inlined: hand it a copy, the caller's descriptor stays in registers)
       // (two instantiations by system size: <= FB_NEWTON_NT rows -- 93 % of the solves -- runs the register-tile code alone, the rest the
@@ -1095,8 +1095,8 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
 #else
       constexpr int MT = 0, MR = 0;
 #endif
-      if (k_in_slot && nefc <= FB_NEWTON_NT) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MT>(M, wc, arp, w.lAR + tri, nefc, lane);
-      else if (k_in_slot) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lAR + tri, nefc, lane);
+      if (k_in_slot && nefc <= FB_NEWTON_NT) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MT>(M, wc, arp, w.lAR() + tri, nefc, lane);
+      else if (k_in_slot) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lAR() + tri, nefc, lane);
       else if (!wide) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lLD, nefc, lane);
       else if (2*tri <= FB_LDS_SCRATCH + LdsCfg<real>::AR_ELEMS) niter = d_newton<real, const FB_LDS real*, FB_LDS real*, MR>(M, wc, arp, w.lLD + tri, nefc, lane);
       else niter = d_newton<real, const FB_LDS real*, real*, MR>(M, wc, arp, w.AR() + tri, nefc, lane);
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; if (i < nv) { w.qfrc_constraint()[i] = acc[q]; w.lx[i] = acc[q]; } }
+    for (int q = 0; q < 2; q++) { int i = lane + q*FB_WAVE; if (i < nv) { w.qfrc_constraint()[i] = acc[q]; w.lx()[i] = acc[q]; } }
     SYNC();
   } else {
   for (int i = lane; i < nv; i += FB_WAVE) w.qfrc_constraint()[i] = 0;
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
     }
   }
   SYNC();
-  for (int i = lane; i < nv; i += FB_WAVE) w.lx[i] = w.qfrc_constraint()[i];
+  for (int i = lane; i < nv; i += FB_WAVE) w.lx()[i] = w.qfrc_constraint()[i];
   SYNC();
   }
   PROF(P_CFIN);
@@ -1204,6 +1204,6 @@ __device__ __forceinline__ bool d_constraint_a(const DevModel<real>& M, const WS
 // qacc = qacc_smooth + M^-1 J^T f (lx), also saved as the next warm start
 template <typename real>
 __device__ __forceinline__ void d_constraint_b(const DevModel<real>& M, const WS<real>& w, int lane) {
-  for (int i = lane; i < M.nv; i += FB_WAVE) { real a = w.qacc_smooth()[i] + w.lx[i]; w.qacc()[i] = a; w.qacc_ws()[i] = a; }
+  for (int i = lane; i < M.nv; i += FB_WAVE) { real a = w.qacc_smooth()[i] + w.lx()[i]; w.qacc()[i] = a; w.qacc_ws()[i] = a; }
   SYNC();
 }

@@ -41,7 +41,7 @@ struct fb_model {
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, pair_body, plane_geoms;
   std::vector<double> geom_box;          // [ngeom][3] oriented-box half extents by geom type (constant: one lookup instead of type -> size -> switch)
-  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band; int ngen = 0, ntrunk = 1;
+  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band, fac_dof; int ngen = 0, ntrunk = 1;
   int nlevel;
   std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom, sens_body, dof_jump, dof_vbef, body_veldof;
@@ -340,6 +340,19 @@ static int model_load_impl(fb_model* m, size_t n) {
         }
       m->fac_band[2*d] = (int)pub; m->fac_band[2*d + 1] = (int)pull;
     }
+    // rows of the factorisation / the solves per lane, dealt by depth: the 64 shallowest dofs outside the trunk are the lanes' first rows
+    // (in dof order, so that neighbouring lanes still hold neighbouring rows), the deeper ones their second rows (fb_smooth.hpp: fac_dof)
+    {
+      std::vector<int> order;
+      for (int i = m->ntrunk; i < nv; i++) order.push_back(i);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m->dof_depth[a] < m->dof_depth[b]; });
+      if ((int)order.size() > 2*FB_WAVE) { return fail("fb_model_load: more dofs than two rows per lane"); }
+      std::vector<int> first(order.begin(), order.begin() + std::min<size_t>(order.size(), FB_WAVE)), second(order.begin() + std::min<size_t>(order.size(), FB_WAVE), order.end());
+      std::sort(first.begin(), first.end()); std::sort(second.begin(), second.end());
+      m->fac_dof.assign(2*FB_WAVE, 255);
+      for (size_t k = 0; k < first.size(); k++) m->fac_dof[k] = first[k];
+      for (size_t k = 0; k < second.size(); k++) m->fac_dof[FB_WAVE + k] = second[k];
+    }
   }
   const int* trn = m->i("actuator_trntype");
   for (int k = 0; k < m->nu; k++) if (trn[k] == TRN_BODY) m->adh_act.push_back(k);
@@ -540,19 +553,15 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
   if (threadIdx.x == 0 && mode == 12345) s_pad[blockIdx.x % FB_LDS_PAD] = 1;
 #endif
   // elimination-tree tables shared by the workgroup's environments ("joint tree staged in LDS")
-  __shared__ uint8_t s_depth[FB_MAXNV];
-  __shared__ uint8_t s_cl[FB_MAXNV];
-  __shared__ uint8_t s_gen[FB_MAXNV];
-  __shared__ uint16_t s_madr[FB_MAXNV + 1];
-  __shared__ uint32_t s_gk[FB_LGEN*FB_MAXCH];
-  __shared__ uint32_t s_gm[FB_LGEN*FB_MAXCH*2];
+  __shared__ LdsTab s_tab;
   // the model lives in constant memory: its fields (sizes, table pointers, workspace offsets) are scalar loads
   const DevModel<real>& M = as_constant(*Mp);
   int tid = threadIdx.x;
   for (int i = tid; i < M.nv; i += FB_WAVE*EPB) {
-    s_depth[i] = (uint8_t)M.dof_depth[i]; s_cl[i] = (uint8_t)M.dof_cl[i]; s_gen[i] = (uint8_t)M.dof_gen[i]; s_madr[i] = (uint16_t)M.dof_Madr[i];
+    s_tab.depth[i] = (uint8_t)M.dof_depth[i]; s_tab.cl[i] = (uint8_t)M.dof_cl[i]; s_tab.gen[i] = (uint8_t)M.dof_gen[i]; s_tab.madr[i] = (uint16_t)M.dof_Madr[i];
   }
-  for (int i = tid; i < FB_LGEN*FB_MAXCH; i += FB_WAVE*EPB) { s_gk[i] = (uint32_t)M.gen_k[i]; s_gm[2*i] = (uint32_t)M.gen_m[2*i]; s_gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
+  for (int i = tid; i < 2*FB_WAVE; i += FB_WAVE*EPB) s_tab.gen[FB_MAXNV + i] = (uint8_t)M.fac_dof[i];      // dof of a lane's first / second factor row (fb_smooth.hpp: fac_dof)
+  for (int i = tid; i < FB_LGEN*FB_MAXCH; i += FB_WAVE*EPB) { s_tab.gk[i] = (uint32_t)M.gen_k[i]; s_tab.gm[2*i] = (uint32_t)M.gen_m[2*i]; s_tab.gm[2*i + 1] = (uint32_t)M.gen_m[2*i + 1]; }
   __syncthreads();                       // the only workgroup-wide barrier of the kernel
   // the wave index is wave-uniform: say so (v_readfirstlane), otherwise every per-environment base address is 64-bit VALU math
   int wave = uniform_int(tid / FB_WAVE), lane = tid % FB_WAVE;
@@ -638,9 +647,7 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
       WS<real> w;
       w.o = (const FB_CONST WSOff*)&M.off;
       w.rb = (FB_GLOBAL real*)(B.rarena + (size_t)env*M.off.nreal); w.ib = (FB_GLOBAL int*)(B.iarena + (size_t)env*M.off.nint);
-      w.lLD = (FB_LDS real*)s_pool[wave]; w.lAR = w.lLD + FB_LDS_SCRATCH; w.lx = w.lAR + LdsCfg<real>::AR_ELEMS;
-      w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
-      w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
+      w.lLD = (FB_LDS real*)s_pool[wave]; w.lt = (const FB_LDS LdsTab*)&s_tab;
       float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
 #ifdef FB_EMULATE
       // (host emulation, test infrastructure: every ticket starts from a POISONED LDS pool -- whatever a stage left there for a later ticket,
@@ -688,9 +695,7 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
   WS<real> w;
   w.o = (const FB_CONST WSOff*)&M.off;
   w.rb = (FB_GLOBAL real*)(B.rarena + (size_t)env*M.off.nreal); w.ib = (FB_GLOBAL int*)(B.iarena + (size_t)env*M.off.nint);
-  w.lLD = (FB_LDS real*)s_pool[wave]; w.lAR = w.lLD + FB_LDS_SCRATCH; w.lx = w.lAR + LdsCfg<real>::AR_ELEMS;
-  w.ldepth = (FB_LDS uint8_t*)s_depth; w.lcl = (FB_LDS uint8_t*)s_cl; w.lgen = (FB_LDS uint8_t*)s_gen; w.lmadr = (FB_LDS uint16_t*)s_madr;
-  w.lgk = (FB_LDS uint32_t*)s_gk; w.lgm = (FB_LDS uint32_t*)s_gm; w.nlevel = M.nlevel;
+  w.lLD = (FB_LDS real*)s_pool[wave]; w.lt = (const FB_LDS LdsTab*)&s_tab;
   float* obs = B.obs ? B.obs + (size_t)env*B.nobs : nullptr;
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
   long long t0_ = clock64(), r0_ = wall_clock64();
@@ -919,7 +924,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
   UV(dof_jump, dof_jump) UV(dof_vbef, dof_vbef) UV(body_veldof, body_veldof)
-  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fwd_pack, fwd_pack) UV(fac_w, fac_w) UV(fac_band, fac_band) M.ntrunk = m->ntrunk;
+  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fwd_pack, fwd_pack) UV(fac_w, fac_w) UV(fac_band, fac_band) UV(fac_dof, fac_dof) M.ntrunk = m->ntrunk;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   {

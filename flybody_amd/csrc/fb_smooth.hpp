@@ -50,12 +50,7 @@ template <typename real>
 __device__ __forceinline__ WS<real> ws_uniform(const WS<real>& w_) {
   WS<real> w = w_;
   w.rb = uniform_p(w.rb); w.ib = uniform_p(w.ib); w.o = uniform_p(w.o);
-  w.lLD = uniform_p(w.lLD); w.lx = uniform_p(w.lx); w.lAR = uniform_p(w.lAR);
-  w.ldepth = uniform_p(w.ldepth); w.lcl = uniform_p(w.lcl); w.lgen = uniform_p(w.lgen); w.lmadr = uniform_p(w.lmadr);
-  w.lgk = uniform_p(w.lgk); w.lgm = uniform_p(w.lgm);
-#ifndef FB_EMULATE
-  w.nlevel = __builtin_amdgcn_readfirstlane(w.nlevel);
-#endif
+  w.lLD = uniform_p(w.lLD); w.lt = uniform_p(w.lt);
   return w;
 }
 
@@ -609,6 +604,26 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
 // sum over the (<= 4) listed descendant rows mk of  RM[mk + oi] * RM[mk + oj] * RM[mk]
 // (the loads are unconditional so that all of them are in flight together; an absent entry reads row `ms`,
 // which always exists, and its product is discarded)
+// Which dof is the lane's q-th row in the factorisation and the solves (-1: none).  Rounds 1-5: dof lane + 64 q, i.e. both row sets held dofs
+// of EVERY depth, and every level of the level loops ran the publish and the pull code of both.  Round 6 (FB_FAC_REMAP): the rows are dealt by
+// DEPTH -- the 64 shallowest dofs outside the trunk are the first rows, the rest (fruit fly: depth >= 12) the second -- so the second set's
+// code only runs on the deep levels and the first set's publish code only on the shallow ones: a level executes one publish and (mostly)
+// one pull block instead of two each.  The table is staged in LDS behind the branching-dof table (fb_engine.hip: s_gen[FB_MAXNV ..]).
+#ifndef FB_FAC_REMAP
+#define FB_FAC_REMAP 1
+#endif
+template <typename real>
+FBD int fac_dof(const WS<real>& w, int nv, int nT, int lane, int q) {
+#if FB_FAC_REMAP
+  const int j = w.lgen()[FB_MAXNV + lane + q*FB_WAVE];
+  (void)nv; (void)nT;
+  return j == 255 ? -1 : j;
+#else
+  const int j = lane + q*FB_WAVE;
+  return (j < nv && j >= nT) ? j : -1;
+#endif
+}
+
 template <typename real>
 FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, int oj, int ms) {
   real p[4];
@@ -648,18 +663,19 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
-  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
-  const FB_LDS uint32_t* gm = w.lgm;          // locals: a fence must not force reloading them from the WS struct
-  const FB_LDS uint32_t* gk = w.lgk;
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(M.nlevel);
+  const FB_LDS uint32_t* gm = w.lgm();          // locals: a fence must not force reloading them from the WS struct
+  const FB_LDS uint32_t* gk = w.lgk();
   // the rows of the two dofs this lane owns: row[q][t] = M[i, ancestor of i at distance t] (t = 0: the diagonal), t <= depth(i)
-  int dep[2], mj[2], cl[2], gen[2], base[2]; bool has[2];
+  int dep[2], mj[2], cl[2], gen[2], base[2], jq[2]; bool has[2];
   real row[2][FB_MAXCH], xa[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int j = lane + q*FB_WAVE;
-    has[q] = j < nv && j >= nT;
-    dep[q] = has[q] ? w.ldepth[j] : 31; mj[q] = has[q] ? w.lmadr[j] : 0; cl[q] = has[q] ? w.lcl[j] : 0;
-    { const int g = has[q] ? w.lgen[j] : 255; gen[q] = (g == 255) ? -1 : g; }
+    const int j = fac_dof(w, nv, nT, lane, q);       // (round 6: the lane's q-th row is NOT dof lane + 64 q any more -- the shallow dofs are the first rows, the deep ones the second: fac_dof)
+    jq[q] = j < 0 ? 0 : j;
+    has[q] = j >= 0;
+    dep[q] = has[q] ? w.ldepth()[j] : 31; mj[q] = has[q] ? w.lmadr()[j] : 0; cl[q] = has[q] ? w.lcl()[j] : 0;
+    { const int g = has[q] ? w.lgen()[j] : 255; gen[q] = (g == 255) ? -1 : g; }
     base[q] = mj[q] - dep[q]*(dep[q] + 1)/2;
   }
   // all loads of both rows in flight together (consecutive lanes own consecutive rows: the wave reads one contiguous piece of qM)
@@ -668,9 +684,9 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
 #pragma unroll
     for (int t = 0; t < FB_MAXCH; t++) { const bool ok = has[q] && t <= dep[q]; const real v = qM[ok ? mj[q] + t : 0]; row[q][t] = ok ? v : (real)0; }
     real da = (real)0;
-    if (diag_add) da = hscale*diag_add[has[q] ? lane + q*FB_WAVE : 0];
+    if (diag_add) da = hscale*diag_add[jq[q]];
     row[q][0] += has[q] ? da : (real)0;
-    xa[q] = has[q] ? x[lane + q*FB_WAVE] : (real)0;
+    xa[q] = has[q] ? x[jq[q]] : (real)0;
   }
   PROF(17);
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)
@@ -687,7 +703,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
     for (int q = 0; q < 2; q++) {
       if (dep[q] == d) {
         const real di = fb_inv(row[q][0]);
-        RM[mj[q]] = di; x[lane + q*FB_WAVE] = xa[q];
+        RM[mj[q]] = di; x[jq[q]] = xa[q];
 #pragma unroll
         for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];        // (exactly the row: the next row in memory belongs to a DEEPER dof, published earlier and still needed)
       }
@@ -705,7 +721,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         // unbranched chain below the dof: the descendant's row starts at base + T(d) (rows of a chain grow by one entry per level)
         const int rk = base[q] + Td, o = d - dep[q];
         const real c = RM[rk + o]*RM[rk];            // M~[k, i] / D[k] = L[k, i] as the normalisation will round it
-        xa[q] -= c*x[lane + q*FB_WAVE + tr + 1];
+        xa[q] -= c*x[jq[q] + tr + 1];
 #pragma unroll
         for (int t0 = 0; t0 < FB_MAXCH; t0 += 4) {
           // (t <= depth(i) <= d - 1 is what matters.  The bound is wave-uniform and tested once per four entries: a lane-varying
@@ -758,12 +774,13 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk);
-  int fd[2];
+  int fd[2], jt[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    int j = lane + q*FB_WAVE;
-    bool has = j < nv && j >= nT;
-    int dp = has ? w.ldepth[j] : 31, mj = has ? w.lmadr[j] : 0;
+    const int j = fac_dof(w, nv, nT, lane, q);
+    bool has = j >= 0;
+    jt[q] = has ? j : 0;
+    int dp = has ? w.ldepth()[j] : 31, mj = has ? w.lmadr()[j] : 0;
     fd[q] = ((mj - dp*(dp + 1)/2) & 0x1fff) | (dp << 13);
   }
   // (the work words of the normalisation below: fetched here, ahead of the reductions, so that their latency is covered)
@@ -781,7 +798,7 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
     int dep = FW_DEP(fd[q]);
     if (dep != 31) {
       int row = FW_BASE(fd[q]) + dep*(dep + 1)/2;
-      real dk = RM[row], col[FB_MAXTRUNK], xk = x[lane + q*FB_WAVE];      // (every non-trunk x was published on its own level)
+      real dk = RM[row], col[FB_MAXTRUNK], xk = x[jt[q]];      // (every non-trunk x was published on its own level)
 #pragma unroll
       for (int a = 0; a < FB_MAXTRUNK; a++) col[a] = (a < nT) ? RM[row + dep - a] : (real)0;
 #pragma unroll
@@ -870,17 +887,18 @@ FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_
   const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
   RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
-  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(w.nlevel);
-  const FB_LDS uint32_t* gk = w.lgk;
-  const FB_LDS uint16_t* lmadr = w.lmadr;
+  const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(M.nlevel);
+  const FB_LDS uint32_t* gk = w.lgk();
+  const FB_LDS uint16_t* lmadr = w.lmadr();
   const FB_GLOBAL int* fwp = M.fwd_pack.p;
   int jd[2], dep[2], cl[2], gen[2], base[2], rowt[2]; real a_[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    int j = lane + q*FB_WAVE;
-    bool has = j < nv && j >= nT;
-    int dp = has ? w.ldepth[j] : 31, mj = has ? lmadr[j] : 0;
-    jd[q] = j; dep[q] = dp; cl[q] = has ? w.lcl[j] : 0; gen[q] = has ? w.lgen[j] : 255;
+    const int j0 = fac_dof(w, nv, nT, lane, q);
+    const bool has = j0 >= 0;
+    const int j = has ? j0 : 0;
+    int dp = has ? w.ldepth()[j] : 31, mj = has ? lmadr[j] : 0;
+    jd[q] = j; dep[q] = dp; cl[q] = has ? w.lcl()[j] : 0; gen[q] = has ? w.lgen()[j] : 255;
     base[q] = mj - dp*(dp + 1)/2; rowt[q] = mj + dp;
     a_[q] = has ? x[j] : (real)0;
   }

@@ -285,7 +285,7 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
       w.act()[aa] = an;
     }
   }
-  for (int i = lane; i < M.nv; i += FB_WAVE) { const real v = w.qvel()[i] + h*w.lx[i]; w.qvel()[i] = v; w.lx[i] = v; }
+  for (int i = lane; i < M.nv; i += FB_WAVE) { const real v = w.qvel()[i] + h*w.lx()[i]; w.qvel()[i] = v; w.lx()[i] = v; }
   SYNC_LDS();
   {
     int jt[2], qa[2], da[2]; bool jok[2]; real qv[2][7], vv[2][6];
@@ -301,7 +301,7 @@ __device__ __forceinline__ void d_integrate(const DevModel<real>& M, const WS<re
 #pragma unroll
       for (int k = 0; k < 7; k++) qv[u][k] = w.qpos()[min(qa[u] + min(k, nqw - 1), nq - 1)];
 #pragma unroll
-      for (int k = 0; k < 6; k++) vv[u][k] = w.lx[min(da[u] + min(k, nvw - 1), nv - 1)];
+      for (int k = 0; k < 6; k++) vv[u][k] = w.lx()[min(da[u] + min(k, nvw - 1), nv - 1)];
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -884,7 +884,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         PROF_BEGIN();
         if (actuate) s_actuation(M, wc, lane);      // (leaves qfrc_actuator in the solve vector lx as well as in the global row)
         else {
-          for (int i = lane; i < M.nv; i += FB_WAVE) { w.qfrc_actuator()[i] = 0; w.lx[i] = 0; }
+          for (int i = lane; i < M.nv; i += FB_WAVE) { w.qfrc_actuator()[i] = 0; w.lx()[i] = 0; }
           for (int i = lane; i < M.na; i += FB_WAVE) w.act_dot()[i] = 0;
           SYNC();
         }
@@ -897,8 +897,8 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         // boundary any more (the factor and the Delassus matrix used to be parked in the global row between control steps).
         PROF_BEGIN();
         for (int i = lane; i < M.nv; i += FB_WAVE) {
-          real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.lx[i];          // lx = qfrc_actuator (assembled there by ST_ACT)
-          w.qfrc_smooth()[i] = f; w.lx[i] = f;
+          real f = w.qfrc_passive()[i] - w.qfrc_bias()[i] + w.lx()[i];          // lx = qfrc_actuator (assembled there by ST_ACT)
+          w.qfrc_smooth()[i] = f; w.lx()[i] = f;
         }
         SYNC();
         PROF(24);
@@ -907,14 +907,14 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         half = true; ret = ST_ACC_POST; pc = ST_SOLVE; break;
       case ST_SOLVE: {
         PROF_BEGIN();
-        d_solve(M, wc, w.lLD, w.lx, half, lane);
+        d_solve(M, wc, w.lLD, w.lx(), half, lane);
         PROF(P_ACC);
         half = false;
         pc = ret; break; }
       case ST_ACC_POST: {
         PROF_BEGIN();
         if (parts & 1) {
-          for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx[i];
+          for (int i = lane; i < M.nv; i += FB_WAVE) w.qacc_smooth()[i] = w.lx()[i];
           SYNC();
         }
         PROF(24);
@@ -937,13 +937,13 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
       case ST_EULER_PRE: {
         // the factor of M is dead after the constraint solve: its LDS slot is reused for M + h*D
         PROF_BEGIN();
-        for (int i = lane; i < M.nv; i += FB_WAVE) w.lx[i] = w.qfrc_smooth()[i] + w.qfrc_constraint()[i];
+        for (int i = lane; i < M.nv; i += FB_WAVE) w.lx()[i] = w.qfrc_smooth()[i] + w.qfrc_constraint()[i];
         SYNC();
         PROF(24);
         damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
-        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lx, lane);
+        d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lx(), lane);
         PROF(P_FACTOR);
         pc = fret; break; }
       case ST_EULER_SOLVE:

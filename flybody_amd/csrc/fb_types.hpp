@@ -136,6 +136,7 @@ struct DevModel {
   GP<const int> fwd_pack;       // [FB_MAXCH/4][FB_MAXNV] the same, four levels per word (8-bit dof ids)
   GP<const int> fac_w;          // factor work list, [slot][lane] packed words (fb_smooth.hpp: d_factor)
   GP<const int> fac_band;       // [32][2] per level: bit masks of the chain slots that publish | that pull, the same for every lane
+  GP<const int> fac_dof;        // [2][64] dof of a lane's first / second row in the factorisation and the solves (255: none; fb_smooth.hpp: fac_dof)
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
   int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
@@ -224,12 +225,30 @@ template <typename real> struct LdsCfg {
   static constexpr int WIDE_ROWS = wide_rows();
 };
 
+// LDS copies of the elimination-tree tables, shared by the environments of a workgroup (dof depths, chain lengths, branching-dof ids + the row
+// assignment of the factorisation behind them, row addresses, the per-level descendant lists of the branching dofs).  ONE struct so that the
+// workspace descriptor carries one pointer for all of them.
+struct LdsTab {
+  uint8_t depth[FB_MAXNV], cl[FB_MAXNV], gen[FB_MAXNV + 2*FB_WAVE];
+  uint16_t madr[FB_MAXNV + 1];
+  uint32_t gk[FB_LGEN*FB_MAXCH], gm[FB_LGEN*FB_MAXCH*2];
+};
+
+// Round 6: the descriptor is FIVE words -- pool base, table base, the two arena rows, the offset table.  It used to carry twelve
+// pointers + a level count; it is copied through memory into every stage call and moved back to SGPRs there, and the step kernel's glue
+// runs out of SGPRs (277 spills): ONE more pointer in it measured -0.9 % env-steps/s, so everything derivable is derived.
 template <typename real>
 struct WS {
-  // LDS-resident hot arrays (per workgroup == per environment)
-  FB_LDS real *lLD, *lx, *lAR;     // lLD: row-major factor, 1/D on the diagonal (see fb_smooth.hpp); the three are one contiguous pool [lLD | lAR | lx]
-  // LDS copies of the elimination-tree tables (dof ancestors, row addresses, depths, pair tables)
-  const FB_LDS uint8_t *ldepth, *lcl, *lgen; const FB_LDS uint16_t *lmadr; const FB_LDS uint32_t *lgk, *lgm; int nlevel;
+  FB_LDS real* lLD;                      // LDS pool of the environment: [factor row (lLD) | Delassus matrix (lAR()) | solve vector (lx())], contiguous
+  const FB_LDS LdsTab* lt;               // elimination-tree tables of the workgroup
+  __device__ __forceinline__ FB_LDS real* lAR() const { return lLD + FB_LDS_SCRATCH; }
+  __device__ __forceinline__ FB_LDS real* lx() const { return lLD + FB_LDS_SCRATCH + LdsCfg<real>::AR_ELEMS; }
+  __device__ __forceinline__ const FB_LDS uint8_t* ldepth() const { return lt->depth; }
+  __device__ __forceinline__ const FB_LDS uint8_t* lcl() const { return lt->cl; }
+  __device__ __forceinline__ const FB_LDS uint8_t* lgen() const { return lt->gen; }      // (lgen()[FB_MAXNV ..]: the row assignment of the factorisation, fb_smooth.hpp: fac_dof)
+  __device__ __forceinline__ const FB_LDS uint16_t* lmadr() const { return lt->madr; }
+  __device__ __forceinline__ const FB_LDS uint32_t* lgk() const { return lt->gk; }
+  __device__ __forceinline__ const FB_LDS uint32_t* lgm() const { return lt->gm; }
   // global arrays of this environment: base of its arena row + the model's offset table.  The base is wave-uniform
   // (SGPRs), the offsets are s_load'ed from the model, so an access is global_load with a scalar base address.
   FB_GLOBAL real* rb; FB_GLOBAL int* ib; const FB_CONST WSOff* o;
