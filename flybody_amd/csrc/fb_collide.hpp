@@ -464,7 +464,7 @@ __device__ __forceinline__ bool boxes_may_touch(const real* pa, const real* ma, 
 
 template <typename real>
 FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   // Two rounds of loads (round 5; before: pair -> geoms -> types -> sizes -> poses, fourteen dependent waits per call, two calls per
   // substep): the pair's packed word and margin, then everything they address at once -- the boxes' half extents come from a
   // per-geom model table, the centres from the bounding spheres the mid phase staged in LDS.
@@ -483,7 +483,7 @@ FB_STAGE_B bool box_filter(const DevModel<real>& M_, const WS<real>& w_, int p) 
 // returns the number of contacts | (penetration query at its iteration limit) << 8
 template <typename real>
 FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   LaneContacts<real> lc;
   lc.first = w.lLD + 6*M.nv; lc.more = (FB_GLOBAL real*)w.efc_Y(); lc.lane = lane; lc.n = 0; lc.ccd_cap = 0;
   const int pw_ = M.pair_word[p]; real margin = M.pair_margin[p];          // (round 1: the pair; round 2: everything its two geoms address)
@@ -551,7 +551,7 @@ FB_STAGE_B int narrow_phase(const DevModel<real>& M_, const WS<real>& w_, int p,
 // and position; the even lane stores the contact in the LDS slot of the lane that owns the candidate.  Returns contacts | cap << 8.
 template <typename real>
 FB_STAGE_B int narrow_mpr_pair(const DevModel<real>& M_, const WS<real>& w_, int p, int slot, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   const bool second = (lane & 1) != 0;
   const int pw_ = M.pair_word[p]; const real margin = M.pair_margin[p];
   const int g = second ? (pw_ >> 10) & 1023 : pw_ & 1023;

@@ -336,7 +336,7 @@ __device__ __forceinline__ void d_project_constraint(const DevModel<real>& M, co
 
 template <typename real, typename ARP>
 FB_STAGE_B void d_build_AR(const DevModel<real>& M_, const WS<real>& w_, ARP AR, int nefc, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   // AR: uniform loop over rows r; lane == column c keeps its own Y in registers
   for (int cbase = 0; cbase < nefc; cbase += FB_WAVE) {
     int c = cbase + lane;

@@ -123,7 +123,7 @@ FBD int nw_lane_i(int v, int src) { return __shfl(v, src, 64); }
 // wave fence.  Inactive columns of F leave identity rows in K; they are factorised like any other (pivot 1).
 template <typename real>
 FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, int nefc, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   const int n = uniform_int(nefc);
   FB_SETPRIO(3);
   real* AR = w.AR(); real* K = AR + FB_MAXEFC_*(FB_MAXEFC_ + 1)/2;
@@ -500,7 +500,7 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
 // (no tile-layout code), 0 = decided at run time.
 template <typename real, typename ARP, typename KP, int MODE = 0>
 FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR, KP K, int nefc, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   const int n = nefc;
   const bool on = lane < n;
 #if defined(FB_PROFILE) && !defined(FB_EMULATE)

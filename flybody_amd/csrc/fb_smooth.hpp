@@ -47,10 +47,11 @@ enum { P_KIN = 0, P_COMPOS, P_CRB, P_FACTOR, P_COLL, P_MAKEC, P_PROJ, P_VEL, P_A
 // Non-inlined stages get the workspace descriptor by reference (it arrives through memory, so per lane): move its
 // wave-uniform base pointers back to SGPRs.  Callers pass a COPY so that the kernel's own descriptor never escapes.
 template <typename real>
-__device__ __forceinline__ WS<real> ws_uniform(const WS<real>& w_) {
-  WS<real> w = w_;
-  w.rb = uniform_p(w.rb); w.ib = uniform_p(w.ib); w.o = uniform_p(w.o);
-  w.lLD = uniform_p(w.lLD); w.lt = uniform_p(w.lt);
+__device__ __forceinline__ WS<real> ws_uniform(const WS<real>& w_, const DevModel<real>& M) {
+  WS<real> w;
+  w.rb = uniform_p(w_.rb); w.ib = uniform_p(w_.ib);
+  w.lLD = uniform_p(w_.lLD); w.lt = uniform_p(w_.lt);
+  w.o = (const FB_CONST WSOff*)&M.off;              // (the offset table is part of the model, which every stage has in SGPRs: not fetched from the descriptor)
   return w;
 }
 
@@ -660,7 +661,7 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
 template <typename real>
 FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
                          FB_LDS real* RM, FB_LDS real* x, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(M.nlevel);
@@ -770,7 +771,7 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
 template <typename real>
 FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
                               FB_LDS real* RM, FB_LDS real* x, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   qM = uniform_p(qM); diag_add = uniform_p(diag_add); RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk);
@@ -884,7 +885,7 @@ FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, con
 // D^-1 and L^-1 are applied.
 template <typename real>
 FB_STAGE_FS void d_solve(const DevModel<real>& M_, const WS<real>& w_, const FB_LDS real* RM, FB_LDS real* x, bool half, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   RM = uniform_p(RM); x = uniform_p(x);
   PROF_BEGIN();
   const int nv = uniform_int(M.nv), nT = uniform_int(M.ntrunk), nlevel = uniform_int(M.nlevel);

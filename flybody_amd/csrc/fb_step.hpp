@@ -800,7 +800,7 @@ enum { ST_PRE = 32, ST_POST = 33 };
 #endif
 #define FB_STAGE_WRAP(name, ...) \
   template <typename real> FB_STAGE_C void name(const DevModel<real>& M_, const WS<real>& w_, int lane) { \
-    const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_); __VA_ARGS__; }
+    const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M); __VA_ARGS__; }
 FB_STAGE_WRAP(s_kinematics, d_kinematics(M, w, lane))
 FB_STAGE_WRAP(s_com_pos, d_com_pos(M, w, lane))
 FB_STAGE_WRAP(s_crb, d_crb(M, w, lane))
@@ -808,7 +808,7 @@ FB_STAGE_WRAP(s_collision, d_collision(M, w, lane))
 FB_STAGE_WRAP(s_make_constraint, d_make_constraint(M, w, lane))
 FB_STAGE_WRAP(s_project_constraint, d_project_constraint(M, w, lane))
 template <typename real> FB_STAGE_C void s_velocity(const DevModel<real>& M_, const WS<real>& w_, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   FB_LDS real* Lv = w.lLD + vel_off_v(M); FB_LDS real* X = w.lLD + vel_off_x(M);        // body velocities / per-body wrenches (fb_smooth.hpp)
   real ab[2][6];                                                                         // bias accelerations of the lane's two bodies
   d_com_vel(M, w, Lv, ab, lane); d_passive(M, w, Lv, X, lane); d_rne_bias(M, w, Lv, X, ab, lane); d_sensor_vel(M, w, lane); }
@@ -817,16 +817,16 @@ FB_STAGE_WRAP(s_constraint_b, d_constraint_b(M, w, lane))
 FB_STAGE_WRAP(s_sensor_acc, d_sensor_acc(M, w, lane))
 FB_STAGE_WRAP(s_integrate, d_integrate(M, w, lane))
 template <typename real> FB_STAGE_C bool s_constraint_a(const DevModel<real>& M_, const WS<real>& w_, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_); return d_constraint_a(M, w, lane); }
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M); return d_constraint_a(M, w, lane); }
 template <typename real> FB_STAGE_C void s_init(const DevModel<real>& M_, const WS<real>& w_, int env, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   if (lane == 0) w.istate()[IS_WARN_EVER] = 0;
   if (M.task == 1) d_flight_init(M, w, env, lane); else if (M.task == 2) d_ball_init(M, w, lane); else d_walk_init(M, w, env, lane); }
 template <typename real> FB_STAGE_C void s_pre(const DevModel<real>& M_, const WS<real>& w_, const float* action, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   if (M.task == 1) d_flight_pre(M, w, action, lane); else d_walk_pre(M, w, action, lane); }
 template <typename real> FB_STAGE_C void s_post(const DevModel<real>& M_, const WS<real>& w_, bool resetting, float* obs, float* reward, float* discount, int* step_type, int lane) {
-  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_);
+  const DevModel<real>& M = as_constant(M_); const WS<real> w = ws_uniform(w_, M);
   if (resetting) {
     d_pack_obs(M, w, w.sens(), obs, lane);
     if (lane == 0) { *reward = 0; *discount = 1; *step_type = 0; w.istate()[IS_STEP_TYPE] = 0; }
