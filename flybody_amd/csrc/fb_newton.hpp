@@ -494,6 +494,86 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
 #else
 #define NW_SUM(x) wave_sum(x)
 #endif
+// ------------------------------------------------------------------ 17 ... 32 ACTIVE columns: Gauss-Jordan on a 32 x 32 register tile
+// Round 6.  The systems a lock-step launch ENDS on (tools/launch_times.py: steps whose largest system has 34-39 rows last 6 % longer than
+// steps without one, >= 40 rows 17 %) spend most of their solve in the right-looking factorisation on LDS rows below: ~75 k cycles per
+// factorisation against 5 k for the 16 x 16 tile, 19 x the mean per control step (tools/ticket_trace.py).  Here the compacted K -- lower
+// triangle in LDS (or in the global row), diagonal in the owners' registers, exactly as the 16-column path reads it -- is loaded into FOUR
+// 16 x 16 tiles over the wave (block (I, J): lane (ti, tc) holds K[16 I + ti][16 J + 4 tc + 0..3]) and eliminated by the same
+// Gauss-Jordan step as the small tile, the right-hand side riding along: per pivot one reciprocal, the scaled pivot row by lane
+// shuffles, one multiply-add per live register.  The pivots of the second block row leave the finished first block column alone.
+// No back substitution, nothing of the factor returns to memory.  Round 5's attempt (2 x 2 blocked Cholesky INSIDE d_newton) spilled
+// the small-system path; this is a function of its own with its own register allocation, called on the rare path only.
+#ifndef FB_NW_TILE32
+#define FB_NW_TILE32 1
+#endif
+template <typename real, typename KP>
+FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg, real y, int lane, bool on) {
+  const int n_act = uniform_int(n_act_);
+  const bool mine = on && ((m_act >> lane) & 1ull);
+  const int my_ci = __popcll(m_act & ((1ull << lane) - 1ull));
+  if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;         // row of compact index my_ci, parked in the (unused) diagonal slot of packed row my_ci
+  SYNC();
+  const int ti = lane >> 2, tc = lane & 3;
+  real T[2][2][4], yv[2];
+  {
+    bool iv[2]; int tri_i[2], ci[2]; real dgt[2];
+#pragma unroll
+    for (int I = 0; I < 2; I++) {
+      ci[I] = 16*I + ti; iv[I] = ci[I] < n_act;
+      const int ri = iv[I] ? (int)K[ci[I]*(ci[I] + 1)/2 + ci[I]] : 0;
+      tri_i[I] = ri*(ri + 1)/2;
+      dgt[I] = nw_lane(dg, ri);
+      const real yr = nw_lane(y, ri);
+      yv[I] = iv[I] ? yr : (real)0;
+    }
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int cj = 16*J + 4*tc + s;
+        const bool jv = cj < n_act;
+        const int rj = jv ? (int)K[cj*(cj + 1)/2 + cj] : 0;
+#pragma unroll
+        for (int I = 0; I < 2; I++) {
+          const bool both = iv[I] && jv;
+          const real e = K[both ? (cj < ci[I] ? tri_i[I] + cj : rj*(rj + 1)/2 + ci[I]) : 0];      // (cj == ci reads a table slot: replaced below)
+          T[I][J][s] = both ? (cj == ci[I] ? dgt[I] : e) : (cj == ci[I] ? (real)1 : (real)0);
+        }
+      }
+  }
+#pragma unroll
+  for (int Ip = 0; Ip < 2; Ip++) {
+    for (int P = 0; P < 4; P++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int pr = 4*P + q, pv = 16*Ip + pr;                    // pivot: row pr of block row Ip
+        if (pv < n_act) {
+          const real invp = fb_inv(rdlane(T[Ip][Ip][q], 4*pr + P));
+          real rp[2][4];
+#pragma unroll
+          for (int J = Ip; J < 2; J++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) rp[J][s] = nw_lane(T[Ip][J][s], 4*pr + tc)*invp;
+          const real yp = rdlane(yv[Ip], 4*pr)*invp;
+#pragma unroll
+          for (int I = 0; I < 2; I++) {
+            const real Lip = nw_lane(T[I][Ip][q], 4*ti + P);
+            const bool prow = (I == Ip) && ti == pr;
+#pragma unroll
+            for (int J = Ip; J < 2; J++)
+#pragma unroll
+              for (int s = 0; s < 4; s++) T[I][J][s] = prow ? rp[J][s] : T[I][J][s] - Lip*rp[J][s];
+            yv[I] = prow ? yp : yv[I] - Lip*yp;
+          }
+        }
+      }
+    }
+  }
+  const real z0 = nw_lane(yv[0], 4*(my_ci & 15)), z1 = nw_lane(yv[1], 4*(my_ci & 15));
+  SYNC();                                                            // (K is rewritten by the next iteration)
+  return mine ? (my_ci < 16 ? z0 : z1) : (real)0;
+}
 // ARP / KP: LDS (address_space(3)) or global pointers to the packed lower triangles of AR and of the work matrix K.
 // Returns the number of Newton iterations; the forces are left in efc_force.
 // MODE: 1 = the caller guarantees nefc <= FB_NEWTON_NT (tile layout only: the lane == row code is not compiled in), 2 = nefc > FB_NEWTON_NT
@@ -858,7 +938,15 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
         z = mine ? zr : (real)0;
         SYNC();                                       // (K is rewritten by the next iteration)
         NW_PROF(4);
-      } else {
+      }
+#if FB_NW_TILE32
+      else if (n_act <= 32) {
+        FB_STAT(46);
+        z = nw_gj32<real, KP>(K, n_act, m_act, dg, y, lane, on);
+        NW_PROF(3); NW_PROF(4);
+      }
+#endif
+      else {
       // Larger systems: right-looking factorisation on the rows in LDS.  These are the environments a lock-step launch WAITS for
       // (tools/ticket_trace.py: the last environments of a launch spent 5-20 x the mean here), so the loop is built for instruction count:
       //  * the ACTIVE rows are re-mapped onto the first n_act lanes (lane c = compact row c; the inactive rows of K are identity rows and

@@ -639,6 +639,65 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
+// Round 6 (FB_FAC_STRAIGHT): the wave-uniform row bounds of the level loop as a BINARY DESCENT on d into straight-line code instead of one
+// compare-and-branch per entry (publish: 19 per row and level) or per group of four (pull: 5 per row and level, each group's LDS reads
+// waited for on their own because a basic block ends behind it).  profiles/r5/icache_counters.txt: 50 k branches per environment-step and
+// 16 % of the wave cycles waiting for the instruction buffer behind them; a third of the branches were these.
+#ifndef FB_FAC_STRAIGHT
+#define FB_FAC_STRAIGHT 1
+#endif
+#ifndef FB_FAC_VOLATILE
+#define FB_FAC_VOLATILE 1
+#endif
+#if FB_FAC_VOLATILE && !defined(FB_EMULATE)
+#define FB_FAC_LD(p) ((const volatile FB_LDS real*)(p))       // experiment: keeps the backend from pairing the reads into ds_read2_b64 (half the LDS rate per byte)
+#else
+#define FB_FAC_LD(p) (p)
+#endif
+#ifndef FB_FAC_CHUNK
+#define FB_FAC_CHUNK 12      // LDS reads of a pull in flight together (all 20 of a deep level: the rows spill at the 168-register budget)
+#endif
+// p[t] = row[t] for t = LO .. min(d, HI)   (precondition: d >= LO - 1)
+template <int LO, int HI, typename real>
+FBD void fac_publish(FB_LDS real* p, const real* row, int d) {
+  if constexpr (LO > HI) { (void)p; (void)row; (void)d; }
+  else if constexpr (LO == HI) { if (d >= LO) p[LO] = row[LO]; }
+  else {
+    constexpr int MID = (LO + HI + 1)/2;
+    if (d >= MID) {
+#pragma unroll
+      for (int t = LO; t <= MID; t++) p[t] = row[t];
+      fac_publish<MID + 1, HI>(p, row, d);
+    } else fac_publish<LO, MID - 1>(p, row, d);
+  }
+}
+// row[t] -= c p[t] for the first NG groups of four entries, c = pc[0] pd[0]; every LDS read of the block in flight before the first is consumed
+template <int NG, typename real>
+FBD real fac_pull_n(real* row, const FB_LDS real* pc, const FB_LDS real* pd, const FB_LDS real* p) {
+  const real c = pc[0]*pd[0];
+#pragma unroll
+  for (int t0 = 0; t0 < 4*NG; t0 += FB_FAC_CHUNK) {
+    real v[FB_FAC_CHUNK];
+#pragma unroll
+    for (int t = 0; t < FB_FAC_CHUNK; t++) if (t0 + t < 4*NG) v[t] = FB_FAC_LD(p)[t0 + t];
+#pragma unroll
+    for (int t = 0; t < FB_FAC_CHUNK; t++) if (t0 + t < 4*NG) row[t0 + t] -= c*v[t];
+  }
+  return c;
+}
+// the groups with t0 < d (d wave-uniform, 1 <= d < FB_MAXCH); returns c
+template <typename real>
+FBD real fac_pull(real* row, const FB_LDS real* pc, const FB_LDS real* pd, const FB_LDS real* p, int d) {
+  static_assert(FB_MAXCH == 20, "fac_pull dispatches on ceil(d / 4) in 1 .. 5");
+  if (d > 8) {
+    if (d > 16) return fac_pull_n<5>(row, pc, pd, p);
+    if (d > 12) return fac_pull_n<4>(row, pc, pd, p);
+    return fac_pull_n<3>(row, pc, pd, p);
+  }
+  if (d > 4) return fac_pull_n<2>(row, pc, pd, p);
+  return fac_pull_n<1>(row, pc, pd, p);
+}
+
 template <typename real>
 FB_STAGE_FS void d_factor_tail(const DevModel<real>& M_, const WS<real>& w_, const FB_GLOBAL real* qM, const FB_GLOBAL real* diag_add, real hscale,
                               FB_LDS real* RM, FB_LDS real* x, int lane);
@@ -705,8 +764,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
       if (dep[q] == d) {
         const real di = fb_inv(row[q][0]);
         RM[mj[q]] = di; x[jq[q]] = xa[q];
+#if FB_FAC_STRAIGHT
+        fac_publish<1, FB_MAXCH - 1>(RM + mj[q], row[q], d);                             // (exactly the row: the next row in memory belongs to a DEEPER dof, published earlier and still needed)
+#else
 #pragma unroll
-        for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];        // (exactly the row: the next row in memory belongs to a DEEPER dof, published earlier and still needed)
+        for (int t = 1; t < FB_MAXCH; t++) if (t <= d) RM[mj[q] + t] = row[q][t];
+#endif
       }
     }
     F_PROF(0);
@@ -721,6 +784,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
       if (tr < cl[q]) {
         // unbranched chain below the dof: the descendant's row starts at base + T(d) (rows of a chain grow by one entry per level)
         const int rk = base[q] + Td, o = d - dep[q];
+#if FB_FAC_STRAIGHT
+        const real xk_ = x[jq[q] + tr + 1];
+        const real c_ = fac_pull(row[q], RM + rk + o, RM + rk, RM + rk + o, d);
+        xa[q] -= c_*xk_;
+        continue;
+#endif
         const real c = RM[rk + o]*RM[rk];            // M~[k, i] / D[k] = L[k, i] as the normalisation will round it
         xa[q] -= c*x[jq[q] + tr + 1];
 #pragma unroll
@@ -740,6 +809,12 @@ FB_STAGE_FS void d_factor(const DevModel<real>& M_, const WS<real>& w_, const FB
         for (int c4 = 0; c4 < 4; c4++) {
           const int mk = ((c4 < 2 ? m01 : m23) >> (16*(c4 & 1))) & 0xffff, k = (pk >> (8*c4)) & 255;
           if (mk != 0xffff) {
+#if FB_FAC_STRAIGHT
+            const real xk_ = x[k];
+            const real c_ = fac_pull(row[q], RM + mk + o, RM + mk, RM + mk + o, d);
+            xa[q] -= c_*xk_;
+            continue;
+#endif
             const real c = RM[mk + o]*RM[mk];
             xa[q] -= c*x[k];
 #pragma unroll
