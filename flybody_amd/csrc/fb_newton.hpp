@@ -475,6 +475,27 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
 #ifndef FB_NW_GJ
 #define FB_NW_GJ 1
 #endif
+// Round 6 (FB_NW_GJ_RAW): the pivot row is NOT scaled in place -- every other row subtracts (K[i][p] / K[p][p]) times the raw pivot row,
+// the pivot row passes through with a zero multiplier, its reciprocal pivot is kept in `invd` and the solution is yv * invd at the end
+// (a finished row's diagonal is never touched again: its entries in later pivot columns are what those pivots eliminate, column p of a
+// later pivot row is zero).  One multiply and one select per step and lane instead of five multiplies and ten selects; plain Gaussian
+// elimination to both sides, same pivots, rounding-level difference in the direction.
+#ifndef FB_NW_GJ_RAW
+#define FB_NW_GJ_RAW 1
+#endif
+#if FB_NW_GJ_RAW
+#define NW_GJ_STEP(pv, P, q, Kr, yv)                                                        \
+  do {                                                                                      \
+    const real invp_ = fb_inv(rdlane(Kr[q], 4*(pv) + (P)));                                 \
+    const bool prow_ = ti == (pv);                                                          \
+    const real Lip_ = nw_lane(Kr[q], 4*ti + (P))*invp_;                                     \
+    const real Lm_ = prow_ ? (real)0 : Lip_;                                                \
+    _Pragma("unroll") for (int s = 0; s < 4; s++) Kr[s] -= Lm_*nw_lane(Kr[s], 4*(pv) + tc); \
+    yv -= Lm_*rdlane(yv, 4*(pv));                                                           \
+    invd = prow_ ? invp_ : invd;                                                            \
+  } while (0)
+#define NW_GJ_SOL(yv) ((yv)*invd)
+#else
 #define NW_GJ_STEP(pv, P, q, Kr, yv)                                                        \
   do {                                                                                      \
     const real invp_ = fb_inv(rdlane(Kr[q], 4*(pv) + (P)));                                 \
@@ -486,6 +507,8 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
     _Pragma("unroll") for (int s = 0; s < 4; s++) Kr[s] = prow_ ? rp_[s] : Kr[s] - Lip_*rp_[s]; \
     yv = prow_ ? yp_ : yv - Lip_*yp_;                                                       \
   } while (0)
+#define NW_GJ_SOL(yv) (yv)
+#endif
 #ifndef FB_NW_ROWSUM
 #define FB_NW_ROWSUM 1
 #endif
@@ -515,7 +538,7 @@ FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg,
   if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;         // row of compact index my_ci, parked in the (unused) diagonal slot of packed row my_ci
   SYNC();
   const int ti = lane >> 2, tc = lane & 3;
-  real T[2][2][4], yv[2];
+  real T[2][2][4], yv[2], invd[2] = {1, 1};
   {
     bool iv[2]; int tri_i[2], ci[2]; real dgt[2];
 #pragma unroll
@@ -549,28 +572,31 @@ FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg,
       for (int q = 0; q < 4; q++) {
         const int pr = 4*P + q, pv = 16*Ip + pr;                    // pivot: row pr of block row Ip
         if (pv < n_act) {
+          // (raw pivot row, reciprocal pivots kept per row: see NW_GJ_STEP)
           const real invp = fb_inv(rdlane(T[Ip][Ip][q], 4*pr + P));
           real rp[2][4];
 #pragma unroll
           for (int J = Ip; J < 2; J++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) rp[J][s] = nw_lane(T[Ip][J][s], 4*pr + tc)*invp;
-          const real yp = rdlane(yv[Ip], 4*pr)*invp;
+            for (int s = 0; s < 4; s++) rp[J][s] = nw_lane(T[Ip][J][s], 4*pr + tc);
+          const real yp = rdlane(yv[Ip], 4*pr);
 #pragma unroll
           for (int I = 0; I < 2; I++) {
-            const real Lip = nw_lane(T[I][Ip][q], 4*ti + P);
+            const real Lip = nw_lane(T[I][Ip][q], 4*ti + P)*invp;
             const bool prow = (I == Ip) && ti == pr;
+            const real Lm = prow ? (real)0 : Lip;
 #pragma unroll
             for (int J = Ip; J < 2; J++)
 #pragma unroll
-              for (int s = 0; s < 4; s++) T[I][J][s] = prow ? rp[J][s] : T[I][J][s] - Lip*rp[J][s];
-            yv[I] = prow ? yp : yv[I] - Lip*yp;
+              for (int s = 0; s < 4; s++) T[I][J][s] -= Lm*rp[J][s];
+            yv[I] -= Lm*yp;
+            if (I == Ip) invd[I] = prow ? invp : invd[I];
           }
         }
       }
     }
   }
-  const real z0 = nw_lane(yv[0], 4*(my_ci & 15)), z1 = nw_lane(yv[1], 4*(my_ci & 15));
+  const real z0 = nw_lane(yv[0]*invd[0], 4*(my_ci & 15)), z1 = nw_lane(yv[1]*invd[1], 4*(my_ci & 15));
   SYNC();                                                            // (K is rewritten by the next iteration)
   return mine ? (my_ci < 16 ? z0 : z1) : (real)0;
 }
@@ -826,7 +852,11 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
         }
       }
 #endif
+#if FB_NW_GJ
+      const real zr = nw_lane(NW_GJ_SOL(yv), 4*(lane & 15));
+#else
       const real zr = nw_lane(yv, 4*(lane & 15));
+#endif
       z = (on && ((m_act >> lane) & 1ull)) ? zr : (real)0;
       NW_PROF(4);
     } else {
@@ -934,7 +964,11 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
           }
         }
 #endif
+#if FB_NW_GJ
+        const real zr = nw_lane(NW_GJ_SOL(yv), mine ? 4*my_ci : 0);
+#else
         const real zr = nw_lane(yv, mine ? 4*my_ci : 0);
+#endif
         z = mine ? zr : (real)0;
         SYNC();                                       // (K is rewritten by the next iteration)
         NW_PROF(4);
