@@ -46,10 +46,13 @@
 // middle of the solver's serial chain.  Unless FB_EXACT_DIV64 is defined the quotient is v_rcp_f64 + two Newton steps + one residual
 // correction (<= 1 ulp for the normal-range operands the solver produces, no denormal / overflow handling).
 #if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+#ifndef FB_DIV_STEPS
+#define FB_DIV_STEPS 2
+#endif
 FBD double fb_div(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+#pragma unroll
+  for (int k = 0; k < FB_DIV_STEPS; k++) r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
   double q = a*r;
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
@@ -62,10 +65,15 @@ FBD float fb_div(float a, float b) { return a / b; }
 FBD float fb_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 #endif
 #if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE)
+// (round 6: ONE Newton step behind v_rsq_f64 -- a few ulp instead of <= 1 -- measured +0.5 % env-steps/s with the 100-control-step divergence from the
+//  oracle unchanged at 7e-15 / 4e-14 on qpos / qvel, profiles/r6/ab_reciprocals.txt; FB_RSQ_STEPS 2 restores the second)
+#ifndef FB_RSQ_STEPS
+#define FB_RSQ_STEPS 1
+#endif
 FBD double fb_rsqrt(double a) {
   double y = __builtin_amdgcn_rsq(a);
-  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
-  y = y*__builtin_fma(-0.5*a*y, y, 1.5);
+#pragma unroll
+  for (int k = 0; k < FB_RSQ_STEPS; k++) y = y*__builtin_fma(-0.5*a*y, y, 1.5);
   return y;
 }
 #else
@@ -86,7 +94,22 @@ FBD float fb_sqrt(float a) { return a > 0 ? a*fb_rsqrt(a) : 0.0f; }
 FBD double fb_sqrt(double a) { return sqrt(a); }
 FBD float fb_sqrt(float a) { return sqrtf(a); }
 #endif
+// 1 / a: v_rcp_f64 + Newton steps.  fb_div(1, a) is rcp + THREE steps (its residual correction of q = 1 * r is a third one): the second already
+// leaves the rounding of the last fma as the only error, and a reciprocal sits on the serial chain of every pivot (Gauss-Jordan on the
+// Newton tiles) and of every level of the factorisations.  FB_INV_STEPS 3 restores the old sequence.
+#ifndef FB_INV_STEPS
+#define FB_INV_STEPS 2
+#endif
+#if !defined(FB_EXACT_DIV64) && !defined(FB_EMULATE) && FB_INV_STEPS < 3
+FBD double fb_inv(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+#pragma unroll
+  for (int k = 0; k < FB_INV_STEPS; k++) r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+  return r;
+}
+#else
 FBD double fb_inv(double a) { return fb_div(1.0, a); }
+#endif
 FBD float fb_inv(float a) { return fb_div(1.0f, a); }
 
 template <typename real> FBD real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }

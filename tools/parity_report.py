@@ -10,7 +10,7 @@ from flybody_amd.model_blob import pack_model
 from flybody_amd.reference import default_walking_reference
 from oracle import fbo
 
-model = engine.Model.from_asset('walk_imitation')
+model = engine.Model.from_asset('walk_imitation', lib_path=os.path.abspath(sys.argv[1])) if len(sys.argv) > 1 else engine.Model.from_asset('walk_imitation')      # (optional: an experimental build, FP64 and FP32 kernels of that library)
 qp, qv = default_walking_reference()
 om = fbo.OracleModel(pack_model(model.arrays)); od = fbo.OracleData(om)
 od.configure_env(qp, qv, terminal_com_dist=float('inf')); od.env_reset()
