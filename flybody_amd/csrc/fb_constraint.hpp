@@ -216,15 +216,22 @@ FBD void project_row(const DevModel<real>& M, const WS<real>& w, int side, int r
   // L[chain[s], chain[t]] lives in row chain[s] (depth s) at offset s - t.  The bound is the wave-uniform longest chain: a slot beyond
   // the lane's own chain carries y[s] = 0 and reads a trunk row (chain[] is padded with dof 0: finite factor entries), so it subtracts
   // exact zeros -- cheaper than an exec-mask round trip per slot for the lane-varying `s < len`
+  // (Round 6, FB_PROJ_STRAIGHT 1: no bound at all -- by the argument above a slot beyond the longest chain is as harmless as one beyond the lane's own,
+  //  and the fruit fly's longest chain IS FB_MAXCH -- makes the triangular solve ONE basic block.  Measured -0.6 % env-steps/s
+  //  (profiles/r6/ab_factor_straight.txt): left off.)
+#ifndef FB_PROJ_STRAIGHT
+#define FB_PROJ_STRAIGHT 0
+#endif
   const int chmax = M.chmax;
 #pragma unroll
   for (int s = FB_MAXCH - 1; s >= 1; s--) {
-    if (s < chmax) {
+    if (FB_PROJ_STRAIGHT || s < chmax) {
       const FB_LDS real* row = w.lLD + rowadr[s];
 #pragma unroll
       for (int t = 0; t < s; t++) y[t] -= row[-t] * y[s];
     }
   }
+  (void)chmax;
 #pragma unroll
   for (int s = 0; s < FB_MAXCH; s++) y[s] = (s < len) ? y[s]*sd[chain[s]] : (real)0;
 }

@@ -555,16 +555,27 @@ __device__ __forceinline__ void d_crb(const DevModel<real>& M, const WS<real>& w
       // (no early exit: the loop must unroll completely, ch[] lives in registers; the row is collected in registers and stored in
       // one go -- a store between two slots makes the next slot's wait for its operands a wait for that store)
       real val[FB_MAXCH];
+      // (round 6, FB_CRB_GROUP: the wave-uniform bound is tested once per FB_CRB_GROUP slots -- a slot beyond it reads dof 0's axis like one beyond the
+      //  dof's own depth and is not stored -- so that a group's 6 x FB_CRB_GROUP LDS reads are in flight together instead of one exposed round trip per slot)
+#ifndef FB_CRB_GROUP
+#define FB_CRB_GROUP 4
+#endif
 #pragma unroll
-      for (int sl = 0; sl < FB_MAXCH; sl++) {
-        val[sl] = 0;
-        if (sl < chmax) {                  // (wave-uniform bound; slots beyond the dof's own depth read dof 0's axis -- ch[] is padded -- and are not stored)
-          real c[6];
+      for (int sl0 = 0; sl0 < FB_MAXCH; sl0 += FB_CRB_GROUP) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) c[k] = Lc[6*ch[q][sl] + k];
-          real v = dot6(c, buf);
-          v += (sl == di[q]) ? arm[q] : (real)0;
-          val[sl] = v;
+        for (int sl = sl0; sl < sl0 + FB_CRB_GROUP; sl++) val[sl] = 0;
+        if (sl0 < chmax) {                  // (wave-uniform bound; slots beyond the dof's own depth read dof 0's axis -- ch[] is padded -- and are not stored)
+          real c[FB_CRB_GROUP][6];
+#pragma unroll
+          for (int sl = sl0; sl < sl0 + FB_CRB_GROUP; sl++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) c[sl - sl0][k] = Lc[6*ch[q][sl] + k];
+#pragma unroll
+          for (int sl = sl0; sl < sl0 + FB_CRB_GROUP; sl++) {
+            real v = dot6(c[sl - sl0], buf);
+            v += (sl == di[q]) ? arm[q] : (real)0;
+            val[sl] = v;
+          }
         }
       }
 #pragma unroll
@@ -650,12 +661,9 @@ FBD real gen_pull3(const FB_LDS real* RM, unsigned m01, unsigned m23, int oi, in
 #define FB_FAC_VOLATILE 1
 #endif
 #if FB_FAC_VOLATILE && !defined(FB_EMULATE)
-#define FB_FAC_LD(p) ((const volatile FB_LDS real*)(p))       // experiment: keeps the backend from pairing the reads into ds_read2_b64 (half the LDS rate per byte)
+#define FB_FAC_LD(p) ((const volatile FB_LDS real*)(p))       // keeps the backend from pairing the reads into ds_read2_b64 (half the LDS rate per byte: MI355X_MICROARCH.md, LDS table; +0.15 %)
 #else
 #define FB_FAC_LD(p) (p)
-#endif
-#ifndef FB_FAC_CHUNK
-#define FB_FAC_CHUNK 12      // LDS reads of a pull in flight together (all 20 of a deep level: the rows spill at the 168-register budget)
 #endif
 // p[t] = row[t] for t = LO .. min(d, HI)   (precondition: d >= LO - 1)
 template <int LO, int HI, typename real>
@@ -671,31 +679,31 @@ FBD void fac_publish(FB_LDS real* p, const real* row, int d) {
     } else fac_publish<LO, MID - 1>(p, row, d);
   }
 }
-// row[t] -= c p[t] for the first NG groups of four entries, c = pc[0] pd[0]; every LDS read of the block in flight before the first is consumed
-template <int NG, typename real>
-FBD real fac_pull_n(real* row, const FB_LDS real* pc, const FB_LDS real* pd, const FB_LDS real* p) {
-  const real c = pc[0]*pd[0];
-#pragma unroll
-  for (int t0 = 0; t0 < 4*NG; t0 += FB_FAC_CHUNK) {
-    real v[FB_FAC_CHUNK];
-#pragma unroll
-    for (int t = 0; t < FB_FAC_CHUNK; t++) if (t0 + t < 4*NG) v[t] = FB_FAC_LD(p)[t0 + t];
-#pragma unroll
-    for (int t = 0; t < FB_FAC_CHUNK; t++) if (t0 + t < 4*NG) row[t0 + t] -= c*v[t];
-  }
-  return c;
-}
-// the groups with t0 < d (d wave-uniform, 1 <= d < FB_MAXCH); returns c
+// row[t] -= c p[t], c = pc[0] pd[0], for the groups of four entries with t0 < d (d wave-uniform, 1 <= d < FB_MAXCH): the first FB_FAC_HEAD entries
+// unconditionally in ONE block (every LDS read in flight before the first is consumed; what lands beyond a row's end is never read back, and the
+// reads stay inside the pool), the rest behind one test.  (An exclusive five-way dispatch on ceil(d / 4) was tail-merged by the compiler into
+// multiply + add pairs: more vector instructions than the branches it saved.)
+#ifndef FB_FAC_HEAD
+#define FB_FAC_HEAD 12
+#endif
 template <typename real>
 FBD real fac_pull(real* row, const FB_LDS real* pc, const FB_LDS real* pd, const FB_LDS real* p, int d) {
-  static_assert(FB_MAXCH == 20, "fac_pull dispatches on ceil(d / 4) in 1 .. 5");
-  if (d > 8) {
-    if (d > 16) return fac_pull_n<5>(row, pc, pd, p);
-    if (d > 12) return fac_pull_n<4>(row, pc, pd, p);
-    return fac_pull_n<3>(row, pc, pd, p);
+  const real c = pc[0]*pd[0];
+  {
+    real v[FB_FAC_HEAD];
+#pragma unroll
+    for (int t = 0; t < FB_FAC_HEAD; t++) v[t] = FB_FAC_LD(p)[t];
+#pragma unroll
+    for (int t = 0; t < FB_FAC_HEAD; t++) row[t] -= c*v[t];
   }
-  if (d > 4) return fac_pull_n<2>(row, pc, pd, p);
-  return fac_pull_n<1>(row, pc, pd, p);
+  if (d > FB_FAC_HEAD) {
+    real v[FB_MAXCH - FB_FAC_HEAD];
+#pragma unroll
+    for (int t = 0; t < FB_MAXCH - FB_FAC_HEAD; t++) v[t] = FB_FAC_LD(p)[FB_FAC_HEAD + t];
+#pragma unroll
+    for (int t = 0; t < FB_MAXCH - FB_FAC_HEAD; t++) row[FB_FAC_HEAD + t] -= c*v[t];
+  }
+  return c;
 }
 
 template <typename real>
