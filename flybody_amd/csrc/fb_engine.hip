@@ -666,7 +666,7 @@ __device__ __forceinline__ void fly_kernel(const DevModel<real>* Mp, const Batch
       const long long tw1_ = wall_clock64();       // (tools/ticket_trace.py) per environment: wait for the predecessor, first start, last end, busy ticks
 #endif
       const bool was_reset = d_run(M, w, env, mode, nsub, nslot, (int*)nullptr, action ? action + (size_t)env*M.nact : nullptr, obs, B.reward + env,
-                                   B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nunit - 1 ? 2 : 0) | (tkhalf == 1 ? 4 : 0) | (tkhalf == 2 ? 8 : 0));
+                                   B.discount + env, B.step_type + env, lane, (round == 0 ? 1 : 0) | (round == nunit - 1 ? 2 : 0) | (tkhalf == 1 ? 4 : 0) | (tkhalf == 2 ? 8 : 0) | (late ? 16 : 0));
 #ifndef FB_EMULATE
       // Release.  What the next holder of this environment (a wave of the SAME XCD: environments are bound to XCDs) must see is this
       // wave's global stores.  On gfx942 / gfx950 the vector L1 is write-through and an XCD has ONE L2, so "visible to the XCD" =

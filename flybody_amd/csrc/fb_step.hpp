@@ -850,6 +850,20 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
   // VGPRs + saved exec masks across every stage call and counts against the register budget of all stages
   mode = uniform_int(mode); nsub_arg = uniform_int(nsub_arg); tk = uniform_int(tk); only = uniform_int(only);
   const bool tk_first = tk < 0 || (tk & 1), tk_last = tk < 0 || (tk & 2), tk_half_a = tk >= 0 && (tk & 4), tk_half_b = tk >= 0 && (tk & 8);
+  // Round 6 (FB_LAT_PRIO; +0.5 %, profiles/r6/ab_stage_priority.txt): issue priority by STAGE CLASS.  The stages that are chains of memory round trips with a few hundred
+  // instructions between them (actuation, factorisations, solves, sensors, integration, kinematics, inertias, constraint rows, velocities) run at
+  // max(ticket priority, FB_LAT_PRIO); the three stages that do nothing but issue (projection, solver, collision) at the ticket's own priority.
+#ifndef FB_LAT_PRIO
+#define FB_LAT_PRIO 2
+#endif
+#if FB_LAT_PRIO > 0
+  const int base_prio_ = uniform_int((tk >= 0 && (tk & 16)) ? 3 : 0);
+#define ST_LAT() FB_SETPRIO(base_prio_ > FB_LAT_PRIO ? base_prio_ : FB_LAT_PRIO)
+#define ST_ISS() FB_SETPRIO(base_prio_)
+#else
+#define ST_LAT() do {} while (0)
+#define ST_ISS() do {} while (0)
+#endif
   int parts = 15;
   bool resetting = (mode == MODE_RESET) || (mode == MODE_STEP && tk_first && uniform_int(w.istate()[IS_RESET_NEXT]) != 0);
   bool env_logic = (mode == MODE_STEP) || (mode == MODE_RESET);
@@ -882,6 +896,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
     switch (pc) {
       case ST_ACT: {
         PROF_BEGIN();
+        ST_LAT();
         if (actuate) s_actuation(M, wc, lane);      // (leaves qfrc_actuator in the solve vector lx as well as in the global row)
         else {
           for (int i = lane; i < M.nv; i += FB_WAVE) { w.qfrc_actuator()[i] = 0; w.lx()[i] = 0; }
@@ -907,6 +922,9 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         half = true; ret = ST_ACC_POST; pc = ST_SOLVE; break;
       case ST_SOLVE: {
         PROF_BEGIN();
+#ifdef FB_LAT_FACTOR_ISS
+        ST_LAT();
+#endif
         d_solve(M, wc, w.lLD, w.lx(), half, lane);
         PROF(P_ACC);
         half = false;
@@ -918,6 +936,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
           SYNC();
         }
         PROF(24);
+        ST_ISS();
         if (parts & 2) s_project_constraint(M, wc, lane);
         PROF(P_PROJ);
         pc = ST_CONSTR_A; break; }
@@ -926,6 +945,7 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         ret = ST_CONSTR_B; pc = need ? ST_SOLVE : ST_CONSTR_B; break; }
       case ST_CONSTR_B: {
         PROF_BEGIN();
+        ST_LAT();
         s_constraint_b(M, wc, lane);
         PROF(25);
         pc = ST_SENS; break; }
@@ -943,6 +963,9 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         damp = true; fret = ST_EULER_SOLVE; pc = ST_FACTOR; break; }
       case ST_FACTOR: {
         PROF_BEGIN();
+#ifdef FB_LAT_FACTOR_ISS
+        ST_ISS();
+#endif
         d_factor(M, wc, (const FB_GLOBAL real*)w.qM(), damp ? M.dof_damping.p : (const FB_GLOBAL real*)nullptr, damp ? M.timestep : (real)0, w.lLD, w.lx(), lane);
         PROF(P_FACTOR);
         pc = fret; break; }
@@ -964,8 +987,10 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
         pc = ST_COLL; break; }
       case ST_COLL: {
         PROF_BEGIN();
+        ST_ISS();
         if (parts & 1) s_collision(M, wc, lane);
         PROF(P_COLL);
+        ST_LAT();
         if (parts & 2) s_make_constraint(M, wc, lane);
         PROF(P_MAKEC);
         if (parts & 4) s_velocity(M, wc, lane);
