@@ -231,6 +231,11 @@ template <typename real> FBD real clampr(real x, real lo, real hi) { return x < 
 #define FB_LDS_AS __attribute__((address_space(3)))
 #endif
 
+// issue priority of the latency-bound stage class (fb_step.hpp: d_run; 0 = no stage classes)
+#ifndef FB_LAT_PRIO
+#define FB_LAT_PRIO 2
+#endif
+
 // Arguments of a non-inlined device function arrive in VGPRs even when they are wave-uniform.  Moving a uniform
 // pointer to SGPRs (v_readfirstlane) frees two VGPRs per pointer and lets loads through it use scalar addressing.
 #ifdef FB_EMULATE

@@ -853,9 +853,6 @@ __device__ __forceinline__ bool d_run(const DevModel<real>& M, const WS<real>& w
   // Round 6 (FB_LAT_PRIO; +0.5 %, profiles/r6/ab_stage_priority.txt): issue priority by STAGE CLASS.  The stages that are chains of memory round trips with a few hundred
   // instructions between them (actuation, factorisations, solves, sensors, integration, kinematics, inertias, constraint rows, velocities) run at
   // max(ticket priority, FB_LAT_PRIO); the three stages that do nothing but issue (projection, solver, collision) at the ticket's own priority.
-#ifndef FB_LAT_PRIO
-#define FB_LAT_PRIO 2
-#endif
 #if FB_LAT_PRIO > 0
   const int base_prio_ = uniform_int((tk >= 0 && (tk & 16)) ? 3 : 0);
 #define ST_LAT() FB_SETPRIO(base_prio_ > FB_LAT_PRIO ? base_prio_ : FB_LAT_PRIO)
