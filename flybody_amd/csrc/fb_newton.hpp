@@ -528,9 +528,10 @@ FB_NEWTON_ATTR int d_newton_wide(const DevModel<real>& M_, const WS<real>& w_, i
 // No back substitution, nothing of the factor returns to memory.  Round 5's attempt (2 x 2 blocked Cholesky INSIDE d_newton) spilled
 // the small-system path; this is a function of its own with its own register allocation, called on the rare path only.
 #ifndef FB_NW_TILE32
-#define FB_NW_TILE32 1
+#define FB_NW_TILE32 3      // 0: rows-in-LDS factorisation for every system with more than 16 active columns; 1-2: register tiles up to 32 active columns; 3: up to 48; 4: up to 64 (the LDS path is not compiled in)
 #endif
-template <typename real, typename KP>
+// NB block rows of 16: n_act <= 16 NB (NB = 2: 32 columns, 16 matrix registers per lane; 3: 48 / 36; 4: 64 / 64 -- every system of one row per lane).
+template <int NB, typename real, typename KP>
 FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg, real y, int lane, bool on) {
   const int n_act = uniform_int(n_act_);
   const bool mine = on && ((m_act >> lane) & 1ull);
@@ -538,27 +539,28 @@ FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg,
   if (mine) K[my_ci*(my_ci + 1)/2 + my_ci] = (real)lane;         // row of compact index my_ci, parked in the (unused) diagonal slot of packed row my_ci
   SYNC();
   const int ti = lane >> 2, tc = lane & 3;
-  real T[2][2][4], yv[2], invd[2] = {1, 1};
+  real T[NB][NB][4], yv[NB], invd[NB];
   {
-    bool iv[2]; int tri_i[2], ci[2]; real dgt[2];
+    bool iv[NB]; int tri_i[NB], ci[NB]; real dgt[NB];
 #pragma unroll
-    for (int I = 0; I < 2; I++) {
+    for (int I = 0; I < NB; I++) {
       ci[I] = 16*I + ti; iv[I] = ci[I] < n_act;
       const int ri = iv[I] ? (int)K[ci[I]*(ci[I] + 1)/2 + ci[I]] : 0;
       tri_i[I] = ri*(ri + 1)/2;
       dgt[I] = nw_lane(dg, ri);
       const real yr = nw_lane(y, ri);
       yv[I] = iv[I] ? yr : (real)0;
+      invd[I] = 1;
     }
 #pragma unroll
-    for (int J = 0; J < 2; J++)
+    for (int J = 0; J < NB; J++)
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         const int cj = 16*J + 4*tc + s;
         const bool jv = cj < n_act;
         const int rj = jv ? (int)K[cj*(cj + 1)/2 + cj] : 0;
 #pragma unroll
-        for (int I = 0; I < 2; I++) {
+        for (int I = 0; I < NB; I++) {
           const bool both = iv[I] && jv;
           const real e = K[both ? (cj < ci[I] ? tri_i[I] + cj : rj*(rj + 1)/2 + ci[I]) : 0];      // (cj == ci reads a table slot: replaced below)
           T[I][J][s] = both ? (cj == ci[I] ? dgt[I] : e) : (cj == ci[I] ? (real)1 : (real)0);
@@ -566,39 +568,43 @@ FB_NEWTON_ATTR real nw_gj32(KP K, int n_act_, unsigned long long m_act, real dg,
       }
   }
 #pragma unroll
-  for (int Ip = 0; Ip < 2; Ip++) {
-    for (int P = 0; P < 4; P++) {
+  for (int Ip = 0; Ip < NB; Ip++) {
+    if (16*Ip < n_act) {
+      for (int P = 0; P < 4; P++) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int pr = 4*P + q, pv = 16*Ip + pr;                    // pivot: row pr of block row Ip
-        if (pv < n_act) {
-          // (raw pivot row, reciprocal pivots kept per row: see NW_GJ_STEP)
-          const real invp = fb_inv(rdlane(T[Ip][Ip][q], 4*pr + P));
-          real rp[2][4];
+        for (int q = 0; q < 4; q++) {
+          const int pr = 4*P + q, pv = 16*Ip + pr;                    // pivot: row pr of block row Ip
+          if (pv < n_act) {
+            // (raw pivot row, reciprocal pivots kept per row: see NW_GJ_STEP)
+            const real invp = fb_inv(rdlane(T[Ip][Ip][q], 4*pr + P));
+            real rp[NB][4];
 #pragma unroll
-          for (int J = Ip; J < 2; J++)
+            for (int J = Ip; J < NB; J++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) rp[J][s] = nw_lane(T[Ip][J][s], 4*pr + tc);
-          const real yp = rdlane(yv[Ip], 4*pr);
+              for (int s = 0; s < 4; s++) rp[J][s] = nw_lane(T[Ip][J][s], 4*pr + tc);
+            const real yp = rdlane(yv[Ip], 4*pr);
 #pragma unroll
-          for (int I = 0; I < 2; I++) {
-            const real Lip = nw_lane(T[I][Ip][q], 4*ti + P)*invp;
-            const bool prow = (I == Ip) && ti == pr;
-            const real Lm = prow ? (real)0 : Lip;
+            for (int I = 0; I < NB; I++) {
+              const real Lip = nw_lane(T[I][Ip][q], 4*ti + P)*invp;
+              const bool prow = (I == Ip) && ti == pr;
+              const real Lm = prow ? (real)0 : Lip;
 #pragma unroll
-            for (int J = Ip; J < 2; J++)
+              for (int J = Ip; J < NB; J++)
 #pragma unroll
-              for (int s = 0; s < 4; s++) T[I][J][s] -= Lm*rp[J][s];
-            yv[I] -= Lm*yp;
-            if (I == Ip) invd[I] = prow ? invp : invd[I];
+                for (int s = 0; s < 4; s++) T[I][J][s] -= Lm*rp[J][s];
+              yv[I] -= Lm*yp;
+              if (I == Ip) invd[I] = prow ? invp : invd[I];
+            }
           }
         }
       }
     }
   }
-  const real z0 = nw_lane(yv[0]*invd[0], 4*(my_ci & 15)), z1 = nw_lane(yv[1]*invd[1], 4*(my_ci & 15));
+  real zr = 0;
+#pragma unroll
+  for (int I = 0; I < NB; I++) { const real zI = nw_lane(yv[I]*invd[I], 4*(my_ci & 15)); zr = (my_ci >> 4) == I ? zI : zr; }
   SYNC();                                                            // (K is rewritten by the next iteration)
-  return mine ? (my_ci < 16 ? z0 : z1) : (real)0;
+  return mine ? zr : (real)0;
 }
 // ARP / KP: LDS (address_space(3)) or global pointers to the packed lower triangles of AR and of the work matrix K.
 // Returns the number of Newton iterations; the forces are left in efc_force.
@@ -976,10 +982,25 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
 #if FB_NW_TILE32
       else if (n_act <= 32) {
         FB_STAT(46);
-        z = nw_gj32<real, KP>(K, n_act, m_act, dg, y, lane, on);
+        z = nw_gj32<2, real, KP>(K, n_act, m_act, dg, y, lane, on);
+        NW_PROF(3); NW_PROF(4);
+      }
+#if FB_NW_TILE32 >= 3
+      else if (n_act <= 48) {
+        FB_STAT(46);
+        z = nw_gj32<3, real, KP>(K, n_act, m_act, dg, y, lane, on);
         NW_PROF(3); NW_PROF(4);
       }
 #endif
+#if FB_NW_TILE32 >= 4
+      else {
+        FB_STAT(46);
+        z = nw_gj32<4, real, KP>(K, n_act, m_act, dg, y, lane, on);
+        NW_PROF(3); NW_PROF(4);
+      }
+#endif
+#endif
+#if FB_NW_TILE32 < 4
       else {
       // Larger systems: right-looking factorisation on the rows in LDS.  These are the environments a lock-step launch WAITS for
       // (tools/ticket_trace.py: the last environments of a launch spent 5-20 x the mean here), so the loop is built for instruction count:
@@ -1065,6 +1086,7 @@ FB_NEWTON_ATTR int d_newton(const DevModel<real>& M_, const WS<real>& w_, ARP AR
       SYNC();                                         // (K is rewritten by the next iteration)
       NW_PROF(4);
       }
+#endif
     }
     real dl;
     {
