@@ -452,7 +452,10 @@ static int model_load_impl(fb_model* m, size_t n) {
   {
     if (FB_MAXCH > (1 << FB_NJUMP) || nv > 2*FB_WAVE) return fail("fb_model_load: dof tree too deep / too wide for the prefix tables");
     m->dof_jump.assign((size_t)FB_NJUMP*nv, -1);
-    for (int i = 0; i < nv; i++) m->dof_jump[i] = dofpar[i];
+    for (int i = 0; i < nv; i++) {
+      if (dofpar[i] >= i) return fail("fb_model_load: dof_parentid must number parents before children (the prefix sums exchange one slot for the ancestors of the first 64 dofs)");
+      m->dof_jump[i] = dofpar[i];
+    }
     for (int k = 1; k < FB_NJUMP; k++)
       for (int i = 0; i < nv; i++) { int a = m->dof_jump[(size_t)(k - 1)*nv + i]; m->dof_jump[(size_t)k*nv + i] = a >= 0 ? m->dof_jump[(size_t)(k - 1)*nv + a] : -1; }
     const int *djnt = m->i("dof_jntid"), *jt = m->i("jnt_type"), *jda = m->i("jnt_dofadr");

@@ -77,9 +77,10 @@ FBD void nw_update(const NwConst<real>& c, real jb0, real jb1, real jb2, NwRow<r
 #else
   const real N = U0, T = fb_sqrt(U1*U1 + U2*U2);
 #endif
-  const bool top = (N >= c.mu*T) || (T <= 0 && N >= 0);
-  const bool bot = !top && ((c.mu*N + T <= 0) || (T <= 0 && N < 0));
-  const bool mid = c.ell && !top && !bot;
+  // (bitwise on purpose: `||` / `&&` between floating-point compares compile to exec-mask branches -- three per call, sixteen calls per solve)
+  const bool top = (N >= c.mu*T) | ((T <= 0) & (N >= 0));
+  const bool bot = !top & ((c.mu*N + T <= 0) | ((T <= 0) & (N < 0)));
+  const bool mid = c.ell & !top & !bot;
   const bool quad = c.ell ? bot : (jo < 0);
 #if FB_NW_RSQ && !defined(FB_EMULATE) && !defined(FB_EXACT_DIV64)
   const real Ti = mid ? Tr : (real)1;

@@ -1103,6 +1103,17 @@ FBD void dof_fetch6(const DofPair<real>& x, int d, real* out) {
     out[c] = d < 0 ? (real)0 : ((d >> 6) ? vb : va);
   }
 }
+// the same for a d that is known to be < 64 on every lane (round 6): an ancestor of one of the first 64 dofs -- dofs are numbered parents first --
+// so only the first slot is exchanged: half the lane exchanges of the general form
+template <typename real>
+FBD void dof_fetch6_lo(const DofPair<real>& x, int d, real* out) {
+  const int src = d & 63;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const real va = __shfl(x.a[c], src, 64);
+    out[c] = d < 0 ? (real)0 : va;
+  }
+}
 template <typename real>
 FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
   const int nv = M.nv;
@@ -1115,7 +1126,14 @@ FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
 #pragma unroll
   for (int k = 0; k < FB_NJUMP; k++) {
     real ga[6], gb[6];
+#ifndef FB_FETCH_LO
+#define FB_FETCH_LO 1
+#endif
+#if FB_FETCH_LO
+    dof_fetch6_lo(x, ja[k], ga); dof_fetch6(x, jb[k], gb);
+#else
     dof_fetch6(x, ja[k], ga); dof_fetch6(x, jb[k], gb);
+#endif
 #pragma unroll
     for (int c = 0; c < 6; c++) { x.a[c] += ga[c]; x.b[c] += gb[c]; }
   }

@@ -88,7 +88,7 @@ def report(a):
     print('# wait% = SQ_WAIT_ANY / SQ_WAVE_CYCLES of the')
     print('# stage launch (cold L2: every stage streams the whole batch, so waits and bytes are UPPER bounds of what the fused kernel sees);')
     print('# KB rd/wr = 2 x FETCH_SIZE / WRITE_SIZE (calibration: profiles/r3/pmc_calibration.json); scr = scratch instructions in the stage function(s) (static).')
-    hdr = '%-20s %5s %8s %8s %7s %7s %6s %5s %5s %9s %6s %7s %7s %5s' % ('stage', 'n/sub', 'VALU', 'SALU', 'LDS', 'VMEM', 'lanes', 'f64%', 'int%', 'wavecyc', 'wait%', 'KB_rd', 'KB_wr', 'scr')
+    hdr = '%-20s %5s %8s %8s %7s %7s %6s %5s %5s %9s %6s %7s %7s %5s %6s' % ('stage', 'n/sub', 'VALU', 'SALU', 'LDS', 'VMEM', 'lanes', 'f64%', 'int%', 'wavecyc', 'wait%', 'KB_rd', 'KB_wr', 'scr', 'branch')
     print(hdr)
     tot = collections.defaultdict(float)
     for n in order:
@@ -106,15 +106,17 @@ def report(a):
         rd, wr = 2*g('FETCH_SIZE'), g('WRITE_SIZE')
         fns = fn_of.get(n, ''); sc = sum(scr.get(f, (0, 0, 0))[2] for f in fns.split('+')) if fns else 0
         i32 = g('SQ_INSTS_VALU_INT32')
-        print('%-20s %5.1f %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %5.1f %9.0f %6.1f %7.2f %7.2f %5d' % (n, k/float(nsub*steps), valu, salu, lds, vmem, lanes, 100*f64/valu if valu > 50 else float('nan'),
-              100*i32/valu if valu > 50 else float('nan'), wc, 100*wt, rd, wr, sc))
+        br = g('SQ_INSTS_BRANCH')          # (branch instructions, taken or not; in the insts pass since round 6)
+        print('%-20s %5.1f %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %5.1f %9.0f %6.1f %7.2f %7.2f %5d %6.0f' % (n, k/float(nsub*steps), valu, salu, lds, vmem, lanes, 100*f64/valu if valu > 50 else float('nan'),
+              100*i32/valu if valu > 50 else float('nan'), wc, 100*wt, rd, wr, sc, br))
+        if n != 'substep_end': tot['br'] += br
         tot['i32'] += 0 if n == 'substep_end' else i32
         if n != 'substep_end':
             for key, v in (('VALU', valu), ('SALU', salu), ('LDS', lds), ('VMEM', vmem), ('wc', wc), ('rd', rd), ('wr', wr), ('f64', f64), ('thr', thr/envsub), ('act', act_/envsub)):
                 tot[key] += v
     print('%-20s %5s %8.0f %8.0f %7.0f %7.0f %6.1f %5.1f %5.1f %9.0f %6s %7.2f %7.2f' % ('SUM (per env-substep)', '', tot['VALU'], tot['SALU'], tot['LDS'], tot['VMEM'],
           tot['thr']/max(tot['act'], 1e-9), 100*tot['f64']/max(tot['VALU'], 1e-9), 100*tot['i32']/max(tot['VALU'], 1e-9), tot['wc'], '', tot['rd'], tot['wr']))
-    print('# x %d substeps = per env-step: VALU %.0f  SALU %.0f  LDS %.0f  VMEM %.0f ; KB fetched %.1f written %.1f' % (nsub, nsub*tot['VALU'], nsub*tot['SALU'], nsub*tot['LDS'], nsub*tot['VMEM'], nsub*tot['rd'], nsub*tot['wr']))
+    print('# x %d substeps = per env-step: VALU %.0f  SALU %.0f  LDS %.0f  VMEM %.0f  branches %.0f ; KB fetched %.1f written %.1f' % (nsub, nsub*tot['VALU'], nsub*tot['SALU'], nsub*tot['LDS'], nsub*tot['VMEM'], nsub*tot['br'], nsub*tot['rd'], nsub*tot['wr']))
 
 
 if __name__ == '__main__':
