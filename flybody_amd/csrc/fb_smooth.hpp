@@ -1130,6 +1130,7 @@ FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
 #define FB_FETCH_LO 1
 #endif
 #if FB_FETCH_LO
+    // (skipping the second slot altogether for models of <= 64 dofs -- flight_imitation has 42 -- behind a wave-uniform test: +0.9 % flight, -0.3 % walking; not taken)
     dof_fetch6_lo(x, ja[k], ga); dof_fetch6(x, jb[k], gb);
 #else
     dof_fetch6(x, ja[k], ga); dof_fetch6(x, jb[k], gb);
@@ -1181,7 +1182,7 @@ __device__ __forceinline__ void d_com_vel(const DevModel<real>& M, const WS<real
   {
     const int va = vbef[0], vb = vbef[1];
     real ua[6], ub[6], da[6], db[6];
-    dof_fetch6(V, va, ua); dof_fetch6(V, vb, ub);
+    dof_fetch6_lo(V, va, ua); dof_fetch6(V, vb, ub);        // (vbef of a dof is an ancestor or an earlier dof of the same body: < 64 for the first slot)
     crossmotion(da, ua, ca); crossmotion(db, ub, cb);
 #pragma unroll
     for (int c = 0; c < 6; c++) { da[c] = (va == -2) ? (real)0 : da[c]; db[c] = (vb == -2) ? (real)0 : db[c]; A.a[c] = da[c]*qa; A.b[c] = db[c]*qb; }
