@@ -41,7 +41,7 @@ struct fb_model {
   std::vector<int> wrap_qadr, act_wn, act_wdof, act_lenadr; std::vector<double> act_wcoef;
   std::vector<int> pair_word, pair_body, plane_geoms;
   std::vector<double> geom_box;          // [ngeom][3] oriented-box half extents by geom type (constant: one lookup instead of type -> size -> switch)
-  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band, fac_dof; int ngen = 0, ntrunk = 1;
+  std::vector<int> dof_cl, dof_gen, gen_k, gen_m, fwd_tab, fwd_pack, fac_w, fac_band, fac_dof; int ngen = 0, ntrunk = 1, prefix_split = 0;
   int nlevel;
   std::vector<double> body_box, body_rec;
   std::vector<int> body_fluid_geom, sens_body, dof_jump, dof_vbef, body_veldof;
@@ -455,6 +455,19 @@ static int model_load_impl(fb_model* m, size_t n) {
     for (int i = 0; i < nv; i++) {
       if (dofpar[i] >= i) return fail("fb_model_load: dof_parentid must number parents before children (the prefix sums exchange one slot for the ancestors of the first 64 dofs)");
       m->dof_jump[i] = dofpar[i];
+    }
+    // Round 6: when every chain is at most 2^(FB_NJUMP - 1) dofs long BELOW the trunk (the fruit fly: 6 trunk dofs + <= 14), the jumps of the other dofs
+    // stop at the trunk: four rounds finish the trunk's own prefixes and everybody else's sum over their non-trunk ancestors, and the trunk's total -- common
+    // to all of them -- is added by one broadcast (tree_prefix6).  One round of lane exchanges less in each of the three prefix sums of a substep.
+    m->prefix_split = 0;
+    {
+      const int nT = m->ntrunk; int below = 0;
+      for (int i = nT; i < nv; i++) below = std::max(below, m->dof_depth[i] + 1 - nT);
+      if (nT > 0 && nT <= (1 << (FB_NJUMP - 1)) && below <= (1 << (FB_NJUMP - 1))) {
+        bool ok = true;
+        for (int i = nT; i < nv; i++) { int a = i; while (dofpar[a] >= nT) a = dofpar[a]; ok = ok && dofpar[a] == nT - 1; }      // (everything hangs off the last trunk dof)
+        if (ok) { m->prefix_split = 1; for (int i = nT; i < nv; i++) if (dofpar[i] < nT) m->dof_jump[i] = -1; }
+      }
     }
     for (int k = 1; k < FB_NJUMP; k++)
       for (int i = 0; i < nv; i++) { int a = m->dof_jump[(size_t)(k - 1)*nv + i]; m->dof_jump[(size_t)k*nv + i] = a >= 0 ? m->dof_jump[(size_t)(k - 1)*nv + a] : -1; }
@@ -927,7 +940,7 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   UI(dof_bodyid, "dof_bodyid") UI(dof_jntid, "dof_jntid") UI(dof_Madr, "dof_Madr") UV(dof_depth, dof_depth)
   UV(dof_ndesc, dof_ndesc) UV(body_fluid_geom, body_fluid_geom) UV(sens_body, sens_body) M.nsensbody = (int)m->sens_body.size();
   UV(dof_jump, dof_jump) UV(dof_vbef, dof_vbef) UV(body_veldof, body_veldof)
-  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fwd_pack, fwd_pack) UV(fac_w, fac_w) UV(fac_band, fac_band) UV(fac_dof, fac_dof) M.ntrunk = m->ntrunk;
+  UV(dof_cl, dof_cl) UV(dof_gen, dof_gen) UV(gen_k, gen_k) UV(gen_m, gen_m) UV(fwd_tab, fwd_tab) UV(fwd_pack, fwd_pack) UV(fac_w, fac_w) UV(fac_band, fac_band) UV(fac_dof, fac_dof) M.ntrunk = m->ntrunk; M.prefix_split = m->prefix_split;
   { int dmax = 0, d2 = 1 << 20; for (int bq = 1; bq < m->nbody; bq++) { dmax = std::max(dmax, m->body_depth[bq]); if (bq >= FB_WAVE) d2 = std::min(d2, m->body_depth[bq]); } M.fk_dmax = dmax; M.fk2_dlo = d2; }
   { int cm = 0; for (int bq = 0; bq < m->nbody; bq++) cm = std::max(cm, m->body_chlen[bq]); M.chmax = cm; }
   {

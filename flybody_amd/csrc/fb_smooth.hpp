@@ -1123,8 +1123,10 @@ FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
   const int la = min(lane, nv - 1), lb = min(lane + FB_WAVE, nv - 1);
 #pragma unroll
   for (int k = 0; k < FB_NJUMP; k++) { const int va = M.dof_jump[k*nv + la], vb = M.dof_jump[k*nv + lb]; ja[k] = lane < nv ? va : -1; jb[k] = lane + FB_WAVE < nv ? vb : -1; }
+  const bool split = M.prefix_split != 0;          // (wave-uniform, a model constant: fb_engine.hip)
 #pragma unroll
   for (int k = 0; k < FB_NJUMP; k++) {
+    if (k == FB_NJUMP - 1 && split) break;         // the last round is the one the split saves
     real ga[6], gb[6];
 #ifndef FB_FETCH_LO
 #define FB_FETCH_LO 1
@@ -1137,6 +1139,15 @@ FBD void tree_prefix6(const DevModel<real>& M, DofPair<real>& x, int lane) {
 #endif
 #pragma unroll
     for (int c = 0; c < 6; c++) { x.a[c] += ga[c]; x.b[c] += gb[c]; }
+  }
+  if (split) {
+    const int nT = M.ntrunk;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const real T = rdlane(x.a[c], nT - 1);       // the trunk's total: the inclusive prefix of its last dof
+      x.a[c] += (lane >= nT && lane < nv) ? T : (real)0;
+      x.b[c] += (lane + FB_WAVE < nv) ? T : (real)0;
+    }
   }
 }
 

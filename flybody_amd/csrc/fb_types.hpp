@@ -138,6 +138,7 @@ struct DevModel {
   GP<const int> fac_band;       // [32][2] per level: bit masks of the chain slots that publish | that pull, the same for every lane
   GP<const int> fac_dof;        // [2][64] dof of a lane's first / second row in the factorisation and the solves (255: none; fb_smooth.hpp: fac_dof)
   int ntrunk;                // dofs 0 .. ntrunk-1: unbranched chain at the root
+  int prefix_split;          // tree prefix sums (fb_smooth.hpp: tree_prefix6): 1 = dof_jump stops at the trunk (4 jumping rounds + the trunk's total by broadcast), 0 = 5 plain rounds
   int chmax;                 // longest dof chain of any body
   int fk_dmax, fk2_dlo;      // deepest body level; shallowest level among bodies >= 64 (second kinematics pass)
   const int* fk_second;      // [64] second body of each lane in the kinematics level loop (-1 = none); null = separate passes
