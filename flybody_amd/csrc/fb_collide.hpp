@@ -606,6 +606,59 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
   C_PROF(0);
   int ncand = 0;
   const int maxcand = 2*FB_MAXCON_ + 64;
+  const real vld = M.vl_delta;                  // slack of the neighbour list (model constant; 0: no list, every substep tests every pair)
+  // Round 6: NEIGHBOUR LIST.  A substep moves a geom by a fraction of its size (h = 0.2 ms), yet every substep tested every one of the ~2 200 pairs
+  // (34 wave passes).  The list holds, in pair order, every pair whose bounding spheres were within margin + 2 delta when it was built, and the geom
+  // centres of that moment; as long as no centre has moved by more than delta since, a pair outside the list cannot pass the test, so the substep tests
+  // the listed pairs only (2-4 passes) -- with the SAME criterion on the SAME data in the SAME order: the candidates, and everything behind them, are
+  // bit for bit those of the full loop.  The list is a function of the positions alone (no history): resets and fb_batch_set need no hook, a centre that
+  // jumped fails the displacement test like one that drifted.  A list that would not fit FB_VLMAX pairs is not kept.
+  // A list that does not survive ONE substep (flight: the wings move by more than the slack every substep) is not worth building: after such a
+  // rebuild the next FB_VL_BACKOFF substeps run the plain loop without list construction.
+#ifndef FB_VL_BACKOFF
+#define FB_VL_BACKOFF 15
+#endif
+  bool use_list = false;
+  int nlist = 0, okf = 0;
+  const int vskip = (vld > 0) ? uniform_int(w.istate()[IS_VL_SKIP]) : 0;
+  if (vld > 0 && vskip == 0) {
+    okf = w.istate()[IS_VL_OK]; nlist = w.istate()[IS_VL_N];
+    const real lim = (real)0.999999*vld*vld;
+    bool moved = false;
+    for (int g = lane; g < M.ngeom; g += FB_WAVE) {
+      const real dx = G[4*g] - w.vl_pos()[3*g], dy = G[4*g + 1] - w.vl_pos()[3*g + 1], dz = G[4*g + 2] - w.vl_pos()[3*g + 2];
+      moved = moved || !(dx*dx + dy*dy + dz*dz <= lim);        // (NaN counts as moved)
+    }
+    okf = uniform_int(okf);
+    use_list = okf != 0 && __ballot(moved) == 0ull;
+    nlist = uniform_int(nlist);
+  }
+  const bool build = vld > 0 && vskip == 0 && !use_list;
+  if (use_list) {
+    for (int base = 0; base < nlist; base += FB_WAVE) {
+      const int i = base + lane;
+      const int p = w.vl_list()[i < nlist ? i : 0];
+      const int pw = M.pair_word[p]; const real mg = M.pair_margin[p];
+      int g1 = pw & 1023, g2 = (pw >> 10) & 1023, ns = (pw >> 20) & 1023;
+      const FB_LDS real* c1 = G + 4*g1; const FB_LDS real* c2 = G + 4*g2;
+      real dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+      bool hit;
+      if (ns) {
+        const FB_LDS real* n = G + 4*ns;
+        hit = dif[0]*n[0] + dif[1]*n[1] + dif[2]*n[2] <= c2[3] + mg;
+      } else {
+        real bound = c1[3] + c2[3] + mg;
+        hit = dot3(dif, dif) <= bound*bound;
+      }
+      hit = hit && i < nlist;
+      unsigned long long bal = __ballot(hit);
+      int idx = ncand + __popcll(bal & lt_mask);
+      if (hit && idx < maxcand) w.cand()[idx] = p;
+      ncand += __popcll(bal);
+    }
+    if (lane == 0 && okf == 1) w.istate()[IS_VL_OK] = 2;          // (the list has paid for itself)
+  } else {
+  int nl = 0;
   // (software-pipelined: the words of the next four passes are in flight while the current four are tested)
   int pwn[4]; real mgn[4];
 #pragma unroll
@@ -641,7 +694,26 @@ __device__ __forceinline__ void d_collision(const DevModel<real>& M, const WS<re
       int idx = ncand + __popcll(bal & lt_mask);
       if (hit && idx < maxcand) w.cand()[idx] = p;
       ncand += __popcll(bal);
+      if (build) {
+        // the same pair against the slack: listed for the substeps to come
+        bool near_;
+        if (ns) { const FB_LDS real* n = G + 4*ns; near_ = dif[0]*n[0] + dif[1]*n[1] + dif[2]*n[2] <= c2[3] + mg[u] + 2*vld; }
+        else { const real bnd = c1[3] + c2[3] + mg[u] + 2*vld; near_ = dot3(dif, dif) <= bnd*bnd; }
+        near_ = (near_ || hit) && p < M.npair;
+        const unsigned long long nb_ = __ballot(near_);
+        const int li = nl + __popcll(nb_ & lt_mask);
+        if (near_ && li < FB_VLMAX) w.vl_list()[li] = p;
+        nl += __popcll(nb_);
+      }
     }
+  }
+  if (build) {
+    for (int g = lane; g < M.ngeom; g += FB_WAVE) { w.vl_pos()[3*g] = G[4*g]; w.vl_pos()[3*g + 1] = G[4*g + 1]; w.vl_pos()[3*g + 2] = G[4*g + 2]; }
+    if (lane == 0) {
+      w.istate()[IS_VL_OK] = nl <= FB_VLMAX ? 1 : 0; w.istate()[IS_VL_N] = nl;
+      if (okf == 1 || nl > FB_VLMAX) w.istate()[IS_VL_SKIP] = FB_VL_BACKOFF;      // the previous list was never used (or this one does not fit): back off
+    }
+  } else if (vskip > 0 && lane == 0) w.istate()[IS_VL_SKIP] = vskip - 1;
   }
   int warn = (ncand > maxcand) ? WARN_CONTACT_CAP : 0;
   if (ncand > maxcand) ncand = maxcand;

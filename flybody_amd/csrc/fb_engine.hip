@@ -928,6 +928,15 @@ static int build_devmodel(fb_batch* b, DevModel<real>& M) {
   for (int k = 0; k < 3; k++) M.grav[k] = (real)m->d("opt_gravity")[k];
   M.density = (real)m->d("opt_density")[0]; M.viscosity = (real)m->d("opt_viscosity")[0];
   M.impratio = (real)m->d("opt_impratio")[0]; M.tolerance = (real)m->d("opt_tolerance")[0];
+  {
+    // neighbour-list slack: half the median bounding radius of the geoms that have one (planes: 0) -- the fruit fly: 0.0083 model units; measured best of
+    // 0.002 ... 0.06 (profiles/r6/ab_neighbour_list.txt).  No list for models whose pair count fits a few wave passes anyway.
+    std::vector<double> rb; const double* r_ = m->d("geom_rbound");
+    for (int g = 0; g < m->ngeom; g++) if (r_[g] > 0) rb.push_back(r_[g]);
+    std::sort(rb.begin(), rb.end());
+    M.vl_delta = (rb.empty() || m->npair <= 4*FB_WAVE) ? (real)0 : (real)(FB_VL_SCALE*rb[rb.size()/2]);
+    { const char* e_ = getenv("FB_NO_NEIGHBOUR_LIST"); if (e_ && e_[0] == '1') M.vl_delta = 0; }      // (read at model load: the tests compare the two paths bit for bit)
+  }
   M.noslip_tolerance = (real)m->d("opt_noslip_tolerance")[0]; M.meaninertia = (real)m->d("stat_meaninertia")[0];
   M.totalmass = (real)m->totalmass;
   size_t c;

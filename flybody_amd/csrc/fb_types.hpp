@@ -50,7 +50,12 @@ enum { CN_LIMIT = 0, CN_FRICTIONLESS = 1, CN_ELLIPTIC = 2 };
 enum { IS_STEP = 0, IS_RESET_NEXT = 1, IS_STEP_TYPE = 2, IS_NCON = 3, IS_NEFC = 4, IS_NITER = 5, IS_NLIMIT = 6, IS_NCAND = 7,
        IS_WB_STEP = 8, IS_WB_FREQ = 9, IS_EPISODE = 10, IS_DS_OFF = 11, IS_DS_LEN = 12, IS_EPSTEPS = 13, IS_PRIO = 14, IS_WARN = 15, IS_WARN_EVER = 16,
        IS_MAX_NCON = 17, IS_MAX_NEFC = 18, IS_N_GT32 = 19, IS_N_GT64 = 20,      // FB_SIZE_STATS: maxima / counts over every substep since the batch was created (or the field was last set)
+       IS_VL_OK = 21, IS_VL_N = 22, IS_VL_SKIP = 23,                             // mid-phase neighbour list (fb_collide.hpp): 1 = vl_list / vl_pos are set (2: and were used at least once); number of listed pairs; substeps left without list building
        IS_N = 24 };
+#ifndef FB_VL_SCALE
+#define FB_VL_SCALE 0.5       // neighbour-list slack in median geom bounding radii (0: no list)
+#endif
+#define FB_VLMAX 448         // capacity of the mid-phase neighbour list (pairs); a list that does not fit is not kept (every substep then tests every pair)
 // IS_WARN bits (include/flybody_engine.h FB_WARN_*): raised during a launch, cleared at the start of the next control step;
 // IS_WARN_EVER accumulates them since the last reset of the environment
 enum { WARN_CONTACT_CAP = 1, WARN_EFC_CAP = 2, WARN_SOLVER_MAXITER = 4, WARN_CCD_MAXITER = 8, WARN_SCHED_WAIT = 16, WARN_SOLVER_FALLBACK = 32 };
@@ -98,12 +103,14 @@ template <typename T> struct GP {
   X(cacc, 6*M.nbody) X(cfrc, 6*M.nbody) X(cfrc_ext, 6*M.nbody) X(cabias, 6*M.nbody) \
   /* cold tail of the row: only systems that do not fit the LDS copies (wide-system Y, Delassus triangle + Newton work matrix) touch it */ \
   X(efc_Y, 2*FB_MAXCH*FB_MAXEFC_) X(AR, FB_MAXEFC_*(FB_MAXEFC_ + 1)) /* Delassus triangle + the Newton work matrix K of systems wider than one row per lane */ \
-  X(nws, FB_NWS_VECS*FB_MAXEFC_) /* work vectors of the wide-system Newton solver (fb_newton.hpp: d_newton_wide) */
+  X(nws, FB_NWS_VECS*FB_MAXEFC_) /* work vectors of the wide-system Newton solver (fb_newton.hpp: d_newton_wide) */ \
+  X(vl_pos, 3*M.ngeom) /* geom centres at the time the mid-phase neighbour list was built */
 
 #define FB_WS_INT(X) \
   X(istate, IS_N) X(prof, 2*FB_NPROF) X(con_pair, FB_MAXCON_) X(con_efc, FB_MAXCON_) X(con_dim, FB_MAXCON_) X(cand, 2*FB_MAXCON_ + 64) \
   X(efc_type, FB_MAXEFC_) X(efc_id, FB_MAXEFC_) X(efc_bA, FB_MAXEFC_) X(efc_bB, FB_MAXEFC_) X(efc_lA, FB_MAXEFC_) X(efc_lB, FB_MAXEFC_) \
-  X(efc_k, FB_MAXEFC_) /* position of the row inside its contact block (0 for scalar rows) */ X(efc_eA, FB_MAXEFC_) X(efc_eB, FB_MAXEFC_) /* last dof of the row's two chains (-1: empty chain) */
+  X(efc_k, FB_MAXEFC_) /* position of the row inside its contact block (0 for scalar rows) */ X(efc_eA, FB_MAXEFC_) X(efc_eB, FB_MAXEFC_) /* last dof of the row's two chains (-1: empty chain) */ \
+  X(vl_list, FB_VLMAX) /* mid-phase neighbour list: pair ids in pair order */
 
 struct WSOff {
 #define X(name, n) uint32_t name;
@@ -120,6 +127,7 @@ struct DevModel {
   int nobsjnt, napp, nforce, ntouch, site_thorax, nadh;
   int iterations, noslip_iterations, solver;      // solver: mjtSolver numbering (0 PGS, 2 Newton)
   real timestep, control_timestep, grav[3], density, viscosity, impratio, tolerance, noslip_tolerance, meaninertia, totalmass;
+  real vl_delta;             // slack of the mid-phase neighbour list (fb_collide.hpp): FB_VL_SCALE x the median bounding radius of the model's geoms (0: no list)
   // topology
   GP<const int> body_parent, body_dofadr, body_nsub, body_depth;
   GP<const int> body_chlen;     // [nbody] number of dofs on the root->body chain

@@ -645,6 +645,32 @@ def test_pipelined_sub_batches_parity_fp64(gpu_model, oracle_model, reference_tr
     assert eq < 1e-6 and ev < 1e-6, (eq, ev)
 
 
+@pytest.mark.parametrize('precision', [64, 32])
+def test_neighbour_list_equals_testing_every_pair_gpu(reference_traj, precision, monkeypatch):
+    """The collision mid phase's neighbour list (round 6, fb_collide.hpp) on the GPU, at the headline size under the substep scheduler (the list lives
+    in the environment's row and is handed from wave to wave with it): 4096 environments x 40 control steps of the bench's action streams with the
+    list and with FB_NO_NEIGHBOUR_LIST=1 (read at model load) -- every state word, contact count and row count identical."""
+    import torch
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    out = []
+    for flag in (None, '1'):
+        if flag is None: monkeypatch.delenv('FB_NO_NEIGHBOUR_LIST', raising=False)
+        else: monkeypatch.setenv('FB_NO_NEIGHBOUR_LIST', flag)
+        M = engine.Model.from_asset('walk_imitation', dense=(precision == 64))
+        B = engine.Batch(M, 4096, precision=precision)
+        B.set_reference(qp, qv, terminal_com_dist=float('inf')); B.reset()
+        a = torch.empty(4096, M.dim('nact'), device='cuda'); st = torch.cuda.current_stream().cuda_stream
+        for k in range(40):
+            B.random_actions(a.data_ptr(), 500 + k, seed=3, stream=st); B.step_ptr(a.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append((B.get('QPOS').copy(), B.get('QVEL').copy(), B.get('NCON').copy(), B.get('NEFC').copy()))
+        del B, M
+    assert np.isfinite(out[0][0]).all() and int(out[0][2].max()) > 4
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_random_actions_keyed_by_global_id(gpu_model):
     """fb_random_actions on the GPU: a shard sees the rows of the whole batch, explicit id lists likewise (tests/test_random_actions.py
     pins the generator itself on the host build)."""

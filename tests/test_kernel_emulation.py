@@ -131,6 +131,38 @@ def test_substep_scheduler_equals_one_environment_per_wave(emu_lib, walk_arrays,
             assert np.array_equal(x, y)
 
 
+def test_neighbour_list_equals_testing_every_pair(emu_lib, walk_arrays, reference_traj, monkeypatch):
+    """Round 6: the collision mid phase keeps a NEIGHBOUR LIST per environment -- the pairs whose bounding spheres were within margin + 2 delta
+    when it was built, and the geom centres of that moment -- and tests only the listed pairs while no centre has moved by more than delta
+    (fb_collide.hpp).  Same criterion, same data, same order for the pairs it does test, and a pair outside a valid list cannot pass: the
+    candidates, the contacts and every number behind them must be those of the loop over all pairs, to the bit -- through an auto-reset
+    (a centre that jumps fails the displacement test like one that drifts) and across substep tickets (the list lives in the environment's
+    row).  FB_NO_NEIGHBOUR_LIST=1, read at model load, switches the list off."""
+    from flybody_amd import engine
+    qp, qv = reference_traj
+    rng = np.random.default_rng(11)
+    acts = rng.uniform(-1, 1, (8, 4, 59)).astype(np.float32)
+    out = []
+    for flag in (None, '1'):
+        if flag is None: monkeypatch.delenv('FB_NO_NEIGHBOUR_LIST', raising=False)
+        else: monkeypatch.setenv('FB_NO_NEIGHBOUR_LIST', flag)
+        M = engine.Model(walk_arrays, lib_path=emu_lib)
+        B = engine.Batch(M, 4, precision=64)
+        B.set_reference(qp[:8], qv[:8], future_steps=2, terminal_com_dist=float('inf')); B.reset()       # a short episode: the rollout crosses LAST -> FIRST
+        rec = []
+        for k in range(8):
+            a = np.ascontiguousarray(acts[k]); B.step_ptr(a.ctypes.data)
+            rec.append((B.get('QPOS').copy(), B.get('QVEL').copy(), B.get('NCON').copy(), B.get('NEFC').copy(), B.get('OBS').copy(), B.get('STEP_TYPE').copy()))
+        out.append(rec)
+        del B, M
+    types = np.array([r[5].ravel() for r in out[0]])
+    assert (types == 2).any() and (types == 0).any()               # the episode ended and restarted inside the rollout
+    assert max(int(r[2].max()) for r in out[0]) > 0                # contacts were made
+    for ra, rb in zip(*out):
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+
+
 def test_lane_order_independence(emu_lib):
     """Running the 64 lanes in reverse order between barriers must not change a single bit:
     a cheap detector for missing synchronisation."""
